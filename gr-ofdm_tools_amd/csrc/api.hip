@@ -1,0 +1,998 @@
+// C ABI of libofdmtools_hip.so (see include/ofdm_tools_hip.h).  Host side only:
+// argument checking, plan bookkeeping, device scratch, launch ordering.  All
+// arithmetic of the path runs in the kernels of this directory; there is no CPU
+// fallback.
+#include "../../include/ofdm_tools_hip.h"
+#include "oth_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace oth;
+
+struct oth_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cu_count = 256;
+    std::string err;
+    std::string name;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+    std::map<int, float2 *> twiddles;
+    float *sink = nullptr;
+    double *acc4 = nullptr;
+};
+
+struct oth_plan {
+    oth_ctx *ctx = nullptr;
+    int nfft = 0, nperseg = 0, noverlap = 0, step = 0, detrend = 0, scaling = 0, fftshift = 0, trim = 0;
+    int db = 0, kernel = OTH_KERNEL_AUTO;
+    double fs = 1.0, scale = 1.0;      // scale applies to the MEAN over segments
+    float *d_win = nullptr;
+    const float2 *d_tw = nullptr;
+    float *d_partial = nullptr;
+    size_t partial_cap = 0;
+    float *d_out = nullptr;            // [4][nfft] + pxy extra
+    size_t out_cap = 0;
+    float2 *d_stage = nullptr;         // host-input staging (x then y)
+    size_t stage_cap = 0;
+    // streaming state
+    float *d_sum = nullptr;            // raw sum |X|^2, natural order
+    uint64_t nseg_total = 0;
+    size_t carry = 0;                  // samples kept at the front of d_stream
+    float2 *d_stream = nullptr;
+    size_t stream_cap = 0;
+};
+
+struct oth_chain {
+    oth_ctx *ctx = nullptr;
+    int nfft = 0, fftshift = 0, epilogue = 0, keep_n = 1, count = 1;
+    float *d_win = nullptr;
+    const float2 *d_tw = nullptr;
+    float2 *d_buf = nullptr;           // leftover + new samples
+    size_t buf_cap = 0;
+    size_t leftover = 0;               // samples at the front of d_buf
+    float *d_rows = nullptr;
+    size_t rows_cap = 0;
+    int do_iir = 0, do_peak = 0;
+    float alpha = 0.f, kdb = 0.f;
+    float *d_iir = nullptr, *d_peak = nullptr;
+    int *d_peak_init = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_err = "no error";
+
+int fail(oth_ctx *c, int code, const std::string &msg) {
+    if (c)
+        c->err = msg;
+    else
+        g_err = msg;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                                 \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail((c), OTH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+int use_device(oth_ctx *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    return OTH_OK;
+}
+
+bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+int get_twiddles(oth_ctx *c, int nfft, const float2 **out) {
+    auto it = c->twiddles.find(nfft);
+    if (it != c->twiddles.end()) {
+        *out = it->second;
+        return OTH_OK;
+    }
+    std::vector<float2> h(nfft);
+    for (int k = 0; k < nfft; ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)nfft;
+        h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    float2 *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(float2) * nfft));
+    HIPCHK(c, hipMemcpyAsync(d, h.data(), sizeof(float2) * nfft, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->twiddles[nfft] = d;
+    *out = d;
+    return OTH_OK;
+}
+
+template <typename P> int ensure(oth_ctx *c, P **ptr, size_t *cap, size_t need_bytes) {
+    if (*cap >= need_bytes && *ptr) return OTH_OK;
+    if (*ptr) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(*ptr));
+        *ptr = nullptr;
+        *cap = 0;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, need_bytes);
+    if (e != hipSuccess) return fail(c, OTH_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    *ptr = reinterpret_cast<P *>(p);
+    *cap = need_bytes;
+    return OTH_OK;
+}
+
+// grow while keeping the first keep_bytes
+template <typename P> int ensure_keep(oth_ctx *c, P **ptr, size_t *cap, size_t need_bytes, size_t keep_bytes) {
+    if (*cap >= need_bytes && *ptr) return OTH_OK;
+    void *p = nullptr;
+    const size_t newcap = need_bytes + need_bytes / 4;
+    hipError_t e = hipMalloc(&p, newcap);
+    if (e != hipSuccess) return fail(c, OTH_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (*ptr) {
+        if (keep_bytes) HIPCHK(c, hipMemcpyAsync(p, *ptr, keep_bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(*ptr));
+    }
+    *ptr = reinterpret_cast<P *>(p);
+    *cap = newcap;
+    return OTH_OK;
+}
+
+struct Timed {
+    oth_ctx *c;
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit Timed(oth_ctx *ctx) : c(ctx) {
+        if (!c->timing) return;
+        if (c->events.size() >= 8192) {   // fold what we have
+            hipStreamSynchronize(c->stream);
+            for (auto &ev : c->events) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) c->total_ms += ms;
+                c->free_events.push_back(ev);
+            }
+            c->events.clear();
+        }
+        if (!c->free_events.empty()) {
+            a = c->free_events.back().first;
+            b = c->free_events.back().second;
+            c->free_events.pop_back();
+        } else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            a = b = nullptr;
+            return;
+        }
+        hipEventRecord(a, c->stream);
+    }
+    ~Timed() {
+        if (!a) return;
+        hipEventRecord(b, c->stream);
+        c->events.emplace_back(a, b);
+        c->launches++;
+    }
+};
+
+int segments(const oth_plan *p, size_t nsamples, long long *nseg) {
+    if (nsamples < (size_t)p->nperseg) return OTH_ERR_INVALID;
+    *nseg = (long long)((nsamples - (size_t)p->noverlap) / (size_t)p->step);
+    return OTH_OK;
+}
+
+int generic_wg(const oth_ctx *c, int nfft, long long nseg, int nstreams) {
+    const size_t lds = generic_lds_bytes(nfft);
+    long long occ = (long long)(160 * 1024 / lds);
+    const long long tocc = 2048 / generic_threads_for(nfft);
+    if (occ > tocc) occ = tocc;
+    if (occ < 1) occ = 1;
+    if (occ > 4) occ = 4;
+    long long w = ((long long)c->cu_count * occ + nstreams - 1) / nstreams;
+    if (w > nseg) w = nseg;
+    if (w < 1) w = 1;
+    return (int)w;
+}
+
+// Launch the averaging kernel: partial sums land in plan->d_partial.
+int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, int nstreams, size_t stride,
+                long long *nseg_out, int *W_out, int *layout_out) {
+    oth_ctx *c = p->ctx;
+    long long nseg = 0;
+    if (segments(p, nsamples, &nseg) != OTH_OK)
+        return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
+    const bool csd = (y != nullptr);
+    bool tuned = tuned4096_supported(p->nfft, p->nperseg, p->step, csd);
+    if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
+    if (p->kernel == OTH_KERNEL_TUNED && !tuned)
+        return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
+    const int W = tuned ? tuned4096_wg_per_stream(nseg, nstreams, c->cu_count)
+                        : generic_wg(c, p->nfft, nseg, nstreams);
+    const int nch = csd ? 4 : 1;
+    int rc = ensure(c, &p->d_partial, &p->partial_cap, sizeof(float) * (size_t)nstreams * W * nch * p->nfft);
+    if (rc) return rc;
+    WelchArgs a;
+    a.x = x;
+    a.y = y;
+    a.win = p->d_win;
+    a.tw = p->d_tw;
+    a.partial = p->d_partial;
+    a.nseg = nseg;
+    a.stream_stride = stride;
+    a.nperseg = p->nperseg;
+    a.step = p->step;
+    a.detrend = p->detrend;
+    a.wg_per_stream = W;
+    a.nstreams = nstreams;
+    {
+        Timed tm(c);
+        HIPCHK(c, tuned ? launch_welch_tuned4096(a, c->stream) : launch_welch_generic(p->nfft, a, c->stream));
+    }
+    *nseg_out = nseg;
+    *W_out = W;
+    *layout_out = tuned ? 1 : 0;
+    return OTH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oth_abi_version(void) { return OTH_ABI_VERSION; }
+
+const char *oth_strerror(int code) {
+    switch (code) {
+        case OTH_OK: return "ok";
+        case OTH_ERR_INVALID: return "invalid argument";
+        case OTH_ERR_HIP: return "HIP runtime error / no usable GPU";
+        case OTH_ERR_UNSUPPORTED: return "unsupported size or mode";
+        case OTH_ERR_NOMEM: return "out of device memory";
+        case OTH_ERR_STATE: return "invalid call order";
+        default: return "unknown error";
+    }
+}
+
+int oth_device_count(int *count) {
+    if (!count) return fail(nullptr, OTH_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, OTH_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return OTH_OK;
+}
+
+static int ctx_create(int device_id, void *stream, bool adopt, oth_ctx **out) {
+    if (!out) return fail(nullptr, OTH_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, OTH_ERR_HIP, "no HIP device available (libofdmtools_hip has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, OTH_ERR_INVALID, "device_id out of range");
+    oth_ctx *c = new (std::nothrow) oth_ctx();
+    if (!c) return fail(nullptr, OTH_ERR_NOMEM, "host allocation failed");
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, OTH_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        c->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    }
+    if (adopt) {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+        c->own_stream = false;
+    } else {
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+            delete c;
+            return fail(nullptr, OTH_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        }
+        c->own_stream = true;
+    }
+    if (hipMalloc(&c->sink, 256) != hipSuccess || hipMalloc(&c->acc4, 4 * sizeof(double)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, OTH_ERR_NOMEM, "hipMalloc failed for context scratch");
+    }
+    *out = c;
+    return OTH_OK;
+}
+
+int oth_ctx_create(int device_id, oth_ctx **out) { return ctx_create(device_id, nullptr, false, out); }
+int oth_ctx_create_on_stream(int device_id, void *hip_stream, oth_ctx **out) {
+    return ctx_create(device_id, hip_stream, true, out);
+}
+
+int oth_ctx_destroy(oth_ctx *c) {
+    if (!c) return OTH_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto &ev : c->events) {
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+    }
+    for (auto &ev : c->free_events) {
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+    }
+    for (auto &kv : c->twiddles) hipFree(kv.second);
+    if (c->sink) hipFree(c->sink);
+    if (c->acc4) hipFree(c->acc4);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return OTH_OK;
+}
+
+const char *oth_last_error(oth_ctx *c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int oth_ctx_sync(oth_ctx *c) {
+    if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OTH_OK;
+}
+
+int oth_ctx_device_name(oth_ctx *c, char *buf, size_t buflen) {
+    if (!c || !buf || !buflen) return fail(c, OTH_ERR_INVALID, "bad argument");
+    std::snprintf(buf, buflen, "%s", c->name.c_str());
+    return OTH_OK;
+}
+
+int oth_ctx_set_timing(oth_ctx *c, int enable) {
+    if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
+    c->timing = enable != 0;
+    return OTH_OK;
+}
+
+int oth_ctx_get_timing(oth_ctx *c, double *total_ms, uint64_t *launches, int reset) {
+    if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &ev : c->events) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, ev.first, ev.second));
+        c->total_ms += ms;
+        c->free_events.push_back(ev);
+    }
+    c->events.clear();
+    if (total_ms) *total_ms = c->total_ms;
+    if (launches) *launches = c->launches;
+    if (reset) {
+        c->total_ms = 0.0;
+        c->launches = 0;
+    }
+    return OTH_OK;
+}
+
+int oth_dev_alloc(oth_ctx *c, size_t bytes, void **dptr) {
+    if (!c || !dptr) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (use_device(c)) return OTH_ERR_HIP;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(c, OTH_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return OTH_OK;
+}
+
+int oth_dev_free(oth_ctx *c, void *dptr) {
+    if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
+    if (!dptr) return OTH_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(dptr));
+    return OTH_OK;
+}
+
+int oth_memcpy_h2d(oth_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || !dst || !src) return fail(c, OTH_ERR_INVALID, "bad argument");
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OTH_OK;
+}
+
+int oth_memcpy_d2h(oth_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || !dst || !src) return fail(c, OTH_ERR_INVALID, "bad argument");
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OTH_OK;
+}
+
+int oth_synth_iq(oth_ctx *c, void *iq_dev, size_t nsamples, uint64_t seed, int ntones, const float *tone_amp,
+                 const float *tone_freq, float dc_re, float dc_im) {
+    if (!c || !iq_dev || ntones < 0 || ntones > 8 || (ntones && (!tone_amp || !tone_freq)))
+        return fail(c, OTH_ERR_INVALID, "bad argument (at most 8 tones)");
+    if (use_device(c)) return OTH_ERR_HIP;
+    HIPCHK(c, launch_synth((float2 *)iq_dev, nsamples, seed, ntones, tone_amp, tone_freq, dc_re, dc_im, c->stream));
+    return OTH_OK;
+}
+
+int oth_stream_read_probe(oth_ctx *c, const void *dptr, size_t bytes, int repeats, double *ms_per_pass) {
+    if (!c || !dptr || bytes < 16 || repeats < 1 || !ms_per_pass) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (use_device(c)) return OTH_ERR_HIP;
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    HIPCHK(c, launch_read_probe(dptr, bytes, c->sink, c->stream));   // warm-up
+    HIPCHK(c, hipEventRecord(a, c->stream));
+    for (int i = 0; i < repeats; ++i) HIPCHK(c, launch_read_probe(dptr, bytes, c->sink, c->stream));
+    HIPCHK(c, hipEventRecord(b, c->stream));
+    HIPCHK(c, hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    *ms_per_pass = (double)ms / repeats;
+    return OTH_OK;
+}
+
+int oth_iq_power(oth_ctx *c, const void *iq_dev, size_t nsamples, double *mean_re, double *mean_im, double *var) {
+    if (!c || !iq_dev || !nsamples) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (use_device(c)) return OTH_ERR_HIP;
+    HIPCHK(c, hipMemsetAsync(c->acc4, 0, 4 * sizeof(double), c->stream));
+    HIPCHK(c, launch_iq_power((const float2 *)iq_dev, nsamples, c->acc4, c->stream));
+    double h[4];
+    HIPCHK(c, hipMemcpyAsync(h, c->acc4, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double mr = h[0] / nsamples, mi = h[1] / nsamples;
+    if (mean_re) *mean_re = mr;
+    if (mean_im) *mean_im = mi;
+    if (var) *var = h[2] / nsamples - (mr * mr + mi * mi);
+    return OTH_OK;
+}
+
+/* ---- Welch ---------------------------------------------------------------- */
+
+int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float *window, int detrend, int scaling,
+                   double fs, int fftshift, int trim_bins, oth_plan **out) {
+    if (!c || !out) return fail(c, OTH_ERR_INVALID, "ctx/out is NULL");
+    *out = nullptr;
+    if (!is_pow2(nfft) || !generic_supported(nfft))
+        return fail(c, OTH_ERR_UNSUPPORTED, "nfft must be a power of two in [64, 16384]");
+    if (nperseg < 1 || nperseg > nfft) return fail(c, OTH_ERR_INVALID, "need 1 <= nperseg <= nfft");
+    if (noverlap < 0 || noverlap >= nperseg) return fail(c, OTH_ERR_INVALID, "need 0 <= noverlap < nperseg");
+    if (detrend != OTH_DETREND_NONE && detrend != OTH_DETREND_CONSTANT)
+        return fail(c, OTH_ERR_INVALID, "unknown detrend");
+    if (scaling < OTH_SCALE_RAW || scaling > OTH_SCALE_SPECTRUM) return fail(c, OTH_ERR_INVALID, "unknown scaling");
+    if (trim_bins < 0 || 2 * trim_bins >= nfft) return fail(c, OTH_ERR_INVALID, "trim_bins out of range");
+    if (!(fs > 0.0)) return fail(c, OTH_ERR_INVALID, "fs must be positive");
+    if (use_device(c)) return OTH_ERR_HIP;
+    oth_plan *p = new (std::nothrow) oth_plan();
+    if (!p) return fail(c, OTH_ERR_NOMEM, "host allocation failed");
+    p->ctx = c;
+    p->nfft = nfft;
+    p->nperseg = nperseg;
+    p->noverlap = noverlap;
+    p->step = nperseg - noverlap;
+    p->detrend = detrend;
+    p->scaling = scaling;
+    p->fs = fs;
+    p->fftshift = fftshift != 0;
+    p->trim = trim_bins;
+    std::vector<float> w(nfft, 0.f);   // zero-extended so that kernels may index [0, nfft)
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nperseg; ++i) {
+        w[i] = window ? window[i] : 1.0f;
+        s1 += (double)w[i];
+        s2 += (double)w[i] * (double)w[i];
+    }
+    switch (scaling) {
+        case OTH_SCALE_DENSITY: p->scale = 1.0 / (fs * s2); break;
+        case OTH_SCALE_OVER_N2: p->scale = 1.0 / ((double)nfft * (double)nfft); break;
+        case OTH_SCALE_SPECTRUM: p->scale = 1.0 / (s1 * s1); break;
+        default: p->scale = 1.0;
+    }
+    int rc = get_twiddles(c, nfft, &p->d_tw);
+    if (rc) {
+        delete p;
+        return rc;
+    }
+    hipError_t e = hipMalloc(&p->d_win, sizeof(float) * nfft);
+    if (e == hipSuccess) e = hipMalloc(&p->d_sum, sizeof(float) * nfft);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->d_win, w.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_sum, 0, sizeof(float) * nfft, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        oth_plan_destroy(p);
+        return fail(c, OTH_ERR_HIP, std::string("plan setup: ") + hipGetErrorString(e));
+    }
+    *out = p;
+    return OTH_OK;
+}
+
+int oth_plan_destroy(oth_plan *p) {
+    if (!p) return OTH_OK;
+    oth_ctx *c = p->ctx;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (p->d_win) hipFree(p->d_win);
+    if (p->d_partial) hipFree(p->d_partial);
+    if (p->d_out) hipFree(p->d_out);
+    if (p->d_stage) hipFree(p->d_stage);
+    if (p->d_sum) hipFree(p->d_sum);
+    if (p->d_stream) hipFree(p->d_stream);
+    delete p;
+    return OTH_OK;
+}
+
+int oth_plan_set_output_db(oth_plan *p, int enable) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    p->db = enable != 0;
+    return OTH_OK;
+}
+
+int oth_plan_set_kernel(oth_plan *p, int which) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    if (which < OTH_KERNEL_AUTO || which > OTH_KERNEL_TUNED) return fail(p->ctx, OTH_ERR_INVALID, "unknown kernel id");
+    p->kernel = which;
+    return OTH_OK;
+}
+
+int oth_plan_out_len(oth_plan *p, int *n) {
+    if (!p || !n) return fail(p ? p->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
+    *n = p->nfft - 2 * p->trim;
+    return OTH_OK;
+}
+
+int oth_welch_exec_dev(oth_plan *p, const void *iq_dev, size_t nsamples, int nstreams, size_t stream_stride,
+                       float *psd_out_dev, uint64_t *nseg_out) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (!iq_dev || !psd_out_dev || nstreams < 1) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (nstreams > 1 && stream_stride < nsamples) return fail(c, OTH_ERR_INVALID, "stream_stride < nsamples");
+    if (use_device(c)) return OTH_ERR_HIP;
+    long long nseg = 0;
+    int W = 0, layout = 0;
+    int rc = run_average(p, (const float2 *)iq_dev, nullptr, nsamples, nstreams, stream_stride, &nseg, &W, &layout);
+    if (rc) return rc;
+    FinalizeArgs f{};
+    f.partial = p->d_partial;
+    f.out0 = psd_out_dev;
+    f.scale = p->scale / (double)nseg;
+    f.W = W;
+    f.nfft = p->nfft;
+    f.nch = 1;
+    f.layout = layout;
+    f.fftshift = p->fftshift;
+    f.trim = p->trim;
+    f.db = p->db;
+    f.nout = p->nfft - 2 * p->trim;
+    HIPCHK(c, launch_finalize(f, nstreams, c->stream));
+    if (nseg_out) *nseg_out = (uint64_t)nseg;
+    return OTH_OK;
+}
+
+static int stage_host(oth_plan *p, const void *x, const void *y, size_t nsamples, const float2 **dx, const float2 **dy) {
+    oth_ctx *c = p->ctx;
+    const size_t bytes = nsamples * sizeof(float2);
+    int rc = ensure(c, &p->d_stage, &p->stage_cap, bytes * (y ? 2 : 1));
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(p->d_stage, x, bytes, hipMemcpyHostToDevice, c->stream));
+    *dx = p->d_stage;
+    if (y) {
+        HIPCHK(c, hipMemcpyAsync(p->d_stage + nsamples, y, bytes, hipMemcpyHostToDevice, c->stream));
+        *dy = p->d_stage + nsamples;
+    }
+    return OTH_OK;
+}
+
+int oth_welch_exec(oth_plan *p, const void *iq, size_t nsamples, int src_is_device, float *psd_out,
+                   uint64_t *nseg_out) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (!iq || !psd_out) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (nsamples < (size_t)p->nperseg) return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
+    if (use_device(c)) return OTH_ERR_HIP;
+    const float2 *dx = (const float2 *)iq, *dy = nullptr;
+    int rc;
+    if (!src_is_device && (rc = stage_host(p, iq, nullptr, nsamples, &dx, &dy))) return rc;
+    const int nout = p->nfft - 2 * p->trim;
+    if ((rc = ensure(c, &p->d_out, &p->out_cap, sizeof(float) * 5 * p->nfft))) return rc;
+    if ((rc = oth_welch_exec_dev(p, dx, nsamples, 1, nsamples, p->d_out, nseg_out))) return rc;
+    HIPCHK(c, hipMemcpyAsync(psd_out, p->d_out, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OTH_OK;
+}
+
+int oth_welch_partial_dev(oth_plan *p, const void *iq_dev, size_t nsamples, float *sum_out_dev, uint64_t *nseg_out) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (!iq_dev || !sum_out_dev) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (use_device(c)) return OTH_ERR_HIP;
+    long long nseg = 0;
+    int W = 0, layout = 0;
+    int rc = run_average(p, (const float2 *)iq_dev, nullptr, nsamples, 1, nsamples, &nseg, &W, &layout);
+    if (rc) return rc;
+    FinalizeArgs f{};
+    f.partial = p->d_partial;
+    f.out0 = sum_out_dev;
+    f.scale = 1.0;
+    f.W = W;
+    f.nfft = p->nfft;
+    f.nch = 1;
+    f.layout = layout;
+    f.nout = p->nfft;
+    HIPCHK(c, launch_finalize(f, 1, c->stream));
+    if (nseg_out) *nseg_out = (uint64_t)nseg;
+    return OTH_OK;
+}
+
+int oth_welch_scale_dev(oth_plan *p, const float *sum_dev, uint64_t nseg_total, float *psd_out_dev) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (!sum_dev || !psd_out_dev || !nseg_total) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (use_device(c)) return OTH_ERR_HIP;
+    HIPCHK(c, launch_scale(sum_dev, psd_out_dev, p->nfft, p->scale / (double)nseg_total, p->fftshift, p->trim, p->db,
+                           c->stream));
+    return OTH_OK;
+}
+
+int oth_welch_reset(oth_plan *p) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (use_device(c)) return OTH_ERR_HIP;
+    HIPCHK(c, hipMemsetAsync(p->d_sum, 0, sizeof(float) * p->nfft, c->stream));
+    p->nseg_total = 0;
+    p->carry = 0;
+    return OTH_OK;
+}
+
+int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (!iq_host && nsamples) return fail(c, OTH_ERR_INVALID, "iq is NULL");
+    if (!nsamples) return OTH_OK;
+    if (use_device(c)) return OTH_ERR_HIP;
+    const size_t total = p->carry + nsamples;
+    int rc = ensure_keep(c, &p->d_stream, &p->stream_cap, total * sizeof(float2), p->carry * sizeof(float2));
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(p->d_stream + p->carry, iq_host, nsamples * sizeof(float2), hipMemcpyHostToDevice,
+                             c->stream));
+    // the caller's buffer is only valid during the call (sync_block.work contract)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (total < (size_t)p->nperseg) {
+        p->carry = total;
+        return OTH_OK;
+    }
+    long long nseg = 0;
+    int W = 0, layout = 0;
+    if ((rc = run_average(p, p->d_stream, nullptr, total, 1, total, &nseg, &W, &layout))) return rc;
+    FinalizeArgs f{};
+    f.partial = p->d_partial;
+    f.out0 = p->d_sum;
+    f.scale = 1.0;
+    f.W = W;
+    f.nfft = p->nfft;
+    f.nch = 1;
+    f.layout = layout;
+    f.nout = p->nfft;
+    f.accumulate = 1;
+    HIPCHK(c, launch_finalize(f, 1, c->stream));
+    p->nseg_total += (uint64_t)nseg;
+    // keep the samples the next segment still needs
+    const size_t consumed = (size_t)nseg * (size_t)p->step;
+    const size_t keep = total - consumed;
+    if (keep) {
+        // regions may overlap when keep > consumed: bounce through the partial-free tail of d_stage
+        if (keep <= consumed) {
+            HIPCHK(c, hipMemcpyAsync(p->d_stream, p->d_stream + consumed, keep * sizeof(float2),
+                                     hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            if ((rc = ensure(c, &p->d_stage, &p->stage_cap, keep * sizeof(float2)))) return rc;
+            HIPCHK(c, hipMemcpyAsync(p->d_stage, p->d_stream + consumed, keep * sizeof(float2),
+                                     hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(p->d_stream, p->d_stage, keep * sizeof(float2), hipMemcpyDeviceToDevice,
+                                     c->stream));
+        }
+    }
+    p->carry = keep;
+    return OTH_OK;
+}
+
+int oth_welch_finalize(oth_plan *p, float *psd_out, uint64_t *nseg_out) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (!psd_out) return fail(c, OTH_ERR_INVALID, "psd_out is NULL");
+    if (!p->nseg_total) return fail(c, OTH_ERR_STATE, "no complete segment accumulated yet");
+    if (use_device(c)) return OTH_ERR_HIP;
+    int rc = ensure(c, &p->d_out, &p->out_cap, sizeof(float) * 5 * p->nfft);
+    if (rc) return rc;
+    const int nout = p->nfft - 2 * p->trim;
+    HIPCHK(c, launch_scale(p->d_sum, p->d_out, p->nfft, p->scale / (double)p->nseg_total, p->fftshift, p->trim,
+                           p->db, c->stream));
+    HIPCHK(c, hipMemcpyAsync(psd_out, p->d_out, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nseg_out) *nseg_out = p->nseg_total;
+    return oth_welch_reset(p);
+}
+
+int oth_csd_exec(oth_plan *p, const void *x, const void *y, size_t nsamples, int src_is_device, float *pxx,
+                 float *pyy, float *pxy, float *cxy, uint64_t *nseg_out) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (!x || !y) return fail(c, OTH_ERR_INVALID, "x/y is NULL");
+    if (p->db) return fail(c, OTH_ERR_UNSUPPORTED, "dB output is not defined for the cross spectrum");
+    if (nsamples < (size_t)p->nperseg) return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
+    if (use_device(c)) return OTH_ERR_HIP;
+    const float2 *dx = (const float2 *)x, *dy = (const float2 *)y;
+    int rc;
+    if (!src_is_device && (rc = stage_host(p, x, y, nsamples, &dx, &dy))) return rc;
+    long long nseg = 0;
+    int W = 0, layout = 0;
+    if ((rc = run_average(p, dx, dy, nsamples, 1, nsamples, &nseg, &W, &layout))) return rc;
+    if ((rc = ensure(c, &p->d_out, &p->out_cap, sizeof(float) * 5 * p->nfft))) return rc;
+    const int nout = p->nfft - 2 * p->trim;
+    FinalizeArgs f{};
+    f.partial = p->d_partial;
+    f.out0 = p->d_out;
+    f.out1 = p->d_out + p->nfft;
+    f.out2 = p->d_out + 2 * p->nfft;
+    f.out3 = p->d_out + 4 * p->nfft;
+    f.scale = p->scale / (double)nseg;
+    f.W = W;
+    f.nfft = p->nfft;
+    f.nch = 4;
+    f.layout = layout;
+    f.fftshift = p->fftshift;
+    f.trim = p->trim;
+    f.nout = nout;
+    HIPCHK(c, launch_finalize(f, 1, c->stream));
+    if (pxx) HIPCHK(c, hipMemcpyAsync(pxx, f.out0, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+    if (pyy) HIPCHK(c, hipMemcpyAsync(pyy, f.out1, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+    if (pxy) HIPCHK(c, hipMemcpyAsync(pxy, f.out2, sizeof(float) * 2 * nout, hipMemcpyDeviceToHost, c->stream));
+    if (cxy) HIPCHK(c, hipMemcpyAsync(cxy, f.out3, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nseg_out) *nseg_out = (uint64_t)nseg;
+    return OTH_OK;
+}
+
+/* ---- periodogram chain ------------------------------------------------------ */
+
+int oth_chain_create(oth_ctx *c, int nfft, const float *window, int fftshift, int epilogue, int keep_one_in_n,
+                     oth_chain **out) {
+    if (!c || !out) return fail(c, OTH_ERR_INVALID, "ctx/out is NULL");
+    *out = nullptr;
+    if (!is_pow2(nfft) || !generic_supported(nfft))
+        return fail(c, OTH_ERR_UNSUPPORTED, "nfft must be a power of two in [64, 16384]");
+    if (epilogue < OTH_EPI_MAG || epilogue > OTH_EPI_MAG2_OVER_N2) return fail(c, OTH_ERR_INVALID, "unknown epilogue");
+    if (keep_one_in_n < 1) return fail(c, OTH_ERR_INVALID, "keep_one_in_n must be >= 1");
+    if (use_device(c)) return OTH_ERR_HIP;
+    oth_chain *h = new (std::nothrow) oth_chain();
+    if (!h) return fail(c, OTH_ERR_NOMEM, "host allocation failed");
+    h->ctx = c;
+    h->nfft = nfft;
+    h->fftshift = fftshift != 0;
+    h->epilogue = epilogue;
+    h->keep_n = h->count = keep_one_in_n;
+    int rc = get_twiddles(c, nfft, &h->d_tw);
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    std::vector<float> w(nfft);
+    for (int i = 0; i < nfft; ++i) w[i] = window ? window[i] : 1.0f;
+    hipError_t e = hipMalloc(&h->d_win, sizeof(float) * nfft);
+    if (e == hipSuccess) e = hipMalloc(&h->d_iir, sizeof(float) * nfft);
+    if (e == hipSuccess) e = hipMalloc(&h->d_peak, sizeof(float) * nfft);
+    if (e == hipSuccess) e = hipMalloc(&h->d_peak_init, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(h->d_win, w.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_iir, 0, sizeof(float) * nfft, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_peak, 0, sizeof(float) * nfft, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_peak_init, 0, sizeof(int), c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        oth_chain_destroy(h);
+        return fail(c, OTH_ERR_HIP, std::string("chain setup: ") + hipGetErrorString(e));
+    }
+    *out = h;
+    return OTH_OK;
+}
+
+int oth_chain_destroy(oth_chain *h) {
+    if (!h) return OTH_OK;
+    oth_ctx *c = h->ctx;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (h->d_win) hipFree(h->d_win);
+    if (h->d_buf) hipFree(h->d_buf);
+    if (h->d_rows) hipFree(h->d_rows);
+    if (h->d_iir) hipFree(h->d_iir);
+    if (h->d_peak) hipFree(h->d_peak);
+    if (h->d_peak_init) hipFree(h->d_peak_init);
+    delete h;
+    return OTH_OK;
+}
+
+int oth_chain_set_keep_one_in_n(oth_chain *h, int n) {
+    if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
+    if (n < 1) return fail(h->ctx, OTH_ERR_INVALID, "keep_one_in_n must be >= 1");
+    h->keep_n = h->count = n;   // keep_one_in_n::set_n restarts the count
+    return OTH_OK;
+}
+
+int oth_chain_set_iir_log(oth_chain *h, float alpha, float k_db) {
+    if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
+    h->do_iir = alpha > 0.f;
+    h->alpha = alpha;
+    h->kdb = k_db;
+    return OTH_OK;
+}
+
+int oth_chain_set_peak_hold(oth_chain *h, int enable) {
+    if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
+    h->do_peak = enable != 0;
+    return OTH_OK;
+}
+
+int oth_chain_reset(oth_chain *h) {
+    if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
+    oth_ctx *c = h->ctx;
+    if (use_device(c)) return OTH_ERR_HIP;
+    HIPCHK(c, hipMemsetAsync(h->d_iir, 0, sizeof(float) * h->nfft, c->stream));
+    HIPCHK(c, hipMemsetAsync(h->d_peak, 0, sizeof(float) * h->nfft, c->stream));
+    HIPCHK(c, hipMemsetAsync(h->d_peak_init, 0, sizeof(int), c->stream));
+    h->leftover = 0;
+    h->count = h->keep_n;
+    return OTH_OK;
+}
+
+int oth_chain_push(oth_chain *h, const void *iq, size_t nsamples, int src_is_device, float *rows_out,
+                   size_t rows_capacity, uint64_t *nrows_out) {
+    if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
+    oth_ctx *c = h->ctx;
+    if (nrows_out) *nrows_out = 0;
+    if (!iq && nsamples) return fail(c, OTH_ERR_INVALID, "iq is NULL");
+    if (!nsamples) return OTH_OK;
+    if (use_device(c)) return OTH_ERR_HIP;
+    const int N = h->nfft;
+    const size_t total = h->leftover + nsamples;
+    int rc = ensure_keep(c, &h->d_buf, &h->buf_cap, total * sizeof(float2), h->leftover * sizeof(float2));
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(h->d_buf + h->leftover, iq, nsamples * sizeof(float2),
+                             src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (!src_is_device) HIPCHK(c, hipStreamSynchronize(c->stream));
+    const long long nvec = (long long)(total / N);
+    long long nrows = 0, first = h->count - 1;
+    if (nvec > first) nrows = 1 + (nvec - 1 - first) / h->keep_n;
+    if (nrows == 0) {
+        h->count -= (int)nvec;
+    } else {
+        const long long last = first + (nrows - 1) * h->keep_n;
+        h->count = h->keep_n - (int)(nvec - 1 - last);
+        if ((rc = ensure(c, &h->d_rows, &h->rows_cap, sizeof(float) * (size_t)nrows * N))) return rc;
+        PgramArgs a;
+        a.x = h->d_buf;
+        a.win = h->d_win;
+        a.tw = h->d_tw;
+        a.rows = h->d_rows;
+        a.first_vec = first;
+        a.nrows = nrows;
+        a.keep_n = h->keep_n;
+        a.fftshift = h->fftshift;
+        a.epilogue = h->epilogue;
+        a.scale = h->epilogue == OTH_EPI_MAG2_OVER_N2 ? (float)(1.0 / ((double)N * (double)N)) : 1.0f;
+        {
+            Timed tm(c);
+            HIPCHK(c, launch_pgram(N, a, c->stream));
+        }
+        if (h->do_iir || h->do_peak)
+            HIPCHK(c, launch_rows_epilogue(h->d_rows, nrows, N, h->alpha, h->kdb, h->d_iir, h->d_peak,
+                                           h->d_peak_init, h->do_iir, h->do_peak, c->stream));
+        if (rows_out && rows_capacity) {
+            const size_t give = (size_t)nrows < rows_capacity ? (size_t)nrows : rows_capacity;
+            HIPCHK(c, hipMemcpyAsync(rows_out, h->d_rows + ((size_t)nrows - give) * N, sizeof(float) * give * N,
+                                     hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    // carry the samples of the incomplete vector
+    const size_t used = (size_t)nvec * N;
+    const size_t keep = total - used;
+    if (keep && used) {
+        // keep < N <= used, so source and destination do not overlap
+        HIPCHK(c, hipMemcpyAsync(h->d_buf, h->d_buf + used, keep * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+    }
+    h->leftover = keep;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nrows_out) *nrows_out = (uint64_t)nrows;
+    return OTH_OK;
+}
+
+int oth_chain_get_peak(oth_chain *h, float *peak_out) {
+    if (!h || !peak_out) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
+    oth_ctx *c = h->ctx;
+    HIPCHK(c, hipMemcpyAsync(peak_out, h->d_peak, sizeof(float) * h->nfft, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OTH_OK;
+}
+
+int oth_chain_get_iir(oth_chain *h, float *lin_out) {
+    if (!h || !lin_out) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
+    oth_ctx *c = h->ctx;
+    HIPCHK(c, hipMemcpyAsync(lin_out, h->d_iir, sizeof(float) * h->nfft, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OTH_OK;
+}
+
+int oth_rows_group_mean(oth_ctx *c, const float *rows_host, size_t nrows, int nfft, int group, float *out_host) {
+    if (!c || !rows_host || !out_host || nfft < 1 || group < 1 || nrows < (size_t)group)
+        return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (use_device(c)) return OTH_ERR_HIP;
+    const size_t ngroups = nrows / group;
+    float *d_in = nullptr, *d_out = nullptr;
+    const size_t in_bytes = sizeof(float) * ngroups * group * nfft, out_bytes = sizeof(float) * ngroups * nfft;
+    if (hipMalloc(&d_in, in_bytes) != hipSuccess || hipMalloc(&d_out, out_bytes) != hipSuccess) {
+        if (d_in) hipFree(d_in);
+        return fail(c, OTH_ERR_NOMEM, "hipMalloc failed");
+    }
+    hipError_t e = hipMemcpyAsync(d_in, rows_host, in_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_group_mean(d_in, (long long)ngroups, nfft, group, d_out, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_in);
+    hipFree(d_out);
+    if (e != hipSuccess) return fail(c, OTH_ERR_HIP, std::string("group_mean: ") + hipGetErrorString(e));
+    return OTH_OK;
+}
+
+int oth_channel_power(oth_ctx *c, const float *psd_host, int nfft, double srch_bins, int nch, const int *lo,
+                      const int *hi, float *power_out, float *movavg_out) {
+    if (!c || !psd_host || !lo || !hi || !power_out || nfft < 1 || nch < 1 || !(srch_bins >= 1.0))
+        return fail(c, OTH_ERR_INVALID, "bad argument (srch_bins must be >= 1)");
+    for (int i = 0; i < nch; ++i)
+        if (lo[i] < 0 || hi[i] > nfft) return fail(c, OTH_ERR_INVALID, "channel slice outside [0, nfft]");
+    if (use_device(c)) return OTH_ERR_HIP;
+    unsigned char *d = nullptr;
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_psd = 0, o_ma = up(o_psd + sizeof(float) * nfft), o_maf = up(o_ma + sizeof(double) * nfft),
+                 o_lo = up(o_maf + sizeof(float) * nfft), o_hi = up(o_lo + sizeof(int) * nch),
+                 o_pw = up(o_hi + sizeof(int) * nch), bytes = up(o_pw + sizeof(float) * nch);
+    if (hipMalloc(&d, bytes) != hipSuccess) return fail(c, OTH_ERR_NOMEM, "hipMalloc failed");
+    hipError_t e = hipMemcpyAsync(d + o_psd, psd_host, sizeof(float) * nfft, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_lo, lo, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_hi, hi, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = launch_channel_power((const float *)(d + o_psd), nfft, srch_bins, nch, (const int *)(d + o_lo),
+                                 (const int *)(d + o_hi), (double *)(d + o_ma), (float *)(d + o_pw),
+                                 (float *)(d + o_maf), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(power_out, d + o_pw, sizeof(float) * nch, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && movavg_out)
+        e = hipMemcpyAsync(movavg_out, d + o_maf, sizeof(float) * nfft, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, OTH_ERR_HIP, std::string("channel_power: ") + hipGetErrorString(e));
+    return OTH_OK;
+}
+
+static int xcorr_impl(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, int L, float *out, int mode) {
+    if (!c || !a || !out || (mode == 0 && !b)) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (!is_pow2(L) || !generic_supported(L)) return fail(c, OTH_ERR_UNSUPPORTED, "L must be a power of two in [64, 16384]");
+    if (na > (size_t)L || nb > (size_t)L) return fail(c, OTH_ERR_INVALID, "input longer than L");
+    if (use_device(c)) return OTH_ERR_HIP;
+    const float2 *tw = nullptr;
+    int rc = get_twiddles(c, L, &tw);
+    if (rc) return rc;
+    float2 *d = nullptr;
+    if (hipMalloc(&d, sizeof(float2) * 3 * L) != hipSuccess) return fail(c, OTH_ERR_NOMEM, "hipMalloc failed");
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(float2) * 3 * L, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, a, sizeof(float2) * na, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && mode == 0) e = hipMemcpyAsync(d + L, b, sizeof(float2) * nb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_xcorr(L, d, d + L, tw, (float *)(d + 2 * L), mode, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + 2 * L, sizeof(float) * (L - L / 2), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, OTH_ERR_HIP, std::string("xcorr: ") + hipGetErrorString(e));
+    return OTH_OK;
+}
+
+int oth_xcorr(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, int L, float *out) {
+    return xcorr_impl(c, a, na, b, nb, L, out, 0);
+}
+
+int oth_fac(oth_ctx *c, const void *data, size_t n, int L, float *out) {
+    return xcorr_impl(c, data, n, nullptr, 0, L, out, 1);
+}
+
+}  // extern "C"

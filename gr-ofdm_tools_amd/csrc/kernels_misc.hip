@@ -1,0 +1,252 @@
+// Small kernels around the FFT kernels: cross-workgroup reduction + scaling +
+// fftshift/trim/dB (spectrum_sweeper.py:265-276), the time-recursive row
+// epilogues (single_pole_iir_filter_ff + nlog10_ff of local_worker.py:66-69,
+// peak hold of psd_logger.py:85), channel power (ofdm_cr_tools.py:168-170,
+// 232-249), the synthetic IQ generator and the measurement probes.
+#include "oth_internal.h"
+
+namespace oth {
+
+// position of bin k inside a partial-sum row
+__device__ __forceinline__ int bin_pos(int k, int layout) {
+    // layout 1: welch4096 leaves bin k0 + 16 k1 + 256 k2 at 16 k0 + k1 + 256 k2
+    return layout ? (((k & 15) << 4) | ((k >> 4) & 15) | (k & ~255)) : k;
+}
+
+__global__ void finalize_kernel(FinalizeArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stream = blockIdx.y;
+    if (i >= a.nout) return;
+    const int ks = i + a.trim;
+    const int k = a.fftshift ? ((ks + a.nfft / 2) & (a.nfft - 1)) : ks;
+    const int pos = bin_pos(k, a.layout);
+    const float *base = a.partial + (size_t)stream * a.W * a.nch * a.nfft + pos;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int w = 0; w < a.W; ++w)
+        for (int c = 0; c < a.nch; ++c) s[c] += (double)base[((size_t)w * a.nch + c) * a.nfft];
+    const size_t o = (size_t)stream * a.nout + i;
+    if (a.nch == 1) {
+        if (a.accumulate) {
+            a.out0[o] += (float)s[0];
+        } else {
+            const double v = s[0] * a.scale;
+            a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
+        }
+    } else {
+        const double pxx = s[0] * a.scale, pyy = s[1] * a.scale, re = s[2] * a.scale, im = s[3] * a.scale;
+        if (a.out0) a.out0[o] = (float)pxx;
+        if (a.out1) a.out1[o] = (float)pyy;
+        if (a.out2) {
+            a.out2[2 * o] = (float)re;
+            a.out2[2 * o + 1] = (float)im;
+        }
+        if (a.out3) a.out3[o] = (float)((s[2] * s[2] + s[3] * s[3]) / (s[0] * s[1]));
+    }
+}
+
+hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s) {
+    const dim3 grid((a.nout + 255) / 256, nstreams);
+    hipLaunchKernelGGL(finalize_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ void scale_kernel(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,
+                             int nout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nout) return;
+    const int ks = i + trim;
+    const int k = fftshift ? ((ks + nfft / 2) & (nfft - 1)) : ks;
+    const double v = (double)sum[k] * scale;
+    out[i] = db ? (float)(10.0 * log10(v)) : (float)v;
+}
+
+hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,
+                        hipStream_t s) {
+    const int nout = nfft - 2 * trim;
+    hipLaunchKernelGGL(scale_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, sum, out, nfft, scale, fftshift,
+                       trim, db, nout);
+    return hipGetLastError();
+}
+
+// One thread per bin walks the rows in time order.
+__global__ void rows_epilogue_kernel(float *rows, long long nrows, int nfft, float alpha, float kdb,
+                                     float *iir_state, float *peak_state, int *peak_init, int do_iir, int do_peak) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nfft) return;
+    float y = do_iir ? iir_state[k] : 0.f;
+    const bool have_peak = do_peak && (*peak_init != 0);
+    float pk = have_peak ? peak_state[k] : 0.f;
+    for (long long r = 0; r < nrows; ++r) {
+        float v = rows[(size_t)r * nfft + k];
+        if (do_peak) pk = (have_peak || r > 0) ? fmaxf(pk, v) : v;
+        if (do_iir) {
+            y = fmaf(alpha, v, (1.0f - alpha) * y);
+            rows[(size_t)r * nfft + k] = 10.0f * log10f(y) + kdb;
+        }
+    }
+    if (do_iir) iir_state[k] = y;
+    if (do_peak && nrows > 0) peak_state[k] = pk;
+}
+
+__global__ void set_flag_kernel(int *flag, int v) { *flag = v; }
+
+hipError_t launch_rows_epilogue(float *rows, long long nrows, int nfft, float alpha, float kdb, float *iir_state,
+                                float *peak_state, int *peak_init, int do_iir, int do_peak, hipStream_t s) {
+    hipLaunchKernelGGL(rows_epilogue_kernel, dim3((nfft + 255) / 256), dim3(256), 0, s, rows, nrows, nfft, alpha,
+                       kdb, iir_state, peak_state, peak_init, do_iir, do_peak);
+    if (do_peak && nrows > 0) hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, s, peak_init, 1);
+    return hipGetLastError();
+}
+
+__global__ void group_mean_kernel(const float *rows, long long ngroups, int nfft, int group, float *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long g = blockIdx.y;
+    if (k >= nfft || g >= ngroups) return;
+    double s = 0.0;
+    for (int r = 0; r < group; ++r) s += (double)rows[((size_t)g * group + r) * nfft + k];
+    out[(size_t)g * nfft + k] = (float)(s / group);
+}
+
+hipError_t launch_group_mean(const float *rows, long long ngroups, int nfft, int group, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(group_mean_kernel, dim3((nfft + 255) / 256, (unsigned)ngroups), dim3(256), 0, s, rows,
+                       ngroups, nfft, group, out);
+    return hipGetLastError();
+}
+
+// movingaverage(): np.convolve(psd, ones(M)/sb, 'same'), M = int(sb):
+// same[i] = (1/sb) * sum_{j<M} psd[i + (M-1)/2 - j]  (terms outside [0,N) dropped), then abs.
+__global__ void movavg_kernel(const float *psd, int nfft, double srch_bins, double *movavg, float *movavg_f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nfft) return;
+    const int M = (int)srch_bins;
+    const int top = i + (M - 1) / 2;
+    double s = 0.0;
+    for (int j = 0; j < M; ++j) {
+        const int n = top - j;
+        if (n >= 0 && n < nfft) s += (double)psd[n];
+    }
+    s = fabs(s / srch_bins);
+    movavg[i] = s;
+    if (movavg_f) movavg_f[i] = (float)s;
+}
+
+__global__ void channel_sum_kernel(const double *movavg, int nch, const int *lo, const int *hi, float *power) {
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int i = lo[c] + threadIdx.x; i < hi[c]; i += 64) s += movavg[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) power[c] = (float)s;
+}
+
+hipError_t launch_channel_power(const float *psd, int nfft, double srch_bins, int nch, const int *lo, const int *hi,
+                                double *movavg, float *power, float *movavg_f, hipStream_t s) {
+    hipLaunchKernelGGL(movavg_kernel, dim3((nfft + 255) / 256), dim3(256), 0, s, psd, nfft, srch_bins, movavg,
+                       movavg_f);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(nch), dim3(64), 0, s, movavg, nch, lo, hi, power);
+    return hipGetLastError();
+}
+
+// ---- synthetic IQ -----------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct ToneSet {
+    float amp[8];
+    float freq[8];
+    int n;
+};
+
+__global__ void synth_kernel(float2 *iq, size_t n, uint64_t seed, ToneSet tones, float dc_re, float dc_im) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t h = splitmix64(seed * 0xD1342543DE82EF95ull + i);
+        const float u1 = ((uint32_t)(h >> 40) + 1) * (1.0f / 16777216.0f);   // (0, 1]
+        const float u2 = (uint32_t)(h & 0xFFFFFF) * (1.0f / 16777216.0f);    // [0, 1)
+        // unit-power complex Gaussian: sqrt(-ln u1) * exp(2 pi i u2)
+        const float r = sqrtf(-logf(u1));
+        float sn, cs;
+        sincospif(2.0f * u2, &sn, &cs);
+        double re = r * cs + dc_re, im = r * sn + dc_im;
+        for (int t = 0; t < tones.n; ++t) {
+            double ph = (double)tones.freq[t] * (double)i;
+            ph -= floor(ph);
+            double s, c;
+            sincospi(2.0 * ph, &s, &c);
+            re += tones.amp[t] * c;
+            im += tones.amp[t] * s;
+        }
+        iq[i] = make_float2((float)re, (float)im);
+    }
+}
+
+hipError_t launch_synth(float2 *iq, size_t n, uint64_t seed, int ntones, const float *amp, const float *freq,
+                        float dc_re, float dc_im, hipStream_t s) {
+    ToneSet t;
+    t.n = ntones > 8 ? 8 : ntones;
+    for (int i = 0; i < t.n; ++i) {
+        t.amp[i] = amp[i];
+        t.freq[i] = freq[i];
+    }
+    hipLaunchKernelGGL(synth_kernel, dim3(4096), dim3(256), 0, s, iq, n, seed, t, dc_re, dc_im);
+    return hipGetLastError();
+}
+
+// ---- probes -----------------------------------------------------------------
+__global__ void read_probe_kernel(const float4 *p, size_t n4, float *sink) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc.x += a.x + b.x + c.x + d.x;
+        acc.y += a.y + b.y + c.y + d.y;
+        acc.z += a.z + b.z + c.z + d.z;
+        acc.w += a.w + b.w + c.w + d.w;
+    }
+    for (; i < n4; i += stride) {
+        const float4 a = p[i];
+        acc.x += a.x;
+        acc.y += a.y;
+        acc.z += a.z;
+        acc.w += a.w;
+    }
+    const float v = acc.x + acc.y + acc.z + acc.w;
+    if (v == 1.2345e-30f) sink[0] = v;   // keeps the loads alive, practically never stores
+}
+
+hipError_t launch_read_probe(const void *p, size_t bytes, float *sink, hipStream_t s) {
+    hipLaunchKernelGGL(read_probe_kernel, dim3(256 * 8), dim3(256), 0, s, (const float4 *)p, bytes / 16, sink);
+    return hipGetLastError();
+}
+
+__global__ void iq_power_kernel(const float2 *iq, size_t n, double *acc4) {
+    double sr = 0, si = 0, sp = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 v = iq[i];
+        sr += v.x;
+        si += v.y;
+        sp += (double)v.x * v.x + (double)v.y * v.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_xor(sr, off, 64);
+        si += __shfl_xor(si, off, 64);
+        sp += __shfl_xor(sp, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc4[0], sr);
+        atomicAdd(&acc4[1], si);
+        atomicAdd(&acc4[2], sp);
+    }
+}
+
+hipError_t launch_iq_power(const float2 *iq, size_t n, double *acc4, hipStream_t s) {
+    hipLaunchKernelGGL(iq_power_kernel, dim3(2048), dim3(256), 0, s, iq, n, acc4);
+    return hipGetLastError();
+}
+
+}  // namespace oth

@@ -1,0 +1,81 @@
+// Internal declarations shared by the HIP translation units of libofdmtools_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace oth {
+
+// Launch description of the segment-averaging (Welch / CSD) kernels.
+struct WelchArgs {
+    const float2 *x;        // device IQ, stream 0
+    const float2 *y;        // second channel (CSD) or nullptr
+    const float *win;       // device window, nperseg floats
+    const float2 *tw;       // device twiddle table W_nfft^k, nfft entries
+    float *partial;         // [nstreams][wg_per_stream][nch][nfft] partial sums
+    long long nseg;         // segments per stream
+    size_t stream_stride;   // samples between streams
+    int nperseg;
+    int step;               // nperseg - noverlap
+    int detrend;
+    int wg_per_stream;
+    int nstreams;
+};
+
+struct PgramArgs {
+    const float2 *x;
+    const float *win;       // nfft floats
+    const float2 *tw;
+    float *rows;            // [nrows][nfft]
+    long long first_vec;    // index of the first kept vector in x
+    long long nrows;
+    int keep_n;
+    int fftshift;
+    int epilogue;
+    float scale;            // applied to |X|^2 (OVER_N2)
+};
+
+struct FinalizeArgs {
+    const float *partial;   // [nstreams][W][nch][nfft]
+    float *out0;            // psd / pxx      [nstreams][nout]
+    float *out1;            // pyy  (CSD)
+    float *out2;            // pxy  interleaved (CSD)
+    float *out3;            // cxy  (CSD)
+    double scale;
+    int W;
+    int nfft;
+    int nch;                // 1 or 4
+    int layout;             // 0 natural, 1 tuned-4096 digit order
+    int fftshift;
+    int trim;
+    int db;
+    int nout;
+    int accumulate;         // out0 += (raw sums; streaming form)
+};
+
+// Every launcher returns hipSuccess / error of the launch only (asynchronous).
+hipError_t launch_welch_generic(int nfft, const WelchArgs &a, hipStream_t s);
+hipError_t launch_welch_tuned4096(const WelchArgs &a, hipStream_t s);      // nfft 4096, nperseg 4096, y == nullptr
+bool tuned4096_supported(int nfft, int nperseg, int step, bool csd);
+int tuned4096_wg_per_stream(long long nseg, int nstreams, int cu_count);
+hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
+hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s);
+hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,
+                        hipStream_t s);
+hipError_t launch_rows_epilogue(float *rows, long long nrows, int nfft, float alpha, float kdb, float *iir_state,
+                                float *peak_state, int *peak_init, int do_iir, int do_peak, hipStream_t s);
+hipError_t launch_group_mean(const float *rows, long long ngroups, int nfft, int group, float *out, hipStream_t s);
+hipError_t launch_channel_power(const float *psd, int nfft, double srch_bins, int nch, const int *lo, const int *hi,
+                                double *movavg, float *power, float *movavg_f, hipStream_t s);
+hipError_t launch_xcorr(int L, const float2 *a, const float2 *b, const float2 *tw, float *out, int mode,
+                        hipStream_t s);
+hipError_t launch_synth(float2 *iq, size_t n, uint64_t seed, int ntones, const float *amp, const float *freq,
+                        float dc_re, float dc_im, hipStream_t s);
+hipError_t launch_read_probe(const void *p, size_t bytes, float *sink, hipStream_t s);
+hipError_t launch_iq_power(const float2 *iq, size_t n, double *acc4, hipStream_t s);
+
+bool generic_supported(int nfft);
+size_t generic_lds_bytes(int nfft);
+int generic_threads_for(int nfft);
+
+}  // namespace oth

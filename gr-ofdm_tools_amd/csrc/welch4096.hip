@@ -1,0 +1,192 @@
+// welch4096: the headline kernel.  Welch-averaged |FFT_4096(detrend(x) * w)|^2
+// over a run of overlapping segments per workgroup, for nperseg = nfft = 4096
+// (scipy.signal.welch as called at ofdm_cr_tools.py:322,342 and :214).
+//
+// Decomposition 4096 = 16 x 16 x 16, decimation in frequency, 256 threads, 16
+// points per thread, three register-resident radix-16 butterflies:
+//
+//   sample index  n = 256 a + 16 b + c        bin index  k = k0 + 16 k1 + 256 k2
+//
+//   pass 1  thread (b,c) = n mod 256 holds a = 0..15   -> k0, times W4096^(k0 (16b+c))
+//   pass 2  thread (k0,c)            holds b = 0..15   -> k1, times W256^(k1 c)
+//   pass 3  thread (k0,k1)           holds c = 0..15   -> k2, accumulate |X|^2
+//
+// Exchange 1 (b <-> k0) crosses waves: one LDS round trip bracketed by the two
+// workgroup barriers of a segment.  Exchange 2 (c <-> k1) stays inside the 16
+// lanes that share k0, so it reuses the same 2176-byte LDS region with
+// wave-level ordering only.  LDS image: region k0 = 16 rows x 17 float2 (one
+// float2 of padding per row): every ds_write_b64 / ds_read_b64 of both
+// exchanges is bank-conflict free ("LDS image").
+//
+// HBM: lane t reads x[s*step + 256 a + t], 512 contiguous bytes per wave
+// instruction.  A workgroup owns a contiguous run of segments, so the second
+// half of segment s is re-read as the first half of s+1 from L2, not HBM.
+// The window (16 values) and the pass-1 twiddles (15 values) depend only on the
+// thread, so they live in registers for the whole run.
+#include "fft_lds.hip.h"
+#include "oth_internal.h"
+
+namespace oth {
+
+namespace {
+
+constexpr int T4 = 256;
+constexpr int RS = 272;                    // float2 per k0 region (16 x 17)
+constexpr int LDS_X = 16 * RS;             // exchange image
+constexpr int LDS_TW2 = 256;               // W256^(k1 c) as [k1][c]
+constexpr int LDS_RED = 8;                 // per-wave segment sums
+constexpr size_t LDS_BYTES = (LDS_X + LDS_TW2 + LDS_RED) * sizeof(float2);
+
+constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
+constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
+constexpr float RH = 0.70710678118654752f;   // sqrt(1/2)
+
+__device__ __forceinline__ float2 mul_w1(float2 a) { return make_float2(fmaf(a.x, C1, a.y * S1), fmaf(a.y, C1, -a.x * S1)); }
+__device__ __forceinline__ float2 mul_w2(float2 a) { return make_float2((a.x + a.y) * RH, (a.y - a.x) * RH); }
+__device__ __forceinline__ float2 mul_w3(float2 a) { return make_float2(fmaf(a.x, S1, a.y * C1), fmaf(a.y, S1, -a.x * C1)); }
+__device__ __forceinline__ float2 mul_w4(float2 a) { return make_float2(a.y, -a.x); }
+__device__ __forceinline__ float2 mul_w6(float2 a) { return make_float2((a.y - a.x) * RH, -(a.x + a.y) * RH); }
+__device__ __forceinline__ float2 mul_w9(float2 a) { return make_float2(-fmaf(a.x, C1, a.y * S1), fmaf(a.x, S1, -a.y * C1)); }
+
+// position of output k of dft16() inside v[]
+__host__ __device__ constexpr int r16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+// Forward 16-point DFT in place: in v[a], a = 0..15; out y[k] at v[r16(k)].
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+#pragma unroll
+    for (int a0 = 0; a0 < 4; ++a0) dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
+    v[5] = mul_w1(v[5]);
+    v[9] = mul_w2(v[9]);
+    v[13] = mul_w3(v[13]);
+    v[6] = mul_w2(v[6]);
+    v[10] = mul_w4(v[10]);
+    v[14] = mul_w6(v[14]);
+    v[7] = mul_w3(v[7]);
+    v[11] = mul_w6(v[11]);
+    v[15] = mul_w9(v[15]);
+#pragma unroll
+    for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool DETREND>
+__global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *lx = reinterpret_cast<float2 *>(smem);
+    float2 *ltw2 = lx + LDS_X;
+    float2 *red = ltw2 + LDS_TW2;
+
+    const int t = threadIdx.x;
+    const int hi = t >> 4, lo = t & 15;
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
+    const float2 *xb = p.x + (size_t)stream * p.stream_stride;
+
+    // thread-constant tables
+    float win[16];
+    float2 tw1[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) win[a] = p.win[256 * a + t];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) tw1[k] = p.tw[t * k];
+    ltw2[t] = p.tw[16 * hi * lo];           // [k1 = hi][c = lo]
+
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+
+    // LDS addresses (in float2): exchange-1 write/read, exchange-2 write/read
+    const int w1 = hi * 17 + lo;            // + k0 * RS      (thread is (b,c))
+    const int r1 = hi * RS + lo;            // + b * 17       (thread is (k0,c))
+    const int w2 = hi * RS + lo;            // + k1 * 17
+    const int r2 = hi * RS + lo * 17;       // + c            (thread is (k0,k1))
+
+    for (long long s = s0; s < s1; ++s) {
+        const float2 *xs = xb + s * p.step + t;
+        float2 v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = xs[256 * a];
+
+        float2 mean = make_float2(0.f, 0.f);
+        if (DETREND) {
+            float2 sum = v[0];
+#pragma unroll
+            for (int a = 1; a < 16; ++a) sum = cadd(sum, v[a]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                sum.x += __shfl_xor(sum.x, off, 64);
+                sum.y += __shfl_xor(sum.y, off, 64);
+            }
+            if ((t & 63) == 0) red[t >> 6] = sum;
+        }
+        __syncthreads();   // A: previous segment's LDS reads are done; red[] visible
+        if (DETREND) {
+            const float2 s01 = cadd(red[0], red[1]), s23 = cadd(red[2], red[3]);
+            mean = make_float2((s01.x + s23.x) * (1.0f / 4096.0f), (s01.y + s23.y) * (1.0f / 4096.0f));
+        }
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
+
+        // pass 1: DFT over a, twiddle W4096^(k0 t), scatter to region k0
+        dft16(v);
+        lx[w1] = v[r16(0)];
+#pragma unroll
+        for (int k0 = 1; k0 < 16; ++k0) lx[k0 * RS + w1] = cmul(v[r16(k0)], tw1[k0]);
+        __syncthreads();   // B
+
+        // pass 2: thread (k0,c) gathers b, DFT over b, twiddle W256^(k1 c)
+#pragma unroll
+        for (int b = 0; b < 16; ++b) v[b] = lx[r1 + b * 17];
+        dft16(v);
+        wave_lds_sync();   // the 16 lanes of this k0 have all read region k0
+        lx[w2] = v[r16(0)];
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) lx[w2 + k1 * 17] = cmul(v[r16(k1)], ltw2[k1 * 16 + lo]);
+        wave_lds_sync();
+
+        // pass 3: thread (k0,k1) gathers c, DFT over c, accumulate |X|^2
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = lx[r2 + c];
+        dft16(v);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const float2 X = v[r16(k2)];
+            acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
+        }
+    }
+
+    // bin k0 + 16 k1 + 256 k2 of this workgroup sits at t + 256 k2 (finalize_kernel layout 1)
+    float *dst = p.partial + ((size_t)stream * W + wg) * 4096;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) dst[256 * k2 + t] = acc[k2];
+}
+
+}  // namespace
+
+bool tuned4096_supported(int nfft, int nperseg, int step, bool csd) {
+    return nfft == 4096 && nperseg == 4096 && step >= 1 && !csd;
+}
+
+int tuned4096_wg_per_stream(long long nseg, int nstreams, int cu_count) {
+    // four 256-thread workgroups per CU are resident (LDS 36 KiB, <= 128 VGPRs)
+    long long w = ((long long)cu_count * 4 + nstreams - 1) / nstreams;
+    if (w > nseg) w = nseg;
+    if (w < 1) w = 1;
+    return (int)w;
+}
+
+hipError_t launch_welch_tuned4096(const WelchArgs &a, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    if (a.detrend)
+        hipLaunchKernelGGL((welch4096_kernel<true>), grid, dim3(T4), LDS_BYTES, s, a);
+    else
+        hipLaunchKernelGGL((welch4096_kernel<false>), grid, dim3(T4), LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace oth

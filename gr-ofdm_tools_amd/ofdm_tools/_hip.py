@@ -1,0 +1,438 @@
+"""ctypes binding of libofdmtools_hip.so (include/ofdm_tools_hip.h).
+
+The only compute back end of this package.  There is no NumPy/SciPy fallback:
+if the shared library is missing or no MI355X is visible every entry point
+raises :class:`HipUnavailable` / :class:`HipError` with the reason.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+OK = 0
+DETREND_NONE, DETREND_CONSTANT = 0, 1
+SCALE_RAW, SCALE_DENSITY, SCALE_OVER_N2, SCALE_SPECTRUM = 0, 1, 2, 3
+EPI_MAG, EPI_MAG2, EPI_MAG2_OVER_N2 = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TUNED = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('OFDM_TOOLS_HIP_LIB',
+                          os.path.join(os.path.dirname(_HERE), 'lib', 'libofdmtools_hip.so'))
+
+
+class HipUnavailable(RuntimeError):
+    """libofdmtools_hip.so could not be loaded (not built, or ROCm runtime missing)."""
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, where, detail):
+        RuntimeError.__init__(self, '%s failed (%d): %s' % (where, code, detail))
+        self.code = code
+
+
+_p = C.c_void_p
+_pp = C.POINTER(C.c_void_p)
+_f = C.POINTER(C.c_float)
+_u64p = C.POINTER(C.c_uint64)
+
+# name -> (restype, argtypes); must list every symbol include/ofdm_tools_hip.h declares
+SIGNATURES = {
+    'oth_abi_version': (C.c_int, []),
+    'oth_strerror': (C.c_char_p, [C.c_int]),
+    'oth_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'oth_ctx_create': (C.c_int, [C.c_int, _pp]),
+    'oth_ctx_create_on_stream': (C.c_int, [C.c_int, _p, _pp]),
+    'oth_ctx_destroy': (C.c_int, [_p]),
+    'oth_last_error': (C.c_char_p, [_p]),
+    'oth_ctx_sync': (C.c_int, [_p]),
+    'oth_ctx_device_name': (C.c_int, [_p, C.c_char_p, C.c_size_t]),
+    'oth_ctx_set_timing': (C.c_int, [_p, C.c_int]),
+    'oth_ctx_get_timing': (C.c_int, [_p, C.POINTER(C.c_double), _u64p, C.c_int]),
+    'oth_dev_alloc': (C.c_int, [_p, C.c_size_t, _pp]),
+    'oth_dev_free': (C.c_int, [_p, _p]),
+    'oth_memcpy_h2d': (C.c_int, [_p, _p, _p, C.c_size_t]),
+    'oth_memcpy_d2h': (C.c_int, [_p, _p, _p, C.c_size_t]),
+    'oth_synth_iq': (C.c_int, [_p, _p, C.c_size_t, C.c_uint64, C.c_int, _f, _f, C.c_float, C.c_float]),
+    'oth_stream_read_probe': (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    'oth_iq_power': (C.c_int, [_p, _p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                               C.POINTER(C.c_double)]),
+    'oth_welch_plan': (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_int, C.c_double, C.c_int,
+                                 C.c_int, _pp]),
+    'oth_plan_destroy': (C.c_int, [_p]),
+    'oth_plan_set_output_db': (C.c_int, [_p, C.c_int]),
+    'oth_plan_set_kernel': (C.c_int, [_p, C.c_int]),
+    'oth_plan_out_len': (C.c_int, [_p, C.POINTER(C.c_int)]),
+    'oth_welch_exec': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f, _u64p]),
+    'oth_welch_exec_dev': (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_size_t, _p, _u64p]),
+    'oth_welch_partial_dev': (C.c_int, [_p, _p, C.c_size_t, _p, _u64p]),
+    'oth_welch_scale_dev': (C.c_int, [_p, _p, C.c_uint64, _p]),
+    'oth_welch_accumulate': (C.c_int, [_p, _p, C.c_size_t]),
+    'oth_welch_finalize': (C.c_int, [_p, _f, _u64p]),
+    'oth_welch_reset': (C.c_int, [_p]),
+    'oth_csd_exec': (C.c_int, [_p, _p, _p, C.c_size_t, C.c_int, _f, _f, _f, _f, _u64p]),
+    'oth_chain_create': (C.c_int, [_p, C.c_int, _f, C.c_int, C.c_int, C.c_int, _pp]),
+    'oth_chain_destroy': (C.c_int, [_p]),
+    'oth_chain_set_keep_one_in_n': (C.c_int, [_p, C.c_int]),
+    'oth_chain_set_iir_log': (C.c_int, [_p, C.c_float, C.c_float]),
+    'oth_chain_set_peak_hold': (C.c_int, [_p, C.c_int]),
+    'oth_chain_reset': (C.c_int, [_p]),
+    'oth_chain_push': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f, C.c_size_t, _u64p]),
+    'oth_chain_get_peak': (C.c_int, [_p, _f]),
+    'oth_chain_get_iir': (C.c_int, [_p, _f]),
+    'oth_rows_group_mean': (C.c_int, [_p, _f, C.c_size_t, C.c_int, C.c_int, _f]),
+    'oth_channel_power': (C.c_int, [_p, _f, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    _f, _f]),
+    'oth_xcorr': (C.c_int, [_p, _p, C.c_size_t, _p, C.c_size_t, C.c_int, _f]),
+    'oth_fac': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load():
+    """Load the shared library once and attach the prototypes."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipUnavailable('%s not found - build it with `make -C gr-ofdm_tools_amd` '
+                                 '(or __graft_entry__.build()); this package has no CPU fallback' % LIB_PATH)
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise HipUnavailable('cannot load %s: %s' % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _c64(x):
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    if x.ndim != 1:
+        x = x.reshape(-1)
+    return x
+
+
+def _fptr(a):
+    return a.ctypes.data_as(_f)
+
+
+class Context(object):
+    """One device + one HIP stream (oth_ctx).  Not thread-safe; serialise per context."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = C.c_void_p()
+        if stream is None:
+            rc = self.lib.oth_ctx_create(int(device), C.byref(h))
+        else:
+            rc = self.lib.oth_ctx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h))
+        if rc != OK:
+            raise HipError(rc, 'oth_ctx_create', self.lib.oth_last_error(None).decode())
+        self.h = h
+        self.device = int(device)
+
+    def check(self, rc, where):
+        if rc != OK:
+            raise HipError(rc, where, self.lib.oth_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.oth_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing -------------------------------------------------------------
+    def sync(self):
+        self.check(self.lib.oth_ctx_sync(self.h), 'oth_ctx_sync')
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self.check(self.lib.oth_ctx_device_name(self.h, buf, 256), 'oth_ctx_device_name')
+        return buf.value.decode()
+
+    def set_timing(self, on):
+        self.check(self.lib.oth_ctx_set_timing(self.h, 1 if on else 0), 'oth_ctx_set_timing')
+
+    def get_timing(self, reset=True):
+        ms, n = C.c_double(), C.c_uint64()
+        self.check(self.lib.oth_ctx_get_timing(self.h, C.byref(ms), C.byref(n), 1 if reset else 0),
+                   'oth_ctx_get_timing')
+        return ms.value, n.value
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.lib.oth_dev_alloc(self.h, nbytes, C.byref(p)), 'oth_dev_alloc')
+        return p.value
+
+    def free(self, ptr):
+        self.check(self.lib.oth_dev_free(self.h, C.c_void_p(ptr)), 'oth_dev_free')
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.oth_memcpy_h2d(self.h, C.c_void_p(dptr), arr.ctypes.data_as(_p), arr.nbytes),
+                   'oth_memcpy_h2d')
+
+    def d2h(self, dptr, shape, dtype):
+        out = np.empty(shape, dtype)
+        self.check(self.lib.oth_memcpy_d2h(self.h, out.ctypes.data_as(_p), C.c_void_p(dptr), out.nbytes),
+                   'oth_memcpy_d2h')
+        return out
+
+    def synth_iq(self, dptr, nsamples, seed, tones=(), dc=0j):
+        amp = np.array([t[0] for t in tones], np.float32)
+        frq = np.array([t[1] for t in tones], np.float32)
+        self.check(self.lib.oth_synth_iq(self.h, C.c_void_p(dptr), nsamples, seed, len(tones),
+                                         _fptr(amp) if len(tones) else None, _fptr(frq) if len(tones) else None,
+                                         float(np.real(dc)), float(np.imag(dc))), 'oth_synth_iq')
+
+    def stream_read_probe(self, dptr, nbytes, repeats=5):
+        ms = C.c_double()
+        self.check(self.lib.oth_stream_read_probe(self.h, C.c_void_p(dptr), nbytes, repeats, C.byref(ms)),
+                   'oth_stream_read_probe')
+        return ms.value
+
+    def iq_power(self, dptr, nsamples):
+        mr, mi, var = C.c_double(), C.c_double(), C.c_double()
+        self.check(self.lib.oth_iq_power(self.h, C.c_void_p(dptr), nsamples, C.byref(mr), C.byref(mi),
+                                         C.byref(var)), 'oth_iq_power')
+        return complex(mr.value, mi.value), var.value
+
+    # -- factories ------------------------------------------------------------
+    def welch_plan(self, nfft, nperseg=None, noverlap=None, window=None, detrend=DETREND_CONSTANT,
+                   scaling=SCALE_DENSITY, fs=1.0, fftshift=False, trim_bins=0, db=False, kernel=KERNEL_AUTO):
+        return WelchPlan(self, nfft, nperseg, noverlap, window, detrend, scaling, fs, fftshift, trim_bins, db,
+                         kernel)
+
+    def chain(self, nfft, window=None, fftshift=True, epilogue=EPI_MAG2, keep_one_in_n=1):
+        return Chain(self, nfft, window, fftshift, epilogue, keep_one_in_n)
+
+    # -- small ops --------------------------------------------------------------
+    def rows_group_mean(self, rows, group):
+        rows = np.ascontiguousarray(rows, np.float32)
+        nrows, nfft = rows.shape
+        out = np.empty((nrows // group, nfft), np.float32)
+        self.check(self.lib.oth_rows_group_mean(self.h, _fptr(rows), nrows, nfft, group, _fptr(out)),
+                   'oth_rows_group_mean')
+        return out
+
+    def channel_power(self, psd, srch_bins, lo, hi, want_movavg=False):
+        psd = np.ascontiguousarray(psd, np.float32)
+        lo = np.ascontiguousarray(lo, np.int32)
+        hi = np.ascontiguousarray(hi, np.int32)
+        out = np.empty(len(lo), np.float32)
+        ma = np.empty(len(psd), np.float32) if want_movavg else None
+        self.check(self.lib.oth_channel_power(self.h, _fptr(psd), len(psd), float(srch_bins), len(lo),
+                                              lo.ctypes.data_as(C.POINTER(C.c_int)),
+                                              hi.ctypes.data_as(C.POINTER(C.c_int)), _fptr(out),
+                                              _fptr(ma) if want_movavg else None), 'oth_channel_power')
+        return (out, ma) if want_movavg else out
+
+    def xcorr(self, a, b, length):
+        a, b = _c64(a)[:length], _c64(b)[:length]
+        out = np.empty(length - length // 2, np.float32)
+        self.check(self.lib.oth_xcorr(self.h, a.ctypes.data_as(_p), len(a), b.ctypes.data_as(_p), len(b),
+                                      int(length), _fptr(out)), 'oth_xcorr')
+        return out
+
+    def fac(self, data, length):
+        a = _c64(data)[:length]
+        out = np.empty(length - length // 2, np.float32)
+        self.check(self.lib.oth_fac(self.h, a.ctypes.data_as(_p), len(a), int(length), _fptr(out)), 'oth_fac')
+        return out
+
+
+class WelchPlan(object):
+    def __init__(self, ctx, nfft, nperseg, noverlap, window, detrend, scaling, fs, fftshift, trim_bins, db, kernel):
+        self.ctx = ctx
+        nperseg = int(nfft if nperseg is None else nperseg)
+        noverlap = int(nperseg // 2 if noverlap is None else noverlap)
+        self.nfft, self.nperseg, self.noverlap = int(nfft), nperseg, noverlap
+        self.step = nperseg - noverlap
+        w = None
+        if window is not None:
+            w = np.ascontiguousarray(window, np.float32)
+            if w.shape != (nperseg,):
+                raise ValueError('window must have nperseg=%d entries' % nperseg)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.oth_welch_plan(ctx.h, int(nfft), nperseg, noverlap, _fptr(w) if w is not None else None,
+                                         int(detrend), int(scaling), float(fs), 1 if fftshift else 0,
+                                         int(trim_bins), C.byref(h)), 'oth_welch_plan')
+        self.h = h
+        n = C.c_int()
+        ctx.check(ctx.lib.oth_plan_out_len(h, C.byref(n)), 'oth_plan_out_len')
+        self.out_len = n.value
+        if db:
+            ctx.check(ctx.lib.oth_plan_set_output_db(h, 1), 'oth_plan_set_output_db')
+        if kernel != KERNEL_AUTO:
+            ctx.check(ctx.lib.oth_plan_set_kernel(h, int(kernel)), 'oth_plan_set_kernel')
+
+    def close(self):
+        if getattr(self, 'h', None) and getattr(self.ctx, 'h', None):
+            self.ctx.lib.oth_plan_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_kernel(self, which):
+        self.ctx.check(self.ctx.lib.oth_plan_set_kernel(self.h, int(which)), 'oth_plan_set_kernel')
+
+    def nseg(self, nsamples):
+        return (nsamples - self.noverlap) // self.step if nsamples >= self.nperseg else 0
+
+    def exec(self, x):
+        """x: host complex64 array -> float32 PSD of out_len bins."""
+        x = _c64(x)
+        out = np.empty(self.out_len, np.float32)
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_welch_exec(self.h, x.ctypes.data_as(_p), len(x), 0, _fptr(out),
+                                                   C.byref(n)), 'oth_welch_exec')
+        self.last_nseg = n.value
+        return out
+
+    def exec_device_src(self, dptr, nsamples):
+        out = np.empty(self.out_len, np.float32)
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_welch_exec(self.h, C.c_void_p(dptr), nsamples, 1, _fptr(out), C.byref(n)),
+                       'oth_welch_exec')
+        self.last_nseg = n.value
+        return out
+
+    def exec_dev(self, dptr, nsamples, out_dptr, nstreams=1, stream_stride=None):
+        """Asynchronous: device in, device out ([nstreams][out_len] float32)."""
+        n = C.c_uint64()
+        stride = nsamples if stream_stride is None else stream_stride
+        self.ctx.check(self.ctx.lib.oth_welch_exec_dev(self.h, C.c_void_p(dptr), nsamples, nstreams, stride,
+                                                       C.c_void_p(out_dptr), C.byref(n)), 'oth_welch_exec_dev')
+        return n.value
+
+    def partial_dev(self, dptr, nsamples, sum_dptr):
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_welch_partial_dev(self.h, C.c_void_p(dptr), nsamples, C.c_void_p(sum_dptr),
+                                                          C.byref(n)), 'oth_welch_partial_dev')
+        return n.value
+
+    def scale_dev(self, sum_dptr, nseg_total, out_dptr):
+        self.ctx.check(self.ctx.lib.oth_welch_scale_dev(self.h, C.c_void_p(sum_dptr), nseg_total,
+                                                        C.c_void_p(out_dptr)), 'oth_welch_scale_dev')
+
+    def accumulate(self, x):
+        x = _c64(x)
+        self.ctx.check(self.ctx.lib.oth_welch_accumulate(self.h, x.ctypes.data_as(_p), len(x)),
+                       'oth_welch_accumulate')
+
+    def finalize(self):
+        out = np.empty(self.out_len, np.float32)
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_welch_finalize(self.h, _fptr(out), C.byref(n)), 'oth_welch_finalize')
+        self.last_nseg = n.value
+        return out
+
+    def reset(self):
+        self.ctx.check(self.ctx.lib.oth_welch_reset(self.h), 'oth_welch_reset')
+
+    def csd(self, x, y):
+        """-> pxx, pyy, pxy (complex64), cxy for host inputs."""
+        x, y = _c64(x), _c64(y)
+        if len(x) != len(y):
+            raise ValueError('x and y must have the same length')
+        m = self.out_len
+        pxx, pyy, cxy = (np.empty(m, np.float32) for _ in range(3))
+        pxy = np.empty(2 * m, np.float32)
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_csd_exec(self.h, x.ctypes.data_as(_p), y.ctypes.data_as(_p), len(x), 0,
+                                                 _fptr(pxx), _fptr(pyy), _fptr(pxy), _fptr(cxy), C.byref(n)),
+                       'oth_csd_exec')
+        self.last_nseg = n.value
+        return pxx, pyy, pxy.view(np.complex64), cxy
+
+
+class Chain(object):
+    """stream_to_vector -> keep_one_in_n -> fft_vcc -> |.|/|.|^2 [-> IIR -> log] with GNU Radio's
+    streaming state kept on the device (oth_chain)."""
+
+    def __init__(self, ctx, nfft, window, fftshift, epilogue, keep_one_in_n):
+        self.ctx = ctx
+        self.nfft = int(nfft)
+        w = None
+        if window is not None and len(window):
+            w = np.ascontiguousarray(window, np.float32)
+            if w.shape != (self.nfft,):
+                raise ValueError('window must have nfft entries')
+        h = C.c_void_p()
+        ctx.check(ctx.lib.oth_chain_create(ctx.h, self.nfft, _fptr(w) if w is not None else None,
+                                           1 if fftshift else 0, int(epilogue), int(keep_one_in_n), C.byref(h)),
+                  'oth_chain_create')
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None) and getattr(self.ctx, 'h', None):
+            self.ctx.lib.oth_chain_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_keep_one_in_n(self, n):
+        self.ctx.check(self.ctx.lib.oth_chain_set_keep_one_in_n(self.h, int(n)), 'oth_chain_set_keep_one_in_n')
+
+    def set_iir_log(self, alpha, k_db):
+        self.ctx.check(self.ctx.lib.oth_chain_set_iir_log(self.h, float(alpha), float(k_db)),
+                       'oth_chain_set_iir_log')
+
+    def set_peak_hold(self, on):
+        self.ctx.check(self.ctx.lib.oth_chain_set_peak_hold(self.h, 1 if on else 0), 'oth_chain_set_peak_hold')
+
+    def reset(self):
+        self.ctx.check(self.ctx.lib.oth_chain_reset(self.h), 'oth_chain_reset')
+
+    def push(self, x, max_rows=None):
+        """Feed samples; returns (rows, nrows_produced).  rows holds the LAST min(nrows, max_rows) rows."""
+        x = _c64(x)
+        cap = (len(x) // self.nfft + 2) if max_rows is None else int(max_rows)
+        rows = np.empty((max(cap, 1), self.nfft), np.float32)
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_chain_push(self.h, x.ctypes.data_as(_p), len(x), 0, _fptr(rows), cap,
+                                                   C.byref(n)), 'oth_chain_push')
+        got = min(int(n.value), cap)
+        return rows[:got], int(n.value)
+
+    def peak(self):
+        out = np.empty(self.nfft, np.float32)
+        self.ctx.check(self.ctx.lib.oth_chain_get_peak(self.h, _fptr(out)), 'oth_chain_get_peak')
+        return out
+
+    def iir(self):
+        out = np.empty(self.nfft, np.float32)
+        self.ctx.check(self.ctx.lib.oth_chain_get_iir(self.h, _fptr(out)), 'oth_chain_get_iir')
+        return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on device $OFDM_TOOLS_HIP_DEVICE (default 0, or LOCAL_RANK)."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get('OFDM_TOOLS_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        _default_ctx = Context(dev)
+    return _default_ctx

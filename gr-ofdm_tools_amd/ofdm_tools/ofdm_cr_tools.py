@@ -1,0 +1,161 @@
+"""Spectrum-scanner helpers of ``ofdm_tools.ofdm_cr_tools`` with the reference's
+names, argument order and return values (python/ofdm_cr_tools.py:136-250,
+:321-345, :471-537), computing on the MI355X through libofdmtools_hip.so.
+
+Host code here is limited to what the reference also does in Python around the
+arithmetic: ``frange`` lists, slice bounds with ``int()`` truncation, threshold
+bookkeeping.  The FFTs, the Welch averaging, the moving average and the channel
+sums run in HIP kernels; nothing here falls back to NumPy/SciPy for them.
+"""
+import math
+
+import numpy as np
+
+from . import _hip
+from . import windows
+
+
+def _is_int(v):
+    return isinstance(v, (int, np.integer)) and not isinstance(v, bool)
+
+
+def _py2div(a, b):
+    """The reference is Python 2: ``/`` between two ints floors."""
+    if _is_int(a) and _is_int(b):
+        return a // b
+    return a / b
+
+
+def frange(x, y, jump):
+    """ofdm_cr_tools.py:136-141."""
+    out = []
+    while x < y:
+        out.append(x)
+        x += jump
+    return out
+
+
+def _slice_bounds(n, Fr, Sf, bb_freqs, srch_bins):
+    """Start/stop of every channel slice exactly as Python evaluates
+    ``psd[0:int(b+sb/2)]`` / ``psd[int(b-sb/2):int(b+sb/2)]`` (ofdm_cr_tools.py:239-248)."""
+    half = _py2div(Sf, 2)
+    lo, hi = [], []
+    for i, f in enumerate(bb_freqs):
+        bin_n = (f + half) / Fr
+        sl = slice(0, int(bin_n + srch_bins / 2)) if i == 0 else \
+            slice(int(bin_n - srch_bins / 2), int(bin_n + srch_bins / 2))
+        a, b, _ = sl.indices(n)
+        lo.append(a)
+        hi.append(max(a, b))
+    return lo, hi
+
+
+def movingaverage(interval, window_size, ctx=None):
+    """ofdm_cr_tools.py:168-170 on the device."""
+    ctx = ctx or _hip.default_context()
+    _, ma = ctx.channel_power(interval, float(window_size), [0], [0], want_movavg=True)
+    return ma
+
+
+def src_power(psd, nFFT, Fr, Sf, bb_freqs, srch_bins, ctx=None):
+    """ofdm_cr_tools.py:232-249: moving average, then per-channel sums."""
+    ctx = ctx or _hip.default_context()
+    lo, hi = _slice_bounds(len(psd), Fr, Sf, bb_freqs, srch_bins)
+    return [float(v) for v in ctx.channel_power(psd, float(srch_bins), lo, hi)]
+
+
+def _plain_channel_sums(psd, Fr, Sf, bb_freqs, srch_bins, ctx):
+    # channel sums without the moving average (src_power_welch / src_power_fft): a 1-tap average
+    lo, hi = _slice_bounds(len(psd), Fr, Sf, bb_freqs, srch_bins)
+    return [float(v) for v in ctx.channel_power(psd, 1.0, lo, hi)]
+
+
+def src_power_welch(vector, npts, nFFT, Fr, Sf, bb_freqs, srch_bins, ctx=None):
+    """ofdm_cr_tools.py:213-230."""
+    ctx = ctx or _hip.default_context()
+    plan = ctx.welch_plan(nFFT, window=windows.get_window('flattop', nFFT), fs=float(Sf), fftshift=True)
+    psd = plan.exec(vector)
+    plan.close()
+    axis = np.fft.fftshift(np.fft.fftfreq(nFFT, 1.0 / Sf))
+    return psd, axis, _plain_channel_sums(psd, Fr, Sf, bb_freqs, srch_bins, ctx)
+
+
+def src_power_fft(vector, npts, nFFT, Fr, Sf, bb_freqs, srch_bins, ctx=None):
+    """ofdm_cr_tools.py:173-192: one flat-top periodogram |FFT(x w, nFFT)|^2 / nFFT, shifted."""
+    ctx = ctx or _hip.default_context()
+    vector = np.asarray(vector)[:nFFT]
+    npts = len(vector)
+    plan = ctx.welch_plan(nFFT, nperseg=npts, noverlap=0, window=windows.flattop(npts),
+                          detrend=_hip.DETREND_NONE, scaling=_hip.SCALE_RAW, fftshift=True)
+    psd = plan.exec(vector) / np.float32(nFFT)
+    plan.close()
+    axis = _py2div(Sf, 2) * np.linspace(-1, 1, nFFT)
+    return psd, axis, _plain_channel_sums(psd, Fr, Sf, bb_freqs, srch_bins, ctx)
+
+
+def clc_power_freq(vector, nFFT, Sf, ctx=None):
+    """ofdm_cr_tools.py:149-153."""
+    ctx = ctx or _hip.default_context()
+    vector = np.asarray(vector)[:nFFT]
+    n = len(vector)
+    plan = ctx.welch_plan(nFFT, nperseg=n, noverlap=0, window=None, detrend=_hip.DETREND_NONE,
+                          scaling=_hip.SCALE_RAW)
+    psd = plan.exec(vector).astype(np.float64) / n / Sf
+    plan.close()
+    return float(psd.sum())
+
+
+def xcorr(a, b, length, ctx=None):
+    """ofdm_cr_tools.py:155-161."""
+    return (ctx or _hip.default_context()).xcorr(a, b, length)
+
+
+def fac(data, length, ctx=None):
+    """ofdm_cr_tools.py:163-166."""
+    return (ctx or _hip.default_context()).fac(data, length)
+
+
+def welch_plot_dB(data, Sf, fc, nfft, ctx=None):
+    """ofdm_cr_tools.py:321-326 (default Hann window, 50 % overlap)."""
+    ctx = ctx or _hip.default_context()
+    plan = ctx.welch_plan(nfft, window=windows.get_window('hann', nfft), fs=float(Sf), fftshift=True)
+    psd = plan.exec(data)
+    plan.close()
+    axis = np.fft.fftshift(np.fft.fftfreq(nfft, 1.0 / Sf))
+    return [item + fc for item in axis], [10 * math.log10(item + 1e-20) for item in psd]
+
+
+def welch_power_estimate(vector, nFFT, Sf, ctx=None):
+    """ofdm_cr_tools.py:341-345."""
+    ctx = ctx or _hip.default_context()
+    plan = ctx.welch_plan(nFFT, window=windows.get_window('hann', nFFT), fs=float(Sf), fftshift=True)
+    psd = plan.exec(vector)
+    plan.close()
+    return float(np.sum(psd, dtype=np.float64))
+
+
+def fast_spectrum_scan(vct_sample, fc, channel_rate, srch_bw, n_fft, samp_rate, method, thr_leveler,
+                       noise_estimate, alpha_avg, show_plot=False, ctx=None):
+    """ofdm_cr_tools.py:471-537 (the matplotlib branch is not carried over)."""
+    npts = len(vct_sample)
+    nFFT = int(2 ** math.ceil(math.log(npts, 2))) if n_fft == 0 else n_fft
+    Fr = float(samp_rate) / float(nFFT)
+    Fstart = fc - _py2div(samp_rate, 2)
+    Ffinish = fc + _py2div(samp_rate, 2)
+    bb_freqs = frange(_py2div(-samp_rate, 2), _py2div(samp_rate, 2), channel_rate)
+    srch_bins = srch_bw / Fr
+    if method == 'welch':
+        psd, axis, power_level_ch = src_power_welch(vct_sample, npts, nFFT, Fr, samp_rate, bb_freqs, srch_bins, ctx)
+    elif method == 'fft':
+        psd, axis, power_level_ch = src_power_fft(vct_sample, npts, nFFT, Fr, samp_rate, bb_freqs, srch_bins, ctx)
+    else:
+        raise ValueError("method must be 'welch' or 'fft'")
+    ax_ch = frange(Fstart, Ffinish, channel_rate)
+    min_power = np.amin(power_level_ch)
+    noise_estimate = (1 - alpha_avg) * noise_estimate + alpha_avg * min_power
+    thr = noise_estimate * thr_leveler
+    spectrum_constraint_hz = []
+    for i, item in enumerate(power_level_ch):
+        if item > thr:
+            spectrum_constraint_hz.append(ax_ch[i])
+    return thr, power_level_ch, noise_estimate, spectrum_constraint_hz

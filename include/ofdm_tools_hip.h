@@ -1,0 +1,202 @@
+/*
+ * ofdm_tools_hip.h - C ABI of libofdmtools_hip.so, the MI355X (gfx950) back end
+ * of the gr-ofdm_tools spectrum-sensing hot path.
+ *
+ * The reference (gercap/gr-ofdm_tools) has NO native boundary of its own
+ * (swig/ofdm_tools_swig.i:1-11 wraps nothing, python/__init__.py:45 leaves the
+ * swig import commented out): its PSD arithmetic is delegated to GNU Radio C++
+ * blocks and to scipy.signal.welch / numpy.fft from Python.  Each entry point
+ * below therefore names the reference call site (file:line, relative to the
+ * upstream tree) whose arithmetic it replaces.  The reference-side binding is a
+ * ctypes stub; INTEGRATION.md shows it.
+ *
+ * Conventions
+ *   - C linkage, plain C types, no C++/torch types in any signature.
+ *   - Every function returns OTH_OK (0) or a negative OTH_ERR_* code; nothing
+ *     throws or aborts.  oth_last_error() gives the text for the last failure
+ *     on that context (or a static string for a NULL context).
+ *   - IQ data is interleaved float32 (re, im) = numpy.complex64 = gr_complex.
+ *   - The caller owns every buffer it passes.  The library owns contexts, plans
+ *     and their device scratch.  A context wraps one device + one HIP stream; a
+ *     context (and its plans) must not be used from two threads at once.
+ *   - "_dev" entry points take device pointers, are asynchronous on the
+ *     context's stream and never synchronise; the others take host pointers
+ *     (or a device source when src_is_device != 0), and return with the host
+ *     output written.
+ *   - No CPU fallback exists: without a usable GPU every compute entry point
+ *     returns OTH_ERR_HIP.
+ */
+#ifndef OFDM_TOOLS_HIP_H
+#define OFDM_TOOLS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OTH_ABI_VERSION 1
+
+#define OTH_OK               0
+#define OTH_ERR_INVALID     -1   /* bad argument */
+#define OTH_ERR_HIP         -2   /* HIP runtime failure / no device */
+#define OTH_ERR_UNSUPPORTED -3   /* size or mode not built */
+#define OTH_ERR_NOMEM       -4
+#define OTH_ERR_STATE       -5   /* call order (e.g. finalize with no data) */
+
+/* detrend (scipy.signal.welch detrend=...) */
+#define OTH_DETREND_NONE     0
+#define OTH_DETREND_CONSTANT 1   /* per-segment mean removal, SciPy default */
+
+/* scaling of the averaged |X|^2 */
+#define OTH_SCALE_RAW        0   /* mean over segments of |X|^2 */
+#define OTH_SCALE_DENSITY    1   /* / (fs * sum(w^2))   scipy scaling='density' */
+#define OTH_SCALE_OVER_N2    2   /* / nfft^2            spectrum_sensor_v2.py:93 */
+#define OTH_SCALE_SPECTRUM   3   /* / sum(w)^2          scipy scaling='spectrum' */
+
+/* epilogue of the per-vector periodogram chain */
+#define OTH_EPI_MAG          0   /* |X|                 blocks.complex_to_mag, psd_logger.py:53 */
+#define OTH_EPI_MAG2         1   /* |X|^2               blocks.complex_to_mag_squared, local_worker.py:65 */
+#define OTH_EPI_MAG2_OVER_N2 2   /* |X|^2 / nfft^2      spectrum_sensor_v2.py:92-93 */
+
+/* kernel selection (diagnostics / parity tests) */
+#define OTH_KERNEL_AUTO      0
+#define OTH_KERNEL_GENERIC   1   /* radix-4 Stockham, any power of two 16..16384 */
+#define OTH_KERNEL_TUNED     2   /* radix-16x16x16 register/LDS kernel (nfft 4096) */
+
+typedef struct oth_ctx oth_ctx;
+typedef struct oth_plan oth_plan;
+typedef struct oth_chain oth_chain;
+
+/* ---- library / context ------------------------------------------------- */
+int         oth_abi_version(void);
+const char *oth_strerror(int code);
+int         oth_device_count(int *count);
+
+int         oth_ctx_create(int device_id, oth_ctx **out);
+/* adopt an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
+int         oth_ctx_create_on_stream(int device_id, void *hip_stream, oth_ctx **out);
+int         oth_ctx_destroy(oth_ctx *ctx);
+const char *oth_last_error(oth_ctx *ctx);
+int         oth_ctx_sync(oth_ctx *ctx);
+int         oth_ctx_device_name(oth_ctx *ctx, char *buf, size_t buflen);
+
+/* HIP-event timing of the dominant (FFT) kernel on the context's stream.
+ * enable != 0 brackets every such launch with events; get() synchronises the
+ * stream and returns the sum / count since the last reset. */
+int         oth_ctx_set_timing(oth_ctx *ctx, int enable);
+int         oth_ctx_get_timing(oth_ctx *ctx, double *total_ms, uint64_t *launches, int reset);
+
+/* ---- device memory helpers (so ctypes-only hosts need no torch) --------- */
+int oth_dev_alloc(oth_ctx *ctx, size_t bytes, void **dptr);
+int oth_dev_free(oth_ctx *ctx, void *dptr);
+int oth_memcpy_h2d(oth_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int oth_memcpy_d2h(oth_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* Synthetic IQ written straight into HBM: unit-power complex
+ * AWGN from a counter-based generator + ntones complex exponentials + DC. */
+int oth_synth_iq(oth_ctx *ctx, void *iq_dev, size_t nsamples, uint64_t seed, int ntones,
+                 const float *tone_amp, const float *tone_freq, float dc_re, float dc_im);
+
+/* Streaming-read probe: a float4 sum over [dptr, dptr+bytes); reports the
+ * kernel time so the caller can state the achievable HBM-read peak. */
+int oth_stream_read_probe(oth_ctx *ctx, const void *dptr, size_t bytes, int repeats, double *ms_per_pass);
+
+/* mean(|x - mean(x)|^2) of a device IQ buffer (Parseval check at full size) */
+int oth_iq_power(oth_ctx *ctx, const void *iq_dev, size_t nsamples, double *mean_re, double *mean_im,
+                 double *var);
+
+/* ---- Welch PSD ----------------------------------------------------------
+ * Replaces scipy.signal.welch as the reference calls it:
+ *   ofdm_cr_tools.py:214  (window='flattop', nperseg=nfft)        src_power_welch
+ *   ofdm_cr_tools.py:322  (default hann, 50 % overlap)            welch_plot_dB
+ *   ofdm_cr_tools.py:342  (same)                                  welch_power_estimate
+ *   spectrum_sweeper.py:263 (flattop, nperseg=nfft/4 zero-padded) _src_power
+ * followed by the fftshift / excess-bin trim / 10*log10 of
+ * spectrum_sweeper.py:265-276.  Two-sided, mean over segments.
+ *
+ * window: nperseg host floats (NULL = rectangular).  trim_bins bins are dropped
+ * from each end AFTER the optional fftshift; output length = nfft - 2*trim_bins.
+ */
+int oth_welch_plan(oth_ctx *ctx, int nfft, int nperseg, int noverlap, const float *window,
+                   int detrend, int scaling, double fs, int fftshift, int trim_bins, oth_plan **out);
+int oth_plan_destroy(oth_plan *plan);
+int oth_plan_set_output_db(oth_plan *plan, int enable);      /* 10*log10 in the finalize kernel */
+int oth_plan_set_kernel(oth_plan *plan, int which);           /* OTH_KERNEL_* */
+int oth_plan_out_len(oth_plan *plan, int *n);
+
+/* one-shot: nsamples complex64 -> psd_out[nfft - 2*trim] (host) */
+int oth_welch_exec(oth_plan *plan, const void *iq, size_t nsamples, int src_is_device,
+                   float *psd_out, uint64_t *nseg_out);
+/* nstreams independent streams laid out every stream_stride samples; device in,
+ * device out [nstreams][out_len]; asynchronous. */
+int oth_welch_exec_dev(oth_plan *plan, const void *iq_dev, size_t nsamples, int nstreams,
+                       size_t stream_stride, float *psd_out_dev, uint64_t *nseg_out);
+/* raw sum over segments of |X|^2 (natural bin order, no scale) for time-sharded
+ * multi-GPU Welch: partial sums from ranks add, then oth_welch_scale_dev(). */
+int oth_welch_partial_dev(oth_plan *plan, const void *iq_dev, size_t nsamples,
+                          float *sum_out_dev, uint64_t *nseg_out);
+int oth_welch_scale_dev(oth_plan *plan, const float *sum_dev, uint64_t nseg_total, float *psd_out_dev);
+
+/* streaming form used by the sync_block work() host (python/spectrum_sensor.py:71-75
+ * contract): chunks of any length; the overlap tail is carried between calls. */
+int oth_welch_accumulate(oth_plan *plan, const void *iq_host, size_t nsamples);
+int oth_welch_finalize(oth_plan *plan, float *psd_out, uint64_t *nseg_out);   /* then resets */
+int oth_welch_reset(oth_plan *plan);
+
+/* ---- two-channel cross spectrum / coherence -------
+ * Semantics of scipy.signal.csd / coherence with the plan's Welch parameters;
+ * produces the first input of coherence_detector (coherence_detector.py:45).
+ * Outputs (host, natural FFT order unless the plan has fftshift): pxx, pyy,
+ * cxy are float[nfft]; pxy is interleaved re,im float[2*nfft].  Any may be NULL. */
+int oth_csd_exec(oth_plan *plan, const void *x, const void *y, size_t nsamples, int src_is_device,
+                 float *pxx, float *pyy, float *pxy, float *cxy, uint64_t *nseg_out);
+
+/* ---- per-vector periodogram chain ----------------------------------------
+ * Replaces the GNU Radio chain
+ *   stream_to_vector -> keep_one_in_n -> fft_vcc(N, True, window, shift) ->
+ *   complex_to_mag[_squared] [-> multiply_const(1/N^2)]
+ *   [-> single_pole_iir_filter_ff -> nlog10_ff]
+ * of spectrum_sensor_v2.py:85-93, psd_logger.py:43-53, local_worker.py:58-69,
+ * multichannel_scanner.py:78-86.  The chain keeps GNU Radio's stream state
+ * between calls: leftover samples of a partial vector, the keep_one_in_n
+ * counter, the IIR memory and the peak-hold vector.
+ */
+int oth_chain_create(oth_ctx *ctx, int nfft, const float *window, int fftshift, int epilogue,
+                     int keep_one_in_n, oth_chain **out);
+int oth_chain_destroy(oth_chain *chain);
+int oth_chain_set_keep_one_in_n(oth_chain *chain, int n);     /* local_worker.py:85-87 set_rate */
+/* single_pole_iir_filter_ff(alpha) + nlog10_ff(10, N, k_db); alpha<=0 disables */
+int oth_chain_set_iir_log(oth_chain *chain, float alpha, float k_db);
+int oth_chain_set_peak_hold(oth_chain *chain, int enable);    /* psd_logger.py:85 */
+int oth_chain_reset(oth_chain *chain);
+/* feed nsamples (host, or device when src_is_device); rows_out (host, may be
+ * NULL) receives up to rows_capacity post-epilogue rows (dB rows when the IIR/log
+ * stage is on); nrows_out = rows produced by this call. */
+int oth_chain_push(oth_chain *chain, const void *iq, size_t nsamples, int src_is_device,
+                   float *rows_out, size_t rows_capacity, uint64_t *nrows_out);
+int oth_chain_get_peak(oth_chain *chain, float *peak_out);    /* float[nfft] */
+int oth_chain_get_iir(oth_chain *chain, float *lin_out);      /* float[nfft], linear IIR state */
+/* mean of each `group` consecutive rows (BASELINE config 1 "8-seg avg") */
+int oth_rows_group_mean(oth_ctx *ctx, const float *rows_host, size_t nrows, int nfft, int group,
+                        float *out_host);
+
+/* ---- channel power -------------------------------------------------------
+ * src_power (ofdm_cr_tools.py:232-249): |convolve(psd, ones(int(sb))/sb, 'same')|
+ * then per-channel slice sums.  lo/hi are the slice bounds the host computed with
+ * the reference's int() arithmetic; power_out[nch]; also returns min power. */
+int oth_channel_power(oth_ctx *ctx, const float *psd_host, int nfft, double srch_bins, int nch,
+                      const int *lo, const int *hi, float *power_out, float *movavg_out /*nullable*/);
+
+/* ---- xcorr (ofdm_cr_tools.py:155-161) ------------------------------------
+ * |fftshift(ifft(fft(b,L) * conj(fft(a,L))))[L/2:]|, L a power of two <= 16384;
+ * a, b host complex64 of na, nb <= L samples (zero-padded); out float[L - L/2]. */
+int oth_xcorr(oth_ctx *ctx, const void *a, size_t na, const void *b, size_t nb, int L, float *out);
+/* fac (ofdm_cr_tools.py:163-166): |fftshift(fft(|fft(data,L)|, L))[L/2:]| */
+int oth_fac(oth_ctx *ctx, const void *data, size_t n, int L, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFDM_TOOLS_HIP_H */

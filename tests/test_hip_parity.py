@@ -1,0 +1,332 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the
+committed golden vectors and the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): <= 1e-4 relative on linear power over ALL
+bins; coherence <= 1e-4 absolute.  dB outputs are compared after conversion back
+to linear power.
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from ofdm_tools import _hip
+    return _hip
+
+
+@pytest.fixture(scope='module')
+def ctx(hip):
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def hann(n):
+    from ofdm_tools import windows
+    return windows.get_window('hann', n)
+
+
+def flattop(n):
+    from ofdm_tools import windows
+    return windows.get_window('flattop', n)
+
+
+# ---------------------------------------------------------------- Welch ----
+
+@pytest.mark.parametrize('kernel', ['tuned', 'generic'])
+def test_welch_hann_4096_golden(ctx, hip, golden, kernel):
+    g = golden('welch_hann_4096_50.npz')
+    plan = ctx.welch_plan(4096, window=hann(4096), fs=float(g['fs']),
+                          kernel=hip.KERNEL_TUNED if kernel == 'tuned' else hip.KERNEL_GENERIC)
+    psd = plan.exec(g['x'])
+    assert plan.last_nseg == 31
+    assert relerr(psd, g['expected_psd']) < RTOL
+
+
+def test_welch_ragged_length_and_fs(ctx, golden):
+    g = golden('welch_hann_1024_ragged.npz')
+    plan = ctx.welch_plan(1024, window=hann(1024), fs=float(g['fs']))
+    assert relerr(plan.exec(g['x']), g['expected_psd']) < RTOL
+    assert plan.last_nseg == (50000 - 512) // 512
+
+
+def test_welch_flattop_2048(ctx, golden):
+    g = golden('welch_flattop_2048.npz')
+    plan = ctx.welch_plan(2048, window=flattop(2048), fs=float(g['fs']))
+    assert relerr(plan.exec(g['x']), g['expected_psd']) < RTOL
+
+
+def test_sweeper_segment_zero_padded_shift_trim_db(ctx, golden):
+    g = golden('welch_flattop_nperseg_quarter.npz')
+    nfft, ex = int(g['nfft']), int(g['excess_bins'])
+    lin = ctx.welch_plan(nfft, nperseg=nfft // 4, window=flattop(nfft // 4), fs=float(g['fs']), fftshift=True,
+                         trim_bins=ex).exec(g['x'])
+    assert lin.shape == (nfft - 2 * ex,)
+    assert relerr(lin, g['expected_psd_lin']) < RTOL
+    db = ctx.welch_plan(nfft, nperseg=nfft // 4, window=flattop(nfft // 4), fs=float(g['fs']), fftshift=True,
+                        trim_bins=ex, db=True).exec(g['x'])
+    assert relerr(10 ** (db.astype(np.float64) / 10), g['expected_psd_lin']) < RTOL
+    assert np.max(np.abs(db - g['expected_psd_db'])) < 1e-3
+
+
+@pytest.mark.parametrize('nfft', [64, 128, 256, 512, 8192, 16384])
+def test_welch_all_sizes_vs_oracle(ctx, nfft):
+    x = R.synth_iq(max(8 * nfft, 16384) + 37, 100 + nfft)
+    _, ref = R.welch_np(x, fs=3.0, nperseg=nfft, nfft=nfft)
+    psd = ctx.welch_plan(nfft, window=hann(nfft), fs=3.0).exec(x)
+    assert relerr(psd, ref) < RTOL
+
+
+def test_welch_no_detrend_rect_raw_scaling(ctx, hip):
+    x = R.synth_iq(20000, 9)
+    _, ref = R.welch_np(x, window='boxcar', nperseg=4096, noverlap=1000, nfft=4096, detrend=False, scaling='none')
+    for kern in (hip.KERNEL_TUNED, hip.KERNEL_GENERIC):
+        plan = ctx.welch_plan(4096, noverlap=1000, window=None, detrend=hip.DETREND_NONE, scaling=hip.SCALE_RAW,
+                              kernel=kern)
+        assert relerr(plan.exec(x), ref) < RTOL
+
+
+def test_welch_exactly_one_segment_and_too_short(ctx, hip):
+    x = R.synth_iq(4096, 3)
+    _, ref = R.welch_np(x, nperseg=4096, nfft=4096)
+    plan = ctx.welch_plan(4096, window=hann(4096))
+    assert relerr(plan.exec(x), ref) < RTOL and plan.last_nseg == 1
+    with pytest.raises(hip.HipError) as ei:
+        plan.exec(x[:4095])
+    assert ei.value.code == -1
+    with pytest.raises(hip.HipError):
+        plan.exec(np.zeros(0, np.complex64))
+
+
+def test_welch_bad_plans_are_rejected(ctx, hip):
+    for kw in (dict(nfft=1000), dict(nfft=32), dict(nfft=32768), dict(nfft=1024, nperseg=2048),
+               dict(nfft=1024, noverlap=1024), dict(nfft=1024, trim_bins=512), dict(nfft=1024, fs=0.0)):
+        with pytest.raises(hip.HipError):
+            ctx.welch_plan(**kw)
+    with pytest.raises(hip.HipError):       # tuned kernel forced on a size it does not cover
+        ctx.welch_plan(1024, kernel=hip.KERNEL_TUNED).exec(R.synth_iq(4096, 1))
+
+
+def test_welch_streaming_chunks_equal_one_shot(ctx):
+    x = R.synth_iq(100000, 12)
+    plan = ctx.welch_plan(4096, window=hann(4096), fs=2.0)
+    one = plan.exec(x)
+    nseg = plan.last_nseg
+    rng = np.random.default_rng(0)
+    pos = 0
+    while pos < len(x):       # ragged chunk sizes incl. chunks shorter than a segment
+        n = int(rng.choice([1, 100, 2047, 2048, 4096, 5000, 30000]))
+        plan.accumulate(x[pos:pos + n])
+        pos += n
+    out = plan.finalize()
+    assert plan.last_nseg == nseg
+    assert relerr(out, one) < 2e-6
+    # finalize() resets: a second stream gives its own result
+    plan.accumulate(x[:50000])
+    _, ref = R.welch_np(x[:50000], fs=2.0, nperseg=4096, nfft=4096)
+    assert relerr(plan.finalize(), ref) < RTOL
+
+
+def test_welch_finalize_without_data_is_a_state_error(ctx, hip):
+    plan = ctx.welch_plan(1024)
+    with pytest.raises(hip.HipError) as ei:
+        plan.finalize()
+    assert ei.value.code == -5
+
+
+def test_welch_batched_streams_device_resident(ctx):
+    ns, n, nfft = 5, 40000, 4096
+    xs = [R.synth_iq(n, 3000 + i) for i in range(ns)]
+    stride = n + 123
+    buf = np.zeros(ns * stride, np.complex64)
+    for i, x in enumerate(xs):
+        buf[i * stride:i * stride + n] = x
+    d_in = ctx.alloc(buf.nbytes)
+    d_out = ctx.alloc(ns * nfft * 4)
+    try:
+        ctx.h2d(d_in, buf)
+        plan = ctx.welch_plan(nfft, window=hann(nfft))
+        plan.exec_dev(d_in, n, d_out, nstreams=ns, stream_stride=stride)
+        out = ctx.d2h(d_out, (ns, nfft), np.float32)
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+    for i, x in enumerate(xs):
+        _, ref = R.welch_np(x, nperseg=nfft, nfft=nfft)
+        assert relerr(out[i], ref) < RTOL
+
+
+def test_time_sharded_partials_add_up(ctx):
+    """Long-stream sharding: partial sums of halo-overlapped chunks add to the whole."""
+    nfft, step = 4096, 2048
+    x = R.synth_iq(64 * step + nfft - step, 77)          # 64 segments
+    plan = ctx.welch_plan(nfft, window=hann(nfft))
+    whole = plan.exec(x)
+    d_in = ctx.alloc(x.nbytes)
+    d_sum = ctx.alloc(2 * nfft * 4)
+    d_out = ctx.alloc(nfft * 4)
+    try:
+        ctx.h2d(d_in, x)
+        tot = np.zeros(nfft, np.float64)
+        nseg = 0
+        for s0, s1 in ((0, 21), (21, 50), (50, 64)):
+            n = (s1 - s0 - 1) * step + nfft
+            nseg += plan.partial_dev(d_in + 8 * s0 * step, n, d_sum)
+            tot += ctx.d2h(d_sum, (nfft,), np.float32)
+        assert nseg == 64
+        ctx.h2d(d_sum, tot.astype(np.float32))
+        plan.scale_dev(d_sum, nseg, d_out)
+        out = ctx.d2h(d_out, (nfft,), np.float32)
+    finally:
+        for p in (d_in, d_sum, d_out):
+            ctx.free(p)
+    assert relerr(out, whole) < 2e-6
+
+
+# ------------------------------------------------------------------ CSD ----
+
+def test_csd_coherence_golden(ctx, golden):
+    g = golden('coherence_csd_4096.npz')
+    plan = ctx.welch_plan(4096, window=hann(4096), fs=float(g['fs']))
+    pxx, pyy, pxy, cxy = plan.csd(g['x'], g['y'])
+    assert relerr(pxx, g['expected_pxx']) < RTOL
+    assert relerr(pyy, g['expected_pyy']) < RTOL
+    e = g['expected_pxy']
+    assert np.max(np.abs(pxy.astype(np.complex128) - e) / np.abs(e)) < 1e-3   # complex: relative to |Pxy|
+    assert np.max(np.abs(pxy.astype(np.complex128) - e) / np.sqrt(g['expected_pxx'] * g['expected_pyy'])) < RTOL
+    assert np.max(np.abs(cxy - g['expected_cxy'])) < RTOL
+
+
+def test_coherence_of_identical_channels_is_one(ctx):
+    x = R.synth_iq(32768, 5)
+    _, _, _, cxy = ctx.welch_plan(1024, window=hann(1024)).csd(x, x)
+    assert np.max(np.abs(cxy - 1.0)) < 1e-5
+
+
+# --------------------------------------------------------------- chains ----
+
+def test_chain_sensor_v2_rows_and_mean8(ctx, hip, golden):
+    g = golden('gr_chain_rect_1024.npz')
+    ch = ctx.chain(1024, None, True, hip.EPI_MAG2_OVER_N2, 1)
+    rows, n = ch.push(g['x'])
+    assert n == 64 and rows.shape == (64, 1024)
+    assert relerr(rows, g['expected_rows']) < RTOL
+    assert relerr(ctx.rows_group_mean(rows, 8), g['expected_mean8']) < RTOL
+
+
+def test_chain_psd_logger_mag_and_peak(ctx, hip, golden):
+    g = golden('gr_chain_bh_mag_peak_4096.npz')
+    ch = ctx.chain(4096, g['window'], False, hip.EPI_MAG, 1)
+    ch.set_peak_hold(True)
+    rows, n = ch.push(g['x'][:5 * 4096])
+    assert n == 5 and relerr(rows, g['expected_mag'][:5]) < RTOL
+    assert relerr(ch.peak(), g['expected_peak'][4]) < RTOL
+    rows, n = ch.push(g['x'][5 * 4096:])
+    assert n == 11 and relerr(rows, g['expected_mag'][5:]) < RTOL
+    assert relerr(ch.peak(), g['expected_peak'][-1]) < RTOL
+
+
+def test_chain_local_worker_iir_log(ctx, hip, golden):
+    g = golden('gr_chain_bh_iir_log_2048.npz')
+    N, Sf, alpha = 2048, int(g['sample_rate']), float(g['average'])
+    k = -10 * np.log10(N) - 10 * np.log10(Sf)
+    ch = ctx.chain(N, g['window'], True, hip.EPI_MAG2, 1)
+    ch.set_iir_log(alpha, k)
+    db_rows = []
+    x = g['x']
+    for lo, hi in ((0, 3000), (3000, 3001), (3001, 20000), (20000, len(x))):   # chunks that split vectors
+        rows, n = ch.push(x[lo:hi])
+        db_rows.append(rows)
+    db = np.concatenate(db_rows)
+    assert db.shape == g['expected_db'].shape
+    assert relerr(10 ** ((db.astype(np.float64) - k) / 10), g['expected_lin']) < RTOL
+    assert relerr(ch.iir(), g['expected_lin'][-1]) < RTOL
+
+
+def test_chain_keep_one_in_n_matches_gnuradio_rule(ctx, hip):
+    N = 256
+    x = R.synth_iq(N * 23 + 17, 8)
+    ref = R.chain_sensor_v2(x, N, decim=5)
+    ch = ctx.chain(N, None, True, hip.EPI_MAG2_OVER_N2, 5)
+    got = []
+    for lo, hi in ((0, 700), (700, 701), (701, 4000), (4000, len(x))):
+        rows, n = ch.push(x[lo:hi])
+        assert n == len(rows)
+        got.append(rows)
+    got = np.concatenate(got)
+    assert got.shape == ref.shape == (4, N)
+    assert relerr(got, ref) < RTOL
+    # latest-wins: a small rows_capacity returns the LAST row only
+    ch.reset()
+    rows, n = ch.push(x, max_rows=1)
+    assert n == 4 and relerr(rows[0], ref[3]) < RTOL
+
+
+# ------------------------------------------------------- channel power ----
+
+def test_channel_power_cases(ctx, golden):
+    g = golden('src_power_cases.npz')
+    from ofdm_tools import ofdm_cr_tools as T
+    for i in range(int(g['n'])):
+        Sf, N = int(g['Sf_%d' % i]), int(g['N_%d' % i])
+        cs, sbw = float(g['cs_%d' % i]), float(g['sbw_%d' % i])
+        Fr = float(Sf) / N
+        psd = g['psd_%d' % i].astype(np.float32)
+        bb = T.frange(-Sf // 2, Sf // 2, cs)
+        ref = R.src_power(psd, N, Fr, Sf, bb, sbw / Fr)
+        got = T.src_power(psd, N, Fr, Sf, bb, sbw / Fr)
+        assert len(got) == len(ref)
+        assert np.allclose(got, ref, rtol=1e-5)
+        assert np.allclose(T.movingaverage(psd, sbw / Fr), R.movingaverage(psd, sbw / Fr), rtol=1e-5)
+
+
+# ------------------------------------------------------------ xcorr/fac ----
+
+def test_xcorr_fac_golden(ctx, golden):
+    g = golden('xcorr_fac.npz')
+    L = int(g['L'])
+    xc = ctx.xcorr(g['a'], g['b'], L)
+    ref = g['expected_xcorr']
+    assert np.max(np.abs(xc - ref)) / np.max(ref) < 1e-5
+    assert int(np.argmax(xc)) == 37
+    fc = ctx.fac(g['a'], L)
+    assert np.max(np.abs(fc - g['expected_fac'])) / np.max(g['expected_fac']) < 1e-5
+
+
+# -------------------------------------------- full size (BASELINE config 2) ----
+
+def test_full_size_256M_properties(ctx, hip):
+    """2^28 samples (2 GiB) generated on the device: the oracle cannot run here, so check
+    (1) the tuned kernel against the independent generic kernel, (2) Parseval against a
+    separate reduction of the raw samples, (3) the prefix against the float64 oracle."""
+    n, nfft = 1 << 28, 4096
+    d_in = ctx.alloc(n * 8)
+    try:
+        ctx.synth_iq(d_in, n, 1002, R.TONES, R.DC)
+        plan = ctx.welch_plan(nfft, window=hann(nfft), fs=1.0, kernel=hip.KERNEL_TUNED)
+        tuned = plan.exec_device_src(d_in, n)
+        assert plan.last_nseg == 131071
+        gen = ctx.welch_plan(nfft, window=hann(nfft), fs=1.0, kernel=hip.KERNEL_GENERIC).exec_device_src(d_in, n)
+        assert relerr(tuned, gen) < 2e-5
+        mean, var = ctx.iq_power(d_in, n)
+        assert abs(mean - R.DC) < 1e-3
+        # sum_k P[k] * fs / nfft ~= mean |x - mean|^2 (Hann-weighted estimate; 131071 segments)
+        assert abs(tuned.astype(np.float64).sum() / nfft - var) / var < 2e-3
+        pre = ctx.d2h(d_in, (1 << 20,), np.complex64)
+        _, ref = R.welch_np(pre, nperseg=nfft, nfft=nfft)
+        assert relerr(plan.exec(pre), ref) < RTOL
+    finally:
+        ctx.free(d_in)
