@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py - IQ Msamples/s through the 4096-point Welch PSD on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic IQ that is already
+resident in HBM: the radix-16 welch4096 kernel + the cross-workgroup finalize
+kernel (scale, fftshift, trim); at N > 1 also the all-gather (RCCL) that
+reassembles the wideband PSD of the sweep on every rank.
+
+N = 1  workload "C2": one 2^28-sample complex64 stream (2 GiB), Hann, nperseg =
+       nfft = 4096, 50 % overlap, detrend constant, density scaling (BASELINE
+       config 2 = the welch() call of ofdm_cr_tools.py:342).
+N > 1  workload "C4-weak": one 2^28-sample RF segment PER RANK with the same Welch
+       parameters + fftshift + 256-bin trim (spectrum_sweeper.py:260-276), then
+       all_gather of the 3584-bin rows in tune order (spectrum_sweeper.py:223).
+       Weak scaling: per-GPU work is fixed.
+
+Prints ONE JSON line on rank 0.  `value` = samples processed by all ranks / the
+max-over-ranks wall time of the K timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'gr-ofdm_tools_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+NFFT = 4096
+LOG2_SAMPLES = 28
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+TONES = ((0.5, 0.1234), (0.05, -0.31), (2.0, 0.4071))
+DC = 0.1 + 0.05j
+
+
+def cpu_baseline(nfft):
+    """The reference's CPU path (scipy.signal.welch on complex64, ofdm_cr_tools.py:342) on a
+    bounded sample of the same workload, one process."""
+    import numpy as np
+    from oracle import ref_cpu as R
+    n = 1 << 26
+    parts = [R.synth_iq(1 << 22, 1002 + i, n0=i << 22) for i in range(n >> 22)]   # chunked: bounds host RAM
+    x = np.concatenate(parts)
+    del parts
+    R.welch_reference_call(x[:1 << 20], nfft, 1.0)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        R.welch_reference_call(x, nfft, 1.0)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[1]
+    model = ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {'value': n / t / 1e6, 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
+            'sample': 'scipy.signal.welch(complex64, hann, nperseg=nfft=4096, 50%% overlap) on the first 2^26 '
+                      'samples of the C2 recipe, median of 3, host has %d cores (%s)' % (os.cpu_count(), model)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--log2-samples', type=int, default=LOG2_SAMPLES)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ofdm_tools import _hip, windows, sweep
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    n = 1 << args.log2_samples
+    multi = world > 1
+    trim = 256 if multi else 0
+    nbins = NFFT - 2 * trim
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = _hip.Context(local_rank, stream=stream.cuda_stream)
+    iq = torch.empty((n, 2), dtype=torch.float32, device=dev)               # the IQ ring buffer in HBM
+    ctx.synth_iq(iq.data_ptr(), n, (2000 + rank) if multi else 1002, TONES, DC)
+    plan = ctx.welch_plan(NFFT, window=windows.get_window('hann', NFFT), fs=1.0, fftshift=multi, trim_bins=trim)
+    nseg = plan.nseg(n)
+    local = torch.zeros((1, nbins), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, 1, nbins), dtype=torch.float32, device=dev) if multi else None
+
+    def step():
+        plan.exec_dev(iq.data_ptr(), n, local.data_ptr())
+        if multi:
+            return sweep.gather_wideband(local, world, rank, world, out=gathered)
+        return local[0]
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.set_timing(True)
+    ctx.get_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wide = step()
+    fence()
+    t1 = time.perf_counter()
+    kern_ms, launches = ctx.get_timing(reset=True)
+    ctx.set_timing(False)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if multi:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    result = None
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * n / (elapsed / args.steps) / 1e6
+        kavg_ms = kern_ms / max(launches, 1)
+        achieved = 8.0 * n / (kavg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get('log2_samples') == args.log2_samples:
+                    traffic = tj.get('hbm_bytes_per_launch')
+            except (OSError, ValueError):
+                pass
+        # sanity / parity on a prefix, outside the timed region
+        from oracle import ref_cpu as R
+        pre = iq[:1 << 20].cpu().numpy().view(np.complex64).reshape(-1)
+        chk = ctx.welch_plan(NFFT, window=windows.get_window('hann', NFFT), fs=1.0)
+        _, ref = R.welch_np(pre, fs=1.0, nperseg=NFFT, nfft=NFFT)
+        err = float(np.max(np.abs(chk.exec(pre) - ref) / ref))
+        probe_ms = ctx.stream_read_probe(iq.data_ptr(), n * 8, 5)
+        result = {
+            'metric': 'IQ Msamples/s Welch-PSD (4096-pt, 50% ovlp)',
+            'value': value, 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': ('C4-weak: one 2^%d-sample RF segment per GPU, 4096-pt Hann Welch 50%% overlap, '
+                                    'fftshift + 256-bin trim, all_gather of %d-bin rows' % (args.log2_samples, nbins))
+                       if multi else
+                       ('C2: 2^%d-sample complex64 stream, 4096-pt Hann Welch, 50%% overlap, detrend constant, '
+                        'density' % args.log2_samples),
+                       'nfft': NFFT, 'noverlap': NFFT // 2, 'window': 'hann', 'samples_per_gpu': n,
+                       'segments_per_gpu': nseg, 'parallelism': 'segment-per-gpu x%d' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                         'kernel': 'welch4096_kernel', 'kernel_avg_ms': kavg_ms, 'launches': int(launches),
+                         'algorithmic_bytes_per_launch': 8 * n,
+                         'read_probe_GBps': 8.0 * n / (probe_ms * 1e-3) / 1e9},
+            'parity_prefix_max_rel_err': err,
+            'device': ctx.device_name(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(NFFT)
+        else:
+            result['cpu_baseline'] = None
+        assert int(wide.numel()) == world * nbins
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == '__main__':
+    main()

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -180,6 +181,26 @@ struct Timed {
     }
 };
 
+// Build variants of the welch4096 kernel; OTH_W4096_VARIANT=<tag> selects one (experiments only).
+struct W4096Variant {
+    const char *tag;
+    hipError_t (*launch)(const WelchArgs &, hipStream_t);
+    int (*blocks_per_cu)();
+};
+const W4096Variant kVariants[] = {
+    {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp},
+    {"pref", launch_welch_tuned4096_pref, tuned4096_blocks_per_cu_pref},
+    {"noslp", launch_welch_tuned4096_noslp, tuned4096_blocks_per_cu_noslp},
+    {"base", launch_welch_tuned4096_base, tuned4096_blocks_per_cu_base},
+};
+const W4096Variant *w4096_variant() {
+    const char *e = getenv("OTH_W4096_VARIANT");
+    if (e)
+        for (const auto &v : kVariants)
+            if (!strcmp(e, v.tag)) return &v;
+    return &kVariants[0];
+}
+
 int segments(const oth_plan *p, size_t nsamples, long long *nseg) {
     if (nsamples < (size_t)p->nperseg) return OTH_ERR_INVALID;
     *nseg = (long long)((nsamples - (size_t)p->noverlap) / (size_t)p->step);
@@ -207,12 +228,17 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     if (segments(p, nsamples, &nseg) != OTH_OK)
         return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
     const bool csd = (y != nullptr);
-    bool tuned = tuned4096_supported(p->nfft, p->nperseg, p->step, csd);
+    bool tuned = p->nfft == 4096 && p->nperseg == 4096 && !csd;
     if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
     if (p->kernel == OTH_KERNEL_TUNED && !tuned)
         return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
-    const int W = tuned ? tuned4096_wg_per_stream(nseg, nstreams, c->cu_count)
-                        : generic_wg(c, p->nfft, nseg, nstreams);
+    const W4096Variant *var = tuned ? w4096_variant() : nullptr;
+    int W = generic_wg(c, p->nfft, nseg, nstreams);
+    if (tuned) {
+        // exactly the resident workgroups: one wave of workgroups, no tail round
+        long long w = ((long long)c->cu_count * var->blocks_per_cu() + nstreams - 1) / nstreams;
+        W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
+    }
     const int nch = csd ? 4 : 1;
     int rc = ensure(c, &p->d_partial, &p->partial_cap, sizeof(float) * (size_t)nstreams * W * nch * p->nfft);
     if (rc) return rc;
@@ -231,7 +257,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.nstreams = nstreams;
     {
         Timed tm(c);
-        HIPCHK(c, tuned ? launch_welch_tuned4096(a, c->stream) : launch_welch_generic(p->nfft, a, c->stream));
+        HIPCHK(c, tuned ? var->launch(a, c->stream) : launch_welch_generic(p->nfft, a, c->stream));
     }
     *nseg_out = nseg;
     *W_out = W;

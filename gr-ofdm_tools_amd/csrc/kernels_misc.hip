@@ -13,17 +13,32 @@ __device__ __forceinline__ int bin_pos(int k, int layout) {
     return layout ? (((k & 15) << 4) | ((k >> 4) & 15) | (k & ~255)) : k;
 }
 
-__global__ void finalize_kernel(FinalizeArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// 256 threads = 32 consecutive bins x 8 slices of the workgroup axis; the 8 slice sums are
+// combined in a fixed order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+    __shared__ double red[4][8][32];
+    const int lane = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    // threads walk partial-sum POSITIONS (coalesced reads); the bin and output slot follow
+    const int pos = blockIdx.x * 32 + lane;
     const int stream = blockIdx.y;
-    if (i >= a.nout) return;
-    const int ks = i + a.trim;
-    const int k = a.fftshift ? ((ks + a.nfft / 2) & (a.nfft - 1)) : ks;
-    const int pos = bin_pos(k, a.layout);
+    const int k = bin_pos(pos, a.layout);                 // the digit swap is its own inverse
+    const int ks = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;
+    const int i = ks - a.trim;
+    const bool live = pos < a.nfft && i >= 0 && i < a.nout;
     const float *base = a.partial + (size_t)stream * a.W * a.nch * a.nfft + pos;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int w = 0; w < a.W; ++w)
-        for (int c = 0; c < a.nch; ++c) s[c] += (double)base[((size_t)w * a.nch + c) * a.nfft];
+    if (live) {
+        for (int w = slice; w < a.W; w += 8)
+            for (int c = 0; c < a.nch; ++c) s[c] += (double)base[((size_t)w * a.nch + c) * a.nfft];
+    }
+    for (int c = 0; c < a.nch; ++c) red[c][slice][lane] = s[c];
+    __syncthreads();
+    if (slice != 0 || !live) return;
+    for (int c = 0; c < a.nch; ++c) {
+        double t = 0.0;
+        for (int q = 0; q < 8; ++q) t += red[c][q][lane];
+        s[c] = t;
+    }
     const size_t o = (size_t)stream * a.nout + i;
     if (a.nch == 1) {
         if (a.accumulate) {
@@ -45,7 +60,7 @@ __global__ void finalize_kernel(FinalizeArgs a) {
 }
 
 hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s) {
-    const dim3 grid((a.nout + 255) / 256, nstreams);
+    const dim3 grid((a.nfft + 31) / 32, nstreams);
     hipLaunchKernelGGL(finalize_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }

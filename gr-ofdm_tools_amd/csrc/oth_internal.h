@@ -55,9 +55,14 @@ struct FinalizeArgs {
 
 // Every launcher returns hipSuccess / error of the launch only (asynchronous).
 hipError_t launch_welch_generic(int nfft, const WelchArgs &a, hipStream_t s);
-hipError_t launch_welch_tuned4096(const WelchArgs &a, hipStream_t s);      // nfft 4096, nperseg 4096, y == nullptr
-bool tuned4096_supported(int nfft, int nperseg, int step, bool csd);
-int tuned4096_wg_per_stream(long long nseg, int nstreams, int cu_count);
+// welch4096.hip is built once per variant tag (Makefile W4096_VARIANTS); nfft 4096, nperseg 4096, y == nullptr
+#define OTH_DECL_W4096(tag)                                                     \
+    hipError_t launch_welch_tuned4096_##tag(const WelchArgs &a, hipStream_t s); \
+    int tuned4096_blocks_per_cu_##tag();
+OTH_DECL_W4096(base)
+OTH_DECL_W4096(noslp)
+OTH_DECL_W4096(dpp)
+OTH_DECL_W4096(pref)
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s);
 hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,

@@ -26,6 +26,22 @@
 #include "fft_lds.hip.h"
 #include "oth_internal.h"
 
+// Build-time variants (the Makefile compiles this file once per variant; api.hip picks one):
+//   OTH_W4096_TAG       suffix of the exported launcher
+//   OTH_W4096_DPP       1: segment-sum wave reduction with DPP row ops + v_readlane (no LDS round trips)
+//   OTH_W4096_PREFETCH  1: the next segment's samples are loaded before this segment's FFT starts
+#ifndef OTH_W4096_TAG
+#define OTH_W4096_TAG base
+#endif
+#ifndef OTH_W4096_DPP
+#define OTH_W4096_DPP 0
+#endif
+#ifndef OTH_W4096_PREFETCH
+#define OTH_W4096_PREFETCH 0
+#endif
+#define OTH_CAT2(a, b) a##b
+#define OTH_CAT(a, b) OTH_CAT2(a, b)
+
 namespace oth {
 
 namespace {
@@ -74,6 +90,28 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+    return v + __int_as_float(x);
+}
+
+// Sum over the 64 lanes of a wave, same value returned in every lane.
+__device__ __forceinline__ float wave_total(float v) {
+#if OTH_W4096_DPP
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror: every lane now holds its row-of-16 sum
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16)) +
+           __int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48));
+#else
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+#endif
+}
+
 template <bool DETREND>
 __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -106,22 +144,38 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
     const int w2 = hi * RS + lo;            // + k1 * 17
     const int r2 = hi * RS + lo * 17;       // + c            (thread is (k0,k1))
 
+#if OTH_W4096_PREFETCH
+    float2 nx[16];
+    if (s0 < s1) {
+        const float2 *xs = xb + s0 * p.step + t;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) nx[a] = xs[256 * a];
+    }
+#endif
     for (long long s = s0; s < s1; ++s) {
-        const float2 *xs = xb + s * p.step + t;
         float2 v[16];
+#if OTH_W4096_PREFETCH
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = nx[a];
+        {   // issue the next segment's loads now; they land while this segment is transformed
+            const long long sn = (s + 1 < s1) ? s + 1 : s;
+            const float2 *xn = xb + sn * p.step + t;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) nx[a] = xn[256 * a];
+        }
+#else
+        const float2 *xs = xb + s * p.step + t;
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = xs[256 * a];
+#endif
 
         float2 mean = make_float2(0.f, 0.f);
         if (DETREND) {
             float2 sum = v[0];
 #pragma unroll
             for (int a = 1; a < 16; ++a) sum = cadd(sum, v[a]);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                sum.x += __shfl_xor(sum.x, off, 64);
-                sum.y += __shfl_xor(sum.y, off, 64);
-            }
+            sum.x = wave_total(sum.x);
+            sum.y = wave_total(sum.y);
             if ((t & 63) == 0) red[t >> 6] = sum;
         }
         __syncthreads();   // A: previous segment's LDS reads are done; red[] visible
@@ -168,19 +222,15 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
 
 }  // namespace
 
-bool tuned4096_supported(int nfft, int nperseg, int step, bool csd) {
-    return nfft == 4096 && nperseg == 4096 && step >= 1 && !csd;
+// resident 256-thread workgroups per CU for this build of the kernel (VGPR / LDS limited)
+int OTH_CAT(tuned4096_blocks_per_cu_, OTH_W4096_TAG)() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, welch4096_kernel<true>, T4, LDS_BYTES) != hipSuccess || n < 1)
+        n = 2;
+    return n;
 }
 
-int tuned4096_wg_per_stream(long long nseg, int nstreams, int cu_count) {
-    // four 256-thread workgroups per CU are resident (LDS 36 KiB, <= 128 VGPRs)
-    long long w = ((long long)cu_count * 4 + nstreams - 1) / nstreams;
-    if (w > nseg) w = nseg;
-    if (w < 1) w = 1;
-    return (int)w;
-}
-
-hipError_t launch_welch_tuned4096(const WelchArgs &a, hipStream_t s) {
+hipError_t OTH_CAT(launch_welch_tuned4096_, OTH_W4096_TAG)(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
     if (a.detrend)
         hipLaunchKernelGGL((welch4096_kernel<true>), grid, dim3(T4), LDS_BYTES, s, a);

@@ -534,3 +534,21 @@ def synth_iq(n, seed, tones=TONES, dc=DC, n0=0):
     for a, f in tones:
         x = x + a * np.exp(2j * np.pi * f * t)
     return (x + dc).astype(np.complex64)
+
+
+# --------------------------------------------------------------------------
+# The reference's own CPU call, for the bench's cpu_baseline leg only.
+# --------------------------------------------------------------------------
+
+
+def welch_reference_call(vector, nFFT, Sf):
+    """Exactly what welch_power_estimate / welch_plot_dB execute on the CPU
+    (ofdm_cr_tools.py:322,342): ``sg.welch(vector, fs=Sf, nperseg=nFFT, nfft=nFFT)``
+    on the complex64 samples GNU Radio delivers (SciPy keeps them in single
+    precision), then fftshift."""
+    import warnings
+    import scipy.signal as sg
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        axis, psd = sg.welch(vector, fs=Sf, nperseg=nFFT, nfft=nFFT)
+    return np.fft.fftshift(psd)
