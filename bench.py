@@ -17,6 +17,10 @@ N > 1  workload "C4-weak": one 2^28-sample RF segment PER RANK with the same Wel
        all_gather of the 3584-bin rows in tune order (spectrum_sweeper.py:223).
        Weak scaling: per-GPU work is fixed.
 
+Before the W warm-up steps the same step runs untimed for --ramp-ms (default 150 ms) so that
+the device has left its idle clock level; the K timed steps are bracketed by barrier +
+torch.cuda.synchronize() on both sides as the contract says.
+
 Prints ONE JSON line on rank 0.  `value` = samples processed by all ranks / the
 max-over-ranks wall time of the K timed steps.
 """
@@ -70,8 +74,10 @@ def cpu_baseline(nfft):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--ramp-ms', type=float, default=150.0,
+                    help='untimed device clock ramp before the warm-up steps (an idle MI355X sits at 775 MHz sclk)')
     ap.add_argument('--log2-samples', type=int, default=LOG2_SAMPLES)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -122,6 +128,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # clock ramp (setup, untimed, not a step count): the part idles at its lowest sclk level and needs
+    # some tens of ms of load before it holds its sustained clock; then the W warm-up steps
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     fence()

@@ -31,17 +31,21 @@ struct oth_ctx {
     std::map<int, float2 *> twiddles;
     float *sink = nullptr;
     double *acc4 = nullptr;
+    unsigned *queue = nullptr;         // 64 chunk tickets for the dynamic segment schedule
 };
 
 struct oth_plan {
     oth_ctx *ctx = nullptr;
     int nfft = 0, nperseg = 0, noverlap = 0, step = 0, detrend = 0, scaling = 0, fftshift = 0, trim = 0;
-    int db = 0, kernel = OTH_KERNEL_AUTO;
+    int db = 0, kernel = OTH_KERNEL_AUTO, sched = OTH_SCHED_DYNAMIC;
     double fs = 1.0, scale = 1.0;      // scale applies to the MEAN over segments
     float *d_win = nullptr;
     const float2 *d_tw = nullptr;
     float *d_partial = nullptr;
     size_t partial_cap = 0;
+    int last_W = 0;
+    float *d_reduce = nullptr;         // stage-1 output of the two-stage partial-sum reduction
+    size_t reduce_cap = 0;
     float *d_out = nullptr;            // [4][nfft] + pxy extra
     size_t out_cap = 0;
     float2 *d_stage = nullptr;         // host-input staging (x then y)
@@ -189,9 +193,9 @@ struct W4096Variant {
 };
 const W4096Variant kVariants[] = {
     {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp},
-    {"pref", launch_welch_tuned4096_pref, tuned4096_blocks_per_cu_pref},
     {"noslp", launch_welch_tuned4096_noslp, tuned4096_blocks_per_cu_noslp},
     {"base", launch_welch_tuned4096_base, tuned4096_blocks_per_cu_base},
+    {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag},
 };
 const W4096Variant *w4096_variant() {
     const char *e = getenv("OTH_W4096_VARIANT");
@@ -240,7 +244,11 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
     }
     const int nch = csd ? 4 : 1;
-    int rc = ensure(c, &p->d_partial, &p->partial_cap, sizeof(float) * (size_t)nstreams * W * nch * p->nfft);
+    // + 32 B per workgroup of stamp space behind the sums (only the diagnostic kernel build writes it)
+    int rc = ensure(c, &p->d_partial, &p->partial_cap,
+                    sizeof(float) * (size_t)nstreams * W * nch * p->nfft + 32 * (size_t)nstreams * W);
+    p->last_W = W * nstreams;
+    if (!rc) rc = ensure(c, &p->d_reduce, &p->reduce_cap, sizeof(float) * (size_t)nstreams * kReduceGroups * nch * p->nfft);
     if (rc) return rc;
     WelchArgs a;
     a.x = x;
@@ -255,6 +263,24 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.detrend = p->detrend;
     a.wg_per_stream = W;
     a.nstreams = nstreams;
+    a.sched = 0;
+    a.chunk = 1;
+    a.queue = nullptr;
+    if (tuned) {
+        const char *e = getenv("OTH_W4096_SCHED");
+        const char *ec = getenv("OTH_W4096_CHUNK");
+        a.sched = e ? atoi(e) : p->sched;
+        a.chunk = ec ? atoi(ec) : 8;
+        if (a.chunk < 1) a.chunk = 1;
+        if (a.sched < 0 || a.sched > 2) a.sched = 0;
+        if (a.sched == 2) {
+            if (nstreams > 64) a.sched = 1;
+            else {
+                a.queue = c->queue;
+                HIPCHK(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned) * nstreams, c->stream));
+            }
+        }
+    }
     {
         Timed tm(c);
         HIPCHK(c, tuned ? var->launch(a, c->stream) : launch_welch_generic(p->nfft, a, c->stream));
@@ -325,7 +351,8 @@ static int ctx_create(int device_id, void *stream, bool adopt, oth_ctx **out) {
         }
         c->own_stream = true;
     }
-    if (hipMalloc(&c->sink, 256) != hipSuccess || hipMalloc(&c->acc4, 4 * sizeof(double)) != hipSuccess) {
+    if (hipMalloc(&c->sink, 256) != hipSuccess || hipMalloc(&c->acc4, 4 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&c->queue, 64 * sizeof(unsigned)) != hipSuccess) {
         delete c;
         return fail(nullptr, OTH_ERR_NOMEM, "hipMalloc failed for context scratch");
     }
@@ -353,6 +380,7 @@ int oth_ctx_destroy(oth_ctx *c) {
     for (auto &kv : c->twiddles) hipFree(kv.second);
     if (c->sink) hipFree(c->sink);
     if (c->acc4) hipFree(c->acc4);
+    if (c->queue) hipFree(c->queue);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return OTH_OK;
@@ -536,6 +564,7 @@ int oth_plan_destroy(oth_plan *p) {
     hipStreamSynchronize(c->stream);
     if (p->d_win) hipFree(p->d_win);
     if (p->d_partial) hipFree(p->d_partial);
+    if (p->d_reduce) hipFree(p->d_reduce);
     if (p->d_out) hipFree(p->d_out);
     if (p->d_stage) hipFree(p->d_stage);
     if (p->d_sum) hipFree(p->d_sum);
@@ -554,6 +583,13 @@ int oth_plan_set_kernel(oth_plan *p, int which) {
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     if (which < OTH_KERNEL_AUTO || which > OTH_KERNEL_TUNED) return fail(p->ctx, OTH_ERR_INVALID, "unknown kernel id");
     p->kernel = which;
+    return OTH_OK;
+}
+
+int oth_plan_set_schedule(oth_plan *p, int which) {
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    if (which < OTH_SCHED_CONTIGUOUS || which > OTH_SCHED_DYNAMIC) return fail(p->ctx, OTH_ERR_INVALID, "unknown schedule");
+    p->sched = which;
     return OTH_OK;
 }
 
@@ -576,6 +612,7 @@ int oth_welch_exec_dev(oth_plan *p, const void *iq_dev, size_t nsamples, int nst
     if (rc) return rc;
     FinalizeArgs f{};
     f.partial = p->d_partial;
+    f.scratch = p->d_reduce;
     f.out0 = psd_out_dev;
     f.scale = p->scale / (double)nseg;
     f.W = W;
@@ -634,6 +671,7 @@ int oth_welch_partial_dev(oth_plan *p, const void *iq_dev, size_t nsamples, floa
     if (rc) return rc;
     FinalizeArgs f{};
     f.partial = p->d_partial;
+    f.scratch = p->d_reduce;
     f.out0 = sum_out_dev;
     f.scale = 1.0;
     f.W = W;
@@ -688,6 +726,7 @@ int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
     if ((rc = run_average(p, p->d_stream, nullptr, total, 1, total, &nseg, &W, &layout))) return rc;
     FinalizeArgs f{};
     f.partial = p->d_partial;
+    f.scratch = p->d_reduce;
     f.out0 = p->d_sum;
     f.scale = 1.0;
     f.W = W;
@@ -753,6 +792,7 @@ int oth_csd_exec(oth_plan *p, const void *x, const void *y, size_t nsamples, int
     const int nout = p->nfft - 2 * p->trim;
     FinalizeArgs f{};
     f.partial = p->d_partial;
+    f.scratch = p->d_reduce;
     f.out0 = p->d_out;
     f.out1 = p->d_out + p->nfft;
     f.out2 = p->d_out + 2 * p->nfft;
@@ -1015,6 +1055,18 @@ static int xcorr_impl(oth_ctx *c, const void *a, size_t na, const void *b, size_
 
 int oth_xcorr(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, int L, float *out) {
     return xcorr_impl(c, a, na, b, nb, L, out, 0);
+}
+
+// Not part of the ABI (not in the header): reads the per-workgroup stamps of the diagnostic kernel build.
+int oth__debug_stamps(oth_plan *p, unsigned long long *out, int max_wg, int *nwg) {
+    if (!p || !out || !nwg) return OTH_ERR_INVALID;
+    oth_ctx *c = p->ctx;
+    const int n = p->last_W < max_wg ? p->last_W : max_wg;
+    HIPCHK(c, hipMemcpyAsync(out, p->d_partial + (size_t)p->last_W * p->nfft, 32 * (size_t)n, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *nwg = n;
+    return OTH_OK;
 }
 
 int oth_fac(oth_ctx *c, const void *data, size_t n, int L, float *out) {

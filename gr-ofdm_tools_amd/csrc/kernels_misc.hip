@@ -59,7 +59,50 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     }
 }
 
-hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s) {
+// Stage 1 of the cross-workgroup reduction when there are many partial rows: row group g of
+// kReduceGroups sums its rows (fixed order) into scratch[stream][g][ch][nfft]; finalize_kernel then
+// runs over the kReduceGroups rows.  256 threads = 64 float4 columns x 4 row lanes.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *partial, float *scratch, int W, int nch,
+                                                              int nfft, int rows_per_group) {
+    __shared__ double red[4][64][4];
+    const int q = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + q) * 4;
+    const int g = blockIdx.y, G = gridDim.y;
+    const int stream = blockIdx.z / nch, ch = blockIdx.z % nch;
+    const int w0 = g * rows_per_group, w1 = min(W, w0 + rows_per_group);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    const float *base = partial + (((size_t)stream * W) * nch + ch) * nfft + col;
+    for (int w = w0 + j; w < w1; w += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)w * nch * nfft);
+        s0 += v.x;
+        s1 += v.y;
+        s2 += v.z;
+        s3 += v.w;
+    }
+    red[j][q][0] = s0;
+    red[j][q][1] = s1;
+    red[j][q][2] = s2;
+    red[j][q][3] = s3;
+    __syncthreads();
+    if (j) return;
+    float4 o;
+    o.x = (float)(red[0][q][0] + red[1][q][0] + red[2][q][0] + red[3][q][0]);
+    o.y = (float)(red[0][q][1] + red[1][q][1] + red[2][q][1] + red[3][q][1]);
+    o.z = (float)(red[0][q][2] + red[1][q][2] + red[2][q][2] + red[3][q][2]);
+    o.w = (float)(red[0][q][3] + red[1][q][3] + red[2][q][3] + red[3][q][3]);
+    *reinterpret_cast<float4 *>(scratch + ((((size_t)stream * G) + g) * nch + ch) * nfft + col) = o;
+}
+
+hipError_t launch_finalize(const FinalizeArgs &a_in, int nstreams, hipStream_t s) {
+    FinalizeArgs a = a_in;
+    if (a.W > 2 * kReduceGroups && a.scratch && (a.nfft % 256) == 0) {
+        const int rpg = (a.W + kReduceGroups - 1) / kReduceGroups;
+        const dim3 g1(a.nfft / 256, kReduceGroups, nstreams * a.nch);
+        hipLaunchKernelGGL(reduce_partials_kernel, g1, dim3(256), 0, s, a.partial, a.scratch, a.W, a.nch, a.nfft,
+                           rpg);
+        a.partial = a.scratch;
+        a.W = kReduceGroups;
+    }
     const dim3 grid((a.nfft + 31) / 32, nstreams);
     hipLaunchKernelGGL(finalize_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();

@@ -20,6 +20,10 @@ struct WelchArgs {
     int detrend;
     int wg_per_stream;
     int nstreams;
+    // welch4096 segment schedule: 0 contiguous, 1 interleaved chunks, 2 dynamic chunk queue
+    int sched;
+    int chunk;              // segments per chunk (sched 1, 2)
+    unsigned *queue;        // [nstreams] tickets, zeroed before the launch (sched 2)
 };
 
 struct PgramArgs {
@@ -35,8 +39,11 @@ struct PgramArgs {
     float scale;            // applied to |X|^2 (OVER_N2)
 };
 
+constexpr int kReduceGroups = 16;   // row groups of the two-stage partial-sum reduction
+
 struct FinalizeArgs {
     const float *partial;   // [nstreams][W][nch][nfft]
+    float *scratch;         // [nstreams][kReduceGroups][nch][nfft] or nullptr (single-stage)
     float *out0;            // psd / pxx      [nstreams][nout]
     float *out1;            // pyy  (CSD)
     float *out2;            // pxy  interleaved (CSD)
@@ -62,7 +69,7 @@ hipError_t launch_welch_generic(int nfft, const WelchArgs &a, hipStream_t s);
 OTH_DECL_W4096(base)
 OTH_DECL_W4096(noslp)
 OTH_DECL_W4096(dpp)
-OTH_DECL_W4096(pref)
+OTH_DECL_W4096(diag)
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s);
 hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,

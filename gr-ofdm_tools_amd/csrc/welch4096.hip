@@ -29,15 +29,14 @@
 // Build-time variants (the Makefile compiles this file once per variant; api.hip picks one):
 //   OTH_W4096_TAG       suffix of the exported launcher
 //   OTH_W4096_DPP       1: segment-sum wave reduction with DPP row ops + v_readlane (no LDS round trips)
-//   OTH_W4096_PREFETCH  1: the next segment's samples are loaded before this segment's FFT starts
 #ifndef OTH_W4096_TAG
 #define OTH_W4096_TAG base
 #endif
 #ifndef OTH_W4096_DPP
 #define OTH_W4096_DPP 0
 #endif
-#ifndef OTH_W4096_PREFETCH
-#define OTH_W4096_PREFETCH 0
+#ifndef OTH_W4096_DIAG
+#define OTH_W4096_DIAG 0     // 1: diagnostic build, every workgroup stamps start/end time + XCC id
 #endif
 #define OTH_CAT2(a, b) a##b
 #define OTH_CAT(a, b) OTH_CAT2(a, b)
@@ -122,6 +121,9 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
     const int t = threadIdx.x;
     const int hi = t >> 4, lo = t & 15;
     const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+#if OTH_W4096_DIAG
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
     const float2 *xb = p.x + (size_t)stream * p.stream_stride;
 
@@ -144,30 +146,26 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
     const int w2 = hi * RS + lo;            // + k1 * 17
     const int r2 = hi * RS + lo * 17;       // + c            (thread is (k0,k1))
 
-#if OTH_W4096_PREFETCH
-    float2 nx[16];
-    if (s0 < s1) {
-        const float2 *xs = xb + s0 * p.step + t;
-#pragma unroll
-        for (int a = 0; a < 16; ++a) nx[a] = xs[256 * a];
-    }
-#endif
-    for (long long s = s0; s < s1; ++s) {
+    // Segment schedule (WelchArgs.sched):
+    //   0  contiguous   workgroup w owns segments [s0, s1)                      (deterministic)
+    //   1  interleaved  chunk c = w, w + W, w + 2W, ... of `chunk` segments       (deterministic)
+    //   2  dynamic      first chunk = w, then chunks drawn from an atomic ticket  (load-balanced;
+    //                   the set of segments a workgroup sums depends on timing)
+    const int sched = p.sched, C = p.chunk;
+    const long long nchunks = sched ? (p.nseg + C - 1) / C : 1;
+    int *lnext = reinterpret_cast<int *>(red + 4);
+    unsigned ticket = 0;
+    for (long long cur = sched ? wg : 0; cur < nchunks;) {
+      long long sb = s0, se = s1;
+      if (sched) {
+          sb = cur * C;
+          se = sb + C < p.nseg ? sb + C : p.nseg;
+      }
+      for (long long s = sb; s < se; ++s) {
         float2 v[16];
-#if OTH_W4096_PREFETCH
-#pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = nx[a];
-        {   // issue the next segment's loads now; they land while this segment is transformed
-            const long long sn = (s + 1 < s1) ? s + 1 : s;
-            const float2 *xn = xb + sn * p.step + t;
-#pragma unroll
-            for (int a = 0; a < 16; ++a) nx[a] = xn[256 * a];
-        }
-#else
         const float2 *xs = xb + s * p.step + t;
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = xs[256 * a];
-#endif
 
         float2 mean = make_float2(0.f, 0.f);
         if (DETREND) {
@@ -179,6 +177,11 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
             if ((t & 63) == 0) red[t >> 6] = sum;
         }
         __syncthreads();   // A: previous segment's LDS reads are done; red[] visible
+        if (sched == 2 && t == 0) {
+            // draw the next chunk while this one is being transformed; publish it in the last segment
+            if (s == sb) ticket = atomicAdd(p.queue + stream, 1u);
+            if (s == se - 1) *lnext = (int)ticket;
+        }
         if (DETREND) {
             const float2 s01 = cadd(red[0], red[1]), s23 = cadd(red[2], red[3]);
             mean = make_float2((s01.x + s23.x) * (1.0f / 4096.0f), (s01.y + s23.y) * (1.0f / 4096.0f));
@@ -212,12 +215,25 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
             const float2 X = v[r16(k2)];
             acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
         }
+      }
+      if (sched == 0) break;
+      cur = (sched == 1) ? cur + W : (long long)W + *lnext;   // *lnext was written before barrier B
     }
 
     // bin k0 + 16 k1 + 256 k2 of this workgroup sits at t + 256 k2 (finalize_kernel layout 1)
     float *dst = p.partial + ((size_t)stream * W + wg) * 4096;
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) dst[256 * k2 + t] = acc[k2];
+#if OTH_W4096_DIAG
+    if (t == 0) {   // stamps live behind the partial sums, in memory nothing else reads
+        unsigned long long *dbg =
+            reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * 4096) + 4 * ((size_t)stream * W + wg);
+        dbg[0] = t_start;
+        dbg[1] = __builtin_amdgcn_s_memrealtime();
+        dbg[2] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID, bits [3:0]
+        dbg[3] = (unsigned long long)(s1 - s0);
+    }
+#endif
 }
 
 }  // namespace

@@ -15,6 +15,7 @@ DETREND_NONE, DETREND_CONSTANT = 0, 1
 SCALE_RAW, SCALE_DENSITY, SCALE_OVER_N2, SCALE_SPECTRUM = 0, 1, 2, 3
 EPI_MAG, EPI_MAG2, EPI_MAG2_OVER_N2 = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TUNED = 0, 1, 2
+SCHED_CONTIGUOUS, SCHED_INTERLEAVED, SCHED_DYNAMIC = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('OFDM_TOOLS_HIP_LIB',
@@ -62,6 +63,7 @@ SIGNATURES = {
     'oth_plan_destroy': (C.c_int, [_p]),
     'oth_plan_set_output_db': (C.c_int, [_p, C.c_int]),
     'oth_plan_set_kernel': (C.c_int, [_p, C.c_int]),
+    'oth_plan_set_schedule': (C.c_int, [_p, C.c_int]),
     'oth_plan_out_len': (C.c_int, [_p, C.POINTER(C.c_int)]),
     'oth_welch_exec': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f, _u64p]),
     'oth_welch_exec_dev': (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_size_t, _p, _u64p]),
@@ -291,6 +293,9 @@ class WelchPlan(object):
 
     def set_kernel(self, which):
         self.ctx.check(self.ctx.lib.oth_plan_set_kernel(self.h, int(which)), 'oth_plan_set_kernel')
+
+    def set_schedule(self, which):
+        self.ctx.check(self.ctx.lib.oth_plan_set_schedule(self.h, int(which)), 'oth_plan_set_schedule')
 
     def nseg(self, nsamples):
         return (nsamples - self.noverlap) // self.step if nsamples >= self.nperseg else 0

@@ -65,6 +65,12 @@ extern "C" {
 #define OTH_KERNEL_GENERIC   1   /* radix-4 Stockham, any power of two 16..16384 */
 #define OTH_KERNEL_TUNED     2   /* radix-16x16x16 register/LDS kernel (nfft 4096) */
 
+/* how the welch4096 kernel hands segments to workgroups */
+#define OTH_SCHED_CONTIGUOUS  0   /* fixed contiguous runs: bit-reproducible sums */
+#define OTH_SCHED_INTERLEAVED 1   /* fixed round-robin chunks: bit-reproducible sums */
+#define OTH_SCHED_DYNAMIC     2   /* chunks drawn from an atomic ticket (default): load-balanced,
+                                     fp32 summation order - hence the last bits - may vary run to run */
+
 typedef struct oth_ctx oth_ctx;
 typedef struct oth_plan oth_plan;
 typedef struct oth_chain oth_chain;
@@ -124,6 +130,7 @@ int oth_welch_plan(oth_ctx *ctx, int nfft, int nperseg, int noverlap, const floa
 int oth_plan_destroy(oth_plan *plan);
 int oth_plan_set_output_db(oth_plan *plan, int enable);      /* 10*log10 in the finalize kernel */
 int oth_plan_set_kernel(oth_plan *plan, int which);           /* OTH_KERNEL_* */
+int oth_plan_set_schedule(oth_plan *plan, int which);         /* OTH_SCHED_* */
 int oth_plan_out_len(oth_plan *plan, int *n);
 
 /* one-shot: nsamples complex64 -> psd_out[nfft - 2*trim] (host) */

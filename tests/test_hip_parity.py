@@ -56,6 +56,22 @@ def test_welch_hann_4096_golden(ctx, hip, golden, kernel):
     assert relerr(psd, g['expected_psd']) < RTOL
 
 
+def test_welch_schedules_agree_and_static_ones_are_bit_reproducible(ctx, hip):
+    x = R.synth_iq(3_000_000, 21)          # 1463 segments: more chunks than resident workgroups
+    _, ref = R.welch_np(x, nperseg=4096, nfft=4096)
+    plan = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_TUNED)
+    outs = {}
+    for sched in (hip.SCHED_CONTIGUOUS, hip.SCHED_INTERLEAVED, hip.SCHED_DYNAMIC):
+        plan.set_schedule(sched)
+        outs[sched] = [plan.exec(x) for _ in range(3)]
+        assert plan.last_nseg == 1463
+        for o in outs[sched]:
+            assert relerr(o, ref) < RTOL
+    for sched in (hip.SCHED_CONTIGUOUS, hip.SCHED_INTERLEAVED):
+        assert np.array_equal(outs[sched][0], outs[sched][1]) and np.array_equal(outs[sched][0], outs[sched][2])
+    assert relerr(outs[hip.SCHED_DYNAMIC][0], outs[hip.SCHED_CONTIGUOUS][0]) < 2e-6
+
+
 def test_welch_ragged_length_and_fs(ctx, golden):
     g = golden('welch_hann_1024_ragged.npz')
     plan = ctx.welch_plan(1024, window=hann(1024), fs=float(g['fs']))

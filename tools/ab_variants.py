@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of the welch4096 build variants in one process.
-usage: ab_variants.py [log2_samples] [rounds] [variant ...]"""
+usage: ab_variants.py [log2_samples] [rounds] [variant[:sched[:chunk]] ...]"""
 import os
 import sys
 
@@ -12,7 +12,16 @@ from ofdm_tools import _hip, windows  # noqa: E402
 
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-variants = sys.argv[3:] or ['base', 'noslp', 'dpp', 'pref']
+variants = sys.argv[3:] or ['noslp:0:8', 'dpp:0:8', 'dpp:1:4', 'dpp:1:16', 'dpp:2:2', 'dpp:2:4', 'dpp:2:8', 'dpp:2:16']
+
+
+def select(v):
+    tag, sched, chunk = (v.split(':') + ['0', '8'])[:3]
+    os.environ['OTH_W4096_VARIANT'] = tag
+    os.environ['OTH_W4096_SCHED'] = sched
+    os.environ['OTH_W4096_CHUNK'] = chunk
+
+
 n = 1 << log2n
 ctx = _hip.Context(0)
 d_in = ctx.alloc(n * 8)
@@ -25,18 +34,30 @@ times = {v: [] for v in variants}
 ctx.set_timing(True)
 for r in range(rounds + 1):
     for v in variants:
-        os.environ['OTH_W4096_VARIANT'] = v
+        select(v)
         plan.exec_dev(d_in, n, d_out)
         ms, k = ctx.get_timing()
         if r:
             times[v].append(ms / k)
+# sustained: bursts of back-to-back launches (what bench.py does); clocks settle lower than in the
+# one-launch-then-sync rounds above
+burst = int(os.environ.get('AB_BURST', '20'))
 for v in variants:
-    os.environ['OTH_W4096_VARIANT'] = v
+    select(v)
+    for _ in range(2):
+        for _ in range(burst):
+            plan.exec_dev(d_in, n, d_out)
+        ms, k = ctx.get_timing()
+    times[v].append(('burst', ms / k))
+for v in variants:
+    select(v)
     got = plan.exec_device_src(d_in, min(n, 1 << 24)).astype(np.float64)
     err = float(np.max(np.abs(got - ref) / ref))
-    t = sorted(times[v])
+    bur = [x[1] for x in times[v] if isinstance(x, tuple)][0]
+    t = sorted(x for x in times[v] if not isinstance(x, tuple))
     med = t[len(t) // 2]
-    print('%-8s median %.4f ms  min %.4f ms  -> %.0f GB/s (%.1f%% of 8 TB/s)  max rel dev vs generic %.2e'
-          % (v, med, t[0], 8.0 * n / med / 1e6, 8.0 * n / med / 1e6 / 80.0, err))
+    print('%-12s median %.4f ms  min %.4f ms  -> %.0f GB/s (%.1f%% of 8 TB/s)  burst-of-%d avg %.4f ms (%.1f%%)  dev vs generic %.2e'
+          % (v, med, t[0], 8.0 * n / med / 1e6, 8.0 * n / med / 1e6 / 80.0, burst, bur, 8.0 * n / bur / 1e6 / 80.0,
+             err))
 ctx.free(d_in)
 ctx.free(d_out)

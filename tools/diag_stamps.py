@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-workgroup start/end stamps of the diagnostic welch4096 build: how even is the finish time?"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'gr-ofdm_tools_amd'))
+import numpy as np  # noqa: E402
+from ofdm_tools import _hip, windows  # noqa: E402
+
+n = 1 << 28
+ctx = _hip.Context(0)
+d_in = ctx.alloc(n * 8)
+d_out = ctx.alloc(4096 * 4)
+ctx.synth_iq(d_in, n, 1002, ((0.5, 0.1234), (0.05, -0.31), (2.0, 0.4071)), 0.1 + 0.05j)
+plan = ctx.welch_plan(4096, window=windows.get_window('hann', 4096), fs=1.0, kernel=_hip.KERNEL_TUNED)
+os.environ['OTH_W4096_VARIANT'] = 'diag'
+for rep in range(3):
+    plan.exec_dev(d_in, n, d_out)
+    ctx.sync()
+    buf = np.zeros((4096, 4), np.uint64)
+    nwg = C.c_int()
+    fn = ctx.lib.oth__debug_stamps
+    fn.restype = C.c_int
+    rc = fn(plan.h, buf.ctypes.data_as(C.c_void_p), 4096, C.byref(nwg))
+    assert rc == 0
+    b = buf[:nwg.value].astype(np.int64)
+    t0 = b[:, 0].min()
+    start = (b[:, 0] - t0) / 100.0   # us (100 MHz)
+    end = (b[:, 1] - t0) / 100.0
+    dur = end - start
+    xcc = b[:, 2] & 15
+    print('rep %d: %d WGs, kernel span %.1f us; start spread %.1f us; duration min/med/max %.1f/%.1f/%.1f us; '
+          'end min/med/max %.1f/%.1f/%.1f' % (rep, nwg.value, end.max(), start.max(), dur.min(), np.median(dur),
+                                               dur.max(), end.min(), np.median(end), end.max()))
+    for x in range(8):
+        m = xcc == x
+        if m.any():
+            print('   xcc %d: %4d WGs  dur med %.1f  max %.1f  end max %.1f' % (x, m.sum(), np.median(dur[m]),
+                                                                              dur[m].max(), end[m].max()))
+    print('   mean wave life / span = %.3f' % (dur.mean() / end.max()))
