@@ -114,7 +114,7 @@ def main():
     plan = ctx.welch_plan(NFFT, window=windows.get_window('hann', NFFT), fs=1.0, fftshift=multi, trim_bins=trim)
     nseg = plan.nseg(n)
     local = torch.zeros((1, nbins), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, 1, nbins), dtype=torch.float32, device=dev) if multi else None
+    gathered = torch.empty((world, nbins), dtype=torch.float32, device=dev) if multi else None
 
     def step():
         plan.exec_dev(iq.data_ptr(), n, local.data_ptr())

@@ -11,22 +11,12 @@ from . import ofdm_cr_tools  # noqa: F401
 from . import windows  # noqa: F401
 from ._hip import HipError, HipUnavailable  # noqa: F401
 
-_LAZY = {
-    'spectrum_sensor_v2': 'spectrum_sensor_v2',
-    'psd_logger': 'psd_logger',
-    'coherence_detector': 'coherence_detector',
-    'coherence_estimator': 'coherence_detector',
-    'spectrum_sweeper': 'spectrum_sweeper',
-    'multichannel_scanner': 'multichannel_scanner',
-    'local_worker': 'local_worker',
-    'spectrum_sensor': 'spectrum_sensor',
-    'message_pdu': 'message_pdu',
-}
-
-
-def __getattr__(name):
-    if name in _LAZY:
-        import importlib
-        mod = importlib.import_module('.' + _LAZY[name], __name__)
-        return getattr(mod, name)
-    raise AttributeError('module %r has no attribute %r' % (__name__, name))
+# as python/__init__.py:49-84 does, the class replaces the same-named submodule attribute
+from .spectrum_sensor import spectrum_sensor  # noqa: F401,E402
+from .psd_logger import psd_logger  # noqa: F401,E402
+from .spectrum_sensor_v2 import spectrum_sensor_v2  # noqa: F401,E402
+from .message_pdu import message_pdu  # noqa: F401,E402
+from .coherence_detector import coherence_detector, coherence_estimator  # noqa: F401,E402
+from .multichannel_scanner import multichannel_scanner  # noqa: F401,E402
+from .local_worker import local_worker  # noqa: F401,E402
+from .spectrum_sweeper import spectrum_sweeper  # noqa: F401,E402

@@ -83,9 +83,12 @@ def src_power_welch(vector, npts, nFFT, Fr, Sf, bb_freqs, srch_bins, ctx=None):
 def src_power_fft(vector, npts, nFFT, Fr, Sf, bb_freqs, srch_bins, ctx=None):
     """ofdm_cr_tools.py:173-192: one flat-top periodogram |FFT(x w, nFFT)|^2 / nFFT, shifted."""
     ctx = ctx or _hip.default_context()
-    vector = np.asarray(vector)[:nFFT]
+    vector = np.asarray(vector)
+    # the reference windows ALL len(vector) samples, then np.fft.fft(., nFFT) keeps the first nFFT
+    win = windows.flattop(len(vector))[:nFFT]
+    vector = vector[:nFFT]
     npts = len(vector)
-    plan = ctx.welch_plan(nFFT, nperseg=npts, noverlap=0, window=windows.flattop(npts),
+    plan = ctx.welch_plan(nFFT, nperseg=npts, noverlap=0, window=win,
                           detrend=_hip.DETREND_NONE, scaling=_hip.SCALE_RAW, fftshift=True)
     psd = plan.exec(vector) / np.float32(nFFT)
     plan.close()
@@ -96,9 +99,9 @@ def src_power_fft(vector, npts, nFFT, Fr, Sf, bb_freqs, srch_bins, ctx=None):
 def clc_power_freq(vector, nFFT, Sf, ctx=None):
     """ofdm_cr_tools.py:149-153."""
     ctx = ctx or _hip.default_context()
+    n = len(vector)                       # normalisation uses the full length even when fft() truncates
     vector = np.asarray(vector)[:nFFT]
-    n = len(vector)
-    plan = ctx.welch_plan(nFFT, nperseg=n, noverlap=0, window=None, detrend=_hip.DETREND_NONE,
+    plan = ctx.welch_plan(nFFT, nperseg=len(vector), noverlap=0, window=None, detrend=_hip.DETREND_NONE,
                           scaling=_hip.SCALE_RAW)
     psd = plan.exec(vector).astype(np.float64) / n / Sf
     plan.close()

@@ -1,0 +1,139 @@
+"""spectrum_sensor - the legacy gr.sync_block sensor (python/spectrum_sensor.py).
+
+``work()`` keeps the latest ``block_length`` samples (:71-75); a PDU request on
+``PDU from_cogeng`` (:77-120) runs ``fast_spectrum_scan`` ('SC' -> 'thre', 'nois', 'cons') or the
+PAPR probe ('PAPR' -> 'papr') and answers on ``PDU spect_msg``.  Constructor as :37."""
+import numpy as np
+
+from . import _hip
+from .gr_compat import HAVE_GNURADIO, sync_block, to_msg
+from .ofdm_cr_tools import fast_spectrum_scan
+
+
+class spectrum_sensor(sync_block):
+    def __init__(self, block_length, sample_rate=1, fft_len=1, channel_space=1, search_bw=1, method='fft',
+                 thr_leveler=10, tune_freq=0, alpha_avg=1, source=None, log=False, ctx=None):
+        sync_block.__init__(self, 'spectrum_sensor', [np.complex64], None)
+        self.block_length = block_length
+        self.sample_rate = sample_rate
+        self.fft_len = fft_len
+        self.channel_space = channel_space
+        self.search_bw = search_bw
+        self.method = method
+        self.thr_leveler = thr_leveler
+        self.tune_freq = tune_freq
+        self.vector_sample = [0, 0]
+        self.papr = 1e-10
+        self.spectrum_constraint_hz = []
+        self.threshold = 0
+        self.power_level_ch = []
+        self.noise_estimate = 1e-11
+        self.alpha_avg = alpha_avg
+        self.source = source
+        self.log = log
+        self.ctx = ctx
+        self.message_port_register_out('PDU spect_msg')
+        self.message_port_register_in('PDU from_cogeng')
+        self.set_msg_handler('PDU from_cogeng', self.cogeng_rx)
+
+    def work(self, input_items, output_items):
+        in0 = input_items[0][0:self.block_length]
+        self.set_vector_sample(np.array(in0, np.complex64))      # the caller's buffer dies after the call
+        return len(in0)
+
+    def cogeng_rx(self, msg):
+        if HAVE_GNURADIO:                                       # pragma: no cover
+            import pmt
+            data = str(pmt.cdr(msg))
+        else:
+            data = str(msg[1]) if isinstance(msg, tuple) else str(msg)
+        if data == 'PAPR':
+            self.set_papr(self.get_vector_sample())
+            self.send_msg('papr', self.get_papr())
+        elif data == 'SC':
+            self.set_spectrum_constraint_hz(self.get_vector_sample())
+            self.send_msg('thre', self.get_threshold())
+            self.send_msg('nois', self.get_noise_estimate())
+            self.send_msg('cons', self.get_spectrum_constraint_hz())
+        else:
+            self.send_msg('unkn', 'received unknown request')
+
+    def send_msg(self, meta, data):
+        self.message_port_pub('PDU spect_msg', to_msg(meta, data))
+
+    def set_spectrum_constraint_hz(self, measure):
+        (self.threshold, self.power_level_ch, self.noise_estimate,
+         self.spectrum_constraint_hz) = fast_spectrum_scan(measure, self.tune_freq, self.channel_space,
+                                                           self.search_bw, self.fft_len, self.sample_rate,
+                                                           self.method, self.thr_leveler, self.get_noise_estimate(),
+                                                           self.get_alpha_avg(), False, self.ctx)
+
+    def set_papr(self, measure):
+        """:144-151 (scalar work on one captured block)."""
+        measure = np.asarray(measure)
+        mean_square = np.vdot(measure, measure) / len(measure)
+        peak = max(measure * np.conjugate(measure))
+        self.papr = 10 * np.log10((peak / mean_square).real + 1e-20)
+
+    def get_papr(self):
+        return self.papr
+
+    def get_spectrum_constraint_hz(self):
+        return self.spectrum_constraint_hz
+
+    def get_threshold(self):
+        return self.threshold
+
+    def get_noise_estimate(self):
+        return self.noise_estimate
+
+    def get_alpha_avg(self):
+        return self.alpha_avg
+
+    def get_power_level_ch(self):
+        return self.power_level_ch
+
+    def get_tune_freq(self):
+        return self.tune_freq
+
+    def set_tune_freq(self, tune_freq):
+        self.tune_freq = tune_freq
+
+    def set_block_length(self, block_length):
+        self.block_length = block_length
+
+    def get_sample_rate(self):
+        return self.sample_rate
+
+    def set_sample_rate(self, sample_rate):
+        self.sample_rate = sample_rate
+
+    def set_fft_len(self, fft_len):
+        self.fft_len = fft_len
+
+    def set_channel_space(self, channel_space):
+        self.channel_space = channel_space
+
+    def get_channel_space(self):
+        return self.channel_space
+
+    def set_search_bw(self, search_bw):
+        self.search_bw = search_bw
+
+    def get_search_bw(self):
+        return self.search_bw
+
+    def set_thr_leveler(self, thr_leveler):
+        self.thr_leveler = thr_leveler
+
+    def get_thr_leveler(self):
+        return self.thr_leveler
+
+    def set_alpha_avg(self, alpha_avg):
+        self.alpha_avg = alpha_avg
+
+    def set_vector_sample(self, v):
+        self.vector_sample = v
+
+    def get_vector_sample(self):
+        return self.vector_sample

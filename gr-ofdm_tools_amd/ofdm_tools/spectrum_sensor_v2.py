@@ -1,0 +1,161 @@
+"""spectrum_sensor_v2 - multichannel energy detector (python/spectrum_sensor_v2.py).
+
+Same constructor as the reference block (spectrum_sensor_v2.py:43-45, GRC make
+template grc/ofdm_tools_spectrum_sensor_v2.xml:7-25).  The GNU Radio chain
+stream_to_vector -> keep_one_in_n -> fft_vcc(rect, shift) -> |.|^2 -> x 1/N^2
+(:85-93,116) runs as one HIP chain (oth_chain_*); the watcher logic (:357-479,
+:186-237, :325-354) keeps its arithmetic and consumes the LAST vector of every
+work() call, as the reference watchers do with their depth-2 message queues.
+"""
+import threading
+import time
+
+import numpy as np
+
+from . import _hip
+from .gr_compat import LossyQueue, sync_block, to_msg
+from .message_pdu import message_pdu
+from .ofdm_cr_tools import _py2div
+from .scanner import ChannelScanner, top4
+from .sensing_log import logger
+
+
+class spectrum_sensor_v2(sync_block):
+    def __init__(self, fft_len, sens_per_sec, sample_rate, channel_space=1, search_bw=1, thr_leveler=10,
+                 tune_freq=0, alpha_avg=1, test_duration=1, period=3600, trunc_band=1, verbose=False,
+                 stats=False, psd=False, waterfall=False, output=False, subject_channels=[],
+                 ctx=None, threaded=False, log_directory=None):
+        sync_block.__init__(self, 'spectrum_sensor_v2', [np.complex64], None)
+        self.fft_len = fft_len
+        self.sens_per_sec = sens_per_sec
+        self.sample_rate = sample_rate
+        self.channel_space = channel_space
+        self.search_bw = search_bw
+        self.thr_leveler = thr_leveler
+        self.tune_freq = tune_freq
+        self.threshold = 0
+        self.alpha_avg = alpha_avg
+        self.verbose = verbose
+        self.trunc_band = trunc_band
+        self.stats = stats
+        self.psd = psd
+        self.waterfall = waterfall
+        self.output = output
+        self.subject_channels = list(subject_channels)
+        self.top4 = [0, 0, 0, 0]
+        for port in ('freq_out_0', 'freq_out_1', 'freq_out_2', 'freq_out_3', 'freq_msg_PDU'):
+            self.message_port_register_hier_out(port)
+
+        self.ctx = ctx or _hip.default_context()
+        self.decimation = max(1, int(_py2div(_py2div(sample_rate, fft_len), sens_per_sec)))   # :86-87
+        self._chain = self.ctx.chain(fft_len, None, True, _hip.EPI_MAG2_OVER_N2, self.decimation)
+        self.msgq0 = LossyQueue(2)
+        self.PDU_messages = message_pdu(None)
+        self.PDU_messages.msg_connect('out', lambda m: self.message_port_pub('freq_msg_PDU', m))
+
+        self._logger = logger(fft_len, period, test_duration, directory=log_directory) \
+            if (stats or psd or waterfall) else None
+        self._scanner = ChannelScanner(fft_len, sample_rate, channel_space, search_bw, tune_freq, trunc_band,
+                                       thr_leveler, alpha_avg, self.ctx)
+        self._idx_subject = self._scanner.subject_index(self.subject_channels) if output else []
+        self.subject_channels_pwr = np.array([1.0] * len(self.subject_channels))
+        self._waterfall_count = 0
+        self._lock = threading.Lock()
+        self._threaded = threaded
+        self._thread = None
+        if threaded:
+            self.keep_running = True
+            self._thread = threading.Thread(target=self._watch, daemon=True)
+            self._thread.start()
+
+    # -- gr.sync_block ----------------------------------------------------------
+    def work(self, input_items, output_items):
+        in0 = input_items[0]
+        rows, n = self._chain.push(in0, max_rows=1)
+        if n:
+            if self._threaded:
+                self.msgq0.insert_tail(rows[-1].copy())      # dropped when the watcher lags (dont_block)
+            else:
+                self._on_vector(rows[-1])
+        return len(in0)
+
+    def _watch(self):
+        while self.keep_running:
+            row = self.msgq0.delete_head(timeout=0.1)
+            if row is not None:
+                self._on_vector(row)
+
+    def stop(self):
+        self.keep_running = False
+        if self._thread:
+            self._thread.join(1.0)
+
+    # -- watchers ---------------------------------------------------------------
+    def _on_vector(self, float_data):
+        with self._lock:
+            if self.stats:
+                self._stats_watcher(float_data)
+            elif self.output:
+                self._scanner.basic_scan(float_data)
+            if self.psd:                                                       # psd_watcher.run :336-354
+                lg = self._logger
+                lg.set_cumulative_psd(float_data.copy() if lg.cumulative_psd is None
+                                      else np.maximum(float_data, lg.cumulative_psd))
+                lg.set_periodic_psd_peaks(float_data.copy() if lg.periodic_psd_peaks is None
+                                          else np.maximum(float_data, lg.periodic_psd_peaks))
+            if self.waterfall:                                                 # keep 1 in sens_per_sec, :102
+                self._waterfall_count += 1
+                if self._waterfall_count >= max(1, int(self.sens_per_sec)):
+                    self._waterfall_count = 0
+                    self._logger.cumulative_waterfall.append(float_data.copy())
+            if self.output:
+                self.publish()
+
+    def _stats_watcher(self, float_data):
+        """stats_watcher.run / spectrum_scanner, :395-479."""
+        sc, lg = self._scanner, self._logger
+        occupied = sc.scan(float_data)
+        self.threshold = sc.threshold
+        lg.set_cumulative_max_power(sc.cumulative_max_power)
+        lg.set_periodic_max_power(sc.periodic_max_power)
+        lg.settings['n_measurements'] = lg.settings.get('n_measurements', 0) + 1
+        lg.n_measurements_period += 1
+        lg.settings['n_measurements_period'] = lg.n_measurements_period
+        lg.settings['noise_estimate'] = sc.noise_estimate
+        for el in occupied:
+            lg.cumulative_statistics[el] = lg.cumulative_statistics.get(el, 0) + 1
+            lg.periodic_statistic[el] = lg.periodic_statistic.get(el, 0) + 1
+        if self.verbose:
+            print('noise_estimate dB (channel)', 10 * np.log10(sc.noise_estimate + 1e-20))
+        self.spectrum_constraint_hz = occupied
+
+    def publish(self):
+        """output_data.publish, :228-237."""
+        if len(self.subject_channels) < 4:
+            return
+        self.subject_channels_pwr, best = top4(self._scanner.plc, self._idx_subject, self.subject_channels)
+        self.set_freqs(best[0], best[1], best[2], best[3])
+
+    def set_freqs(self, freq0, freq1, freq2, freq3):
+        """:157-165 - the strobes carry the differential frequency."""
+        for i, f in enumerate((freq0, freq1, freq2, freq3)):
+            self.top4[i] = f
+            self.message_port_pub('freq_out_%d' % i, to_msg('freq', f - self.tune_freq))
+
+    def send_PDU_data(self):
+        """send_PDU_data.run body, :178-183 (one round)."""
+        for freq in self.top4:
+            self.PDU_messages.post_message('freq', str(freq))
+
+    # accessors the tests and hosts use
+    @property
+    def power_level_ch(self):
+        return self._scanner.plc
+
+    @property
+    def noise_estimate(self):
+        return self._scanner.noise_estimate
+
+    @property
+    def ax_ch(self):
+        return self._scanner.ax_ch

@@ -33,10 +33,10 @@ def gather_wideband(local_psd, nseg_total, rank=None, world=None, group=None, ou
     if world == 1:
         return local_psd[:nseg_total].reshape(-1)
     if out is None:
-        out = torch.empty((world, spr, nbins), dtype=local_psd.dtype, device=local_psd.device)
+        out = torch.empty((world * spr, nbins), dtype=local_psd.dtype, device=local_psd.device)
     dist.all_gather_into_tensor(out, local_psd.contiguous(), group=group)
-    # out[r][j] is segment r + world*j  ->  tune order
-    return out.permute(1, 0, 2).reshape(spr * world, nbins)[:nseg_total].reshape(-1)
+    # row r*spr + j is segment r + world*j  ->  tune order
+    return out.view(world, spr, nbins).permute(1, 0, 2).reshape(spr * world, nbins)[:nseg_total].reshape(-1)
 
 
 def sweep_psd(segment_iq, compute_psd, nseg_total, nbins, device, rank, world, group=None):

@@ -1,0 +1,221 @@
+"""GPU tests of the block classes (same names / constructor signatures as the reference) against
+the CPU oracle: the whole chain from complex64 stream to decisions, messages and PDUs."""
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from ofdm_tools import _hip
+    c = _hip.Context(0)
+    yield c
+    c.close()
+
+
+def test_spectrum_sensor_v2_state_sequence(ctx, golden, tmp_path):
+    import ofdm_tools
+    g = golden('scanner_state_seq.npz')
+    subj = list(g['subject_channels'])
+    blk = ofdm_tools.spectrum_sensor_v2(1024, 1000, 1000000, channel_space=25e3, search_bw=12.5e3, thr_leveler=4,
+                                        tune_freq=100000000, alpha_avg=0.5, trunc_band=800000, stats=True, psd=True,
+                                        output='o', subject_channels=subj, ctx=ctx, log_directory=str(tmp_path))
+    assert blk.decimation == 1 and np.allclose(blk.ax_ch, g['ax_ch'])
+    msgs = []
+    for i in range(4):
+        blk.msg_connect('freq_out_%d' % i, lambda m, i=i: msgs.append((i, m)))
+    x = g['x']
+    for i in range(16):                                   # one vector per work() call, like one message each
+        assert blk.work([x[i * 1024:(i + 1) * 1024]], []) == 1024
+        assert np.allclose(blk.power_level_ch, g['plc_seq'][i], rtol=1e-4)
+        assert np.isclose(blk.noise_estimate, g['noise_seq'][i], rtol=1e-4)
+        occ = [1.0 if a in blk.spectrum_constraint_hz else 0.0 for a in blk.ax_ch]
+        assert occ == list(g['occupied_seq'][i])
+    assert np.allclose(blk._logger.cumulative_max_power, g['cumulative_max'], rtol=1e-4)
+    assert relerr(blk._logger.cumulative_psd, g['peak']) < RTOL
+    assert blk.top4 == list(g['top4'])
+    last = {i: m for i, m in msgs}
+    assert [last[i][1] for i in range(4)] == [f - 100000000 for f in g['top4']]
+    files = blk._logger.flush()
+    assert relerr(np.load(files['psd']), g['peak']) < RTOL
+    assert str(blk._logger.cumulative_statistics) in open(files['stat']).read()
+
+
+def test_spectrum_sensor_v2_decimation_and_scheduler_chunks(ctx):
+    import ofdm_tools
+    fft_len, Sf = 256, 256 * 100
+    blk = ofdm_tools.spectrum_sensor_v2(fft_len, 20, Sf, channel_space=1600, search_bw=800, trunc_band=Sf - 3200,
+                                        stats=True, ctx=ctx)
+    assert blk.decimation == 5                             # int(25600/256/20), keep_one_in_n(5)
+    x = R.synth_iq(fft_len * 40 + 13, 17)
+    assert blk.feed(x, max_items=1000) == len(x)           # ragged scheduler chunks
+    rows = R.chain_sensor_v2(x, fft_len, decim=5)
+    st = R.ScannerState(fft_len, Sf, 1600, 800, trunc_band=Sf - 3200)
+    # the watcher sees the last kept vector of each work() call; with 1000-sample calls no call
+    # completes two kept vectors, so every row is seen
+    for r in rows:
+        st.scan(r.astype(np.float32))
+    assert np.allclose(blk.power_level_ch, st.plc, rtol=1e-4)
+    assert blk._scanner.n_measurements == len(rows) == 8
+
+
+def test_multichannel_scanner_top4(ctx):
+    import ofdm_tools
+    fft_len, Sf = 16384, 1000000
+    st = R.ScannerState(fft_len, Sf, 15625.0, 10e3, tune_freq=0, trunc_band=Sf)     # trunc = 0: all 64 channels
+    subj = [st.ax_ch[i] for i in (5, 12, 20, 33, 40, 51)]
+    blk = ofdm_tools.multichannel_scanner(fft_len, 1000, Sf, channel_space=15625.0, search_bw=10e3, tune_freq=0,
+                                          trunc_band=Sf, subject_channels=subj, ctx=ctx)
+    x = R.synth_iq(fft_len * 3, 3000)
+    dec = blk.decimation
+    assert dec == 1
+    blk.feed(x, max_items=fft_len)
+    rows = R.chain_sensor_v2(x, fft_len, decim=dec)
+    for r in rows:
+        st.scan(r.astype(np.float32))
+    assert np.allclose(blk.power_level_ch, st.plc, rtol=1e-4)
+    pwr, best = R.publish_top4(st.plc, st.ax_ch, subj)
+    assert blk.top4 == best and np.allclose(blk.subject_channels_pwr, pwr, atol=1e-3)
+
+
+def test_psd_logger_peak_file(ctx, golden, tmp_path):
+    import ofdm_tools
+    g = golden('gr_chain_bh_mag_peak_4096.npz')
+    path = str(tmp_path / 'psd_log.npy')
+    blk = ofdm_tools.psd_logger(4096, 1000, 4096 * 1000, ctx=ctx, mat_file=path)
+    assert blk.decimation == 1
+    blk.feed(g['x'], max_items=4096)
+    assert relerr(blk.peak_vals, g['expected_peak'][-1]) < RTOL
+    assert relerr(np.load(path), g['expected_peak'][-1]) < RTOL
+
+
+def test_local_worker_pdus(ctx, golden):
+    import ofdm_tools
+    from ofdm_tools import packets
+    g = golden('gr_chain_bh_iir_log_2048.npz')
+    N, Sf, alpha = 2048, int(g['sample_rate']), float(g['average'])
+    blk = ofdm_tools.local_worker(N, Sf, alpha, Sf / N, 1472, True, ctx=ctx)   # rate = one PSD per vector
+    frames = []
+    blk.msg_connect('pdus', lambda m: frames.append(m[1]))
+    x = g['x']
+    blk.work([x[:N]], [])
+    assert len(frames) == 6 and frames[0][0] == 6                              # ceil(8192/1470)
+    db0 = np.frombuffer(packets.reassemble(frames), '<f4')
+    k = -10 * np.log10(N) - 10 * np.log10(Sf)
+    assert relerr(10 ** ((db0.astype(np.float64) - k) / 10), g['expected_lin'][0]) < RTOL
+    blk.feed(x[N:], max_items=N)
+    assert relerr(10 ** ((blk.last_db.astype(np.float64) - k) / 10), g['expected_lin'][-1]) < RTOL
+    assert frames[-6:] == R.worker_fragments(blk.last_db, 1470, N, True)
+    # 8-bit mode: int8 cast of the dB values, ceil(2048/1470) = 2 frames
+    blk.set_data_precision(False)
+    del frames[:]
+    blk.send_packet(blk.last_db)
+    assert frames == R.worker_fragments(blk.last_db, 1470, N, False) and len(frames) == 2
+
+
+class FakeReceiver(object):
+    def __init__(self):
+        self.tuned = []
+
+    def set_center_freq(self, f, chan):
+        self.tuned.append(f)
+
+
+def test_spectrum_sweeper_sweep_and_wire_format(ctx):
+    import ofdm_tools
+    from ofdm_tools import packets
+    rx = FakeReceiver()
+    fft_len, Sf, tSf = 4096, 2000000, 1750000
+    blk = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 15, 0.0, 8, 0, 1472, ctx=ctx)
+    pts, tune, excess = R.sweeper_geometry(fft_len, Sf, tSf, 100e6, 107e6, 8)
+    assert (blk.vector_probe_pts, blk.tune_frequencies, blk.excess_bins) == (pts, tune, excess) == (16384, tune, 256)
+    assert len(tune) == 4
+    vectors = [R.synth_iq(pts, 2000 + i) for i in range(len(tune))]
+    it = iter(vectors)
+    blk.get_samples = lambda: next(it)                    # what data_colector would have stored after each retune
+    frames = []
+    blk.msg_connect('pdus', lambda m: frames.append(m[1]))
+    psd = blk.sweep_once(sleep=lambda s: None)
+    ref = R.sweeper_stitch(vectors, fft_len, Sf, excess, 0.0)
+    assert rx.tuned == tune and psd.shape == ref.shape == (4 * 3584,)
+    assert relerr(10 ** (psd / 10), 10 ** (ref / 10)) < RTOL
+    payload = packets.reassemble(frames)
+    assert np.allclose(np.frombuffer(payload, '<f4'), psd.astype(np.float32))
+    assert frames == R.sweeper_fragments(struct.pack('<%df' % len(psd), *psd), 1470)
+    # flowgraph side: work() keeps the last complete capture
+    blk2 = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 1e9, 0.0, 8, 0, 1472, ctx=ctx)
+    x = R.synth_iq(pts * 2 + 100, 5)
+    blk2.feed(x, max_items=5000)
+    assert np.array_equal(blk2.get_samples(), x[pts:2 * pts])
+
+
+def test_coherence_estimator_feeds_detector(ctx, golden):
+    import ofdm_tools
+    g = golden('coherence_csd_4096.npz')
+    N, Sf, tune = 4096, 2000000, 433000000
+    est = ofdm_tools.coherence_estimator(N, Sf, block_len=65536, ctx=ctx)
+    est.work([g['x'], g['y']], [])
+    assert np.max(np.abs(est.cxy - np.fft.fftshift(g['expected_cxy']))) < RTOL
+    # x and y share the tones and the noise -> coherent everywhere the delayed copy dominates
+    calls = []
+    det = ofdm_tools.coherence_detector(N, Sf, threshold=1.2, threshold_mtm=0.2, tune_freq=tune,
+                                        subject_channels=[tune + 0.1234 * Sf, tune - 0.31 * Sf],
+                                        valve_callback=calls.append)
+    quiet = np.zeros(N, np.float32)
+    det.work([est.cxy.reshape(1, N), quiet.reshape(1, N), quiet.reshape(1, N)], [])
+    coh, outcome, valve = R.coherence_scanner(np.fft.fftshift(g['expected_cxy']), quiet, quiet,
+                                              det.idx_subject_channels, 1.2, 0.2)
+    assert det.get_subject_channels_outcome() == outcome and calls == valve
+    assert np.allclose(det.subject_channels_coherence, coh, atol=2e-4)
+
+
+def test_legacy_spectrum_sensor_request_response(ctx):
+    import ofdm_tools
+    Sf, N = 1000000, 1024
+    for method in ('welch', 'fft'):
+        blk = ofdm_tools.spectrum_sensor(8192, sample_rate=Sf, fft_len=N, channel_space=50e3, search_bw=25e3,
+                                         method=method, thr_leveler=5, tune_freq=0, alpha_avg=1, ctx=ctx)
+        out = []
+        blk.msg_connect('PDU spect_msg', out.append)
+        x = R.synth_iq(20000, 41)
+        assert blk.work([x], []) == 8192                    # consumes at most block_length items
+        blk.post('PDU from_cogeng', ({}, 'SC'))
+        thr, plc, noise, cons = R.fast_spectrum_scan(x[:8192], 0, 50e3, 25e3, N, Sf, method, 5, 1e-11, 1)
+        got = dict(out)
+        assert np.isclose(got['thre'], thr, rtol=1e-4) and np.isclose(got['nois'], noise, rtol=1e-4)
+        assert got['cons'] == cons and len(cons) > 0
+        assert np.allclose(blk.get_power_level_ch(), plc, rtol=1e-4)
+        blk.post('PDU from_cogeng', ({}, 'PAPR'))
+        blk.post('PDU from_cogeng', ({}, 'bogus'))
+        assert out[-2][0] == 'papr' and out[-1] == ('unkn', 'received unknown request')
+
+
+def test_helper_functions_match_oracle(ctx):
+    from ofdm_tools import ofdm_cr_tools as T
+    x = R.synth_iq(40000, 9)
+    Sf, N = 2000000, 2048
+    assert np.isclose(T.welch_power_estimate(x, N, Sf, ctx), R.welch_power_estimate(x, N, Sf), rtol=1e-5)
+    ax, db = T.welch_plot_dB(x, Sf, 1e6, N, ctx)
+    ax2, db2 = R.welch_plot_dB(x, Sf, 1e6, N)
+    assert np.allclose(ax, ax2) and np.max(np.abs(np.array(db) - np.array(db2))) < 1e-3
+    assert np.isclose(T.clc_power_freq(x[:2000], N, Sf, ctx), R.clc_power_freq(x[:2000], N, Sf), rtol=1e-5)
+    assert np.isclose(T.clc_power_freq(x[:5000], N, Sf, ctx), R.clc_power_freq(x[:5000], N, Sf), rtol=1e-5)   # truncating fft
+    Fr = float(Sf) / N
+    bb = T.frange(-Sf // 2, Sf // 2, 100e3)
+    for fn_t, fn_r in ((T.src_power_welch, R.src_power_welch), (T.src_power_fft, R.src_power_fft)):
+        v = x if fn_t is T.src_power_welch else x[:1500]
+        psd, axis, plc = fn_t(v, len(v), N, Fr, Sf, bb, 50e3 / Fr, ctx)
+        psd2, axis2, plc2 = fn_r(v, len(v), N, Fr, Sf, bb, 50e3 / Fr)
+        assert relerr(psd, psd2) < RTOL and np.allclose(plc, plc2, rtol=1e-4) and np.allclose(axis, axis2)

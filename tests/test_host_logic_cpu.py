@@ -1,0 +1,175 @@
+"""CPU tests of the host logic around the HIP path: wire format, decision stage, block API
+surface, and the multi-rank sweep sharding over gloo (world_size 2)."""
+import inspect
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import ref_cpu as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_packet_framing_matches_golden_and_oracle():
+    from ofdm_tools import packets
+    raw = open(os.path.join(ROOT, 'tests', 'golden', 'fragments.bin'), 'rb').read()
+    pos, groups = 0, []
+    for _ in range(3):
+        n = struct.unpack_from('<I', raw, pos)[0]
+        pos += 4
+        frames = []
+        for _ in range(n):
+            ln = struct.unpack_from('<I', raw, pos)[0]
+            pos += 4
+            frames.append(raw[pos:pos + ln])
+            pos += ln
+        groups.append(frames)
+    db = (np.arange(4096, dtype=np.float32) * 0.01 - 90).astype('<f4')
+    assert packets.worker_fragments(db, 1470, 4096, True) == groups[0]
+    assert packets.worker_fragments(db, 1470, 4096, False) == groups[1]
+    assert packets.sweeper_fragments(db.tobytes(), 1470) == groups[2]
+    assert packets.reassemble(groups[0]) == db.tobytes()
+    assert packets.reassemble(list(reversed(groups[2]))) == db.tobytes()       # any arrival order
+    with pytest.raises(ValueError):
+        packets.reassemble(groups[0][:-1])
+    # the sweeper's floor+1 rule emits an empty last frame when the length divides exactly
+    fr = packets.sweeper_fragments(b'x' * 2940, 1470)
+    assert len(fr) == 3 and fr[2][2:] == b'' and fr == R.sweeper_fragments(b'x' * 2940, 1470)
+
+
+def test_coherence_detector_decision_stage(golden):
+    import ofdm_tools
+    g = golden('coherence_scanner.npz')
+    calls = []
+    det = ofdm_tools.coherence_detector(int(g['N']), int(g['sample_rate']), threshold=10, threshold_mtm=0.2,
+                                        tune_freq=int(g['tune_freq']), subject_channels=list(g['subject_channels']),
+                                        valve_callback=calls.append)
+    assert det.idx_subject_channels == list(g['idx'])
+    stale = np.zeros_like(g['d0'])
+    # two vectors in one call: only the last one is scanned (last-vector rule)
+    n = det.work([np.stack([stale, g['d0']]), np.stack([stale, g['d1']]), np.stack([stale, g['d2']])], [])
+    assert n == 2
+    assert det.get_subject_channels_outcome() == list(g['outcome'])
+    assert calls == list(g['valve'])
+    assert np.allclose(det.subject_channels_coherence, g['coherence'])
+
+
+def test_block_constructor_signatures_match_the_reference():
+    """Argument names/order/defaults of the reference constructors."""
+    import ofdm_tools
+
+    def names(cls):
+        sig = inspect.signature(cls.__init__)
+        return [(p.name, p.default) for p in list(sig.parameters.values())[1:]]
+
+    def check(cls, expected):
+        got = names(cls)[:len(expected)]
+        assert [n for n, _ in got] == [n for n, _ in expected], cls
+        for (n, d), (_, e) in zip(got, expected):
+            if e is not inspect.Parameter.empty:
+                assert d == e, (cls, n)
+    E = inspect.Parameter.empty
+    check(ofdm_tools.spectrum_sensor_v2, [('fft_len', E), ('sens_per_sec', E), ('sample_rate', E),
+                                          ('channel_space', 1), ('search_bw', 1), ('thr_leveler', 10),
+                                          ('tune_freq', 0), ('alpha_avg', 1), ('test_duration', 1), ('period', 3600),
+                                          ('trunc_band', 1), ('verbose', False), ('stats', False), ('psd', False),
+                                          ('waterfall', False), ('output', False), ('subject_channels', [])])
+    check(ofdm_tools.psd_logger, [('fft_len', E), ('rate', E), ('sample_rate', E)])
+    check(ofdm_tools.coherence_detector, [('N', E), ('sample_rate', E), ('search_bw', 1), ('threshold', 10),
+                                          ('threshold_mtm', 0.2), ('tune_freq', 0), ('alpha_avg', 1),
+                                          ('test_duration', 1), ('period', 3600), ('stats', False), ('output', False),
+                                          ('rate', 10), ('subject_channels', []), ('valve_callback', None)])
+    check(ofdm_tools.spectrum_sweeper, [('rf_receiver', E), ('receiver_type', E), ('fft_len', E), ('sample_rate', E),
+                                        ('trunc_sample_rate', E), ('fstart', E), ('ffinish', E), ('rate', E),
+                                        ('average', E), ('t_obs', E), ('tune_delay', E), ('max_tu', E)])
+    check(ofdm_tools.multichannel_scanner, [('fft_len', E), ('sens_per_sec', E), ('sample_rate', E),
+                                            ('channel_space', 1), ('search_bw', 1), ('tune_freq', 0),
+                                            ('trunc_band', 1), ('verbose', False), ('output', False),
+                                            ('subject_channels', [])])
+    check(ofdm_tools.local_worker, [('fft_len', E), ('sample_rate', E), ('average', E), ('rate', E), ('max_tu', E),
+                                    ('data_precision', E)])
+    check(ofdm_tools.spectrum_sensor, [('block_length', E), ('sample_rate', 1), ('fft_len', 1), ('channel_space', 1),
+                                       ('search_bw', 1), ('method', 'fft'), ('thr_leveler', 10), ('tune_freq', 0),
+                                       ('alpha_avg', 1), ('source', None), ('log', False)])
+    for fn in ('frange', 'movingaverage', 'src_power', 'src_power_welch', 'src_power_fft', 'xcorr', 'fac',
+               'fast_spectrum_scan', 'welch_plot_dB', 'welch_power_estimate', 'clc_power_freq'):
+        assert callable(getattr(ofdm_tools.ofdm_cr_tools, fn))
+
+
+def test_scanner_geometry_and_slice_bounds_match_oracle():
+    from ofdm_tools import ofdm_cr_tools as T
+    from ofdm_tools.scanner import ChannelScanner
+    for (N, Sf, cs, sbw, tb) in [(1024, 1000000, 25e3, 12.5e3, 800000), (16384, 1000000, 15625.0, 10e3, 1000000),
+                                 (512, 250001, 12.5e3, 3e3, 200000)]:
+        a = ChannelScanner.__new__(ChannelScanner)
+        ChannelScanner.__init__(a, N, Sf, cs, sbw, tune_freq=5000, trunc_band=tb)
+        b = R.ScannerState(N, Sf, cs, sbw, tune_freq=5000, trunc_band=tb)
+        assert a.ax_ch == b.ax_ch and a.trunc_ch == b.trunc_ch and a.bb_freqs == b.bb_freqs
+        lo, hi = T._slice_bounds(N, a.Fr, Sf, a.bb_freqs, a.srch_bins)
+        psd = np.arange(N, dtype=np.float64)
+        ref = R._channel_sums(psd, a.Fr, Sf, a.bb_freqs, a.srch_bins)
+        assert [float(psd[l:h].sum()) for l, h in zip(lo, hi)] == ref
+
+
+def test_keep_one_in_n_capture_of_the_sweeper_without_gpu():
+    # the capture side of spectrum_sweeper is pure host logic; build it without a context
+    import ofdm_tools
+    blk = ofdm_tools.spectrum_sweeper.__new__(ofdm_tools.spectrum_sweeper)
+    blk.vector_probe_pts, blk._decim, blk._count = 64, 3, 3
+    blk._partial = np.empty(0, np.complex64)
+    blk.samples = None
+    x = np.arange(64 * 7 + 5).astype(np.complex64)
+    for lo in range(0, len(x), 50):
+        assert blk.work([x[lo:lo + 50]], []) == len(x[lo:lo + 50])
+    assert np.array_equal(blk.get_samples(), x[64 * 5:64 * 6])       # vectors 2 and 5 kept; 5 is the latest
+
+
+GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'gr-ofdm_tools_amd'))
+import numpy as np, torch, torch.distributed as dist
+from ofdm_tools import sweep
+from oracle import ref_cpu as R
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+nseg, nfft, excess, fs = %(nseg)d, 1024, 64, 2.0e6
+nbins = nfft - 2 * excess
+done = []
+def capture(i):
+    return R.synth_iq(8192, 2000 + i)
+def compute(iq, out_row):            # the oracle stands in for the HIP plan on CPU ranks
+    done.append(1)
+    out_row.copy_(torch.from_numpy(R.sweeper_src_power(iq, nfft, fs, excess).astype(np.float32)))
+wide = sweep.sweep_psd(capture, compute, nseg, nbins, torch.device('cpu'), rank, world)
+ref = np.concatenate([R.sweeper_src_power(capture(i), nfft, fs, excess) for i in range(nseg)]).astype(np.float32)
+assert wide.shape == (nseg * nbins,), wide.shape
+assert np.array_equal(wide.numpy(), ref), 'tune order broken'
+assert len(done) == len(sweep.shard_segments(nseg, rank, world))
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'ok', len(done))
+'''
+
+
+@pytest.mark.parametrize('nseg', [8, 5])
+def test_sweep_sharding_world_size_2_gloo(nseg, tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(GLOO_WORKER % {'root': ROOT, 'nseg': nseg})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + nseg), WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert 'ok %d' % ((nseg + 1) // 2) in outs[0] and 'ok %d' % (nseg // 2) in outs[1]
+
+
+def test_sweep_shard_assignment():
+    from ofdm_tools import sweep
+    assert sweep.shard_segments(8, 3, 8) == [3]
+    assert sweep.shard_segments(8, 1, 4) == [1, 5]
+    assert sorted(sum((sweep.shard_segments(13, r, 4) for r in range(4)), [])) == list(range(13))
+    assert sweep.segments_per_rank(13, 4) == 4
