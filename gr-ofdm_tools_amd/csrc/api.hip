@@ -192,17 +192,22 @@ struct W4096Variant {
     int (*blocks_per_cu)();
 };
 const W4096Variant kVariants[] = {
-    {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp},
+    {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp},           // any step
+    {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe},        // step 2048 (50 % overlap)
     {"noslp", launch_welch_tuned4096_noslp, tuned4096_blocks_per_cu_noslp},
     {"base", launch_welch_tuned4096_base, tuned4096_blocks_per_cu_base},
     {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag},
+    {"noload", launch_welch_tuned4096_noload, tuned4096_blocks_per_cu_noload},
 };
-const W4096Variant *w4096_variant() {
+const W4096Variant *w4096_variant(int step) {
     const char *e = getenv("OTH_W4096_VARIANT");
+    const W4096Variant *pick = (step == 2048) ? &kVariants[1] : &kVariants[0];
     if (e)
         for (const auto &v : kVariants)
-            if (!strcmp(e, v.tag)) return &v;
-    return &kVariants[0];
+            if (!strcmp(e, v.tag)) pick = &v;
+    // the pipelined build keeps the overlapped half in registers: only for step = nperseg / 2
+    if (!strcmp(pick->tag, "pipe") && step != 2048) pick = &kVariants[0];
+    return pick;
 }
 
 int segments(const oth_plan *p, size_t nsamples, long long *nseg) {
@@ -236,7 +241,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
     if (p->kernel == OTH_KERNEL_TUNED && !tuned)
         return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
-    const W4096Variant *var = tuned ? w4096_variant() : nullptr;
+    const W4096Variant *var = tuned ? w4096_variant(p->step) : nullptr;
     int W = generic_wg(c, p->nfft, nseg, nstreams);
     if (tuned) {
         // exactly the resident workgroups: one wave of workgroups, no tail round

@@ -70,6 +70,8 @@ OTH_DECL_W4096(base)
 OTH_DECL_W4096(noslp)
 OTH_DECL_W4096(dpp)
 OTH_DECL_W4096(diag)
+OTH_DECL_W4096(noload)
+OTH_DECL_W4096(pipe)
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s);
 hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,

@@ -35,6 +35,12 @@
 #ifndef OTH_W4096_DPP
 #define OTH_W4096_DPP 0
 #endif
+#ifndef OTH_W4096_PIPE
+#define OTH_W4096_PIPE 0     // 1: 50 %-overlap pipeline - the overlapped half stays in registers, the next
+#endif                       //    half is prefetched, pass-1 twiddles are rebuilt from W^t and W^4t (needs step 2048)
+#ifndef OTH_W4096_NOLOAD
+#define OTH_W4096_NOLOAD 0   // 1: timing-only build without the in-loop global loads
+#endif
 #ifndef OTH_W4096_DIAG
 #define OTH_W4096_DIAG 0     // 1: diagnostic build, every workgroup stamps start/end time + XCC id
 #endif
@@ -49,7 +55,7 @@ constexpr int T4 = 256;
 constexpr int RS = 272;                    // float2 per k0 region (16 x 17)
 constexpr int LDS_X = 16 * RS;             // exchange image
 constexpr int LDS_TW2 = 256;               // W256^(k1 c) as [k1][c]
-constexpr int LDS_RED = 8;                 // per-wave segment sums
+constexpr int LDS_RED = 16;                // per-wave half-segment sums (2 x 4) + chunk ticket
 constexpr size_t LDS_BYTES = (LDS_X + LDS_TW2 + LDS_RED) * sizeof(float2);
 
 constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
@@ -112,7 +118,7 @@ __device__ __forceinline__ float wave_total(float v) {
 }
 
 template <bool DETREND>
-__global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
+__global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(WelchArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lx = reinterpret_cast<float2 *>(smem);
     float2 *ltw2 = lx + LDS_X;
@@ -129,11 +135,17 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
 
     // thread-constant tables
     float win[16];
-    float2 tw1[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) win[a] = p.win[256 * a + t];
+#if OTH_W4096_PIPE
+    const float2 b1 = p.tw[t], b4 = p.tw[4 * t];      // W4096^t, W4096^(4t)
+    float2 keep[8], nxt[8];
+    float2 prev_tot = make_float2(0.f, 0.f);
+#else
+    float2 tw1[16];
 #pragma unroll
     for (int k = 1; k < 16; ++k) tw1[k] = p.tw[t * k];
+#endif
     ltw2[t] = p.tw[16 * hi * lo];           // [k1 = hi][c = lo]
 
     float acc[16];
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
     //                   the set of segments a workgroup sums depends on timing)
     const int sched = p.sched, C = p.chunk;
     const long long nchunks = sched ? (p.nseg + C - 1) / C : 1;
-    int *lnext = reinterpret_cast<int *>(red + 4);
+    int *lnext = reinterpret_cast<int *>(red + 8);
     unsigned ticket = 0;
     for (long long cur = sched ? wg : 0; cur < nchunks;) {
       long long sb = s0, se = s1;
@@ -161,13 +173,61 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
           sb = cur * C;
           se = sb + C < p.nseg ? sb + C : p.nseg;
       }
+#if OTH_W4096_PIPE
+      {   // chunk prologue: both halves of its first segment (half-block h = samples [2048 h, 2048 h + 2048))
+          const float2 *xs = xb + sb * 2048 + t;
+#pragma unroll
+          for (int a = 0; a < 8; ++a) keep[a] = xs[256 * a];
+#pragma unroll
+          for (int a = 0; a < 8; ++a) nxt[a] = xs[2048 + 256 * a];
+      }
+#endif
       for (long long s = sb; s < se; ++s) {
         float2 v[16];
+#if OTH_W4096_PIPE
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            v[a] = keep[a];
+            v[8 + a] = nxt[a];
+            keep[a] = nxt[a];
+        }
+        if (s + 1 < se) {   // the half the NEXT segment adds; lands while this segment is transformed
+            const float2 *xn = xb + (s + 2) * 2048 + t;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) nxt[a] = xn[256 * a];
+        }
+#elif OTH_W4096_NOLOAD
+        // timing-only experiment: no global loads inside the loop (results are wrong on purpose)
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            v[a] = make_float2(win[a] + (float)s, tw1[a | 1].x);
+            asm volatile("" : "+v"(v[a].x), "+v"(v[a].y));
+        }
+#else
         const float2 *xs = xb + s * p.step + t;
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = xs[256 * a];
+#endif
 
         float2 mean = make_float2(0.f, 0.f);
+#if OTH_W4096_PIPE
+        if (DETREND) {      // only the new half is summed; the other half's total is carried over
+            float2 sum = v[8];
+#pragma unroll
+            for (int a = 9; a < 16; ++a) sum = cadd(sum, v[a]);
+            sum.x = wave_total(sum.x);
+            sum.y = wave_total(sum.y);
+            if ((t & 63) == 0) red[t >> 6] = sum;
+            if (s == sb) {
+                float2 s0h = v[0];
+#pragma unroll
+                for (int a = 1; a < 8; ++a) s0h = cadd(s0h, v[a]);
+                s0h.x = wave_total(s0h.x);
+                s0h.y = wave_total(s0h.y);
+                if ((t & 63) == 0) red[4 + (t >> 6)] = s0h;
+            }
+        }
+#else
         if (DETREND) {
             float2 sum = v[0];
 #pragma unroll
@@ -176,6 +236,7 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
             sum.y = wave_total(sum.y);
             if ((t & 63) == 0) red[t >> 6] = sum;
         }
+#endif
         __syncthreads();   // A: previous segment's LDS reads are done; red[] visible
         if (sched == 2 && t == 0) {
             // draw the next chunk while this one is being transformed; publish it in the last segment
@@ -184,7 +245,14 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
         }
         if (DETREND) {
             const float2 s01 = cadd(red[0], red[1]), s23 = cadd(red[2], red[3]);
+#if OTH_W4096_PIPE
+            if (s == sb) prev_tot = cadd(cadd(red[4], red[5]), cadd(red[6], red[7]));
+            const float2 new_tot = cadd(s01, s23);
+            mean = make_float2((prev_tot.x + new_tot.x) * (1.0f / 4096.0f), (prev_tot.y + new_tot.y) * (1.0f / 4096.0f));
+            prev_tot = new_tot;
+#else
             mean = make_float2((s01.x + s23.x) * (1.0f / 4096.0f), (s01.y + s23.y) * (1.0f / 4096.0f));
+#endif
         }
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
@@ -192,8 +260,28 @@ __global__ __launch_bounds__(T4) void welch4096_kernel(WelchArgs p) {
         // pass 1: DFT over a, twiddle W4096^(k0 t), scatter to region k0
         dft16(v);
         lx[w1] = v[r16(0)];
+#if OTH_W4096_PIPE
+        {   // W^(k0 t), k0 = 4i + j, as W^(4i t) * W^(j t) from the two stored powers (13 complex products
+            // per segment buy back 26 VGPRs); the asm keeps the compiler from hoisting them into registers
+            float2 wj[4], wi[4];
+            wj[1] = b1;
+            wi[1] = b4;
+            asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wi[1].x), "+v"(wi[1].y));
+            wj[2] = cmul(wj[1], wj[1]);
+            wj[3] = cmul(wj[2], wj[1]);
+            wi[2] = cmul(wi[1], wi[1]);
+            wi[3] = cmul(wi[2], wi[1]);
+#pragma unroll
+            for (int k0 = 1; k0 < 16; ++k0) {
+                const int i = k0 >> 2, j = k0 & 3;
+                const float2 w = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
+                lx[k0 * RS + w1] = cmul(v[r16(k0)], w);
+            }
+        }
+#else
 #pragma unroll
         for (int k0 = 1; k0 < 16; ++k0) lx[k0 * RS + w1] = cmul(v[r16(k0)], tw1[k0]);
+#endif
         __syncthreads();   // B
 
         // pass 2: thread (k0,c) gathers b, DFT over b, twiddle W256^(k1 c)

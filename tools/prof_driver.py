@@ -21,6 +21,7 @@ ctx.set_timing(True)
 for _ in range(reps):
     plan.exec_dev(d_in, n, d_out)
 ms, k = ctx.get_timing()
-print('kernel avg ms %.4f over %d launches -> %.1f GB/s' % (ms / k, k, 8.0 * n / (ms / k) / 1e6))
+probe = ctx.stream_read_probe(d_in, n * 8, 2)
+print('kernel avg ms %.4f over %d launches -> %.1f GB/s; read probe %.1f GB/s' % (ms / k, k, 8.0 * n / (ms / k) / 1e6, 8.0 * n / probe / 1e6))
 ctx.free(d_in)
 ctx.free(d_out)
