@@ -237,15 +237,18 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     if (segments(p, nsamples, &nseg) != OTH_OK)
         return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
     const bool csd = (y != nullptr);
-    bool tuned = p->nfft == 4096 && p->nperseg == 4096 && !csd;
+    // welch4096 covers nperseg = 256, 512, ..., 4096 (zero-padded to 4096)
+    bool tuned = p->nfft == 4096 && p->nperseg >= 256 && (p->nperseg & (p->nperseg - 1)) == 0 && !csd;
+    const bool tuned_csd = csd && p->nfft == 4096 && p->nperseg == 4096 && p->kernel != OTH_KERNEL_GENERIC;
     if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
-    if (p->kernel == OTH_KERNEL_TUNED && !tuned)
+    if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd)
         return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
-    const W4096Variant *var = tuned ? w4096_variant(p->step) : nullptr;
+    const W4096Variant *var = tuned ? w4096_variant(p->nperseg == 4096 ? p->step : 0) : nullptr;
     int W = generic_wg(c, p->nfft, nseg, nstreams);
-    if (tuned) {
+    if (tuned || tuned_csd) {
         // exactly the resident workgroups: one wave of workgroups, no tail round
-        long long w = ((long long)c->cu_count * var->blocks_per_cu() + nstreams - 1) / nstreams;
+        const int bpc = tuned ? var->blocks_per_cu() : csd4096_blocks_per_cu();
+        long long w = ((long long)c->cu_count * bpc + nstreams - 1) / nstreams;
         W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
     }
     const int nch = csd ? 4 : 1;
@@ -271,7 +274,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.sched = 0;
     a.chunk = 1;
     a.queue = nullptr;
-    if (tuned) {
+    if (tuned || tuned_csd) {
         const char *e = getenv("OTH_W4096_SCHED");
         const char *ec = getenv("OTH_W4096_CHUNK");
         a.sched = e ? atoi(e) : p->sched;
@@ -288,11 +291,12 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     }
     {
         Timed tm(c);
-        HIPCHK(c, tuned ? var->launch(a, c->stream) : launch_welch_generic(p->nfft, a, c->stream));
+        HIPCHK(c, tuned ? var->launch(a, c->stream)
+                        : (tuned_csd ? launch_csd_tuned4096(a, c->stream) : launch_welch_generic(p->nfft, a, c->stream)));
     }
     *nseg_out = nseg;
     *W_out = W;
-    *layout_out = tuned ? 1 : 0;
+    *layout_out = (tuned || tuned_csd) ? 1 : 0;
     return OTH_OK;
 }
 

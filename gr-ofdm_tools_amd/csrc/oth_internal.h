@@ -72,6 +72,9 @@ OTH_DECL_W4096(dpp)
 OTH_DECL_W4096(diag)
 OTH_DECL_W4096(noload)
 OTH_DECL_W4096(pipe)
+// csd4096.hip: two-channel cross spectrum, nfft = nperseg = 4096
+hipError_t launch_csd_tuned4096(const WelchArgs &a, hipStream_t s);
+int csd4096_blocks_per_cu();
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s);
 hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,

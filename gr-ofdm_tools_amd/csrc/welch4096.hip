@@ -47,77 +47,15 @@
 #define OTH_CAT2(a, b) a##b
 #define OTH_CAT(a, b) OTH_CAT2(a, b)
 
+#include "fft4096.hip.h"
+
 namespace oth {
 
 namespace {
 
-constexpr int T4 = 256;
-constexpr int RS = 272;                    // float2 per k0 region (16 x 17)
-constexpr int LDS_X = 16 * RS;             // exchange image
-constexpr int LDS_TW2 = 256;               // W256^(k1 c) as [k1][c]
-constexpr int LDS_RED = 16;                // per-wave half-segment sums (2 x 4) + chunk ticket
-constexpr size_t LDS_BYTES = (LDS_X + LDS_TW2 + LDS_RED) * sizeof(float2);
-
-constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
-constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
-constexpr float RH = 0.70710678118654752f;   // sqrt(1/2)
-
-__device__ __forceinline__ float2 mul_w1(float2 a) { return make_float2(fmaf(a.x, C1, a.y * S1), fmaf(a.y, C1, -a.x * S1)); }
-__device__ __forceinline__ float2 mul_w2(float2 a) { return make_float2((a.x + a.y) * RH, (a.y - a.x) * RH); }
-__device__ __forceinline__ float2 mul_w3(float2 a) { return make_float2(fmaf(a.x, S1, a.y * C1), fmaf(a.y, S1, -a.x * C1)); }
-__device__ __forceinline__ float2 mul_w4(float2 a) { return make_float2(a.y, -a.x); }
-__device__ __forceinline__ float2 mul_w6(float2 a) { return make_float2((a.y - a.x) * RH, -(a.x + a.y) * RH); }
-__device__ __forceinline__ float2 mul_w9(float2 a) { return make_float2(-fmaf(a.x, C1, a.y * S1), fmaf(a.x, S1, -a.y * C1)); }
-
-// position of output k of dft16() inside v[]
-__host__ __device__ constexpr int r16(int k) { return 4 * (k & 3) + (k >> 2); }
-
-// Forward 16-point DFT in place: in v[a], a = 0..15; out y[k] at v[r16(k)].
-__device__ __forceinline__ void dft16(float2 (&v)[16]) {
-#pragma unroll
-    for (int a0 = 0; a0 < 4; ++a0) dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
-    v[5] = mul_w1(v[5]);
-    v[9] = mul_w2(v[9]);
-    v[13] = mul_w3(v[13]);
-    v[6] = mul_w2(v[6]);
-    v[10] = mul_w4(v[10]);
-    v[14] = mul_w6(v[14]);
-    v[7] = mul_w3(v[7]);
-    v[11] = mul_w6(v[11]);
-    v[15] = mul_w9(v[15]);
-#pragma unroll
-    for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
-}
-
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
-    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
-    return v + __int_as_float(x);
-}
-
-// Sum over the 64 lanes of a wave, same value returned in every lane.
-__device__ __forceinline__ float wave_total(float v) {
-#if OTH_W4096_DPP
-    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);   // row_half_mirror
-    v = dpp_add<0x140>(v);   // row_mirror: every lane now holds its row-of-16 sum
-    const int i = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16)) +
-           __int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48));
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-#endif
-}
-
-template <bool DETREND>
+// NA = nperseg / 256: rows a < NA of a segment hold samples, the rest is the zero padding up to 4096
+// (NA = 16: nperseg = nfft; NA = 4: the sweeper's nperseg = nfft / 4, spectrum_sweeper.py:263).
+template <bool DETREND, int NA>
 __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(WelchArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lx = reinterpret_cast<float2 *>(smem);
@@ -206,7 +144,7 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 #else
         const float2 *xs = xb + s * p.step + t;
 #pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = xs[256 * a];
+        for (int a = 0; a < 16; ++a) v[a] = (a < NA) ? xs[256 * a] : make_float2(0.f, 0.f);
 #endif
 
         float2 mean = make_float2(0.f, 0.f);
@@ -231,7 +169,7 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         if (DETREND) {
             float2 sum = v[0];
 #pragma unroll
-            for (int a = 1; a < 16; ++a) sum = cadd(sum, v[a]);
+            for (int a = 1; a < NA; ++a) sum = cadd(sum, v[a]);
             sum.x = wave_total(sum.x);
             sum.y = wave_total(sum.y);
             if ((t & 63) == 0) red[t >> 6] = sum;
@@ -251,11 +189,11 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
             mean = make_float2((prev_tot.x + new_tot.x) * (1.0f / 4096.0f), (prev_tot.y + new_tot.y) * (1.0f / 4096.0f));
             prev_tot = new_tot;
 #else
-            mean = make_float2((s01.x + s23.x) * (1.0f / 4096.0f), (s01.y + s23.y) * (1.0f / 4096.0f));
+            mean = make_float2((s01.x + s23.x) * (1.0f / (256.0f * NA)), (s01.y + s23.y) * (1.0f / (256.0f * NA)));
 #endif
         }
 #pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
+        for (int a = 0; a < NA; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
 
         // pass 1: DFT over a, twiddle W4096^(k0 t), scatter to region k0
         dft16(v);
@@ -329,17 +267,32 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 // resident 256-thread workgroups per CU for this build of the kernel (VGPR / LDS limited)
 int OTH_CAT(tuned4096_blocks_per_cu_, OTH_W4096_TAG)() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, welch4096_kernel<true>, T4, LDS_BYTES) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, welch4096_kernel<true, 16>, T4, LDS_BYTES) != hipSuccess || n < 1)
         n = 2;
     return n;
 }
 
 hipError_t OTH_CAT(launch_welch_tuned4096_, OTH_W4096_TAG)(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
-    if (a.detrend)
-        hipLaunchKernelGGL((welch4096_kernel<true>), grid, dim3(T4), LDS_BYTES, s, a);
-    else
-        hipLaunchKernelGGL((welch4096_kernel<false>), grid, dim3(T4), LDS_BYTES, s, a);
+#define OTH_W4096_LAUNCH(NA)                                                                         \
+    case 256 * NA:                                                                                   \
+        if (a.detrend)                                                                               \
+            hipLaunchKernelGGL((welch4096_kernel<true, NA>), grid, dim3(T4), LDS_BYTES, s, a);      \
+        else                                                                                         \
+            hipLaunchKernelGGL((welch4096_kernel<false, NA>), grid, dim3(T4), LDS_BYTES, s, a);     \
+        break;
+    switch (a.nperseg) {
+        OTH_W4096_LAUNCH(16)
+#if !OTH_W4096_PIPE
+        OTH_W4096_LAUNCH(8)
+        OTH_W4096_LAUNCH(4)
+        OTH_W4096_LAUNCH(2)
+        OTH_W4096_LAUNCH(1)
+#endif
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef OTH_W4096_LAUNCH
     return hipGetLastError();
 }
 

@@ -98,6 +98,17 @@ def test_sweeper_segment_zero_padded_shift_trim_db(ctx, golden):
     assert np.max(np.abs(db - g['expected_psd_db'])) < 1e-3
 
 
+@pytest.mark.parametrize('nperseg', [256, 512, 1024, 2048])
+def test_welch4096_zero_padded_segments_tuned_and_generic(ctx, hip, nperseg):
+    x = R.synth_iq(60000, 300 + nperseg)
+    for nov in (nperseg // 2, 0, nperseg - 1):
+        _, ref = R.welch_np(x, fs=5.0, window='flattop', nperseg=nperseg, noverlap=nov, nfft=4096)
+        for kern in (hip.KERNEL_TUNED, hip.KERNEL_GENERIC):
+            plan = ctx.welch_plan(4096, nperseg=nperseg, noverlap=nov, window=flattop(nperseg), fs=5.0, kernel=kern)
+            assert relerr(plan.exec(x), ref) < RTOL
+            plan.close()
+
+
 @pytest.mark.parametrize('nfft', [64, 128, 256, 512, 8192, 16384])
 def test_welch_all_sizes_vs_oracle(ctx, nfft):
     x = R.synth_iq(max(8 * nfft, 16384) + 37, 100 + nfft)
@@ -214,9 +225,11 @@ def test_time_sharded_partials_add_up(ctx):
 
 # ------------------------------------------------------------------ CSD ----
 
-def test_csd_coherence_golden(ctx, golden):
+@pytest.mark.parametrize('kernel', ['tuned', 'generic'])
+def test_csd_coherence_golden(ctx, hip, golden, kernel):
     g = golden('coherence_csd_4096.npz')
-    plan = ctx.welch_plan(4096, window=hann(4096), fs=float(g['fs']))
+    plan = ctx.welch_plan(4096, window=hann(4096), fs=float(g['fs']),
+                          kernel=hip.KERNEL_TUNED if kernel == 'tuned' else hip.KERNEL_GENERIC)
     pxx, pyy, pxy, cxy = plan.csd(g['x'], g['y'])
     assert relerr(pxx, g['expected_pxx']) < RTOL
     assert relerr(pyy, g['expected_pyy']) < RTOL
@@ -224,6 +237,26 @@ def test_csd_coherence_golden(ctx, golden):
     assert np.max(np.abs(pxy.astype(np.complex128) - e) / np.abs(e)) < 1e-3   # complex: relative to |Pxy|
     assert np.max(np.abs(pxy.astype(np.complex128) - e) / np.sqrt(g['expected_pxx'] * g['expected_pyy'])) < RTOL
     assert np.max(np.abs(cxy - g['expected_cxy'])) < RTOL
+
+
+def test_csd_many_segments_no_detrend_shifted(ctx, hip):
+    """More chunks than workgroups, fftshift + trim, detrend off: tuned CSD kernel vs oracle."""
+    n = 4096 + 2048 * 2999
+    x = R.synth_iq(n, 61)
+    y = (0.5 * np.roll(x, 3) + 0.8 * R.synth_iq(n, 62)).astype(np.complex64)
+    _, pxy = R.csd_np(x, y, fs=2.0, nperseg=4096, nfft=4096, detrend=False)
+    _, pxx = R.welch_np(x, fs=2.0, nperseg=4096, nfft=4096, detrend=False)
+    _, pyy = R.welch_np(y, fs=2.0, nperseg=4096, nfft=4096, detrend=False)
+    plan = ctx.welch_plan(4096, window=hann(4096), fs=2.0, detrend=hip.DETREND_NONE, fftshift=True, trim_bins=100,
+                          kernel=hip.KERNEL_TUNED)
+    gxx, gyy, gxy, gc = plan.csd(x, y)
+    assert plan.last_nseg == 3000
+    sl = slice(100, -100)
+    assert relerr(gxx, np.fft.fftshift(pxx)[sl]) < RTOL and relerr(gyy, np.fft.fftshift(pyy)[sl]) < RTOL
+    e = np.fft.fftshift(pxy)[sl]
+    scale = np.sqrt(np.fft.fftshift(pxx)[sl] * np.fft.fftshift(pyy)[sl])
+    assert np.max(np.abs(gxy.astype(np.complex128) - e) / scale) < RTOL
+    assert np.max(np.abs(gc - np.abs(e) ** 2 / scale ** 2)) < RTOL
 
 
 def test_coherence_of_identical_channels_is_one(ctx):
