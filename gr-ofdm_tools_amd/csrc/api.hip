@@ -198,6 +198,7 @@ const W4096Variant kVariants[] = {
     {"base", launch_welch_tuned4096_base, tuned4096_blocks_per_cu_base},
     {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag},
     {"noload", launch_welch_tuned4096_noload, tuned4096_blocks_per_cu_noload},
+    {"pipeasm", launch_welch_tuned4096_pipeasm, tuned4096_blocks_per_cu_pipeasm},
 };
 const W4096Variant *w4096_variant(int step) {
     const char *e = getenv("OTH_W4096_VARIANT");
@@ -206,7 +207,7 @@ const W4096Variant *w4096_variant(int step) {
         for (const auto &v : kVariants)
             if (!strcmp(e, v.tag)) pick = &v;
     // the pipelined build keeps the overlapped half in registers: only for step = nperseg / 2
-    if (!strcmp(pick->tag, "pipe") && step != 2048) pick = &kVariants[0];
+    if (!strncmp(pick->tag, "pipe", 4) && step != 2048) pick = &kVariants[0];
     return pick;
 }
 
@@ -240,21 +241,22 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     // welch4096 covers nperseg = 256, 512, ..., 4096 (zero-padded to 4096)
     bool tuned = p->nfft == 4096 && p->nperseg >= 256 && (p->nperseg & (p->nperseg - 1)) == 0 && !csd;
     const bool tuned_csd = csd && p->nfft == 4096 && p->nperseg == 4096 && p->kernel != OTH_KERNEL_GENERIC;
+    const bool tuned_16k = !csd && p->nfft == 16384 && p->nperseg == 16384 && p->kernel != OTH_KERNEL_GENERIC;
     if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
-    if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd)
+    if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd && !tuned_16k)
         return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
     const W4096Variant *var = tuned ? w4096_variant(p->nperseg == 4096 ? p->step : 0) : nullptr;
     int W = generic_wg(c, p->nfft, nseg, nstreams);
-    if (tuned || tuned_csd) {
+    if (tuned || tuned_csd || tuned_16k) {
         // exactly the resident workgroups: one wave of workgroups, no tail round
-        const int bpc = tuned ? var->blocks_per_cu() : csd4096_blocks_per_cu();
+        const int bpc = tuned ? var->blocks_per_cu() : (tuned_csd ? csd4096_blocks_per_cu() : 1);
         long long w = ((long long)c->cu_count * bpc + nstreams - 1) / nstreams;
         W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
     }
     const int nch = csd ? 4 : 1;
     // + 32 B per workgroup of stamp space behind the sums (only the diagnostic kernel build writes it)
     int rc = ensure(c, &p->d_partial, &p->partial_cap,
-                    sizeof(float) * (size_t)nstreams * W * nch * p->nfft + 32 * (size_t)nstreams * W);
+                    sizeof(float) * (size_t)nstreams * W * nch * p->nfft + (32 + 4 * 64) * (size_t)nstreams * W);
     p->last_W = W * nstreams;
     if (!rc) rc = ensure(c, &p->d_reduce, &p->reduce_cap, sizeof(float) * (size_t)nstreams * kReduceGroups * nch * p->nfft);
     if (rc) return rc;
@@ -274,11 +276,11 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.sched = 0;
     a.chunk = 1;
     a.queue = nullptr;
-    if (tuned || tuned_csd) {
+    if (tuned || tuned_csd || tuned_16k) {
         const char *e = getenv("OTH_W4096_SCHED");
         const char *ec = getenv("OTH_W4096_CHUNK");
         a.sched = e ? atoi(e) : p->sched;
-        a.chunk = ec ? atoi(ec) : 8;
+        a.chunk = ec ? atoi(ec) : (tuned_16k ? 2 : 8);
         if (a.chunk < 1) a.chunk = 1;
         if (a.sched < 0 || a.sched > 2) a.sched = 0;
         if (a.sched == 2) {
@@ -292,11 +294,13 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     {
         Timed tm(c);
         HIPCHK(c, tuned ? var->launch(a, c->stream)
-                        : (tuned_csd ? launch_csd_tuned4096(a, c->stream) : launch_welch_generic(p->nfft, a, c->stream)));
+                        : (tuned_csd ? launch_csd_tuned4096(a, c->stream)
+                                     : (tuned_16k ? launch_welch_tuned16k(a, c->stream)
+                                                  : launch_welch_generic(p->nfft, a, c->stream))));
     }
     *nseg_out = nseg;
     *W_out = W;
-    *layout_out = (tuned || tuned_csd) ? 1 : 0;
+    *layout_out = (tuned || tuned_csd) ? 1 : (tuned_16k ? 2 : 0);
     return OTH_OK;
 }
 
@@ -1071,8 +1075,9 @@ int oth__debug_stamps(oth_plan *p, unsigned long long *out, int max_wg, int *nwg
     if (!p || !out || !nwg) return OTH_ERR_INVALID;
     oth_ctx *c = p->ctx;
     const int n = p->last_W < max_wg ? p->last_W : max_wg;
-    HIPCHK(c, hipMemcpyAsync(out, p->d_partial + (size_t)p->last_W * p->nfft, 32 * (size_t)n, hipMemcpyDeviceToHost,
-                             c->stream));
+    if (n != p->last_W) return OTH_ERR_INVALID;      // records [n][4] then phases [n][4 waves][8]
+    HIPCHK(c, hipMemcpyAsync(out, p->d_partial + (size_t)p->last_W * p->nfft, (32 + 256) * (size_t)n,
+                             hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *nwg = n;
     return OTH_OK;

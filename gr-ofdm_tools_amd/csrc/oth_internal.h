@@ -52,7 +52,7 @@ struct FinalizeArgs {
     int W;
     int nfft;
     int nch;                // 1 or 4
-    int layout;             // 0 natural, 1 tuned-4096 digit order
+    int layout;             // 0 natural, 1 welch4096 digit order, 2 welch16k order (kernels_misc.hip bin_pos)
     int fftshift;
     int trim;
     int db;
@@ -72,9 +72,12 @@ OTH_DECL_W4096(dpp)
 OTH_DECL_W4096(diag)
 OTH_DECL_W4096(noload)
 OTH_DECL_W4096(pipe)
+OTH_DECL_W4096(pipeasm)
 // csd4096.hip: two-channel cross spectrum, nfft = nperseg = 4096
 hipError_t launch_csd_tuned4096(const WelchArgs &a, hipStream_t s);
 int csd4096_blocks_per_cu();
+// welch16k.hip: nfft = nperseg = 16384, one 1024-thread workgroup per CU
+hipError_t launch_welch_tuned16k(const WelchArgs &a, hipStream_t s);
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s);
 hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,

@@ -38,6 +38,9 @@
 #ifndef OTH_W4096_PIPE
 #define OTH_W4096_PIPE 0     // 1: 50 %-overlap pipeline - the overlapped half stays in registers, the next
 #endif                       //    half is prefetched, pass-1 twiddles are rebuilt from W^t and W^4t (needs step 2048)
+#ifndef OTH_W4096_ASMLDS
+#define OTH_W4096_ASMLDS 0   // 1: exchange reads as plain ds_read_b64 through one asm statement each
+#endif
 #ifndef OTH_W4096_NOLOAD
 #define OTH_W4096_NOLOAD 0   // 1: timing-only build without the in-loop global loads
 #endif
@@ -55,6 +58,20 @@ namespace {
 
 // NA = nperseg / 256: rows a < NA of a segment hold samples, the rest is the zero padding up to 4096
 // (NA = 16: nperseg = nfft; NA = 4: the sweeper's nperseg = nfft / 4, spectrum_sweeper.py:263).
+#if OTH_W4096_DIAG
+#define OTH_STAMP(i)                                                     \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): s_memtime */  \
+        phase[i] += now_ - last_;                                        \
+        last_ = now_;                                                    \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    } while (0)
+#else
+#define OTH_STAMP(i)
+#endif
+
 template <bool DETREND, int NA>
 __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(WelchArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -67,6 +84,8 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
     const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
 #if OTH_W4096_DIAG
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
     const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
     const float2 *xb = p.x + (size_t)stream * p.stream_stride;
@@ -122,6 +141,11 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 #endif
       for (long long s = sb; s < se; ++s) {
         float2 v[16];
+        OTH_STAMP(5);       // loop overhead / chunk prologue
+#if OTH_W4096_DIAG && OTH_W4096_PIPE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic only: isolate the wait for the prefetch
+        OTH_STAMP(6);
+#endif
 #if OTH_W4096_PIPE
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
@@ -175,7 +199,9 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
             if ((t & 63) == 0) red[t >> 6] = sum;
         }
 #endif
-        __syncthreads();   // A: previous segment's LDS reads are done; red[] visible
+        OTH_STAMP(0);       // loads issued, sums reduced
+        lds_barrier();     // A: previous segment's LDS reads are done; red[] visible
+        OTH_STAMP(1);       // wait at barrier A
         if (sched == 2 && t == 0) {
             // draw the next chunk while this one is being transformed; publish it in the last segment
             if (s == sb) ticket = atomicAdd(p.queue + stream, 1u);
@@ -220,11 +246,17 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 #pragma unroll
         for (int k0 = 1; k0 < 16; ++k0) lx[k0 * RS + w1] = cmul(v[r16(k0)], tw1[k0]);
 #endif
-        __syncthreads();   // B
+        OTH_STAMP(2);       // detrend, window, pass 1, exchange-1 writes
+        lds_barrier();     // B
+        OTH_STAMP(3);       // wait at barrier B
 
         // pass 2: thread (k0,c) gathers b, DFT over b, twiddle W256^(k1 c)
+#if OTH_W4096_ASMLDS
+        lds_read16_b64<17 * 8>(v, lx + r1);
+#else
 #pragma unroll
         for (int b = 0; b < 16; ++b) v[b] = lx[r1 + b * 17];
+#endif
         dft16(v);
         wave_lds_sync();   // the 16 lanes of this k0 have all read region k0
         lx[w2] = v[r16(0)];
@@ -233,14 +265,19 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         wave_lds_sync();
 
         // pass 3: thread (k0,k1) gathers c, DFT over c, accumulate |X|^2
+#if OTH_W4096_ASMLDS
+        lds_read16_b64<8>(v, lx + r2);
+#else
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] = lx[r2 + c];
+#endif
         dft16(v);
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             const float2 X = v[r16(k2)];
             acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
         }
+        OTH_STAMP(4);       // passes 2 and 3
       }
       if (sched == 0) break;
       cur = (sched == 1) ? cur + W : (long long)W + *lnext;   // *lnext was written before barrier B
@@ -258,6 +295,12 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         dbg[1] = __builtin_amdgcn_s_memrealtime();
         dbg[2] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID, bits [3:0]
         dbg[3] = (unsigned long long)(s1 - s0);
+    }
+    if ((t & 63) == 0) {   // per-wave phase cycle sums, 8 x u64 per wave behind the 32-byte records
+        unsigned long long *ph = reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * 4096) +
+                                 4 * (size_t)p.nstreams * W + 8 * (((size_t)stream * W + wg) * 4 + (t >> 6));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ph[i] = phase[i];
     }
 #endif
 }

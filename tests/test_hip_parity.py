@@ -117,6 +117,36 @@ def test_welch_all_sizes_vs_oracle(ctx, nfft):
     assert relerr(psd, ref) < RTOL
 
 
+@pytest.mark.parametrize('kernel', ['tuned', 'generic'])
+def test_welch16k_scanner_config_batched(ctx, hip, kernel):
+    """BASELINE config 5 shape: channel streams x 16384-point, rect window, no overlap, |X|^2/N^2 mean."""
+    N, ns, n = 16384, 6, 16384 * 9 + 100
+    xs = [R.synth_iq(n, 3000 + i) for i in range(ns)]
+    buf = np.concatenate(xs)
+    d_in, d_out = ctx.alloc(buf.nbytes), ctx.alloc(ns * N * 4)
+    try:
+        ctx.h2d(d_in, buf)
+        plan = ctx.welch_plan(N, noverlap=0, window=None, detrend=hip.DETREND_NONE, scaling=hip.SCALE_OVER_N2,
+                              fftshift=True, kernel=hip.KERNEL_TUNED if kernel == 'tuned' else hip.KERNEL_GENERIC)
+        assert plan.exec_dev(d_in, n, d_out, nstreams=ns, stream_stride=n) == 9
+        out = ctx.d2h(d_out, (ns, N), np.float32)
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+    for i, x in enumerate(xs):
+        ref = R.chain_sensor_v2(x, N).mean(axis=0)
+        assert relerr(out[i], ref) < RTOL
+
+
+def test_welch16k_hann_overlap_detrend_many_segments(ctx, hip):
+    x = R.synth_iq(16384 + 4096 * 700, 16)            # 701 segments at 75 % overlap > resident workgroups
+    _, ref = R.welch_np(x, fs=4.0, nperseg=16384, noverlap=12288, nfft=16384)
+    for sched in (hip.SCHED_DYNAMIC, hip.SCHED_CONTIGUOUS):
+        plan = ctx.welch_plan(16384, noverlap=12288, window=hann(16384), fs=4.0, kernel=hip.KERNEL_TUNED)
+        plan.set_schedule(sched)
+        assert relerr(plan.exec(x), ref) < RTOL and plan.last_nseg == 701
+
+
 def test_welch_no_detrend_rect_raw_scaling(ctx, hip):
     x = R.synth_iq(20000, 9)
     _, ref = R.welch_np(x, window='boxcar', nperseg=4096, noverlap=1000, nfft=4096, detrend=False, scaling='none')

@@ -30,34 +30,29 @@ ctx.synth_iq(d_in, n, 1002, ((0.5, 0.1234), (0.05, -0.31), (2.0, 0.4071)), 0.1 +
 plan = ctx.welch_plan(4096, window=windows.get_window('hann', 4096), fs=1.0, kernel=_hip.KERNEL_TUNED)
 gen = ctx.welch_plan(4096, window=windows.get_window('hann', 4096), fs=1.0, kernel=_hip.KERNEL_GENERIC)
 ref = gen.exec_device_src(d_in, min(n, 1 << 24)).astype(np.float64)
+burst = int(os.environ.get('AB_BURST', '20'))
 times = {v: [] for v in variants}
 ctx.set_timing(True)
-for r in range(rounds + 1):
+# clock ramp
+select(variants[0])
+for _ in range(200):
+    plan.exec_dev(d_in, n, d_out)
+ctx.get_timing()
+# interleaved rounds of sustained bursts (what bench.py does): `rounds` bursts of `burst` launches per variant
+for r in range(rounds):
     for v in variants:
         select(v)
-        plan.exec_dev(d_in, n, d_out)
-        ms, k = ctx.get_timing()
-        if r:
-            times[v].append(ms / k)
-# sustained: bursts of back-to-back launches (what bench.py does); clocks settle lower than in the
-# one-launch-then-sync rounds above
-burst = int(os.environ.get('AB_BURST', '20'))
-for v in variants:
-    select(v)
-    for _ in range(2):
         for _ in range(burst):
             plan.exec_dev(d_in, n, d_out)
         ms, k = ctx.get_timing()
-    times[v].append(('burst', ms / k))
+        times[v].append(ms / k)
 for v in variants:
     select(v)
     got = plan.exec_device_src(d_in, min(n, 1 << 24)).astype(np.float64)
     err = float(np.max(np.abs(got - ref) / ref))
-    bur = [x[1] for x in times[v] if isinstance(x, tuple)][0]
-    t = sorted(x for x in times[v] if not isinstance(x, tuple))
+    t = sorted(times[v])
     med = t[len(t) // 2]
-    print('%-12s median %.4f ms  min %.4f ms  -> %.0f GB/s (%.1f%% of 8 TB/s)  burst-of-%d avg %.4f ms (%.1f%%)  dev vs generic %.2e'
-          % (v, med, t[0], 8.0 * n / med / 1e6, 8.0 * n / med / 1e6 / 80.0, burst, bur, 8.0 * n / bur / 1e6 / 80.0,
-             err))
+    print('%-14s burst-of-%d median %.4f ms  min %.4f  max %.4f -> %.0f GB/s (%.1f%% of 8 TB/s)  dev vs generic %.2e'
+          % (v, burst, med, t[0], t[-1], 8.0 * n / med / 1e6, 8.0 * n / med / 1e6 / 80.0, err))
 ctx.free(d_in)
 ctx.free(d_out)
