@@ -96,11 +96,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
+    # rehearsal on a one-GPU box: BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo (RCCL refuses
+    # two ranks on one device); the driver's real multi-GPU runs use one GPU per rank and nccl (= RCCL)
+    rehearse = os.environ.get('BENCH_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     n = 1 << args.log2_samples
     multi = world > 1

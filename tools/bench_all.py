@@ -18,7 +18,7 @@ ctx = _hip.Context(0)
 REPS = int(os.environ.get('REPS', '20'))
 
 
-def timed(fn, reps=REPS, warm=3):
+def timed(fn, reps=REPS, warm=30):
     for _ in range(warm):
         fn()
     ctx.sync()
@@ -50,7 +50,7 @@ def ramp():
     ctx.synth_iq(d, n, 1, TONES, DC)
     plan = ctx.welch_plan(4096, window=windows.get_window('hann', 4096))
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.2:
+    while time.perf_counter() - t0 < 0.5:
         for _ in range(8):
             plan.exec_dev(d, n, o)
         ctx.sync()
@@ -70,7 +70,7 @@ if 'C2' in which:
     w, k = timed(lambda: plan.exec_dev(d, n, o))
     report('C2 welch hann 4096 50% 2^28', n, 8, w, k)
     gen = ctx.welch_plan(4096, window=windows.get_window('hann', 4096), kernel=_hip.KERNEL_GENERIC)
-    w, k = timed(lambda: gen.exec_dev(d, n, o), reps=3, warm=1)
+    w, k = timed(lambda: gen.exec_dev(d, n, o), reps=3, warm=3)
     report('C2 (generic Stockham kernel)', n, 8, w, k)
     ctx.free(d)
     ctx.free(o)
@@ -103,7 +103,7 @@ if 'C3' in which:
         ctx.check(ctx.lib.oth_csd_exec(plan.h, C.c_void_p(dx), C.c_void_p(dy), n, 1, _hip._fptr(outs[0]),
                                        _hip._fptr(outs[1]), _hip._fptr(outs[3]), _hip._fptr(outs[2]),
                                        C.byref(nseg)), 'csd')
-    w, k = timed(run, reps=5, warm=1)
+    w, k = timed(run, reps=10, warm=30)
     report('C3 csd/coherence hann 4096 2x2^26', n, 16, w, k)
     ctx.free(dx)
     ctx.free(dy)
@@ -117,7 +117,7 @@ for tag, kw in (('C4', dict(window=windows.get_window('hann', 4096))),
         for i in range(nseg_rf):
             ctx.synth_iq(d + i * S * 8, S, 2000 + i, TONES, DC)
         plan = ctx.welch_plan(4096, fs=2.0e6, fftshift=True, trim_bins=256, db=True, **kw)
-        w, k = timed(lambda: plan.exec_dev(d, S, o, nstreams=nseg_rf, stream_stride=S), reps=5, warm=1)
+        w, k = timed(lambda: plan.exec_dev(d, S, o, nstreams=nseg_rf, stream_stride=S), reps=10, warm=30)
         report('%s sweep 8 x 2^25, 1 GPU (%s)' % (tag, 'hann 4096' if tag == 'C4' else 'flattop nperseg 1024 -> 4096'),
                nseg_rf * S, 8, w, k)
         ctx.free(d)
@@ -131,7 +131,7 @@ if 'C5' in which:
         ctx.synth_iq(d + i * S * 8, S, 3000 + i, TONES, DC)
     plan = ctx.welch_plan(N, noverlap=0, window=None, detrend=_hip.DETREND_NONE, scaling=_hip.SCALE_OVER_N2,
                           fftshift=True)
-    w, k = timed(lambda: plan.exec_dev(d, S, o, nstreams=nch, stream_stride=S), reps=5, warm=1)
+    w, k = timed(lambda: plan.exec_dev(d, S, o, nstreams=nch, stream_stride=S), reps=10, warm=30)
     report('C5 scanner 64 ch x 2^22, 16384-pt rect mean', nch * S, 8, w, k)
     ctx.free(d)
     ctx.free(o)
