@@ -1045,6 +1045,28 @@ int oth_channel_power(oth_ctx *c, const float *psd_host, int nfft, double srch_b
     return OTH_OK;
 }
 
+int oth_bin_threshold(oth_ctx *c, const float *psd_host, int nrows, int nfft, double srch_bins, float thr_leveler,
+                      unsigned char *mask_out, float *noise_out) {
+    if (!c || !psd_host || !mask_out || nrows < 1 || nfft < 1 || !(srch_bins >= 1.0))
+        return fail(c, OTH_ERR_INVALID, "bad argument (srch_bins must be >= 1)");
+    if (use_device(c)) return OTH_ERR_HIP;
+    const size_t nb = (size_t)nrows * nfft;
+    unsigned char *d = nullptr;
+    const size_t o_mask = sizeof(float) * nb, o_noise = (o_mask + nb + 15) & ~(size_t)15;
+    if (hipMalloc(&d, o_noise + sizeof(float) * nrows) != hipSuccess) return fail(c, OTH_ERR_NOMEM, "hipMalloc failed");
+    hipError_t e = hipMemcpyAsync(d, psd_host, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = launch_bin_threshold((const float *)d, nrows, nfft, srch_bins, thr_leveler, d + o_mask,
+                                 (float *)(d + o_noise), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mask_out, d + o_mask, nb, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && noise_out)
+        e = hipMemcpyAsync(noise_out, d + o_noise, sizeof(float) * nrows, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, OTH_ERR_HIP, std::string("bin_threshold: ") + hipGetErrorString(e));
+    return OTH_OK;
+}
+
 static int xcorr_impl(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, int L, float *out, int mode) {
     if (!c || !a || !out || (mode == 0 && !b)) return fail(c, OTH_ERR_INVALID, "bad argument");
     if (!is_pow2(L) || !generic_supported(L)) return fail(c, OTH_ERR_UNSUPPORTED, "L must be a power of two in [64, 16384]");

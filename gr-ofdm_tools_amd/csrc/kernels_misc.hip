@@ -210,6 +210,38 @@ hipError_t launch_channel_power(const float *psd, int nfft, double srch_bins, in
     return hipGetLastError();
 }
 
+// Per-bin threshold: one workgroup per PSD row; noise = min over bins of the moving average.
+__global__ __launch_bounds__(256) void bin_threshold_kernel(const float *psd, int nfft, double srch_bins, float thr,
+                                                            unsigned char *mask, float *noise_out) {
+    __shared__ float red[4];
+    const float *row = psd + (size_t)blockIdx.x * nfft;
+    const int M = (int)srch_bins;
+    float mn = 3.4e38f;
+    for (int i = threadIdx.x; i < nfft; i += 256) {
+        const int top = i + (M - 1) / 2;
+        double s = 0.0;
+        for (int j = 0; j < M; ++j) {
+            const int n = top - j;
+            if (n >= 0 && n < nfft) s += (double)row[n];
+        }
+        mn = fminf(mn, (float)fabs(s / srch_bins));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    const float noise = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    if (threadIdx.x == 0 && noise_out) noise_out[blockIdx.x] = noise;
+    const float level = noise * thr;
+    for (int i = threadIdx.x; i < nfft; i += 256) mask[(size_t)blockIdx.x * nfft + i] = row[i] > level ? 1 : 0;
+}
+
+hipError_t launch_bin_threshold(const float *psd, int nrows, int nfft, double srch_bins, float thr,
+                                unsigned char *mask, float *noise, hipStream_t s) {
+    hipLaunchKernelGGL(bin_threshold_kernel, dim3(nrows), dim3(256), 0, s, psd, nfft, srch_bins, thr, mask, noise);
+    return hipGetLastError();
+}
+
 // ---- synthetic IQ -----------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;

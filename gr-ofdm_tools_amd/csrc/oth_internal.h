@@ -87,6 +87,8 @@ hipError_t launch_rows_epilogue(float *rows, long long nrows, int nfft, float al
 hipError_t launch_group_mean(const float *rows, long long ngroups, int nfft, int group, float *out, hipStream_t s);
 hipError_t launch_channel_power(const float *psd, int nfft, double srch_bins, int nch, const int *lo, const int *hi,
                                 double *movavg, float *power, float *movavg_f, hipStream_t s);
+hipError_t launch_bin_threshold(const float *psd, int nrows, int nfft, double srch_bins, float thr,
+                                unsigned char *mask, float *noise, hipStream_t s);
 hipError_t launch_xcorr(int L, const float2 *a, const float2 *b, const float2 *tw, float *out, int mode,
                         hipStream_t s);
 hipError_t launch_synth(float2 *iq, size_t n, uint64_t seed, int ntones, const float *amp, const float *freq,

@@ -85,6 +85,7 @@ SIGNATURES = {
     'oth_rows_group_mean': (C.c_int, [_p, _f, C.c_size_t, C.c_int, C.c_int, _f]),
     'oth_channel_power': (C.c_int, [_p, _f, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     _f, _f]),
+    'oth_bin_threshold': (C.c_int, [_p, _f, C.c_int, C.c_int, C.c_double, C.c_float, C.POINTER(C.c_ubyte), _f]),
     'oth_xcorr': (C.c_int, [_p, _p, C.c_size_t, _p, C.c_size_t, C.c_int, _f]),
     'oth_fac': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f]),
 }
@@ -240,6 +241,17 @@ class Context(object):
                                               hi.ctypes.data_as(C.POINTER(C.c_int)), _fptr(out),
                                               _fptr(ma) if want_movavg else None), 'oth_channel_power')
         return (out, ma) if want_movavg else out
+
+    def bin_threshold(self, psd_rows, srch_bins, thr_leveler):
+        """-> (mask uint8[nrows][nfft], noise float32[nrows]) for PSD rows (2-D) or one row (1-D)."""
+        rows = np.ascontiguousarray(np.atleast_2d(psd_rows), np.float32)
+        nrows, nfft = rows.shape
+        mask = np.empty((nrows, nfft), np.uint8)
+        noise = np.empty(nrows, np.float32)
+        self.check(self.lib.oth_bin_threshold(self.h, _fptr(rows), nrows, nfft, float(srch_bins), float(thr_leveler),
+                                              mask.ctypes.data_as(C.POINTER(C.c_ubyte)), _fptr(noise)),
+                   'oth_bin_threshold')
+        return mask, noise
 
     def xcorr(self, a, b, length):
         a, b = _c64(a)[:length], _c64(b)[:length]

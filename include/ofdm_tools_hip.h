@@ -196,6 +196,13 @@ int oth_rows_group_mean(oth_ctx *ctx, const float *rows_host, size_t nrows, int 
 int oth_channel_power(oth_ctx *ctx, const float *psd_host, int nfft, double srch_bins, int nch,
                       const int *lo, const int *hi, float *power_out, float *movavg_out /*nullable*/);
 
+/* Per-bin energy detection for the batched scanner (BASELINE config 5; the per-bin analogue of the
+ * channel threshold of spectrum_sensor_v2.py:465-477): noise = min_k movingaverage(psd)[k],
+ * mask[k] = psd[k] > thr_leveler * noise.  nrows PSD rows of nfft bins each (host); mask_out is
+ * uint8[nrows][nfft], noise_out float[nrows] (nullable). */
+int oth_bin_threshold(oth_ctx *ctx, const float *psd_host, int nrows, int nfft, double srch_bins,
+                      float thr_leveler, unsigned char *mask_out, float *noise_out);
+
 /* ---- xcorr (ofdm_cr_tools.py:155-161) ------------------------------------
  * |fftshift(ifft(fft(b,L) * conj(fft(a,L))))[L/2:]|, L a power of two <= 16384;
  * a, b host complex64 of na, nb <= L samples (zero-padded); out float[L - L/2]. */

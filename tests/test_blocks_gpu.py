@@ -219,3 +219,67 @@ def test_helper_functions_match_oracle(ctx):
         psd, axis, plc = fn_t(v, len(v), N, Fr, Sf, bb, 50e3 / Fr, ctx)
         psd2, axis2, plc2 = fn_r(v, len(v), N, Fr, Sf, bb, 50e3 / Fr)
         assert relerr(psd, psd2) < RTOL and np.allclose(plc, plc2, rtol=1e-4) and np.allclose(axis, axis2)
+
+
+def test_batched_scan_config5(ctx):
+    """64-channel-style batch (here 5 streams x 4 vectors of 16384): PSD rows, per-bin mask, channel powers."""
+    from ofdm_tools.scan_batch import BatchScanPlan
+    N, Sf, ns, n = 16384, 1000000, 5, 16384 * 4
+    xs = [R.synth_iq(n, 3000 + i) for i in range(ns)]
+    buf = np.concatenate(xs)
+    plan = BatchScanPlan(ctx, N, Sf, 15625.0, 10e3, thr_leveler=3)
+    d_in, d_out = ctx.alloc(buf.nbytes), ctx.alloc(ns * N * 4)
+    try:
+        ctx.h2d(d_in, buf)
+        assert plan.psd_rows_dev(d_in, n, ns, n, d_out) == 4
+        rows = ctx.d2h(d_out, (ns, N), np.float32)
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+    mask, noise, plc = plan.decide(rows)
+    st = R.ScannerState(N, Sf, 15625.0, 10e3, trunc_band=Sf)
+    for i, x in enumerate(xs):
+        ref = R.chain_sensor_v2(x, N).mean(axis=0)
+        assert relerr(rows[i], ref) < RTOL
+        ma = R.movingaverage(ref, st.srch_bins)
+        assert np.isclose(noise[i], ma.min(), rtol=1e-4)
+        want = ref > 3 * ma.min()
+        margin = np.abs(ref - 3 * ma.min()) > 1e-3 * ref          # bins that are not on the decision edge
+        assert np.array_equal(mask[i].astype(bool)[margin], want[margin])
+        assert 0 < mask[i].sum() < N                                # tones above, noise floor below
+        assert np.allclose(plc[i], R.src_power(ref, N, st.Fr, Sf, st.bb_freqs, st.srch_bins), rtol=1e-4)
+
+
+TORCH_STREAM_SCRIPT = r'''
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + '/gr-ofdm_tools_amd')
+import numpy as np, torch                      # torch first: both then share ONE HIP runtime (torch's)
+from ofdm_tools import _hip, windows
+from oracle import ref_cpu as R
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    c2 = _hip.Context(0, stream=s.cuda_stream)
+    x = R.synth_iq(40000, 4)
+    xt = torch.from_numpy(x.view(np.float32).copy()).cuda()
+    out = torch.empty(4096, dtype=torch.float32, device='cuda')
+    plan = c2.welch_plan(4096, window=windows.get_window('hann', 4096))
+    assert plan.exec_dev(xt.data_ptr(), len(x), out.data_ptr()) == 18
+    s.synchronize()
+_, ref = R.welch_np(x, nperseg=4096, nfft=4096)
+err = float(np.max(np.abs(out.cpu().numpy() - ref) / ref))
+assert err < 1e-4, err
+print('ok', err)
+'''
+
+
+def test_context_on_torch_stream(tmp_path):
+    """oth_ctx_create_on_stream: the library runs on a caller-owned HIP stream (torch's).  Own process,
+    torch imported first, as bench.py does - the library then binds to the HIP runtime torch loaded."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'torch_stream.py'
+    script.write_text(TORCH_STREAM_SCRIPT % {'root': root})
+    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0, p.stdout.decode()
