@@ -7,7 +7,8 @@
 A step = one pass of the hot path over one batch of synthetic IQ that is already
 resident in HBM: the radix-16 welch4096 kernel + the cross-workgroup finalize
 kernel (scale, fftshift, trim); at N > 1 also the all-gather (RCCL) that
-reassembles the wideband PSD of the sweep on every rank.
+reassembles the wideband PSD of the sweep on every rank (issued asynchronously so that it
+overlaps the next sweep's kernel; all gathers are complete before the clock stops).
 
 N = 1  workload "C2": one 2^28-sample complex64 stream (2 GiB), Hann, nperseg =
        nfft = 4096, 50 % overlap, detrend constant, density scaling (BASELINE
@@ -85,7 +86,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ofdm_tools import _hip, windows, sweep
+    from ofdm_tools import _hip, windows
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -121,16 +122,32 @@ def main():
     ctx.synth_iq(iq.data_ptr(), n, (2000 + rank) if multi else 1002, TONES, DC)
     plan = ctx.welch_plan(NFFT, window=windows.get_window('hann', NFFT), fs=1.0, fftshift=multi, trim_bins=trim)
     nseg = plan.nseg(n)
-    local = torch.zeros((1, nbins), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, nbins), dtype=torch.float32, device=dev) if multi else None
+    # two sets of buffers: the all-gather of sweep i overlaps the Welch kernel of sweep i+1
+    local = [torch.zeros((1, nbins), dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.empty((world, nbins), dtype=torch.float32, device=dev) for _ in range(2)] if multi else None
+    pending = [None, None]
+    count = [0]
 
     def step():
-        plan.exec_dev(iq.data_ptr(), n, local.data_ptr())
+        i = count[0] & 1
+        count[0] += 1
+        if multi and pending[i] is not None:
+            pending[i].wait()                     # sweep i-2 has been gathered: its buffers are free again
+            pending[i] = None
+        plan.exec_dev(iq.data_ptr(), n, local[i].data_ptr())
         if multi:
-            return sweep.gather_wideband(local, world, rank, world, out=gathered)
-        return local[0]
+            pending[i] = dist.all_gather_into_tensor(gathered[i], local[i], async_op=True)
+            return gathered[i]
+        return local[i][0]
+
+    def drain():
+        for i in range(2):
+            if multi and pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
 
     def fence():
+        drain()
         torch.cuda.synchronize(dev)
         if multi:
             dist.barrier()
@@ -207,6 +224,7 @@ def main():
         else:
             result['cpu_baseline'] = None
         assert int(wide.numel()) == world * nbins
+        assert bool(torch.isfinite(wide).all())
     if multi:
         dist.barrier()
         dist.destroy_process_group()

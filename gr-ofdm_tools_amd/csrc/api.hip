@@ -194,11 +194,7 @@ struct W4096Variant {
 const W4096Variant kVariants[] = {
     {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp},           // any step
     {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe},        // step 2048 (50 % overlap)
-    {"noslp", launch_welch_tuned4096_noslp, tuned4096_blocks_per_cu_noslp},
-    {"base", launch_welch_tuned4096_base, tuned4096_blocks_per_cu_base},
     {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag},
-    {"noload", launch_welch_tuned4096_noload, tuned4096_blocks_per_cu_noload},
-    {"pipeasm", launch_welch_tuned4096_pipeasm, tuned4096_blocks_per_cu_pipeasm},
 };
 const W4096Variant *w4096_variant(int step) {
     const char *e = getenv("OTH_W4096_VARIANT");
@@ -275,6 +271,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.nstreams = nstreams;
     a.sched = 0;
     a.chunk = 1;
+    a.tail_chunk = 1;
+    a.nbig = 0;
     a.queue = nullptr;
     if (tuned || tuned_csd || tuned_16k) {
         const char *e = getenv("OTH_W4096_SCHED");
@@ -282,11 +280,19 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         a.sched = e ? atoi(e) : p->sched;
         a.chunk = ec ? atoi(ec) : (tuned_16k ? 2 : 8);
         if (a.chunk < 1) a.chunk = 1;
+        a.tail_chunk = a.chunk;
+        a.nbig = nseg / a.chunk;
         if (a.sched < 0 || a.sched > 2) a.sched = 0;
         if (a.sched == 2) {
             if (nstreams > 64) a.sched = 1;
             else {
                 a.queue = c->queue;
+                // guided tail: the last half round of work goes out in quarter-size chunks
+                const char *et = getenv("OTH_W4096_TAIL");
+                a.tail_chunk = et ? atoi(et) : (a.chunk >= 4 ? a.chunk / 4 : 1);
+                if (a.tail_chunk < 1) a.tail_chunk = 1;
+                const long long tail_segs = (long long)W * a.chunk / 2;
+                a.nbig = nseg > tail_segs ? (nseg - tail_segs) / a.chunk : 0;
                 HIPCHK(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned) * nstreams, c->stream));
             }
         }

@@ -99,16 +99,13 @@ __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
         dft16(v);
     };
 
-    const int sched = p.sched, C = p.chunk;
-    const long long nchunks = sched ? (p.nseg + C - 1) / C : 1;
+    const int sched = p.sched;
+    const long long nchunks = sched ? chunk_count(p) : 1;
     int *lnext = reinterpret_cast<int *>(red + 8);
     unsigned ticket = 0;
     for (long long cur = sched ? wg : 0; cur < nchunks;) {
         long long sb = s0, se = s1;
-        if (sched) {
-            sb = cur * C;
-            se = sb + C < p.nseg ? sb + C : p.nseg;
-        }
+        if (sched) chunk_range(p, cur, sb, se);
         for (long long s = sb; s < se; ++s) {
             float2 X[16], v[16];
             transform(xb + s * p.step + t, X);

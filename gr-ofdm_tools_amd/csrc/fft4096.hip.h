@@ -5,10 +5,6 @@
 #include "fft_lds.hip.h"
 #include "oth_internal.h"
 
-#ifndef OTH_W4096_DPP
-#define OTH_W4096_DPP 1      // segment-sum wave reduction with DPP row ops + v_readlane (no LDS round trips)
-#endif
-
 namespace oth {
 namespace {
 
@@ -50,38 +46,26 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
 }
 
+// Chunk c of the segment schedule: the first `nbig` chunks have `chunk` segments, the rest `tail_chunk`
+// (smaller chunks for the last round even out the finish of the dynamic schedule).
+__device__ __forceinline__ long long chunk_count(const WelchArgs &p) {
+    const long long rest = p.nseg - p.nbig * p.chunk;
+    return p.nbig + (rest + p.tail_chunk - 1) / p.tail_chunk;
+}
+__device__ __forceinline__ void chunk_range(const WelchArgs &p, long long c, long long &sb, long long &se) {
+    if (c < p.nbig) {
+        sb = c * p.chunk;
+        se = sb + p.chunk;
+    } else {
+        sb = p.nbig * p.chunk + (c - p.nbig) * p.tail_chunk;
+        se = sb + p.tail_chunk < p.nseg ? sb + p.tail_chunk : p.nseg;
+    }
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
 // wait for the global prefetch of the next half-segment right after it was issued; here outstanding
 // global loads stay in flight across the barrier (the compiler still waits for them at first use).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// 16 x ds_read_b64 at byte offsets i * STRIDE_BYTES from one LDS address, issued as plain b64 reads
-// (hipcc pairs them into ds_read2_b64, which moves half the bytes per LDS cycle) and waited for in
-// the same statement, so the compiler never sees a register whose data is still in flight.
-typedef float oth_v2f __attribute__((ext_vector_type(2)));
-template <int STRIDE_BYTES>
-__device__ __forceinline__ void lds_read16_b64(float2 (&v)[16], const float2 *lds_ptr) {
-    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const float2 *)lds_ptr;
-    oth_v2f r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
-    asm volatile(
-        "ds_read_b64 %0, %16 offset:%17\n\tds_read_b64 %1, %16 offset:%18\n\tds_read_b64 %2, %16 offset:%19\n\t"
-        "ds_read_b64 %3, %16 offset:%20\n\tds_read_b64 %4, %16 offset:%21\n\tds_read_b64 %5, %16 offset:%22\n\t"
-        "ds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %16 offset:%24\n\tds_read_b64 %8, %16 offset:%25\n\t"
-        "ds_read_b64 %9, %16 offset:%26\n\tds_read_b64 %10, %16 offset:%27\n\tds_read_b64 %11, %16 offset:%28\n\t"
-        "ds_read_b64 %12, %16 offset:%29\n\tds_read_b64 %13, %16 offset:%30\n\tds_read_b64 %14, %16 offset:%31\n\t"
-        "ds_read_b64 %15, %16 offset:%32\n\ts_waitcnt lgkmcnt(0)"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8),
-          "=&v"(r9), "=&v"(r10), "=&v"(r11), "=&v"(r12), "=&v"(r13), "=&v"(r14), "=&v"(r15)
-        : "v"(a), "n"(0 * STRIDE_BYTES), "n"(1 * STRIDE_BYTES), "n"(2 * STRIDE_BYTES), "n"(3 * STRIDE_BYTES),
-          "n"(4 * STRIDE_BYTES), "n"(5 * STRIDE_BYTES), "n"(6 * STRIDE_BYTES), "n"(7 * STRIDE_BYTES),
-          "n"(8 * STRIDE_BYTES), "n"(9 * STRIDE_BYTES), "n"(10 * STRIDE_BYTES), "n"(11 * STRIDE_BYTES),
-          "n"(12 * STRIDE_BYTES), "n"(13 * STRIDE_BYTES), "n"(14 * STRIDE_BYTES), "n"(15 * STRIDE_BYTES)
-        : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const oth_v2f r[16] = {r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15};
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = make_float2(r[i].x, r[i].y);
-}
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -96,7 +80,7 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
 
 // Sum over the 64 lanes of a wave, same value returned in every lane.
 __device__ __forceinline__ float wave_total(float v) {
-#if OTH_W4096_DPP
+    // DPP row operations + v_readlane: no LDS round trips (six dependent ds_bpermute otherwise)
     v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
     v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
     v = dpp_add<0x141>(v);   // row_half_mirror
@@ -104,11 +88,6 @@ __device__ __forceinline__ float wave_total(float v) {
     const int i = __float_as_int(v);
     return __int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16)) +
            __int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48));
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-#endif
 }
 
 

@@ -23,6 +23,8 @@ struct WelchArgs {
     // welch4096 segment schedule: 0 contiguous, 1 interleaved chunks, 2 dynamic chunk queue
     int sched;
     int chunk;              // segments per chunk (sched 1, 2)
+    int tail_chunk;         // segments per chunk after the first nbig chunks
+    long long nbig;         // number of full-size chunks
     unsigned *queue;        // [nstreams] tickets, zeroed before the launch (sched 2)
 };
 
@@ -66,13 +68,9 @@ hipError_t launch_welch_generic(int nfft, const WelchArgs &a, hipStream_t s);
 #define OTH_DECL_W4096(tag)                                                     \
     hipError_t launch_welch_tuned4096_##tag(const WelchArgs &a, hipStream_t s); \
     int tuned4096_blocks_per_cu_##tag();
-OTH_DECL_W4096(base)
-OTH_DECL_W4096(noslp)
 OTH_DECL_W4096(dpp)
 OTH_DECL_W4096(diag)
-OTH_DECL_W4096(noload)
 OTH_DECL_W4096(pipe)
-OTH_DECL_W4096(pipeasm)
 // csd4096.hip: two-channel cross spectrum, nfft = nperseg = 4096
 hipError_t launch_csd_tuned4096(const WelchArgs &a, hipStream_t s);
 int csd4096_blocks_per_cu();

@@ -78,16 +78,13 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
     float2 *lx = lds + kp * REGION;                   // this sub-FFT's image
     const int w1 = hi * 17 + lo, r1 = hi * RS + lo, w2 = hi * RS + lo, r2 = hi * RS + lo * 17;
 
-    const int sched = p.sched, C = p.chunk;
-    const long long nchunks = sched ? (p.nseg + C - 1) / C : 1;
+    const int sched = p.sched;
+    const long long nchunks = sched ? chunk_count(p) : 1;
     int *lnext = reinterpret_cast<int *>(red + 16);
     unsigned ticket = 0;
     for (long long cur = sched ? wg : 0; cur < nchunks;) {
         long long sb = s0, se = s1;
-        if (sched) {
-            sb = cur * C;
-            se = sb + C < p.nseg ? sb + C : p.nseg;
-        }
+        if (sched) chunk_range(p, cur, sb, se);
         for (long long s = sb; s < se; ++s) {
             float2 v[16];
             const float2 *xs = xb + s * p.step + tid;

@@ -19,31 +19,31 @@
 // exchanges is bank-conflict free ("LDS image").
 //
 // HBM: lane t reads x[s*step + 256 a + t], 512 contiguous bytes per wave
-// instruction.  A workgroup owns a contiguous run of segments, so the second
-// half of segment s is re-read as the first half of s+1 from L2, not HBM.
-// The window (16 values) and the pass-1 twiddles (15 values) depend only on the
-// thread, so they live in registers for the whole run.
+// instruction.  The window (16 values per thread) stays in registers for the
+// whole launch.
+//
+// Two builds of this file ship (Makefile):
+//   dpp   any step / zero-padded nperseg: 16 loads per segment (the overlapped half comes back from
+//         L2), all 15 pass-1 twiddles in registers.
+//   pipe  step = 2048 (the 50 % overlap of the reference's welch() calls): the overlapped half of a
+//         segment stays in registers, the half the NEXT segment adds is prefetched while this one
+//         is transformed (LDS-only barriers keep it in flight), and only the new half is summed
+//         for the detrend.  The 32 extra data registers are paid for by rebuilding the pass-1
+//         twiddles W^(k0 t) from W^t and W^(4t) each segment (13 complex products), which keeps
+//         the kernel at 128 VGPRs = 4 workgroups per CU.
+// Segments reach workgroups in chunks through WelchArgs.sched (contiguous / interleaved /
+// atomic ticket); see the comment at the chunk loop.
 #include "fft_lds.hip.h"
 #include "oth_internal.h"
 
-// Build-time variants (the Makefile compiles this file once per variant; api.hip picks one):
+// Build-time switches (the Makefile compiles this file once per shipped build; api.hip picks one):
 //   OTH_W4096_TAG       suffix of the exported launcher
-//   OTH_W4096_DPP       1: segment-sum wave reduction with DPP row ops + v_readlane (no LDS round trips)
 #ifndef OTH_W4096_TAG
-#define OTH_W4096_TAG base
-#endif
-#ifndef OTH_W4096_DPP
-#define OTH_W4096_DPP 0
+#define OTH_W4096_TAG dpp
 #endif
 #ifndef OTH_W4096_PIPE
 #define OTH_W4096_PIPE 0     // 1: 50 %-overlap pipeline - the overlapped half stays in registers, the next
 #endif                       //    half is prefetched, pass-1 twiddles are rebuilt from W^t and W^4t (needs step 2048)
-#ifndef OTH_W4096_ASMLDS
-#define OTH_W4096_ASMLDS 0   // 1: exchange reads as plain ds_read_b64 through one asm statement each
-#endif
-#ifndef OTH_W4096_NOLOAD
-#define OTH_W4096_NOLOAD 0   // 1: timing-only build without the in-loop global loads
-#endif
 #ifndef OTH_W4096_DIAG
 #define OTH_W4096_DIAG 0     // 1: diagnostic build, every workgroup stamps start/end time + XCC id
 #endif
@@ -120,16 +120,13 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
     //   1  interleaved  chunk c = w, w + W, w + 2W, ... of `chunk` segments       (deterministic)
     //   2  dynamic      first chunk = w, then chunks drawn from an atomic ticket  (load-balanced;
     //                   the set of segments a workgroup sums depends on timing)
-    const int sched = p.sched, C = p.chunk;
-    const long long nchunks = sched ? (p.nseg + C - 1) / C : 1;
+    const int sched = p.sched;
+    const long long nchunks = sched ? chunk_count(p) : 1;
     int *lnext = reinterpret_cast<int *>(red + 8);
     unsigned ticket = 0;
     for (long long cur = sched ? wg : 0; cur < nchunks;) {
       long long sb = s0, se = s1;
-      if (sched) {
-          sb = cur * C;
-          se = sb + C < p.nseg ? sb + C : p.nseg;
-      }
+      if (sched) chunk_range(p, cur, sb, se);
 #if OTH_W4096_PIPE
       {   // chunk prologue: both halves of its first segment (half-block h = samples [2048 h, 2048 h + 2048))
           const float2 *xs = xb + sb * 2048 + t;
@@ -157,13 +154,6 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
             const float2 *xn = xb + (s + 2) * 2048 + t;
 #pragma unroll
             for (int a = 0; a < 8; ++a) nxt[a] = xn[256 * a];
-        }
-#elif OTH_W4096_NOLOAD
-        // timing-only experiment: no global loads inside the loop (results are wrong on purpose)
-#pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            v[a] = make_float2(win[a] + (float)s, tw1[a | 1].x);
-            asm volatile("" : "+v"(v[a].x), "+v"(v[a].y));
         }
 #else
         const float2 *xs = xb + s * p.step + t;
@@ -251,12 +241,8 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         OTH_STAMP(3);       // wait at barrier B
 
         // pass 2: thread (k0,c) gathers b, DFT over b, twiddle W256^(k1 c)
-#if OTH_W4096_ASMLDS
-        lds_read16_b64<17 * 8>(v, lx + r1);
-#else
 #pragma unroll
         for (int b = 0; b < 16; ++b) v[b] = lx[r1 + b * 17];
-#endif
         dft16(v);
         wave_lds_sync();   // the 16 lanes of this k0 have all read region k0
         lx[w2] = v[r16(0)];
@@ -265,12 +251,8 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         wave_lds_sync();
 
         // pass 3: thread (k0,k1) gathers c, DFT over c, accumulate |X|^2
-#if OTH_W4096_ASMLDS
-        lds_read16_b64<8>(v, lx + r2);
-#else
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] = lx[r2 + c];
-#endif
         dft16(v);
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {

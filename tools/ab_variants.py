@@ -12,14 +12,18 @@ from ofdm_tools import _hip, windows  # noqa: E402
 
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-variants = sys.argv[3:] or ['noslp:0:8', 'dpp:0:8', 'dpp:1:4', 'dpp:1:16', 'dpp:2:2', 'dpp:2:4', 'dpp:2:8', 'dpp:2:16']
+variants = sys.argv[3:] or ['dpp:0:8', 'dpp:2:8', 'pipe:0:8', 'pipe:2:8', 'pipe:2:16']
 
 
 def select(v):
-    tag, sched, chunk = (v.split(':') + ['0', '8'])[:3]
+    tag, sched, chunk, tail = (v.split(':') + ['0', '8', ''])[:4]
     os.environ['OTH_W4096_VARIANT'] = tag
     os.environ['OTH_W4096_SCHED'] = sched
     os.environ['OTH_W4096_CHUNK'] = chunk
+    if tail:
+        os.environ['OTH_W4096_TAIL'] = tail
+    else:
+        os.environ.pop('OTH_W4096_TAIL', None)
 
 
 n = 1 << log2n
@@ -52,7 +56,7 @@ for v in variants:
     err = float(np.max(np.abs(got - ref) / ref))
     t = sorted(times[v])
     med = t[len(t) // 2]
-    print('%-14s burst-of-%d median %.4f ms  min %.4f  max %.4f -> %.0f GB/s (%.1f%% of 8 TB/s)  dev vs generic %.2e'
+    print('%-16s burst-of-%d median %.4f ms  min %.4f  max %.4f -> %.0f GB/s (%.1f%% of 8 TB/s)  dev vs generic %.2e'
           % (v, burst, med, t[0], t[-1], 8.0 * n / med / 1e6, 8.0 * n / med / 1e6 / 80.0, err))
 ctx.free(d_in)
 ctx.free(d_out)

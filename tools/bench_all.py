@@ -59,7 +59,7 @@ def ramp():
 
 
 ramp()
-which = sys.argv[1:] or ['C1', 'C2', 'C3', 'C4', 'C4ref', 'C5']
+which = sys.argv[1:] or ['C1', 'C2', 'C3', 'C4', 'C4ref', 'C5', 'H2D']
 
 if 'C2' in which:
     n = 1 << 28
@@ -74,6 +74,21 @@ if 'C2' in which:
     report('C2 (generic Stockham kernel)', n, 8, w, k)
     ctx.free(d)
     ctx.free(o)
+
+if 'H2D' in which:
+    # host buffer -> PSD on the host (pageable numpy memory through oth_welch_exec): PCIe-inclusive
+    n = 1 << 26
+    x = np.zeros(n, np.complex64)
+    x.real = 1.0
+    plan = ctx.welch_plan(4096, window=windows.get_window('hann', 4096))
+    plan.exec(x)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        plan.exec(x)
+    w = (time.perf_counter() - t0) / 3 * 1e3
+    print(json.dumps(dict(config='C2 host->host (PCIe-inclusive, pageable numpy buffer, 2^26 samples)', samples=n,
+                          wall_ms=round(w, 3), Msamples_per_s=round(n / w / 1e3, 1),
+                          GBps=round(8.0 * n / w / 1e6, 2))), flush=True)
 
 if 'C1' in which:
     n = 1 << 20
