@@ -141,10 +141,12 @@ __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
 }  // namespace
 
 int csd4096_blocks_per_cu() {
+    static int cached = 0;
+    if (cached) return cached;
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, csd4096_kernel<true>, T4, CSD_LDS_BYTES) != hipSuccess || n < 1)
         n = 2;
-    return n;
+    return cached = n;
 }
 
 hipError_t launch_csd_tuned4096(const WelchArgs &a, hipStream_t s) {

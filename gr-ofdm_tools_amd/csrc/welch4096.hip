@@ -291,10 +291,12 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 
 // resident 256-thread workgroups per CU for this build of the kernel (VGPR / LDS limited)
 int OTH_CAT(tuned4096_blocks_per_cu_, OTH_W4096_TAG)() {
+    static int cached = 0;      // same answer for every device of the node (all gfx950)
+    if (cached) return cached;
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, welch4096_kernel<true, 16>, T4, LDS_BYTES) != hipSuccess || n < 1)
         n = 2;
-    return n;
+    return cached = n;
 }
 
 hipError_t OTH_CAT(launch_welch_tuned4096_, OTH_W4096_TAG)(const WelchArgs &a, hipStream_t s) {

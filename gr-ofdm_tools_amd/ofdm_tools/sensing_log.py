@@ -62,31 +62,45 @@ class logger(object):
     def set_cumulative_waterfall(self, v):
         self.cumulative_waterfall = v
 
-    def _path(self, stem, ext):
-        return os.path.join(self.directory, '%s-%s-%s.%s' % (stem, self.start_dat, self.start_tim, ext))
+    def _path(self, stem, ext, dat=None, tim=None):
+        return os.path.join(self.directory, '%s-%s-%s.%s' % (stem, dat or self.start_dat, tim or self.start_tim, ext))
+
+    @staticmethod
+    def _write_stats(path, settings, statistics):
+        # file_logger writes the pair twice (ofdm_cr_tools.py:2013-2017)
+        with open(path, 'w') as fh:
+            for _ in range(2):
+                fh.write('settings ' + str(settings) + '\n')
+                fh.write('statistics ' + str(statistics) + '\n')
 
     def flush(self, directory=None):
-        """Write the cumulative files the way file_logger.run does (ofdm_cr_tools.py:2010-2046)."""
+        """One pass of file_logger.run (ofdm_cr_tools.py:2010-2058): rewrite the cumulative files, write the
+        periodic ones, append the waterfall rows, then start a new period (new periodic file names, periodic
+        state and waterfall buffer reset).  Returns the paths written."""
         if directory is not None:
             self.directory = directory
         if self.directory is None:
             raise ValueError('no log directory configured')
         os.makedirs(self.directory, exist_ok=True)
-        out = {}
-        if self.cumulative_psd is not None:
-            out['psd'] = self._path('sdr_psd_cumulative_log', 'matz')
-            with open(out['psd'], 'wb') as fh:
-                np.save(fh, self.cumulative_psd)
-        if self.cumulative_max_power is not None:
-            out['max_power'] = self._path('sdr_max_power_cumulative_log', 'matz')
-            with open(out['max_power'], 'wb') as fh:
-                np.save(fh, self.cumulative_max_power)
-        out['stat'] = self._path('sdr_ss_cumulative_log', 'log')
-        with open(out['stat'], 'w') as fh:
-            fh.write('Settings' + '\n' + str(self.settings) + '\n')
-            fh.write('Statistics' + '\n' + str(self.cumulative_statistics) + '\n')
-        if self.cumulative_waterfall:
-            out['waterfall'] = self._path('sdr_waterfall_cumulative_log', 'matz')
-            with open(out['waterfall'], 'ab') as fh:
+        if not hasattr(self, '_period_stamp'):
+            self._period_stamp = (self.start_dat, self.start_tim)
+        pd, pt = self._period_stamp
+        out = {'stat': self._path('sdr_ss_cumulative_log', 'log'),
+               'periodic_stat': self._path('sdr_ss_periodic_log', 'log', pd, pt),
+               'psd': self._path('sdr_psd_cumulative_log', 'matz'),
+               'periodic_psd': self._path('sdr_psd_periodic_log', 'matz', pd, pt),
+               'max_power': self._path('sdr_max_power_cumulative_log', 'matz'),
+               'periodic_max_power': self._path('sdr_max_power_periodic_log', 'matz', pd, pt),
+               'waterfall': self._path('sdr_waterfall_cumulative_log', 'matz')}
+        self._write_stats(out['stat'], self.settings, self.cumulative_statistics)
+        self._write_stats(out['periodic_stat'], self.settings, self.periodic_statistic)
+        for key, val in (('psd', self.cumulative_psd), ('periodic_psd', self.periodic_psd_peaks),
+                         ('max_power', self.cumulative_max_power), ('periodic_max_power', self.periodic_max_power)):
+            with open(out[key], 'wb') as fh:
+                np.save(fh, val)            # np.save(None) stores an object array, as the reference does
+        with open(out['waterfall'], 'ab') as fh:
+            if len(self.cumulative_waterfall):
                 np.savetxt(fh, np.array(self.cumulative_waterfall), fmt='%1.2e', delimiter=',')
+        self._period_stamp = (time.strftime('%y%m%d'), time.strftime('%H%M%S'))
+        self.reset_periodic_vars()
         return out

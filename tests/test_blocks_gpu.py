@@ -50,7 +50,7 @@ def test_spectrum_sensor_v2_state_sequence(ctx, golden, tmp_path):
     assert [last[i][1] for i in range(4)] == [f - 100000000 for f in g['top4']]
     files = blk._logger.flush()
     assert relerr(np.load(files['psd']), g['peak']) < RTOL
-    assert str(blk._logger.cumulative_statistics) in open(files['stat']).read()
+    assert 'statistics ' + str(blk._logger.cumulative_statistics) in open(files['stat']).read()
 
 
 def test_spectrum_sensor_v2_decimation_and_scheduler_chunks(ctx):

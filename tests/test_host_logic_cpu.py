@@ -173,3 +173,32 @@ def test_sweep_shard_assignment():
     assert sweep.shard_segments(8, 1, 4) == [1, 5]
     assert sorted(sum((sweep.shard_segments(13, r, 4) for r in range(4)), [])) == list(range(13))
     assert sweep.segments_per_rank(13, 4) == 4
+
+
+def test_sensing_log_file_formats(tmp_path):
+    """On-disk formats of the reference's file_logger (python/ofdm_cr_tools.py:2010-2058)."""
+    from ofdm_tools.sensing_log import logger
+    lg = logger(1024, 3600, 10, directory=str(tmp_path))
+    lg.settings = {'fft_len': 1024, 'n_measurements': 3}
+    lg.cumulative_statistics = {100.0e6: 2}
+    lg.periodic_statistic = {100.0e6: 1}
+    lg.set_cumulative_psd(np.arange(4, dtype=np.float32))
+    lg.set_periodic_psd_peaks(np.arange(4, dtype=np.float32) * 2)
+    lg.set_cumulative_max_power(np.array([1.0, 2.0]))
+    lg.set_periodic_max_power(np.array([0.5, 2.0]))
+    lg.cumulative_waterfall.append(np.array([1.234e-5, 6.5e-7], np.float32))
+    out = lg.flush()
+    want = ("settings {'fft_len': 1024, 'n_measurements': 3}\nstatistics {100000000.0: 2}\n") * 2
+    assert open(out['stat']).read() == want
+    assert 'statistics {100000000.0: 1}' in open(out['periodic_stat']).read()
+    assert np.array_equal(np.load(out['psd']), np.arange(4, dtype=np.float32))
+    assert np.array_equal(np.load(out['periodic_psd']), np.arange(4, dtype=np.float32) * 2)
+    assert np.array_equal(np.load(out['periodic_max_power']), [0.5, 2.0])
+    assert open(out['waterfall']).read() == '1.23e-05,6.50e-07\n'
+    # a new period started: periodic state is reset, cumulative state kept, waterfall appends
+    assert lg.periodic_psd_peaks is None and lg.periodic_statistic == {} and lg.cumulative_waterfall == []
+    assert lg.cumulative_statistics == {100.0e6: 2}
+    lg.cumulative_waterfall.append(np.array([2.0, 3.0], np.float32))
+    out2 = lg.flush()
+    assert open(out2['waterfall']).read() == '1.23e-05,6.50e-07\n2.00e+00,3.00e+00\n'
+    assert np.load(out2['periodic_psd'], allow_pickle=True).item() is None
