@@ -195,6 +195,12 @@ const W4096Variant kVariants[] = {
     {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp},           // any step
     {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe},        // step 2048 (50 % overlap)
     {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag},
+#ifdef OTH_EXPERIMENTS
+    {"exp1", launch_welch_tuned4096_exp1, tuned4096_blocks_per_cu_exp1},
+    {"exp2", launch_welch_tuned4096_exp2, tuned4096_blocks_per_cu_exp2},
+    {"exp3", launch_welch_tuned4096_exp3, tuned4096_blocks_per_cu_exp3},
+    {"exp4", launch_welch_tuned4096_exp4, tuned4096_blocks_per_cu_exp4},
+#endif
 };
 const W4096Variant *w4096_variant(int step) {
     const char *e = getenv("OTH_W4096_VARIANT");
@@ -203,7 +209,7 @@ const W4096Variant *w4096_variant(int step) {
         for (const auto &v : kVariants)
             if (!strcmp(e, v.tag)) pick = &v;
     // the pipelined build keeps the overlapped half in registers: only for step = nperseg / 2
-    if (!strncmp(pick->tag, "pipe", 4) && step != 2048) pick = &kVariants[0];
+    if ((!strncmp(pick->tag, "pipe", 4) || !strncmp(pick->tag, "exp", 3)) && step != 2048) pick = &kVariants[0];
     return pick;
 }
 
@@ -252,7 +258,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     const int nch = csd ? 4 : 1;
     // + 32 B per workgroup of stamp space behind the sums (only the diagnostic kernel build writes it)
     int rc = ensure(c, &p->d_partial, &p->partial_cap,
-                    sizeof(float) * (size_t)nstreams * W * nch * p->nfft + (32 + 4 * 64) * (size_t)nstreams * W);
+                    sizeof(float) * (size_t)nstreams * W * nch * p->nfft + (32 + 4 * 96) * (size_t)nstreams * W);
     p->last_W = W * nstreams;
     if (!rc) rc = ensure(c, &p->d_reduce, &p->reduce_cap, sizeof(float) * (size_t)nstreams * kReduceGroups * nch * p->nfft);
     if (rc) return rc;
@@ -1103,8 +1109,8 @@ int oth__debug_stamps(oth_plan *p, unsigned long long *out, int max_wg, int *nwg
     if (!p || !out || !nwg) return OTH_ERR_INVALID;
     oth_ctx *c = p->ctx;
     const int n = p->last_W < max_wg ? p->last_W : max_wg;
-    if (n != p->last_W) return OTH_ERR_INVALID;      // records [n][4] then phases [n][4 waves][8]
-    HIPCHK(c, hipMemcpyAsync(out, p->d_partial + (size_t)p->last_W * p->nfft, (32 + 256) * (size_t)n,
+    if (n != p->last_W) return OTH_ERR_INVALID;      // records [n][4] then phases [n][4 waves][12]
+    HIPCHK(c, hipMemcpyAsync(out, p->d_partial + (size_t)p->last_W * p->nfft, (32 + 384) * (size_t)n,
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *nwg = n;

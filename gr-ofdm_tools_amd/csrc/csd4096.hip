@@ -22,8 +22,7 @@ template <bool DETREND>
 __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lx = reinterpret_cast<float2 *>(smem);
-    float2 *ltw2 = lx + LDS_X;
-    float2 *red = ltw2 + LDS_TW2;
+    float2 *red = lx + LDS_X;
     float *lwin = reinterpret_cast<float *>(red + LDS_RED);
 
     const int t = threadIdx.x;
@@ -36,7 +35,7 @@ __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
 #pragma unroll
     for (int a = 0; a < 16; ++a) lwin[256 * a + t] = p.win[256 * a + t];
     const float2 b1 = p.tw[t], b4 = p.tw[4 * t];
-    ltw2[t] = p.tw[16 * hi * lo];
+    const float2 c1 = p.tw[16 * lo], c4 = p.tw[64 * lo];
 
     float axx[16], ayy[16], are[16], aim[16];
 #pragma unroll
@@ -46,6 +45,7 @@ __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
 
     // One 4096-point transform of the segment at xs; result bins k0 + 16 k1 + 256 k2 in v[r16(k2)].
     auto transform = [&](const float2 *xs, float2(&v)[16]) {
+        prio_latency();
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = xs[256 * a];
         float2 mean = make_float2(0.f, 0.f);
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
             if ((t & 63) == 0) red[t >> 6] = sum;
         }
         __syncthreads();   // A
+        prio_compute();
         if (DETREND) {
             const float2 s01 = cadd(red[0], red[1]), s23 = cadd(red[2], red[3]);
             mean = make_float2((s01.x + s23.x) * (1.0f / 4096.0f), (s01.y + s23.y) * (1.0f / 4096.0f));
@@ -68,34 +69,20 @@ __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
             v[a] = make_float2((v[a].x - mean.x) * w, (v[a].y - mean.y) * w);
         }
         dft16(v);
-        lx[w1] = v[r16(0)];
-        {
-            float2 wj[4], wi[4];
-            wj[1] = b1;
-            wi[1] = b4;
-            asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wi[1].x), "+v"(wi[1].y));
-            wj[2] = cmul(wj[1], wj[1]);
-            wj[3] = cmul(wj[2], wj[1]);
-            wi[2] = cmul(wi[1], wi[1]);
-            wi[3] = cmul(wi[2], wi[1]);
-#pragma unroll
-            for (int k0 = 1; k0 < 16; ++k0) {
-                const int i = k0 >> 2, j = k0 & 3;
-                const float2 w = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
-                lx[k0 * RS + w1] = cmul(v[r16(k0)], w);
-            }
-        }
+        prio_latency();
+        scatter_pow16<RS>(v, lx + w1, b1, b4);
         __syncthreads();   // B
 #pragma unroll
         for (int b = 0; b < 16; ++b) v[b] = lx[r1 + b * 17];
+        prio_compute();
         dft16(v);
+        prio_latency();
         wave_lds_sync();
-        lx[w2] = v[r16(0)];
-#pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) lx[w2 + k1 * 17] = cmul(v[r16(k1)], ltw2[k1 * 16 + lo]);
+        scatter_pow16<17>(v, lx + w2, c1, c4);
         wave_lds_sync();
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] = lx[r2 + c];
+        prio_compute();
         dft16(v);
     };
 

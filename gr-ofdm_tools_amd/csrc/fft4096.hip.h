@@ -11,9 +11,8 @@ namespace {
 constexpr int T4 = 256;
 constexpr int RS = 272;                    // float2 per k0 region (16 x 17)
 constexpr int LDS_X = 16 * RS;             // exchange image
-constexpr int LDS_TW2 = 256;               // W256^(k1 c) as [k1][c]
 constexpr int LDS_RED = 16;                // per-wave half-segment sums (2 x 4) + chunk ticket
-constexpr size_t LDS_BYTES = (LDS_X + LDS_TW2 + LDS_RED) * sizeof(float2);
+constexpr size_t LDS_BYTES = (LDS_X + LDS_RED) * sizeof(float2);
 
 constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
 constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
@@ -62,10 +61,41 @@ __device__ __forceinline__ void chunk_range(const WelchArgs &p, long long c, lon
     }
 }
 
+// Wave priority.  Everything that starts long-latency work or releases other waves (global loads, the
+// segment sum, LDS exchanges, barriers) runs at raised priority so that it is issued as early as
+// possible; the three 16-point butterflies, pure VALU, run at base priority and fill the gaps of the
+// other waves on the SIMD.  Measured on welch4096: 0.676 -> 0.655 ms.
+__device__ __forceinline__ void prio_latency() { __builtin_amdgcn_s_setprio(2); }
+__device__ __forceinline__ void prio_compute() { __builtin_amdgcn_s_setprio(0); }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
 // wait for the global prefetch of the next half-segment right after it was issued; here outstanding
 // global loads stay in flight across the barrier (the compiler still waits for them at first use).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// out[STRIDE * k] = v[r16(k)] * W^k for k = 0..15, where W^k is rebuilt from p1 = W and p4 = W^4 as
+// (W^4)^i * W^j, k = 4i + j: 13 complex products per call instead of 15 stored (30 VGPRs) or loaded
+// values.  Loading them from an LDS table costs more than the arithmetic: hipcc issues one table read,
+// waits lgkmcnt(0), multiplies and writes, fifteen exposed LDS round trips per exchange.  The empty asm
+// keeps the loop-invariant powers from being hoisted back into registers.
+template <int STRIDE>
+__device__ __forceinline__ void scatter_pow16(const float2 (&v)[16], float2 *out, float2 p1, float2 p4) {
+    float2 wj[4], wi[4];
+    wj[1] = p1;
+    wi[1] = p4;
+    asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wi[1].x), "+v"(wi[1].y));
+    wj[2] = cmul(wj[1], wj[1]);
+    wj[3] = cmul(wj[2], wj[1]);
+    wi[2] = cmul(wi[1], wi[1]);
+    wi[3] = cmul(wi[2], wi[1]);
+    out[0] = v[0];                              // r16(0) == 0
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const int i = k >> 2, j = k & 3;
+        const float2 w = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
+        out[STRIDE * k] = cmul(v[r16(k)], w);
+    }
+}
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

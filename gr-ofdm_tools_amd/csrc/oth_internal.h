@@ -70,6 +70,12 @@ hipError_t launch_welch_generic(int nfft, const WelchArgs &a, hipStream_t s);
     int tuned4096_blocks_per_cu_##tag();
 OTH_DECL_W4096(dpp)
 OTH_DECL_W4096(diag)
+#ifdef OTH_EXPERIMENTS
+OTH_DECL_W4096(exp1)
+OTH_DECL_W4096(exp2)
+OTH_DECL_W4096(exp3)
+OTH_DECL_W4096(exp4)
+#endif
 OTH_DECL_W4096(pipe)
 // csd4096.hip: two-channel cross spectrum, nfft = nperseg = 4096
 hipError_t launch_csd_tuned4096(const WelchArgs &a, hipStream_t s);

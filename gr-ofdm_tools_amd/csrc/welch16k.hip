@@ -21,7 +21,7 @@ namespace {
 constexpr int T16 = 1024;
 constexpr int REGION = 16 * RS;                     // float2 per sub-FFT image
 constexpr int LDS16_RED = 32;                       // 16 wave sums + ticket
-constexpr size_t LDS16_BYTES = (4 * REGION + LDS_TW2 + LDS16_RED) * sizeof(float2);
+constexpr size_t LDS16_BYTES = (4 * REGION + LDS16_RED) * sizeof(float2);
 
 // multiply by exp(-2 pi i q / 16), q a compile-time constant 0..9 (the products j * k' that occur)
 template <int Q> __device__ __forceinline__ float2 mul_w16(float2 a) {
@@ -47,8 +47,7 @@ template <bool DETREND>
 __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
-    float2 *ltw2 = lds + 4 * REGION;
-    float2 *red = ltw2 + LDS_TW2;
+    float2 *red = lds + 4 * REGION;
 
     const int tid = threadIdx.x;
     const int kp = tid >> 8, t = tid & 255;          // sub-FFT k', thread inside it
@@ -68,7 +67,7 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
 #pragma unroll
     for (int k = 1; k < 4; ++k) wt[k] = p.tw[k * tid];
     const float2 b1 = p.tw[4 * t], b4 = p.tw[16 * t];
-    if (tid < 256) ltw2[tid] = p.tw[64 * hi * lo];    // W256^(k1 c) = W16384^(64 k1 c), [k1 = hi][c = lo]
+    const float2 c1 = p.tw[64 * lo], c4 = p.tw[256 * lo];   // W256^c = W16384^(64 c), W256^(4c)
 
     float acc[16];
 #pragma unroll
@@ -87,6 +86,7 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
         if (sched) chunk_range(p, cur, sb, se);
         for (long long s = sb; s < se; ++s) {
             float2 v[16];
+            prio_latency();
             const float2 *xs = xb + s * p.step + tid;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
                 if ((tid & 63) == 0) red[tid >> 6] = sum;
             }
             lds_barrier();   // A0: previous segment's reads are done; red[] visible
+            prio_compute();
             if (sched == 2 && tid == 0) {
                 if (s == sb) ticket = atomicAdd(p.queue + stream, 1u);
                 if (s == se - 1) *lnext = (int)ticket;
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
             }
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
+            prio_latency();
             pass0_scatter<0>(v, wt, l0);
             pass0_scatter<1>(v, wt, l0);
             pass0_scatter<2>(v, wt, l0);
@@ -122,37 +124,24 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = lx[256 * a + t];
             lds_barrier();   // A: every thread holds its 16 points, the image may be overwritten
+            prio_compute();
 
             // 4096-point transform of sub-FFT k' (welch4096.hip passes 1..3)
             dft16(v);
-            lx[w1] = v[r16(0)];
-            {
-                float2 wj[4], wi[4];
-                wj[1] = b1;
-                wi[1] = b4;
-                asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wi[1].x), "+v"(wi[1].y));
-                wj[2] = cmul(wj[1], wj[1]);
-                wj[3] = cmul(wj[2], wj[1]);
-                wi[2] = cmul(wi[1], wi[1]);
-                wi[3] = cmul(wi[2], wi[1]);
-#pragma unroll
-                for (int k0 = 1; k0 < 16; ++k0) {
-                    const int i = k0 >> 2, j = k0 & 3;
-                    const float2 w = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
-                    lx[k0 * RS + w1] = cmul(v[r16(k0)], w);
-                }
-            }
+            prio_latency();
+            scatter_pow16<RS>(v, lx + w1, b1, b4);
             lds_barrier();   // B
 #pragma unroll
             for (int b = 0; b < 16; ++b) v[b] = lx[r1 + b * 17];
+            prio_compute();
             dft16(v);
+            prio_latency();
             wave_lds_sync();
-            lx[w2] = v[r16(0)];
-#pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) lx[w2 + k1 * 17] = cmul(v[r16(k1)], ltw2[k1 * 16 + lo]);
+            scatter_pow16<17>(v, lx + w2, c1, c4);
             wave_lds_sync();
 #pragma unroll
             for (int c = 0; c < 16; ++c) v[c] = lx[r2 + c];
+            prio_compute();
             dft16(v);
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {

@@ -76,15 +76,14 @@ template <bool DETREND, int NA>
 __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(WelchArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lx = reinterpret_cast<float2 *>(smem);
-    float2 *ltw2 = lx + LDS_X;
-    float2 *red = ltw2 + LDS_TW2;
+    float2 *red = lx + LDS_X;
 
     const int t = threadIdx.x;
     const int hi = t >> 4, lo = t & 15;
     const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
 #if OTH_W4096_DIAG
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long phase[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
     const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 #pragma unroll
     for (int k = 1; k < 16; ++k) tw1[k] = p.tw[t * k];
 #endif
-    ltw2[t] = p.tw[16 * hi * lo];           // [k1 = hi][c = lo]
+    const float2 c1 = p.tw[16 * lo], c4 = p.tw[64 * lo];   // pass-2 twiddle seeds W256^c, W256^(4c)
 
     float acc[16];
 #pragma unroll
@@ -138,6 +137,7 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 #endif
       for (long long s = sb; s < se; ++s) {
         float2 v[16];
+        prio_latency();
         OTH_STAMP(5);       // loop overhead / chunk prologue
 #if OTH_W4096_DIAG && OTH_W4096_PIPE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic only: isolate the wait for the prefetch
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         OTH_STAMP(0);       // loads issued, sums reduced
         lds_barrier();     // A: previous segment's LDS reads are done; red[] visible
         OTH_STAMP(1);       // wait at barrier A
+        prio_compute();
         if (sched == 2 && t == 0) {
             // draw the next chunk while this one is being transformed; publish it in the last segment
             if (s == sb) ticket = atomicAdd(p.queue + stream, 1u);
@@ -213,26 +214,11 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 
         // pass 1: DFT over a, twiddle W4096^(k0 t), scatter to region k0
         dft16(v);
-        lx[w1] = v[r16(0)];
+        prio_latency();
 #if OTH_W4096_PIPE
-        {   // W^(k0 t), k0 = 4i + j, as W^(4i t) * W^(j t) from the two stored powers (13 complex products
-            // per segment buy back 26 VGPRs); the asm keeps the compiler from hoisting them into registers
-            float2 wj[4], wi[4];
-            wj[1] = b1;
-            wi[1] = b4;
-            asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wi[1].x), "+v"(wi[1].y));
-            wj[2] = cmul(wj[1], wj[1]);
-            wj[3] = cmul(wj[2], wj[1]);
-            wi[2] = cmul(wi[1], wi[1]);
-            wi[3] = cmul(wi[2], wi[1]);
-#pragma unroll
-            for (int k0 = 1; k0 < 16; ++k0) {
-                const int i = k0 >> 2, j = k0 & 3;
-                const float2 w = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
-                lx[k0 * RS + w1] = cmul(v[r16(k0)], w);
-            }
-        }
+        scatter_pow16<RS>(v, lx + w1, b1, b4);
 #else
+        lx[w1] = v[r16(0)];
 #pragma unroll
         for (int k0 = 1; k0 < 16; ++k0) lx[k0 * RS + w1] = cmul(v[r16(k0)], tw1[k0]);
 #endif
@@ -243,16 +229,26 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         // pass 2: thread (k0,c) gathers b, DFT over b, twiddle W256^(k1 c)
 #pragma unroll
         for (int b = 0; b < 16; ++b) v[b] = lx[r1 + b * 17];
+#if OTH_W4096_DIAG
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        OTH_STAMP(7);       // exchange-1 reads landed
+#endif
+        prio_compute();
         dft16(v);
+        prio_latency();
         wave_lds_sync();   // the 16 lanes of this k0 have all read region k0
-        lx[w2] = v[r16(0)];
-#pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) lx[w2 + k1 * 17] = cmul(v[r16(k1)], ltw2[k1 * 16 + lo]);
+        scatter_pow16<17>(v, lx + w2, c1, c4);
         wave_lds_sync();
+        OTH_STAMP(8);       // second butterfly, W256 twiddles, exchange-2 writes issued
 
         // pass 3: thread (k0,k1) gathers c, DFT over c, accumulate |X|^2
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] = lx[r2 + c];
+#if OTH_W4096_DIAG
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        OTH_STAMP(9);       // exchange-2 writes + reads landed
+#endif
+        prio_compute();
         dft16(v);
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
@@ -278,11 +274,11 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         dbg[2] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID, bits [3:0]
         dbg[3] = (unsigned long long)(s1 - s0);
     }
-    if ((t & 63) == 0) {   // per-wave phase cycle sums, 8 x u64 per wave behind the 32-byte records
+    if ((t & 63) == 0) {   // per-wave phase cycle sums, 12 x u64 per wave behind the 32-byte records
         unsigned long long *ph = reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * 4096) +
-                                 4 * (size_t)p.nstreams * W + 8 * (((size_t)stream * W + wg) * 4 + (t >> 6));
+                                 4 * (size_t)p.nstreams * W + 12 * (((size_t)stream * W + wg) * 4 + (t >> 6));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ph[i] = phase[i];
+        for (int i = 0; i < 12; ++i) ph[i] = phase[i];
     }
 #endif
 }

@@ -19,18 +19,18 @@ os.environ['OTH_W4096_VARIANT'] = 'diag'
 for rep in range(3):
     plan.exec_dev(d_in, n, d_out)
     ctx.sync()
-    buf = np.zeros(1024 * (4 + 32), np.uint64)
+    buf = np.zeros(1024 * (4 + 48), np.uint64)
     nwg = C.c_int()
     fn = ctx.lib.oth__debug_stamps
     fn.restype = C.c_int
     rc = fn(plan.h, buf.ctypes.data_as(C.c_void_p), 1024, C.byref(nwg))
     assert rc == 0 and nwg.value == 1024
     b = buf[:1024 * 4].reshape(1024, 4).astype(np.int64)
-    ph = buf[1024 * 4:].reshape(1024, 4, 8).astype(np.float64)
+    ph = buf[1024 * 4:].reshape(1024, 4, 12).astype(np.float64)
     tot = ph.sum(axis=2, keepdims=True)
     share = (ph / tot).mean(axis=(0, 1)) * 100
-    print('   phase shares %%: prefetch-wait + copy + loads + sums %.1f | wait A %.1f | pass1+ex1 %.1f | wait B %.1f | pass2+3 %.1f | loop/chunk %.1f | prefetch wait %.1f  '
-          '(cycles per wave %.3g)' % (share[0], share[1], share[2], share[3], share[4], share[5], share[6], tot.mean()))
+    print('   phase shares %%: prefetch-wait + copy + loads + sums %.1f | wait A %.1f | pass1+ex1 %.1f | wait B %.1f | ex1 read wait %.1f | dft2+tw2+ex2 write %.1f | ex2 landed %.1f | dft3+acc %.1f | loop/chunk %.1f | prefetch wait %.1f  '
+          '(cycles per wave %.3g)' % (share[0], share[1], share[2], share[3], share[7], share[8], share[9], share[4], share[5], share[6], tot.mean()))
     t0 = b[:, 0].min()
     start = (b[:, 0] - t0) / 100.0   # us (100 MHz)
     end = (b[:, 1] - t0) / 100.0
