@@ -154,6 +154,10 @@ def test_spectrum_sweeper_sweep_and_wire_format(ctx):
     payload = packets.reassemble(frames)
     assert np.allclose(np.frombuffer(payload, '<f4'), psd.astype(np.float32))
     assert frames == R.sweeper_fragments(struct.pack('<%df' % len(psd), *psd), 1470)
+    # the sharded sweep (one process here: rank 0 of 1) gives the same wideband PSD
+    import torch
+    wide = blk.sweep_once_sharded(lambda i, f: vectors[i], 0, 1, torch.device('cpu'))
+    assert np.allclose(wide, psd, rtol=1e-6)
     # flowgraph side: work() keeps the last complete capture
     blk2 = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 1e9, 0.0, 8, 0, 1472, ctx=ctx)
     x = R.synth_iq(pts * 2 + 100, 5)

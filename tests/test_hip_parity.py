@@ -409,3 +409,48 @@ def test_full_size_256M_properties(ctx, hip):
         assert relerr(plan.exec(pre), ref) < RTOL
     finally:
         ctx.free(d_in)
+
+
+# ------------------------------------------------- randomized plan sweep ----
+
+def test_randomized_welch_plans_vs_oracle(ctx, hip):
+    """60 random plans (sizes, segment lengths, overlaps, windows, detrend, scaling, shift/trim/dB,
+    kernel choice) against the float64 oracle - catches dispatch mistakes between the kernels."""
+    rng = np.random.default_rng(20261004)
+    x_all = R.synth_iq(300000, 99)
+    for it in range(60):
+        nfft = int(rng.choice([64, 256, 1024, 2048, 4096, 4096, 4096, 8192, 16384]))
+        if rng.random() < 0.5:
+            nperseg = nfft
+        else:
+            nperseg = int(rng.choice([nfft // 4, nfft // 2, nfft - 1, max(8, nfft // 3)]))
+        noverlap = int(rng.choice([0, nperseg // 2, nperseg // 4, nperseg - 1, min(nperseg - 1, 7)]))
+        detrend = bool(rng.integers(2))
+        scaling = str(rng.choice(['density', 'spectrum']))
+        fs = float(rng.choice([1.0, 2.5e6]))
+        shift = bool(rng.integers(2))
+        trim = int(rng.choice([0, 0, nfft // 16]))
+        db = bool(rng.integers(2))
+        wkind = str(rng.choice(['hann', 'flattop', 'blackmanharris', 'random']))
+        w = (R.get_window(wkind, nperseg) if wkind != 'random' else 0.2 + rng.random(nperseg))
+        n = int(rng.integers(nperseg, min(len(x_all), nperseg + 40 * max(1, nperseg - noverlap)) + 1))
+        x = x_all[:n]
+        _, ref = R.welch_np(x, fs=fs, window=w, nperseg=nperseg, noverlap=noverlap, nfft=nfft,
+                            detrend='constant' if detrend else False, scaling=scaling)
+        if shift:
+            ref = np.fft.fftshift(ref)
+        if trim:
+            ref = ref[trim:-trim]
+        kern = hip.KERNEL_GENERIC if rng.random() < 0.25 else hip.KERNEL_AUTO
+        plan = ctx.welch_plan(nfft, nperseg=nperseg, noverlap=noverlap, window=w,
+                              detrend=hip.DETREND_CONSTANT if detrend else hip.DETREND_NONE,
+                              scaling=hip.SCALE_DENSITY if scaling == 'density' else hip.SCALE_SPECTRUM, fs=fs,
+                              fftshift=shift, trim_bins=trim, db=db, kernel=kern)
+        got = plan.exec(x).astype(np.float64)
+        if db:
+            got = 10 ** (got / 10)
+        assert got.shape == ref.shape
+        # a detrended rectangular-ish window can leave a bin near zero; judge against the spectrum's scale
+        err = np.max(np.abs(got - ref) / np.maximum(ref, 1e-6 * ref.max()))
+        assert err < RTOL, (it, nfft, nperseg, noverlap, detrend, scaling, wkind, shift, trim, db, kern, err)
+        plan.close()
