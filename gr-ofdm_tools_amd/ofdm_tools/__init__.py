@@ -14,9 +14,11 @@ from ._hip import HipError, HipUnavailable  # noqa: F401
 # as python/__init__.py:49-84 does, the class replaces the same-named submodule attribute
 from .spectrum_sensor import spectrum_sensor  # noqa: F401,E402
 from .psd_logger import psd_logger  # noqa: F401,E402
+from .spectrum_sensor_v1 import spectrum_sensor_v1  # noqa: F401,E402
 from .spectrum_sensor_v2 import spectrum_sensor_v2  # noqa: F401,E402
 from .message_pdu import message_pdu  # noqa: F401,E402
 from .coherence_detector import coherence_detector, coherence_estimator  # noqa: F401,E402
 from .multichannel_scanner import multichannel_scanner  # noqa: F401,E402
 from .local_worker import local_worker  # noqa: F401,E402
 from .spectrum_sweeper import spectrum_sweeper  # noqa: F401,E402
+from .flanck_detector import flanck_detector  # noqa: F401,E402

@@ -552,3 +552,59 @@ def welch_reference_call(vector, nFFT, Sf):
         warnings.simplefilter('ignore')
         axis, psd = sg.welch(vector, fs=Sf, nperseg=nFFT, nfft=nFFT)
     return np.fft.fftshift(psd)
+
+
+# --------------------------------------------------------------------------
+# flanck_detector (python/flanck_detector.py) - rising / falling edges of channel power
+# --------------------------------------------------------------------------
+
+
+class FlankState(object):
+    """_queue0_watcher.__init__ / flank_detector, flanck_detector.py:262-311 and :345-399."""
+
+    def __init__(self, fft_len, sample_rate, channel_space, search_bw, subject_channels, tune_freq=0,
+                 trunc_band=1, thr_leveler=10, alpha_avg=1, peak_alpha=0):
+        base = ScannerState(fft_len, sample_rate, channel_space, search_bw, tune_freq, trunc_band,
+                            thr_leveler, alpha_avg)
+        self.base = base
+        self.ax_ch = base.ax_ch
+        self.thr_leveler = thr_leveler
+        self.alpha_avg = alpha_avg
+        self.noise_estimate = 1e-11
+        self.subject_channels = list(subject_channels)
+        self.idx_subject_channels = [self.ax_ch.index(ch) for ch in self.subject_channels]
+        n = len(self.subject_channels)
+        self.prev_power = np.array([1.0] * n)
+        self.curr_power = np.array([1.0] * n)
+        self.flag = [True] * n
+        self.peak_alpha = np.array([0.0] * n)
+        self.peak_alpha_original = peak_alpha
+        self.cumulative_statistics = {}
+
+    def detect(self, samples):
+        b = self.base
+        plc = src_power(samples, b.fft_len, b.Fr, b.sample_rate, b.bb_freqs, b.srch_bins)
+        if b.trunc > 0:
+            plc = plc[b.trunc_ch:-b.trunc_ch]
+        min_power = np.amin(plc)
+        self.noise_estimate = (1 - self.alpha_avg) * self.noise_estimate + self.alpha_avg * min_power
+        thr = self.noise_estimate * self.thr_leveler
+        thr2 = thr * 20
+        self.prev_power[:] = self.curr_power[:]
+        events = []
+        for k, channel in enumerate(self.idx_subject_channels):
+            self.curr_power[k] = ((1 - self.peak_alpha[k]) * np.clip(plc[channel], 0, thr2)
+                                  + self.peak_alpha[k] * self.prev_power[k])
+            if self.curr_power[k] < thr2 and self.curr_power[k] > thr:
+                self.curr_power[k] = thr2
+            if self.curr_power[k] > self.prev_power[k] and self.curr_power[k] > thr and self.flag[k] is False:
+                self.flag[k] = True
+                self.peak_alpha[k] = 0
+                f = self.ax_ch[channel]
+                self.cumulative_statistics[f] = self.cumulative_statistics.get(f, 0) + 1
+                events.append((f, +1))
+            elif self.flag[k] is True and self.curr_power[k] < thr:
+                self.flag[k] = False
+                self.peak_alpha[k] = self.peak_alpha_original
+                events.append((self.ax_ch[channel], -1))
+        return events

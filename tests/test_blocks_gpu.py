@@ -53,6 +53,18 @@ def test_spectrum_sensor_v2_state_sequence(ctx, golden, tmp_path):
     assert 'statistics ' + str(blk._logger.cumulative_statistics) in open(files['stat']).read()
 
 
+def test_spectrum_sensor_v1_is_the_stats_path(ctx, golden, tmp_path):
+    import ofdm_tools
+    g = golden('scanner_state_seq.npz')
+    blk = ofdm_tools.spectrum_sensor_v1(1024, 1000, 1000000, channel_space=25e3, search_bw=12.5e3, thr_leveler=4,
+                                        tune_freq=100000000, alpha_avg=0.5, trunc_band=800000, psd=True, ctx=ctx,
+                                        log_directory=str(tmp_path))
+    blk.feed(g['x'], max_items=1024)
+    assert np.isclose(blk.noise_estimate, g['noise_seq'][-1], rtol=1e-4)
+    assert np.allclose(blk._logger.cumulative_max_power, g['cumulative_max'], rtol=1e-4)
+    assert relerr(blk._logger.cumulative_psd, g['peak']) < RTOL
+
+
 def test_spectrum_sensor_v2_decimation_and_scheduler_chunks(ctx):
     import ofdm_tools
     fft_len, Sf = 256, 256 * 100
@@ -287,3 +299,31 @@ def test_context_on_torch_stream(tmp_path):
     script.write_text(TORCH_STREAM_SCRIPT % {'root': root})
     p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert p.returncode == 0, p.stdout.decode()
+
+
+def test_flanck_detector_edges(ctx, tmp_path):
+    """A burst that switches on and off in one subject channel: one rising and one falling edge there,
+    the same sequence as the oracle's restatement of flanck_detector.py:345-399."""
+    import ofdm_tools
+    N, Sf, cs = 1024, 1024000, 32000.0
+    st0 = R.ScannerState(N, Sf, cs, 16e3, trunc_band=Sf)
+    subj = [st0.ax_ch[10], st0.ax_ch[20]]
+    f_on = (st0.ax_ch[20]) / Sf                                     # tone in the middle of channel 20
+    nvec = 30
+    x = R.synth_iq(N * nvec, 71, tones=(), dc=0)
+    t = np.arange(N * nvec)
+    gate = ((t // N >= 8) & (t // N < 18)).astype(np.float64)        # on for vectors 8..17
+    x = (x + 3.0 * gate * np.exp(2j * np.pi * f_on * t)).astype(np.complex64)
+    kw = dict(channel_space=cs, search_bw=16e3, thr_leveler=4, alpha_avg=0.2, trunc_band=Sf, peak_alpha=0.5)
+    blk = ofdm_tools.flanck_detector(N, Sf / N, Sf, subject_channels=subj, ctx=ctx, log_directory=str(tmp_path), **kw)
+    ref = R.FlankState(N, Sf, cs, 16e3, subj, trunc_band=Sf, thr_leveler=4, alpha_avg=0.2, peak_alpha=0.5)
+    rows = R.chain_sensor_v2(x, N)
+    want = []
+    for i in range(nvec):
+        blk.work([x[i * N:(i + 1) * N]], [])
+        want += ref.detect(rows[i].astype(np.float32))
+        assert np.allclose(blk.curr_power, ref.curr_power, rtol=1e-4) and blk.flag == ref.flag
+    assert blk.events == want
+    ch20 = [e for e in blk.events if e[0] == subj[1]]
+    assert (subj[1], +1) in ch20 and ch20[-1] == (subj[1], -1)
+    assert blk._logger.cumulative_statistics == ref.cumulative_statistics

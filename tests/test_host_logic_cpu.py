@@ -92,6 +92,15 @@ def test_block_constructor_signatures_match_the_reference():
                                             ('subject_channels', [])])
     check(ofdm_tools.local_worker, [('fft_len', E), ('sample_rate', E), ('average', E), ('rate', E), ('max_tu', E),
                                     ('data_precision', E)])
+    check(ofdm_tools.spectrum_sensor_v1, [('fft_len', E), ('sens_per_sec', E), ('sample_rate', E),
+                                          ('channel_space', 1), ('search_bw', 1), ('thr_leveler', 10),
+                                          ('tune_freq', 0), ('alpha_avg', 1), ('test_duration', 1), ('period', 3600),
+                                          ('trunc_band', 1), ('verbose', False), ('psd', False), ('waterfall', False),
+                                          ('subject_channels', [])])
+    check(ofdm_tools.flanck_detector, [('fft_len', E), ('sens_per_sec', E), ('sample_rate', E), ('channel_space', 1),
+                                       ('search_bw', 1), ('thr_leveler', 10), ('tune_freq', 0), ('alpha_avg', 1),
+                                       ('test_duration', 1), ('period', 3600), ('trunc_band', 1), ('verbose', False),
+                                       ('peak_alpha', 0), ('subject_channels', [])])
     check(ofdm_tools.spectrum_sensor, [('block_length', E), ('sample_rate', 1), ('fft_len', 1), ('channel_space', 1),
                                        ('search_bw', 1), ('method', 'fft'), ('thr_leveler', 10), ('tune_freq', 0),
                                        ('alpha_avg', 1), ('source', None), ('log', False)])
