@@ -29,8 +29,10 @@
 //         segment stays in registers, the half the NEXT segment adds is prefetched while this one
 //         is transformed (LDS-only barriers keep it in flight), and only the new half is summed
 //         for the detrend.  The 32 extra data registers are paid for by rebuilding the pass-1
-//         twiddles W^(k0 t) from W^t and W^(4t) each segment (13 complex products), which keeps
-//         the kernel at 128 VGPRs = 4 workgroups per CU.
+//         twiddles W^(k0 t) from W^t and W^(4t) each segment (scatter_pow16, 13 complex products),
+//         which keeps the kernel at 128 VGPRs = 4 workgroups per CU.
+// Both builds rebuild the pass-2 twiddles W256^(k1 c) the same way (reading them from an LDS table
+// costs fifteen dependent LDS round trips) and raise the wave priority outside the butterflies.
 // Segments reach workgroups in chunks through WelchArgs.sched (contiguous / interleaved /
 // atomic ticket); see the comment at the chunk loop.
 #include "fft_lds.hip.h"
@@ -43,7 +45,7 @@
 #endif
 #ifndef OTH_W4096_PIPE
 #define OTH_W4096_PIPE 0     // 1: 50 %-overlap pipeline - the overlapped half stays in registers, the next
-#endif                       //    half is prefetched, pass-1 twiddles are rebuilt from W^t and W^4t (needs step 2048)
+#endif                       //    half is prefetched, pass-1 twiddles are rebuilt from two powers (needs step 2048)
 #ifndef OTH_W4096_DIAG
 #define OTH_W4096_DIAG 0     // 1: diagnostic build, every workgroup stamps start/end time + XCC id
 #endif
@@ -56,8 +58,6 @@ namespace oth {
 
 namespace {
 
-// NA = nperseg / 256: rows a < NA of a segment hold samples, the rest is the zero padding up to 4096
-// (NA = 16: nperseg = nfft; NA = 4: the sweeper's nperseg = nfft / 4, spectrum_sweeper.py:263).
 #if OTH_W4096_DIAG
 #define OTH_STAMP(i)                                                     \
     do {                                                                 \
@@ -72,6 +72,8 @@ namespace {
 #define OTH_STAMP(i)
 #endif
 
+// NA = nperseg / 256: rows a < NA of a segment hold samples, the rest is the zero padding up to 4096
+// (NA = 16: nperseg = nfft; NA = 4: the sweeper's nperseg = nfft / 4, spectrum_sweeper.py:263).
 template <bool DETREND, int NA>
 __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(WelchArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
