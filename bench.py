@@ -116,7 +116,11 @@ def main():
     trim = 256 if multi else 0
     nbins = NFFT - 2 * trim
 
-    stream = torch.cuda.current_stream(dev)
+    # a dedicated non-blocking stream, made torch's current stream: the library's kernels, torch's fills and the
+    # event dependencies of the NCCL collectives all refer to it (the legacy null stream would serialise
+    # against every blocking stream in the process)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx = _hip.Context(local_rank, stream=stream.cuda_stream)
     iq = torch.empty((n, 2), dtype=torch.float32, device=dev)               # the IQ ring buffer in HBM
     ctx.synth_iq(iq.data_ptr(), n, (2000 + rank) if multi else 1002, TONES, DC)
