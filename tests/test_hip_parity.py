@@ -454,3 +454,35 @@ def test_randomized_welch_plans_vs_oracle(ctx, hip):
         err = np.max(np.abs(got - ref) / np.maximum(ref, 1e-6 * ref.max()))
         assert err < RTOL, (it, nfft, nperseg, noverlap, detrend, scaling, wkind, shift, trim, db, kern, err)
         plan.close()
+
+
+def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip):
+    """Chunked schedules at the edges: segment counts around multiples of the chunk size and of the
+    resident workgroup count, one to three streams, all three schedules - tuned kernel vs the
+    independent generic kernel on device-resident data."""
+    rng = np.random.default_rng(7)
+    nmax = 4096 + 2048 * 9000
+    d_in = ctx.alloc(3 * nmax * 8)
+    d_a, d_b = ctx.alloc(3 * 4096 * 4), ctx.alloc(3 * 4096 * 4)
+    try:
+        ctx.synth_iq(d_in, 3 * nmax, 31, R.TONES, R.DC)
+        tuned = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_TUNED)
+        gen = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_GENERIC)
+        counts = [1, 2, 3, 7, 8, 9, 15, 16, 17, 1023, 1024, 1025, 4095, 4097, 8191, 8192, 8193, 9000] + \
+            [int(v) for v in rng.integers(1, 9000, 6)]
+        for nseg in counts:
+            n = 4096 + 2048 * (nseg - 1) + int(rng.integers(0, 2048))
+            ns = int(rng.integers(1, 4))
+            sched = int(rng.integers(0, 3))
+            tuned.set_schedule(sched)
+            assert tuned.exec_dev(d_in, n, d_a, nstreams=ns, stream_stride=nmax) == nseg
+            assert gen.exec_dev(d_in, n, d_b, nstreams=ns, stream_stride=nmax) == nseg
+            a = ctx.d2h(d_a, (ns, 4096), np.float32)
+            b = ctx.d2h(d_b, (ns, 4096), np.float32)
+            # few-segment periodograms have near-empty bins: judge those against the spectrum's typical level
+            # (two fp32 FFTs differ by ~1e-6 of the typical amplitude, which is 1e-5 of a bin 10x below it)
+            err = np.max(np.abs(a.astype(np.float64) - b) / np.maximum(b, 0.1 * np.median(b)))
+            assert err < 5e-5, (nseg, ns, sched, err)
+    finally:
+        for ptr in (d_in, d_a, d_b):
+            ctx.free(ptr)
