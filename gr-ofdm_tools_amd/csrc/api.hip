@@ -41,6 +41,7 @@ struct oth_plan {
     double fs = 1.0, scale = 1.0;      // scale applies to the MEAN over segments
     float *d_win = nullptr;
     const float2 *d_tw = nullptr;
+    float4 *d_fd = nullptr;            // window spectrum for the frequency-domain detrend (welch4096ws), or nullptr
     float *d_partial = nullptr;
     size_t partial_cap = 0;
     int last_W = 0;
@@ -190,27 +191,75 @@ struct W4096Variant {
     const char *tag;
     hipError_t (*launch)(const WelchArgs &, hipStream_t);
     int (*blocks_per_cu)();
+    int chunk;      // default segments per chunk of the dynamic schedule (same-box A/B, tools/ab_variants.py)
 };
 const W4096Variant kVariants[] = {
-    {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp},           // any step
-    {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe},        // step 2048 (50 % overlap)
-    {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag},
+    {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp, 8},            // any step
+    {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe, 16},        // step 2048 (50 % overlap)
+    {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16},
+    {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 32},              // step 2048, confined window spectrum
 #ifdef OTH_EXPERIMENTS
-    {"exp1", launch_welch_tuned4096_exp1, tuned4096_blocks_per_cu_exp1},
-    {"exp2", launch_welch_tuned4096_exp2, tuned4096_blocks_per_cu_exp2},
-    {"exp3", launch_welch_tuned4096_exp3, tuned4096_blocks_per_cu_exp3},
-    {"exp4", launch_welch_tuned4096_exp4, tuned4096_blocks_per_cu_exp4},
+    {"exp1", launch_welch_tuned4096_exp1, tuned4096_blocks_per_cu_exp1, 16},
+    {"exp2", launch_welch_tuned4096_exp2, tuned4096_blocks_per_cu_exp2, 16},
+    {"exp3", launch_welch_tuned4096_exp3, tuned4096_blocks_per_cu_exp3, 16},
+    {"exp4", launch_welch_tuned4096_exp4, tuned4096_blocks_per_cu_exp4, 16},
+    {"wsx1", launch_welch_tuned4096_wsx1, tuned4096_blocks_per_cu_wsx1, 32},
+    {"wsx2", launch_welch_tuned4096_wsx2, tuned4096_blocks_per_cu_wsx2, 32},
+    {"wsx3", launch_welch_tuned4096_wsx3, tuned4096_blocks_per_cu_wsx3, 32},
+    {"wsx4", launch_welch_tuned4096_wsx4, tuned4096_blocks_per_cu_wsx4, 32},
 #endif
 };
-const W4096Variant *w4096_variant(int step) {
+const W4096Variant *w4096_variant(int step, bool fd_ok) {
     const char *e = getenv("OTH_W4096_VARIANT");
-    const W4096Variant *pick = (step == 2048) ? &kVariants[1] : &kVariants[0];
+    const W4096Variant *pick = (step == 2048) ? (fd_ok ? &kVariants[3] : &kVariants[1]) : &kVariants[0];
     if (e)
         for (const auto &v : kVariants)
             if (!strcmp(e, v.tag)) pick = &v;
-    // the pipelined build keeps the overlapped half in registers: only for step = nperseg / 2
-    if ((!strncmp(pick->tag, "pipe", 4) || !strncmp(pick->tag, "exp", 3)) && step != 2048) pick = &kVariants[0];
+    // the wave-specialised build detrends in the frequency domain: only with a confined window spectrum
+    if (!strncmp(pick->tag, "ws", 2) && !fd_ok) pick = &kVariants[1];
+    // the pipelined builds keep the overlapped half in registers: only for step = nperseg / 2
+    if (pick != &kVariants[0] && step != 2048) pick = &kVariants[0];
     return pick;
+}
+
+// Window spectrum table for welch4096ws (WelchArgs.fd).  FFT((x - m) w) = FFT(x w) - m FFT(w): the kernel
+// corrects only bins [0, 256) and [3840, 4096), so the table exists only when FFT(w) is negligible elsewhere:
+// |W[k]|^2 <= 1e-10 sum(w^2) there bounds the uncorrected term by 1e-10 |m|^2 / sigma^2 of a white-noise
+// bin's level.  True for boxcar and the periodic cosine-sum windows (hann, blackman-harris, flattop, ...).
+bool window_spectrum_table(const std::vector<float> &w, std::vector<float> &fd) {
+    const int n = 4096;
+    std::vector<double> re(n), im(n, 0.0);
+    double s2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        int r = 0;
+        for (int b = 0; b < 12; ++b) r |= ((i >> b) & 1) << (11 - b);
+        re[r] = (double)w[i];
+        s2 += (double)w[i] * (double)w[i];
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / len;
+        for (int i = 0; i < n; i += len)
+            for (int j = 0; j < len / 2; ++j) {
+                const double c = cos(ang * j), s = sin(ang * j);
+                const int a = i + j, b = a + len / 2;
+                const double tr = re[b] * c - im[b] * s, ti = re[b] * s + im[b] * c;
+                re[b] = re[a] - tr;
+                im[b] = im[a] - ti;
+                re[a] += tr;
+                im[a] += ti;
+            }
+    }
+    for (int k = 256; k < 3840; ++k)
+        if (re[k] * re[k] + im[k] * im[k] > 1e-10 * s2) return false;
+    fd.resize(4 * 256);
+    for (int t = 0; t < 256; ++t) {
+        const int k = (t >> 4) + 16 * (t & 15);
+        fd[4 * t] = (float)re[k];
+        fd[4 * t + 1] = (float)im[k];
+        fd[4 * t + 2] = (float)re[k + 3840];
+        fd[4 * t + 3] = (float)im[k + 3840];
+    }
+    return true;
 }
 
 int segments(const oth_plan *p, size_t nsamples, long long *nseg) {
@@ -247,7 +296,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
     if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd && !tuned_16k)
         return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
-    const W4096Variant *var = tuned ? w4096_variant(p->nperseg == 4096 ? p->step : 0) : nullptr;
+    const W4096Variant *var =
+        tuned ? w4096_variant(p->nperseg == 4096 ? p->step : 0, p->detrend == OTH_DETREND_NONE || p->d_fd) : nullptr;
     int W = generic_wg(c, p->nfft, nseg, nstreams);
     if (tuned || tuned_csd || tuned_16k) {
         // exactly the resident workgroups: one wave of workgroups, no tail round
@@ -258,7 +308,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     const int nch = csd ? 4 : 1;
     // + 32 B per workgroup of stamp space behind the sums (only the diagnostic kernel build writes it)
     int rc = ensure(c, &p->d_partial, &p->partial_cap,
-                    sizeof(float) * (size_t)nstreams * W * nch * p->nfft + (32 + 4 * 96) * (size_t)nstreams * W);
+                    sizeof(float) * (size_t)nstreams * W * nch * p->nfft + 1024 * (size_t)nstreams * W);
     p->last_W = W * nstreams;
     if (!rc) rc = ensure(c, &p->d_reduce, &p->reduce_cap, sizeof(float) * (size_t)nstreams * kReduceGroups * nch * p->nfft);
     if (rc) return rc;
@@ -280,11 +330,16 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.tail_chunk = 1;
     a.nbig = 0;
     a.queue = nullptr;
+    a.fd = p->d_fd;
+    {
+        const char *et = getenv("OTH_WS_TUNE");
+        a.tune = et ? (int)strtol(et, nullptr, 0) : 0;
+    }
     if (tuned || tuned_csd || tuned_16k) {
         const char *e = getenv("OTH_W4096_SCHED");
         const char *ec = getenv("OTH_W4096_CHUNK");
         a.sched = e ? atoi(e) : p->sched;
-        a.chunk = ec ? atoi(ec) : (tuned_16k ? 2 : 8);
+        a.chunk = ec ? atoi(ec) : (tuned_16k ? 2 : (tuned ? var->chunk : 8));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;
@@ -573,6 +628,13 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     if (e == hipSuccess) e = hipMalloc(&p->d_sum, sizeof(float) * nfft);
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_win, w.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_sum, 0, sizeof(float) * nfft, c->stream);
+    std::vector<float> fd;
+    if (e == hipSuccess && nfft == 4096 && nperseg == 4096 && detrend == OTH_DETREND_CONSTANT &&
+        window_spectrum_table(w, fd)) {
+        e = hipMalloc(&p->d_fd, sizeof(float) * fd.size());
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(p->d_fd, fd.data(), sizeof(float) * fd.size(), hipMemcpyHostToDevice, c->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         oth_plan_destroy(p);
@@ -588,6 +650,7 @@ int oth_plan_destroy(oth_plan *p) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (p->d_win) hipFree(p->d_win);
+    if (p->d_fd) hipFree(p->d_fd);
     if (p->d_partial) hipFree(p->d_partial);
     if (p->d_reduce) hipFree(p->d_reduce);
     if (p->d_out) hipFree(p->d_out);
@@ -1102,6 +1165,17 @@ static int xcorr_impl(oth_ctx *c, const void *a, size_t na, const void *b, size_
 
 int oth_xcorr(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, int L, float *out) {
     return xcorr_impl(c, a, na, b, nb, L, out, 0);
+}
+
+// Not part of the ABI (not in the header): raw bytes behind the partial sums (diagnostic kernel builds).
+int oth__debug_tail(oth_plan *p, void *out, size_t nbytes, int *nwg) {
+    if (!p || !out || !nwg) return OTH_ERR_INVALID;
+    oth_ctx *c = p->ctx;
+    if (nbytes > 1024 * (size_t)p->last_W) return OTH_ERR_INVALID;
+    HIPCHK(c, hipMemcpyAsync(out, p->d_partial + (size_t)p->last_W * p->nfft, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *nwg = p->last_W;
+    return OTH_OK;
 }
 
 // Not part of the ABI (not in the header): reads the per-workgroup stamps of the diagnostic kernel build.

@@ -26,6 +26,10 @@ struct WelchArgs {
     int tail_chunk;         // segments per chunk after the first nbig chunks
     long long nbig;         // number of full-size chunks
     unsigned *queue;        // [nstreams] tickets, zeroed before the launch (sched 2)
+    // welch4096ws frequency-domain detrend: per consumer thread t = 16 k0 + k1 the window spectrum at bins
+    // k0 + 16 k1 and k0 + 16 k1 + 3840 (re, im, re, im); nullptr when the window's spectrum is not confined
+    const float4 *fd;
+    int tune;               // experiment knob (OTH_WS_TUNE), 0 in production
 };
 
 struct PgramArgs {
@@ -77,6 +81,15 @@ OTH_DECL_W4096(exp3)
 OTH_DECL_W4096(exp4)
 #endif
 OTH_DECL_W4096(pipe)
+// welch4096ws.hip: wave-specialised producer/consumer form; step 2048, detrend needs WelchArgs.fd
+// (built once per tag like welch4096.hip)
+OTH_DECL_W4096(ws)
+#ifdef OTH_EXPERIMENTS
+OTH_DECL_W4096(wsx1)
+OTH_DECL_W4096(wsx2)
+OTH_DECL_W4096(wsx3)
+OTH_DECL_W4096(wsx4)
+#endif
 // csd4096.hip: two-channel cross spectrum, nfft = nperseg = 4096
 hipError_t launch_csd_tuned4096(const WelchArgs &a, hipStream_t s);
 int csd4096_blocks_per_cu();

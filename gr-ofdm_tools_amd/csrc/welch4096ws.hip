@@ -1,0 +1,362 @@
+// welch4096ws: wave-specialised form of the headline kernel (nperseg = nfft = 4096, 50 % overlap).
+//
+// Same arithmetic as welch4096.hip (radix-16 x 16 x 16, same LDS image), but a 512-thread workgroup is
+// split into a PRODUCER half (threads 0..255: loads, window, pass 1, exchange-1 writes) and a CONSUMER
+// half (threads 256..511: pass 2, exchange 2, pass 3, |X|^2 accumulation) that work one segment apart on
+// two LDS images.  Why: in the one-role kernel every thread carries the constants of all three passes
+// (window, both twiddle sets, accumulators, the kept half and the prefetch) and has to rebuild both
+// twiddle sets every segment to stay at 128 VGPRs.  Split by role, the producer holds window + data
+// pipeline and rebuilds only its twiddles, the consumer holds its 15 twiddles and the accumulators in
+// registers: about 100 fewer VALU instructions per segment, one workgroup barrier per segment instead of
+// two, and the loads of the producer overlap the butterflies of the consumer by construction.
+//
+// The constant detrend runs in the frequency domain: FFT((x - m) w) = FFT(x w) - m FFT(w).  For every
+// window whose spectrum is confined to bins [0,256) U [3840,4096) (host check at plan time; exact for the
+// periodic cosine-sum windows scipy.signal.welch builds) those are the k2 = 0 and k2 = 15 outputs of
+// pass 3, so each consumer thread fixes two of its sixteen bins with its own pair of FFT(w) values
+// (WelchArgs.fd).  The producer therefore never needs the mean: it publishes the per-wave sums of the raw
+// half-segments next to the image, and windows samples as soon as they arrive.
+//
+// Per step `it` (one barrier):  producer: segment it -> image[it & 1];  consumer: image[(it-1) & 1].
+#ifndef OTH_WS_TAG
+#define OTH_WS_TAG ws
+#endif
+#ifndef OTH_WS_DIAG
+#define OTH_WS_DIAG 0        // 1: per-wave phase cycle counters behind the partial sums (tools/diag_ws.py)
+#endif
+// wave priorities: producer latency sections / butterflies, consumer latency sections / butterflies
+#ifndef OTH_WS_PAL
+#define OTH_WS_PAL 2
+#endif
+#ifndef OTH_WS_PAC
+#define OTH_WS_PAC 0
+#endif
+#ifndef OTH_WS_PBL
+#define OTH_WS_PBL 2
+#endif
+#ifndef OTH_WS_PBC
+#define OTH_WS_PBC 0
+#endif
+#define OTH_CAT2(a, b) a##b
+#define OTH_CAT(a, b) OTH_CAT2(a, b)
+
+#include <type_traits>
+#include "fft4096.hip.h"
+
+namespace oth {
+namespace {
+
+#if OTH_WS_DIAG
+#define WS_STAMP(i)                                                      \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                              \
+        phase[i] += now_ - last_;                                        \
+        last_ = now_;                                                    \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    } while (0)
+#else
+#define WS_STAMP(i)
+#endif
+
+constexpr int TWS = 512;
+constexpr int WS_RED = 32;                 // float2: per image 4 new-half wave sums + 4 first-half wave sums (x2 images)
+constexpr int WS_CTRL = 16;                // ints: valid[2], first[2], lnext
+constexpr size_t WS_LDS_BYTES = (2 * LDS_X + WS_RED) * sizeof(float2) + WS_CTRL * sizeof(int);
+
+enum { ITEM_STOP = 0, ITEM_DATA = 1, ITEM_BUBBLE = 2 };
+
+
+template <bool DETREND>
+__global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *img = reinterpret_cast<float2 *>(smem);             // two images of LDS_X float2
+    float2 *red = img + 2 * LDS_X;                              // [2][8]
+    int *ctrl = reinterpret_cast<int *>(red + WS_RED);          // item[0..1], first[2..3], next ticket [4]; re-read after
+                                                                // every lds_barrier() (it is a compiler memory barrier)
+
+    const int tid = threadIdx.x;
+    const bool producer = tid < 256;
+    const int t = tid & 255;
+    const int hi = t >> 4, lo = t & 15;
+    const int wave = t >> 6;
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const float2 *xb = p.x + (size_t)stream * p.stream_stride;
+    const int sched = p.sched;
+    const long long nchunks = sched ? chunk_count(p) : 1;
+
+    // LDS addresses inside an image (float2): exchange-1 write/read, exchange-2 write/read
+    const int w1 = hi * 17 + lo, r1 = hi * RS + lo, w2 = hi * RS + lo, r2 = hi * RS + lo * 17;
+#if OTH_WS_DIAG
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
+
+    if (producer) {
+        // ------------------------------------------------------------------ producer
+        float win[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) win[a] = p.win[256 * a + t];
+        const float2 b1 = p.tw[t], b4 = p.tw[4 * t];            // pass-1 twiddle seeds W4096^t, W4096^(4t)
+        float2 kw[8], nxt[8], raw0[8];
+        int it = 0;
+        unsigned ticket = 0;
+        using std::false_type;
+        using std::true_type;
+        using mid = std::integral_constant<int, 0>;     // prefetch the half after next of this chunk
+        using head = std::integral_constant<int, 1>;    // last segment of the chunk: prefetch the next chunk's first segment
+        using none = std::integral_constant<int, 2>;    // nothing to prefetch
+
+        auto load_chunk_head = [&](long long first_seg) {
+            const float2 *xs = xb + first_seg * 2048 + t;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) raw0[a] = xs[256 * a];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) nxt[a] = xs[2048 + 256 * a];
+        };
+        auto step_end = [&](int item) {
+            if (t == 0) ctrl[it & 1] = item;
+            lds_barrier();
+            WS_STAMP(4);
+            ++it;
+        };
+        // One segment: image (it & 1).  Every flavour leaves the same state behind - kw = windowed first half of the
+        // following segment, nxt = its second half in flight - so the hot (false, mid) flavour is straight-line code
+        // with one group of eight loads per step.
+        auto item = [&](auto first_, auto mode_, long long s, long long nsb, bool publish) {
+            constexpr bool FIRST = decltype(first_)::value;
+            constexpr int MODE = decltype(mode_)::value;
+            const int q = it & 1;
+            float2 *lx = img + q * LDS_X;
+            __builtin_amdgcn_s_setprio(OTH_WS_PAL);
+            float2 v[16];
+#if OTH_WS_DIAG
+            WS_STAMP(5);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            WS_STAMP(0);
+#endif
+            float2 sumf = make_float2(0.f, 0.f), sum = make_float2(0.f, 0.f);
+            if (FIRST) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    sumf = cadd(sumf, raw0[a]);
+                    kw[a] = make_float2(raw0[a].x * win[a], raw0[a].y * win[a]);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {      // the new half is windowed for both of its roles as it arrives
+                const float2 r = nxt[a];
+                v[a] = kw[a];
+                v[8 + a] = make_float2(r.x * win[8 + a], r.y * win[8 + a]);
+                kw[a] = make_float2(r.x * win[a], r.y * win[a]);
+                sum = cadd(sum, r);
+            }
+            // dynamic schedule: the ticket of the chunk after this one is drawn with the chunk's first segment and
+            // published (a wait for the atomic's return) before this step's loads go out, one step later if possible
+            if (sched == 2 && t == 0) {
+                if (FIRST) ticket = atomicAdd(p.queue + stream, 1u);
+                if (publish) ctrl[4] = (int)ticket;
+            }
+            if (MODE == 0) {
+                const float2 *xn = xb + (s + 2) * 2048 + t;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) nxt[a] = xn[256 * a];
+            } else if (MODE == 1) {
+                load_chunk_head(nsb);
+            }
+            if (DETREND) {
+                sum.x = wave_total(sum.x);
+                sum.y = wave_total(sum.y);
+                if ((t & 63) == 0) red[q * 8 + wave] = sum;
+                if (FIRST) {
+                    sumf.x = wave_total(sumf.x);
+                    sumf.y = wave_total(sumf.y);
+                    if ((t & 63) == 0) red[q * 8 + 4 + wave] = sumf;
+                }
+            }
+            if (t == 0) ctrl[2 + q] = FIRST ? 1 : 0;
+            WS_STAMP(1);
+            __builtin_amdgcn_s_setprio(OTH_WS_PAC);
+            dft16(v);
+            WS_STAMP(2);
+            __builtin_amdgcn_s_setprio(OTH_WS_PAL);
+            scatter_pow16<RS>(v, lx + w1, b1, b4);
+#if OTH_WS_DIAG
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            WS_STAMP(3);
+#endif
+            step_end(ITEM_DATA);
+        };
+
+        long long cur = 0, sb = 0, se = 0;
+        auto open_chunk = [&](long long c) -> bool {
+            cur = c;
+            if (sched) {
+                if (cur >= nchunks) return false;
+                chunk_range(p, cur, sb, se);
+                return true;
+            }
+            sb = (p.nseg * wg) / W;
+            se = (p.nseg * (wg + 1)) / W;
+            return sb < se;
+        };
+        bool have = open_chunk(sched ? wg : 0);
+        if (have) load_chunk_head(sb);
+        while (have) {
+            const long long n = se - sb;
+            long long ncur = 0;
+            if (n >= 2) {
+                item(true_type{}, mid{}, sb, 0, n == 2);
+                long long s = sb + 1;
+                if (s < se - 1) item(false_type{}, mid{}, s++, 0, true);
+                for (; s + 1 < se - 1; s += 2) {      // two per trip: kw's registers swap roles instead of being copied
+                    item(false_type{}, mid{}, s, 0, false);
+                    item(false_type{}, mid{}, s + 1, 0, false);
+                }
+                if (s < se - 1) item(false_type{}, mid{}, s, 0, false);
+                // last segment: the next chunk's ticket was published at least one barrier ago
+                ncur = (sched == 1) ? cur + W : (long long)W + __builtin_amdgcn_readfirstlane(ctrl[4]);
+                long long nsb = 0, nse = 0;
+                const bool have_next = sched && ncur < nchunks;
+                if (have_next) {
+                    chunk_range(p, ncur, nsb, nse);
+                    item(false_type{}, head{}, se - 1, nsb, false);
+                    cur = ncur;
+                    sb = nsb;
+                    se = nse;
+                    continue;
+                }
+                item(false_type{}, none{}, se - 1, 0, false);
+                break;
+            }
+            // one-segment chunk: no prefetch across the chunk boundary; the ticket needs a barrier to become visible
+            item(true_type{}, none{}, sb, 0, true);
+            if (sched == 0) break;
+            if (sched == 2) {
+                step_end(ITEM_BUBBLE);
+                ncur = (long long)W + __builtin_amdgcn_readfirstlane(ctrl[4]);
+            } else {
+                ncur = cur + W;
+            }
+            have = open_chunk(ncur);
+            if (have) load_chunk_head(sb);
+        }
+        step_end(ITEM_STOP);
+    } else {
+        // ------------------------------------------------------------------ consumer
+        float2 tw2[16];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tw2[k] = p.tw[16 * lo * k];      // W256^(k1 c), c = lo
+        float4 fw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DETREND) fw = p.fd[t];      // FFT(w) at this thread's k2 = 0 and k2 = 15 bins
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        float2 prev_tot = make_float2(0.f, 0.f), mean = make_float2(0.f, 0.f);
+        float2 v[16];
+        int item = ITEM_BUBBLE;           // nothing to consume in the first step
+        for (int it = 0;; ++it) {
+            if (item == ITEM_DATA) {      // v holds the exchange-1 reads of image (it - 1) & 1
+                float2 *lx = img + ((it & 1) ^ 1) * LDS_X;
+#if OTH_WS_DIAG
+                WS_STAMP(5);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                WS_STAMP(0);
+#endif
+                __builtin_amdgcn_s_setprio(OTH_WS_PBC);
+                dft16(v);
+                WS_STAMP(1);
+                __builtin_amdgcn_s_setprio(OTH_WS_PBL);
+                wave_lds_sync();
+                lx[w2] = v[r16(0)];
+#pragma unroll
+                for (int k1 = 1; k1 < 16; ++k1) lx[w2 + k1 * 17] = cmul(v[r16(k1)], tw2[k1]);
+                wave_lds_sync();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) v[c] = lx[r2 + c];
+#if OTH_WS_DIAG
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                WS_STAMP(2);
+#endif
+                __builtin_amdgcn_s_setprio(OTH_WS_PBC);
+                dft16(v);
+                if (DETREND) {          // X[k] -= mean * FFT(w)[k] where FFT(w) is not negligible
+                    v[r16(0)] = make_float2(v[r16(0)].x - (mean.x * fw.x - mean.y * fw.y),
+                                            v[r16(0)].y - (mean.x * fw.y + mean.y * fw.x));
+                    v[r16(15)] = make_float2(v[r16(15)].x - (mean.x * fw.z - mean.y * fw.w),
+                                             v[r16(15)].y - (mean.x * fw.w + mean.y * fw.z));
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    const float2 X = v[r16(k2)];
+                    acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
+                }
+                WS_STAMP(3);
+                __builtin_amdgcn_s_setprio(OTH_WS_PBL);
+            }
+            lds_barrier();
+            WS_STAMP(4);
+            // what the producer left in image it & 1: the item type and, in the same batch of LDS reads (harmless
+            // when it is not a segment), the exchange-1 reads and the half-segment sums
+            const int q = it & 1;
+            const float2 *lq = img + q * LDS_X;
+            item = ctrl[q];
+            const int first = ctrl[2 + q];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) v[b] = lq[r1 + b * 17];
+            if (DETREND) {
+                const float2 nt = cadd(cadd(red[q * 8], red[q * 8 + 1]), cadd(red[q * 8 + 2], red[q * 8 + 3]));
+                const float2 ft = cadd(cadd(red[q * 8 + 4], red[q * 8 + 5]), cadd(red[q * 8 + 6], red[q * 8 + 7]));
+                if (item == ITEM_DATA) {
+                    if (first) prev_tot = ft;
+                    mean = make_float2((prev_tot.x + nt.x) * (1.0f / 4096.0f), (prev_tot.y + nt.y) * (1.0f / 4096.0f));
+                    prev_tot = nt;
+                }
+            }
+            if (item == ITEM_STOP) break;
+        }
+        // bin k0 + 16 k1 + 256 k2 of this workgroup sits at t + 256 k2 (finalize_kernel layout 1)
+        float *dst = p.partial + ((size_t)stream * W + wg) * 4096;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) dst[256 * k2 + t] = acc[k2];
+    }
+#if OTH_WS_DIAG
+    if ((tid & 63) == 0) {   // 8 waves x 8 phase counters per workgroup, behind the partial sums
+        unsigned long long *ph = reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * 4096) +
+                                 64 * ((size_t)stream * W + wg) + 8 * (tid >> 6);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ph[i] = phase[i];
+    }
+#endif
+}
+
+}  // namespace
+
+int OTH_CAT(tuned4096_blocks_per_cu_, OTH_WS_TAG)() {
+    static int cached = 0;
+    if (cached) return cached;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, welch4096ws_kernel<true>, TWS, WS_LDS_BYTES) != hipSuccess || n < 1)
+        n = 1;
+    return cached = n;
+}
+
+hipError_t OTH_CAT(launch_welch_tuned4096_, OTH_WS_TAG)(const WelchArgs &a, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    hipError_t e;
+    if (a.detrend) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(welch4096ws_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((welch4096ws_kernel<true>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(welch4096ws_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((welch4096ws_kernel<false>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace oth

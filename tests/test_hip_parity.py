@@ -456,10 +456,14 @@ def test_randomized_welch_plans_vs_oracle(ctx, hip):
         plan.close()
 
 
-def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip):
+@pytest.mark.parametrize('variant', ['', 'ws', 'pipe', 'dpp'])
+def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip, monkeypatch, variant):
     """Chunked schedules at the edges: segment counts around multiples of the chunk size and of the
-    resident workgroup count, one to three streams, all three schedules - tuned kernel vs the
-    independent generic kernel on device-resident data."""
+    resident workgroup count, one to three streams, all three schedules, default and tiny chunks
+    (one- and two-segment chunks take their own paths in the wave-specialised kernel) - every build of
+    the tuned kernel vs the independent generic kernel on device-resident data."""
+    if variant:
+        monkeypatch.setenv('OTH_W4096_VARIANT', variant)
     rng = np.random.default_rng(7)
     nmax = 4096 + 2048 * 9000
     d_in = ctx.alloc(3 * nmax * 8)
@@ -474,6 +478,11 @@ def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip):
             n = 4096 + 2048 * (nseg - 1) + int(rng.integers(0, 2048))
             ns = int(rng.integers(1, 4))
             sched = int(rng.integers(0, 3))
+            chunk = int(rng.integers(0, 6))
+            if chunk:
+                monkeypatch.setenv('OTH_W4096_CHUNK', str(chunk))
+            else:
+                monkeypatch.delenv('OTH_W4096_CHUNK', raising=False)
             tuned.set_schedule(sched)
             assert tuned.exec_dev(d_in, n, d_a, nstreams=ns, stream_stride=nmax) == nseg
             assert gen.exec_dev(d_in, n, d_b, nstreams=ns, stream_stride=nmax) == nseg
@@ -482,7 +491,39 @@ def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip):
             # few-segment periodograms have near-empty bins: judge those against the spectrum's typical level
             # (two fp32 FFTs differ by ~1e-6 of the typical amplitude, which is 1e-5 of a bin 10x below it)
             err = np.max(np.abs(a.astype(np.float64) - b) / np.maximum(b, 0.1 * np.median(b)))
-            assert err < 5e-5, (nseg, ns, sched, err)
+            assert err < 5e-5, (variant, nseg, ns, sched, chunk, err)
     finally:
         for ptr in (d_in, d_a, d_b):
             ctx.free(ptr)
+
+
+@pytest.mark.parametrize('variant', ['', 'pipe'])
+def test_welch4096_large_dc_offset(ctx, hip, monkeypatch, variant):
+    """A DC offset 30x the noise level (uncalibrated SDR front end): the default build removes the mean in
+    the frequency domain (X - mean * FFT(w)), the fallback in the time domain; both must hold 1e-4 on every
+    bin, the ones under the removed DC line included."""
+    if variant:
+        monkeypatch.setenv('OTH_W4096_VARIANT', variant)
+    rng = np.random.default_rng(11)
+    n = 4096 + 2048 * 63
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n) + (30.0 - 18.0j)).astype(np.complex64)
+    plan = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_TUNED)
+    got = plan.exec(x)
+    plan.close()
+    _, want = R.welch_np(x, fs=1.0, window=hann(4096), nperseg=4096, noverlap=2048, nfft=4096)
+    assert relerr(got, want) < RTOL
+
+
+def test_welch4096_window_with_wide_spectrum_takes_the_time_domain_detrend(ctx, hip):
+    """A symmetric Hamming window has 1/k sidelobes: its spectrum is not confined to the bins the
+    frequency-domain detrend corrects, so the plan must fall back to the kernel that subtracts the
+    mean before windowing - visible as parity with a strong DC offset in the input."""
+    rng = np.random.default_rng(12)
+    n = 4096 + 2048 * 40
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n) + (5.0 + 2.0j)).astype(np.complex64)
+    w = (0.54 - 0.46 * np.cos(2 * np.pi * np.arange(4096) / 4095.0)).astype(np.float32)
+    plan = ctx.welch_plan(4096, window=w, kernel=hip.KERNEL_TUNED)
+    got = plan.exec(x)
+    plan.close()
+    _, want = R.welch_np(x, fs=1.0, window=w, nperseg=4096, noverlap=2048, nfft=4096)
+    assert relerr(got, want) < RTOL

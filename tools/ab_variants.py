@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of the welch4096 build variants in one process.
-usage: ab_variants.py [log2_samples] [rounds] [variant[:sched[:chunk]] ...]"""
+usage: ab_variants.py [log2_samples] [rounds] [variant[:sched[:chunk[:tail[:tune]]]] ...]"""
 import os
 import sys
 
@@ -16,7 +16,12 @@ variants = sys.argv[3:] or ['dpp:0:8', 'dpp:2:8', 'pipe:0:8', 'pipe:2:8', 'pipe:
 
 
 def select(v):
-    tag, sched, chunk, tail = (v.split(':') + ['0', '8', ''])[:4]
+    f = v.split(':')
+    tag, sched, chunk, tail, tune = f + ['', '0', '8', '', ''][len(f):]
+    if tune:
+        os.environ['OTH_WS_TUNE'] = tune
+    else:
+        os.environ.pop('OTH_WS_TUNE', None)
     os.environ['OTH_W4096_VARIANT'] = tag
     os.environ['OTH_W4096_SCHED'] = sched
     os.environ['OTH_W4096_CHUNK'] = chunk
