@@ -217,7 +217,7 @@ def main():
                        'segments_per_gpu': nseg, 'parallelism': 'segment-per-gpu x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'kernel': 'welch4096_kernel', 'kernel_avg_ms': kavg_ms, 'launches': int(launches),
+                         'kernel': 'welch4096ws_kernel', 'kernel_avg_ms': kavg_ms, 'launches': int(launches),
                          'algorithmic_bytes_per_launch': 8 * n,
                          'read_probe_GBps': 8.0 * n / (probe_ms * 1e-3) / 1e9},
             'parity_prefix_max_rel_err': err,

@@ -32,6 +32,8 @@ struct oth_ctx {
     float *sink = nullptr;
     double *acc4 = nullptr;
     unsigned *queue = nullptr;         // 64 chunk tickets for the dynamic segment schedule
+    bool queue_clean = false;          // all zero on the stream's timeline (finalize_kernel re-zeroes what a launch used)
+    int queue_used = 0;                // counters the last averaging launch drew from
 };
 
 struct oth_plan {
@@ -354,7 +356,9 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
                 if (a.tail_chunk < 1) a.tail_chunk = 1;
                 const long long tail_segs = (long long)W * a.chunk / 2;
                 a.nbig = nseg > tail_segs ? (nseg - tail_segs) / a.chunk : 0;
-                HIPCHK(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned) * nstreams, c->stream));
+                if (!c->queue_clean) HIPCHK(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned) * 64, c->stream));
+                c->queue_clean = false;      // until the finalize launch that follows has re-zeroed them
+                c->queue_used = nstreams;
             }
         }
     }
@@ -368,6 +372,22 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     *nseg_out = nseg;
     *W_out = W;
     *layout_out = (tuned || tuned_csd) ? 1 : (tuned_16k ? 2 : 0);
+    return OTH_OK;
+}
+
+// finalize_kernel zeroes the ticket counters the averaging launch before it used (saves a memset per call)
+int finalize_and_rearm(oth_ctx *c, FinalizeArgs &f, int nstreams) {
+    f.queue_reset = nullptr;
+    f.queue_n = 0;
+    if (!c->queue_clean && c->queue_used > 0) {
+        f.queue_reset = c->queue;
+        f.queue_n = c->queue_used;
+    }
+    HIPCHK(c, launch_finalize(f, nstreams, c->stream));
+    if (f.queue_reset) {
+        c->queue_clean = true;
+        c->queue_used = 0;
+    }
     return OTH_OK;
 }
 
@@ -711,7 +731,7 @@ int oth_welch_exec_dev(oth_plan *p, const void *iq_dev, size_t nsamples, int nst
     f.trim = p->trim;
     f.db = p->db;
     f.nout = p->nfft - 2 * p->trim;
-    HIPCHK(c, launch_finalize(f, nstreams, c->stream));
+    if (int frc = finalize_and_rearm(c, f, nstreams)) return frc;
     if (nseg_out) *nseg_out = (uint64_t)nseg;
     return OTH_OK;
 }
@@ -767,7 +787,7 @@ int oth_welch_partial_dev(oth_plan *p, const void *iq_dev, size_t nsamples, floa
     f.nch = 1;
     f.layout = layout;
     f.nout = p->nfft;
-    HIPCHK(c, launch_finalize(f, 1, c->stream));
+    if (int frc = finalize_and_rearm(c, f, 1)) return frc;
     if (nseg_out) *nseg_out = (uint64_t)nseg;
     return OTH_OK;
 }
@@ -823,7 +843,7 @@ int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
     f.layout = layout;
     f.nout = p->nfft;
     f.accumulate = 1;
-    HIPCHK(c, launch_finalize(f, 1, c->stream));
+    if (int frc = finalize_and_rearm(c, f, 1)) return frc;
     p->nseg_total += (uint64_t)nseg;
     // keep the samples the next segment still needs
     const size_t consumed = (size_t)nseg * (size_t)p->step;
@@ -893,7 +913,7 @@ int oth_csd_exec(oth_plan *p, const void *x, const void *y, size_t nsamples, int
     f.fftshift = p->fftshift;
     f.trim = p->trim;
     f.nout = nout;
-    HIPCHK(c, launch_finalize(f, 1, c->stream));
+    if (int frc = finalize_and_rearm(c, f, 1)) return frc;
     if (pxx) HIPCHK(c, hipMemcpyAsync(pxx, f.out0, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
     if (pyy) HIPCHK(c, hipMemcpyAsync(pyy, f.out1, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
     if (pxy) HIPCHK(c, hipMemcpyAsync(pxy, f.out2, sizeof(float) * 2 * nout, hipMemcpyDeviceToHost, c->stream));

@@ -22,6 +22,7 @@ __device__ __forceinline__ int bin_pos(int pos, int layout) {
 // combined in a fixed order, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     __shared__ double red[4][8][32];
+    if (a.queue_reset && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < a.queue_n) a.queue_reset[threadIdx.x] = 0u;
     const int lane = threadIdx.x & 31, slice = threadIdx.x >> 5;
     // threads walk partial-sum POSITIONS (coalesced reads); the bin and output slot follow
     const int pos = blockIdx.x * 32 + lane;

@@ -64,6 +64,8 @@ struct FinalizeArgs {
     int db;
     int nout;
     int accumulate;         // out0 += (raw sums; streaming form)
+    unsigned *queue_reset;  // chunk-ticket counters of the averaging kernel, zeroed here for the next launch (or null)
+    int queue_n;
 };
 
 // Every launcher returns hipSuccess / error of the launch only (asynchronous).

@@ -344,18 +344,23 @@ int OTH_CAT(tuned4096_blocks_per_cu_, OTH_WS_TAG)() {
 
 hipError_t OTH_CAT(launch_welch_tuned4096_, OTH_WS_TAG)(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
-    hipError_t e;
-    if (a.detrend) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(welch4096ws_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
+    static bool armed[64] = {};        // 70 KiB of dynamic LDS needs the opt-in, once per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63, armed[63] = false;
+    bool &big_lds = armed[dev];
+    if (!big_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(welch4096ws_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(welch4096ws_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((welch4096ws_kernel<true>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(welch4096ws_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((welch4096ws_kernel<false>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
+        big_lds = true;
     }
+    if (a.detrend)
+        hipLaunchKernelGGL((welch4096ws_kernel<true>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
+    else
+        hipLaunchKernelGGL((welch4096ws_kernel<false>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
