@@ -333,10 +333,6 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.nbig = 0;
     a.queue = nullptr;
     a.fd = p->d_fd;
-    {
-        const char *et = getenv("OTH_WS_TUNE");
-        a.tune = et ? (int)strtol(et, nullptr, 0) : 0;
-    }
     if (tuned || tuned_csd || tuned_16k) {
         const char *e = getenv("OTH_W4096_SCHED");
         const char *ec = getenv("OTH_W4096_CHUNK");

@@ -29,7 +29,6 @@ struct WelchArgs {
     // welch4096ws frequency-domain detrend: per consumer thread t = 16 k0 + k1 the window spectrum at bins
     // k0 + 16 k1 and k0 + 16 k1 + 3840 (re, im, re, im); nullptr when the window's spectrum is not confined
     const float4 *fd;
-    int tune;               // experiment knob (OTH_WS_TUNE), 0 in production
 };
 
 struct PgramArgs {

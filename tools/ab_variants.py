@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of the welch4096 build variants in one process.
-usage: ab_variants.py [log2_samples] [rounds] [variant[:sched[:chunk[:tail[:tune]]]] ...]"""
+usage: ab_variants.py [log2_samples] [rounds] [variant[:sched[:chunk[:tail]]] ...]"""
 import os
 import sys
 
@@ -17,11 +17,7 @@ variants = sys.argv[3:] or ['dpp:0:8', 'dpp:2:8', 'pipe:0:8', 'pipe:2:8', 'pipe:
 
 def select(v):
     f = v.split(':')
-    tag, sched, chunk, tail, tune = f + ['', '0', '8', '', ''][len(f):]
-    if tune:
-        os.environ['OTH_WS_TUNE'] = tune
-    else:
-        os.environ.pop('OTH_WS_TUNE', None)
+    tag, sched, chunk, tail = f + ['', '0', '8', ''][len(f):]
     os.environ['OTH_W4096_VARIANT'] = tag
     os.environ['OTH_W4096_SCHED'] = sched
     os.environ['OTH_W4096_CHUNK'] = chunk
