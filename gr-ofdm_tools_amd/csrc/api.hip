@@ -194,21 +194,23 @@ struct W4096Variant {
     hipError_t (*launch)(const WelchArgs &, hipStream_t);
     int (*blocks_per_cu)();
     int chunk;      // default segments per chunk of the dynamic schedule (same-box A/B, tools/ab_variants.py)
+    int rows;       // rows of partial sums each workgroup writes
+    bool fd;        // detrends in the frequency domain: needs WelchArgs.fd (a window with a confined spectrum)
 };
 const W4096Variant kVariants[] = {
-    {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp, 8},            // any step
-    {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe, 16},        // step 2048 (50 % overlap)
-    {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16},
-    {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 32},              // step 2048, confined window spectrum
+    {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp, 8, 1, false},            // any step
+    {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe, 16, 1, false},        // step 2048 (50 % overlap)
+    {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16, 1, false},
+    {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 32, 1, true},     // step 2048, confined window spectrum
 #ifdef OTH_EXPERIMENTS
-    {"exp1", launch_welch_tuned4096_exp1, tuned4096_blocks_per_cu_exp1, 16},
-    {"exp2", launch_welch_tuned4096_exp2, tuned4096_blocks_per_cu_exp2, 16},
-    {"exp3", launch_welch_tuned4096_exp3, tuned4096_blocks_per_cu_exp3, 16},
-    {"exp4", launch_welch_tuned4096_exp4, tuned4096_blocks_per_cu_exp4, 16},
-    {"wsx1", launch_welch_tuned4096_wsx1, tuned4096_blocks_per_cu_wsx1, 32},
-    {"wsx2", launch_welch_tuned4096_wsx2, tuned4096_blocks_per_cu_wsx2, 32},
-    {"wsx3", launch_welch_tuned4096_wsx3, tuned4096_blocks_per_cu_wsx3, 32},
-    {"wsx4", launch_welch_tuned4096_wsx4, tuned4096_blocks_per_cu_wsx4, 32},
+    {"exp1", launch_welch_tuned4096_exp1, tuned4096_blocks_per_cu_exp1, 16, 1, false},
+    {"exp2", launch_welch_tuned4096_exp2, tuned4096_blocks_per_cu_exp2, 16, 1, false},
+    {"exp3", launch_welch_tuned4096_exp3, tuned4096_blocks_per_cu_exp3, 16, 1, false},
+    {"exp4", launch_welch_tuned4096_exp4, tuned4096_blocks_per_cu_exp4, 16, 1, false},
+    {"wsx1", launch_welch_tuned4096_wsx1, tuned4096_blocks_per_cu_wsx1, 32, 1, true},
+    {"wsx2", launch_welch_tuned4096_wsx2, tuned4096_blocks_per_cu_wsx2, 32, 1, true},
+    {"wsx3", launch_welch_tuned4096_wsx3, tuned4096_blocks_per_cu_wsx3, 32, 1, true},
+    {"wsx4", launch_welch_tuned4096_wsx4, tuned4096_blocks_per_cu_wsx4, 32, 1, true},
 #endif
 };
 const W4096Variant *w4096_variant(int step, bool fd_ok) {
@@ -218,7 +220,7 @@ const W4096Variant *w4096_variant(int step, bool fd_ok) {
         for (const auto &v : kVariants)
             if (!strcmp(e, v.tag)) pick = &v;
     // the wave-specialised build detrends in the frequency domain: only with a confined window spectrum
-    if (!strncmp(pick->tag, "ws", 2) && !fd_ok) pick = &kVariants[1];
+    if (pick->fd && !fd_ok) pick = &kVariants[1];
     // the pipelined builds keep the overlapped half in registers: only for step = nperseg / 2
     if (pick != &kVariants[0] && step != 2048) pick = &kVariants[0];
     return pick;
@@ -308,10 +310,11 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
     }
     const int nch = csd ? 4 : 1;
-    // + 32 B per workgroup of stamp space behind the sums (only the diagnostic kernel build writes it)
+    const int rows = tuned ? var->rows : 1;      // rows of partial sums per workgroup
+    // + 1 KiB per row of stamp space behind the sums (only the diagnostic kernel builds write it)
     int rc = ensure(c, &p->d_partial, &p->partial_cap,
-                    sizeof(float) * (size_t)nstreams * W * nch * p->nfft + 1024 * (size_t)nstreams * W);
-    p->last_W = W * nstreams;
+                    sizeof(float) * (size_t)nstreams * W * rows * nch * p->nfft + 1024 * (size_t)nstreams * W * rows);
+    p->last_W = W * rows * nstreams;
     if (!rc) rc = ensure(c, &p->d_reduce, &p->reduce_cap, sizeof(float) * (size_t)nstreams * kReduceGroups * nch * p->nfft);
     if (rc) return rc;
     WelchArgs a;
@@ -366,7 +369,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
                                                   : launch_welch_generic(p->nfft, a, c->stream))));
     }
     *nseg_out = nseg;
-    *W_out = W;
+    *W_out = W * rows;
     *layout_out = (tuned || tuned_csd) ? 1 : (tuned_16k ? 2 : 0);
     return OTH_OK;
 }
