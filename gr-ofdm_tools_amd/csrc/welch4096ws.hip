@@ -108,12 +108,23 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
         using head = std::integral_constant<int, 1>;    // last segment of the chunk: prefetch the next chunk's first segment
         using none = std::integral_constant<int, 2>;    // nothing to prefetch
 
-        auto load_chunk_head = [&](long long first_seg) {
-            const float2 *xs = xb + first_seg * 2048 + t;
+        // segment indices are wave-uniform ints pinned to scalar registers (the launcher checks nseg < 2^30), so
+        // the loads use scalar base + per-thread offset and cost no vector address arithmetic
+        auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        auto load_chunk_head = [&](int first_seg) {
+            const float2 *xs = xb + (size_t)uni(first_seg) * 2048;      // scalar base, unsigned 32-bit lane offset
 #pragma unroll
-            for (int a = 0; a < 8; ++a) raw0[a] = xs[256 * a];
+            for (int j = 0; j < 4; ++j) {      // one scalar base per pair of rows: offsets t and t + 256 (immediate)
+                const float2 *xj = xs + 512 * j;
+                raw0[2 * j] = xj[(unsigned)t];
+                raw0[2 * j + 1] = xj[(unsigned)t + 256u];
+            }
 #pragma unroll
-            for (int a = 0; a < 8; ++a) nxt[a] = xs[2048 + 256 * a];
+            for (int j = 0; j < 4; ++j) {
+                const float2 *xj = xs + 2048 + 512 * j;
+                nxt[2 * j] = xj[(unsigned)t];
+                nxt[2 * j + 1] = xj[(unsigned)t + 256u];
+            }
         };
         auto step_end = [&](int item) {
             if (t == 0) ctrl[it & 1] = item;
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
         // One segment: image (it & 1).  Every flavour leaves the same state behind - kw = windowed first half of the
         // following segment, nxt = its second half in flight - so the hot (false, mid) flavour is straight-line code
         // with one group of eight loads per step.
-        auto item = [&](auto first_, auto mode_, long long s, long long nsb, bool publish) {
+        auto item = [&](auto first_, auto mode_, int s, int nsb, bool publish) {
             constexpr bool FIRST = decltype(first_)::value;
             constexpr int MODE = decltype(mode_)::value;
             const int q = it & 1;
@@ -159,9 +170,13 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
                 if (publish) ctrl[4] = (int)ticket;
             }
             if (MODE == 0) {
-                const float2 *xn = xb + (s + 2) * 2048 + t;
+                const float2 *xn = xb + (size_t)uni(s + 2) * 2048;
 #pragma unroll
-                for (int a = 0; a < 8; ++a) nxt[a] = xn[256 * a];
+                for (int j = 0; j < 4; ++j) {
+                    const float2 *xj = xn + 512 * j;
+                    nxt[2 * j] = xj[(unsigned)t];
+                    nxt[2 * j + 1] = xj[(unsigned)t + 256u];
+                }
             } else if (MODE == 1) {
                 load_chunk_head(nsb);
             }
@@ -189,26 +204,32 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             step_end(ITEM_DATA);
         };
 
-        long long cur = 0, sb = 0, se = 0;
-        auto open_chunk = [&](long long c) -> bool {
+        int cur = 0, sb = 0, se = 0;
+        auto range = [&](int c, int &b, int &e) {
+            long long lb, le;
+            chunk_range(p, c, lb, le);
+            b = uni((int)lb);
+            e = uni((int)le);
+        };
+        auto open_chunk = [&](int c) -> bool {
             cur = c;
             if (sched) {
                 if (cur >= nchunks) return false;
-                chunk_range(p, cur, sb, se);
+                range(cur, sb, se);
                 return true;
             }
-            sb = (p.nseg * wg) / W;
-            se = (p.nseg * (wg + 1)) / W;
+            sb = uni((int)((p.nseg * wg) / W));
+            se = uni((int)((p.nseg * (wg + 1)) / W));
             return sb < se;
         };
         bool have = open_chunk(sched ? wg : 0);
         if (have) load_chunk_head(sb);
         while (have) {
-            const long long n = se - sb;
-            long long ncur = 0;
+            const int n = se - sb;
+            int ncur = 0;
             if (n >= 2) {
                 item(true_type{}, mid{}, sb, 0, n == 2);
-                long long s = sb + 1;
+                int s = sb + 1;
                 if (s < se - 1) item(false_type{}, mid{}, s++, 0, true);
                 for (; s + 1 < se - 1; s += 2) {      // two per trip: kw's registers swap roles instead of being copied
                     item(false_type{}, mid{}, s, 0, false);
@@ -216,11 +237,11 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
                 }
                 if (s < se - 1) item(false_type{}, mid{}, s, 0, false);
                 // last segment: the next chunk's ticket was published at least one barrier ago
-                ncur = (sched == 1) ? cur + W : (long long)W + __builtin_amdgcn_readfirstlane(ctrl[4]);
-                long long nsb = 0, nse = 0;
+                ncur = (sched == 1) ? cur + W : W + uni(ctrl[4]);
+                int nsb = 0, nse = 0;
                 const bool have_next = sched && ncur < nchunks;
                 if (have_next) {
-                    chunk_range(p, ncur, nsb, nse);
+                    range(ncur, nsb, nse);
                     item(false_type{}, head{}, se - 1, nsb, false);
                     cur = ncur;
                     sb = nsb;
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             if (sched == 0) break;
             if (sched == 2) {
                 step_end(ITEM_BUBBLE);
-                ncur = (long long)W + __builtin_amdgcn_readfirstlane(ctrl[4]);
+                ncur = W + uni(ctrl[4]);
             } else {
                 ncur = cur + W;
             }
