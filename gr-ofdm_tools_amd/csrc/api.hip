@@ -301,7 +301,9 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd && !tuned_16k)
         return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
     const W4096Variant *var =
-        tuned ? w4096_variant(p->nperseg == 4096 ? p->step : 0, p->detrend == OTH_DETREND_NONE || p->d_fd) : nullptr;
+        tuned ? w4096_variant(p->nperseg == 4096 ? p->step : 0,
+                              (p->detrend == OTH_DETREND_NONE || p->d_fd) && nseg < (1LL << 30))   // ws: 32-bit segment indices
+              : nullptr;
     int W = generic_wg(c, p->nfft, nseg, nstreams);
     if (tuned || tuned_csd || tuned_16k) {
         // exactly the resident workgroups: one wave of workgroups, no tail round
