@@ -527,3 +527,32 @@ def test_welch4096_window_with_wide_spectrum_takes_the_time_domain_detrend(ctx, 
     plan.close()
     _, want = R.welch_np(x, fs=1.0, window=w, nperseg=4096, noverlap=2048, nfft=4096)
     assert relerr(got, want) < RTOL
+
+
+def test_tuned_kernels_repeat_without_drift(ctx, hip, monkeypatch):
+    """300 launches of the tuned builds on one input, schedules and chunk sizes drawn at random: every result
+    must stay within rounding of the generic kernel's (a missed barrier or a stale ticket shows up as an
+    occasional outlier, not as a steady error)."""
+    rng = np.random.default_rng(99)
+    n = 4096 + 2048 * 2046 + 777
+    d_in = ctx.alloc(2 * n * 8)
+    d_a, d_b = ctx.alloc(2 * 4096 * 4), ctx.alloc(2 * 4096 * 4)
+    try:
+        ctx.synth_iq(d_in, 2 * n, 5, R.TONES, R.DC)
+        tuned = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_TUNED)
+        gen = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_GENERIC)
+        gen.exec_dev(d_in, n, d_b, nstreams=2, stream_stride=n)
+        want = ctx.d2h(d_b, (2, 4096), np.float32).astype(np.float64)
+        worst = 0.0
+        for it in range(300):
+            monkeypatch.setenv('OTH_W4096_VARIANT', ('ws', 'pipe', 'dpp')[it % 3])
+            monkeypatch.setenv('OTH_W4096_CHUNK', str(int(rng.choice([1, 2, 3, 5, 8, 16, 32, 64]))))
+            tuned.set_schedule(int(rng.integers(0, 3)))
+            assert tuned.exec_dev(d_in, n, d_a, nstreams=2, stream_stride=n) == 2047
+            got = ctx.d2h(d_a, (2, 4096), np.float32)
+            err = float(np.max(np.abs(got - want) / want))
+            worst = max(worst, err)
+            assert err < 2e-5, (it, err)
+    finally:
+        for ptr in (d_in, d_a, d_b):
+            ctx.free(ptr)
