@@ -65,6 +65,44 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     }
 }
 
+// One-launch form for the one-channel case with many partial rows (the headline Welch path): 256 threads = 8
+// float4 columns (32 consecutive positions) x 32 row slices; slice sums in double, combined in a fixed order.
+__global__ __launch_bounds__(256) void finalize_wide_kernel(FinalizeArgs a) {
+    __shared__ double red[32][33];
+    if (a.queue_reset && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < a.queue_n) a.queue_reset[threadIdx.x] = 0u;
+    const int col = threadIdx.x & 7, slice = threadIdx.x >> 3;
+    const int stream = blockIdx.y;
+    const float *base = a.partial + (size_t)stream * a.W * a.nfft + blockIdx.x * 32 + col * 4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int w = slice; w < a.W; w += 32) {
+        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)w * a.nfft);
+        s0 += v.x;
+        s1 += v.y;
+        s2 += v.z;
+        s3 += v.w;
+    }
+    red[slice][col * 4] = s0;
+    red[slice][col * 4 + 1] = s1;
+    red[slice][col * 4 + 2] = s2;
+    red[slice][col * 4 + 3] = s3;
+    __syncthreads();
+    if (threadIdx.x >= 32) return;
+    const int pos = blockIdx.x * 32 + threadIdx.x;
+    const int k = bin_pos(pos, a.layout);
+    const int ks = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;
+    const int i = ks - a.trim;
+    if (i < 0 || i >= a.nout) return;
+    double t = 0.0;
+    for (int q = 0; q < 32; ++q) t += red[q][threadIdx.x];
+    const size_t o = (size_t)stream * a.nout + i;
+    if (a.accumulate) {
+        a.out0[o] += (float)t;
+    } else {
+        const double v = t * a.scale;
+        a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
+    }
+}
+
 // Stage 1 of the cross-workgroup reduction when there are many partial rows: row group g of
 // kReduceGroups sums its rows (fixed order) into scratch[stream][g][ch][nfft]; finalize_kernel then
 // runs over the kReduceGroups rows.  256 threads = 64 float4 columns x 4 row lanes.
@@ -101,6 +139,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *parti
 
 hipError_t launch_finalize(const FinalizeArgs &a_in, int nstreams, hipStream_t s) {
     FinalizeArgs a = a_in;
+    if (a.nch == 1 && a.W >= 64 && (a.nfft % 32) == 0) {
+        hipLaunchKernelGGL(finalize_wide_kernel, dim3(a.nfft / 32, nstreams), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.W > 2 * kReduceGroups && a.scratch && (a.nfft % 256) == 0) {
         const int rpg = (a.W + kReduceGroups - 1) / kReduceGroups;
         const dim3 g1(a.nfft / 256, kReduceGroups, nstreams * a.nch);
