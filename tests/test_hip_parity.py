@@ -411,6 +411,33 @@ def test_full_size_256M_properties(ctx, hip):
         ctx.free(d_in)
 
 
+def test_beyond_4GiB_offsets(ctx, hip):
+    """2^29 + 5000 samples (4 GiB + a ragged tail): byte offsets pass 2^32.  The PSD of the whole stream equals
+    the segment-weighted mean of the PSDs of its two halves cut with a 2048-sample halo (integer/pointer
+    overflow anywhere in the schedule or the loads would break the identity), tuned and generic kernels."""
+    nfft = 4096
+    n = (1 << 29) + 5000
+    nseg = (n - 2048) // 2048
+    s1 = nseg // 2 + 3                       # segments in the first part
+    n1 = 2048 * (s1 + 1)                     # its samples; the second part starts s1 hops in
+    d_in = ctx.alloc(n * 8)
+    try:
+        ctx.synth_iq(d_in, n, 77, R.TONES, R.DC)
+        for kern in (hip.KERNEL_TUNED, hip.KERNEL_GENERIC):
+            plan = ctx.welch_plan(nfft, window=hann(nfft), fs=1.0, kernel=kern)
+            whole = plan.exec_device_src(d_in, n).astype(np.float64)
+            assert plan.last_nseg == nseg
+            a = plan.exec_device_src(d_in, n1).astype(np.float64)
+            assert plan.last_nseg == s1
+            b = plan.exec_device_src(d_in + 8 * 2048 * s1, n - 2048 * s1).astype(np.float64)
+            assert plan.last_nseg == nseg - s1
+            mix = (a * s1 + b * (nseg - s1)) / nseg
+            assert relerr(whole, mix) < 2e-5, kern
+            plan.close()
+    finally:
+        ctx.free(d_in)
+
+
 # ------------------------------------------------- randomized plan sweep ----
 
 def test_randomized_welch_plans_vs_oracle(ctx, hip):
