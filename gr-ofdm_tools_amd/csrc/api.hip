@@ -201,7 +201,7 @@ const W4096Variant kVariants[] = {
     {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp, 8, 1, false},            // any step
     {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe, 16, 1, false},        // step 2048 (50 % overlap)
     {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16, 1, false},
-    {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 32, 1, true},     // step 2048, confined window spectrum
+    {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 20, 1, true},     // step 2048, confined window spectrum
 #ifdef OTH_EXPERIMENTS
     {"exp1", launch_welch_tuned4096_exp1, tuned4096_blocks_per_cu_exp1, 16, 1, false},
     {"exp2", launch_welch_tuned4096_exp2, tuned4096_blocks_per_cu_exp2, 16, 1, false},

@@ -62,7 +62,7 @@ namespace {
 
 constexpr int TWS = 512;
 constexpr int WS_RED = 32;                 // float2: per image 4 new-half wave sums + 4 first-half wave sums (x2 images)
-constexpr int WS_CTRL = 16;                // ints: valid[2], first[2], lnext
+constexpr int WS_CTRL = 16;                // ints: item kind per image [0..1], next-chunk ticket [4]
 constexpr size_t WS_LDS_BYTES = (2 * LDS_X + WS_RED) * sizeof(float2) + WS_CTRL * sizeof(int);
 
 enum { ITEM_STOP = 0, ITEM_DATA = 1, ITEM_BUBBLE = 2 };
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
         for (int a = 0; a < 16; ++a) win[a] = p.win[256 * a + t];
         const float2 b1 = p.tw[t], b4 = p.tw[4 * t];            // pass-1 twiddle seeds W4096^t, W4096^(4t)
         float2 kw[8], nxt[8], raw0[8];
+        float2 prev_new = make_float2(0.f, 0.f);     // this wave's sum of the previous segment's new half
         int it = 0;
         unsigned ticket = 0;
         using std::false_type;
@@ -180,17 +181,17 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             } else if (MODE == 1) {
                 load_chunk_head(nsb);
             }
-            if (DETREND) {
+            if (DETREND) {      // per-wave sums of both halves of this segment, side by side for the consumer
                 sum.x = wave_total(sum.x);
                 sum.y = wave_total(sum.y);
-                if ((t & 63) == 0) red[q * 8 + wave] = sum;
-                if (FIRST) {
-                    sumf.x = wave_total(sumf.x);
-                    sumf.y = wave_total(sumf.y);
-                    if ((t & 63) == 0) red[q * 8 + 4 + wave] = sumf;
+                float2 other = prev_new;
+                if (FIRST) other = make_float2(wave_total(sumf.x), wave_total(sumf.y));
+                if ((t & 63) == 0) {
+                    red[q * 8 + wave] = sum;
+                    red[q * 8 + 4 + wave] = other;
                 }
+                prev_new = sum;
             }
-            if (t == 0) ctrl[2 + q] = FIRST ? 1 : 0;
             WS_STAMP(1);
             __builtin_amdgcn_s_setprio(OTH_WS_PAC);
             dft16(v);
@@ -274,10 +275,11 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
         float acc[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        float2 prev_tot = make_float2(0.f, 0.f), mean = make_float2(0.f, 0.f);
+        float2 mean = make_float2(0.f, 0.f);
         float2 v[16];
         int item = ITEM_BUBBLE;           // nothing to consume in the first step
         for (int it = 0;; ++it) {
+            if (item == ITEM_STOP) break; // the producer left after the barrier of the step that published it
             if (item == ITEM_DATA) {      // v holds the exchange-1 reads of image (it - 1) & 1
                 float2 *lx = img + ((it & 1) ^ 1) * LDS_X;
 #if OTH_WS_DIAG
@@ -323,19 +325,14 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             const int q = it & 1;
             const float2 *lq = img + q * LDS_X;
             item = ctrl[q];
-            const int first = ctrl[2 + q];
 #pragma unroll
             for (int b = 0; b < 16; ++b) v[b] = lq[r1 + b * 17];
-            if (DETREND) {
-                const float2 nt = cadd(cadd(red[q * 8], red[q * 8 + 1]), cadd(red[q * 8 + 2], red[q * 8 + 3]));
-                const float2 ft = cadd(cadd(red[q * 8 + 4], red[q * 8 + 5]), cadd(red[q * 8 + 6], red[q * 8 + 7]));
-                if (item == ITEM_DATA) {
-                    if (first) prev_tot = ft;
-                    mean = make_float2((prev_tot.x + nt.x) * (1.0f / 4096.0f), (prev_tot.y + nt.y) * (1.0f / 4096.0f));
-                    prev_tot = nt;
-                }
+            if (DETREND) {      // the segment's mean from the eight per-wave half sums the producer left
+                float2 tot = red[q * 8];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) tot = cadd(tot, red[q * 8 + i]);
+                mean = make_float2(tot.x * (1.0f / 4096.0f), tot.y * (1.0f / 4096.0f));
             }
-            if (item == ITEM_STOP) break;
         }
         // bin k0 + 16 k1 + 256 k2 of this workgroup sits at t + 256 k2 (finalize_kernel layout 1)
         float *dst = p.partial + ((size_t)stream * W + wg) * 4096;
