@@ -98,6 +98,22 @@ def test_sweeper_segment_zero_padded_shift_trim_db(ctx, golden):
     assert np.max(np.abs(db - g['expected_psd_db'])) < 1e-3
 
 
+@pytest.mark.parametrize('kernel', ['tuned', 'generic'])
+def test_many_segments_shift_trim_db_vs_oracle(ctx, hip, kernel):
+    """The sweep segment of the multi-GPU bench at a size the oracle still handles: 1023 segments, i.e. a
+    full grid of workgroups and the one-launch cross-workgroup reduction, with fftshift + trim + dB."""
+    n = 4096 + 2048 * 1022
+    x = np.concatenate([R.synth_iq(1 << 19, 40 + i, n0=i << 19) for i in range(5)])[:n]
+    k = hip.KERNEL_TUNED if kernel == 'tuned' else hip.KERNEL_GENERIC
+    plan = ctx.welch_plan(4096, window=hann(4096), fs=2.5e6, fftshift=True, trim_bins=256, db=True, kernel=k)
+    got = plan.exec(x)
+    assert plan.last_nseg == 1023 and got.shape == (3584,)
+    _, ref = R.welch_np(x, fs=2.5e6, nperseg=4096, nfft=4096)
+    ref = np.fft.fftshift(ref)[256:-256]
+    assert relerr(10 ** (got.astype(np.float64) / 10), ref) < RTOL
+    plan.close()
+
+
 @pytest.mark.parametrize('nperseg', [256, 512, 1024, 2048])
 def test_welch4096_zero_padded_segments_tuned_and_generic(ctx, hip, nperseg):
     x = R.synth_iq(60000, 300 + nperseg)
