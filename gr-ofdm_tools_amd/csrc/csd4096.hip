@@ -72,18 +72,12 @@ __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
         prio_latency();
         scatter_pow16<RS>(v, lx + w1, b1, b4);
         __syncthreads();   // B
-#pragma unroll
-        for (int b = 0; b < 16; ++b) v[b] = lx[r1 + b * 17];
-        prio_compute();
-        dft16(v);
+        dft16_from_lds<17>(v, lx + r1, [] { prio_compute(); });      // ordered reads, counted waits
         prio_latency();
         wave_lds_sync();
         scatter_pow16<17>(v, lx + w2, c1, c4);
         wave_lds_sync();
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = lx[r2 + c];
-        prio_compute();
-        dft16(v);
+        dft16_from_lds<1>(v, lx + r2, [] { prio_compute(); });
     };
 
     const int sched = p.sched;

@@ -45,6 +45,57 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
 }
 
+// dft16() of sixteen float2 read from LDS at base[STRIDE * i]: the reads are issued as plain ds_read_b64 in the
+// order the first butterfly layer takes them (hipcc pairs them into ds_read2_b64 - half the LDS rate on gfx950 -
+// and waits for all sixteen), each butterfly waits only for its own four.  The reads must be the wave's most
+// recent LDS operations when this is called; older LDS/scalar-memory operations only make the waits longer.
+// `issued()` runs once the reads are out (e.g. to drop the wave's priority for the butterflies).
+template <int STRIDE, class F>
+__device__ __forceinline__ void dft16_from_lds(float2 (&v)[16], const float2 *base, F issued) {
+#ifdef OTH_PLAIN_LDS_READS      // A/B switch: compiler-scheduled reads
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = base[STRIDE * i];
+    issued();
+    dft16(v);
+    return;
+#endif
+    const unsigned addr = (unsigned)(unsigned long long)base;      // LDS byte address = low half of the flat address
+    double r[16];
+#define OTH_LDS_READ(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[i]) : "v"(addr), "n"(8 * STRIDE * (i)))
+    OTH_LDS_READ(0); OTH_LDS_READ(4); OTH_LDS_READ(8); OTH_LDS_READ(12);
+    OTH_LDS_READ(1); OTH_LDS_READ(5); OTH_LDS_READ(9); OTH_LDS_READ(13);
+    OTH_LDS_READ(2); OTH_LDS_READ(6); OTH_LDS_READ(10); OTH_LDS_READ(14);
+    OTH_LDS_READ(3); OTH_LDS_READ(7); OTH_LDS_READ(11); OTH_LDS_READ(15);
+#undef OTH_LDS_READ
+    issued();
+    // each wait also names an output of the butterfly before it, which keeps that butterfly in front of the wait
+#define OTH_LDS_WAIT(n, a, dep) \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r[a]), "+v"(r[a + 4]), "+v"(r[a + 8]), "+v"(r[a + 12]), "+v"(dep))
+    float dep = 0.f;
+#pragma unroll
+    for (int a0 = 0; a0 < 4; ++a0) {
+        if (a0 == 0) OTH_LDS_WAIT(12, 0, dep);
+        else if (a0 == 1) OTH_LDS_WAIT(8, 1, v[0].x);
+        else if (a0 == 2) OTH_LDS_WAIT(4, 2, v[1].x);
+        else OTH_LDS_WAIT(0, 3, v[2].x);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = __builtin_bit_cast(float2, r[a0 + 4 * j]);
+        dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
+    }
+#undef OTH_LDS_WAIT
+    v[5] = mul_w1(v[5]);
+    v[9] = mul_w2(v[9]);
+    v[13] = mul_w3(v[13]);
+    v[6] = mul_w2(v[6]);
+    v[10] = mul_w4(v[10]);
+    v[14] = mul_w6(v[14]);
+    v[7] = mul_w3(v[7]);
+    v[11] = mul_w6(v[11]);
+    v[15] = mul_w9(v[15]);
+#pragma unroll
+    for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
+}
+
 // Chunk c of the segment schedule: the first `nbig` chunks have `chunk` segments, the rest `tail_chunk`
 // (smaller chunks for the last round even out the finish of the dynamic schedule).
 __device__ __forceinline__ long long chunk_count(const WelchArgs &p) {

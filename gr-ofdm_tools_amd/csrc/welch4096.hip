@@ -229,14 +229,16 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         OTH_STAMP(3);       // wait at barrier B
 
         // pass 2: thread (k0,c) gathers b, DFT over b, twiddle W256^(k1 c)
+#if OTH_W4096_DIAG
 #pragma unroll
         for (int b = 0; b < 16; ++b) v[b] = lx[r1 + b * 17];
-#if OTH_W4096_DIAG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         OTH_STAMP(7);       // exchange-1 reads landed
-#endif
         prio_compute();
         dft16(v);
+#else
+        dft16_from_lds<17>(v, lx + r1, [] { prio_compute(); });      // ordered reads, counted waits (fft4096.hip.h)
+#endif
         prio_latency();
         wave_lds_sync();   // the 16 lanes of this k0 have all read region k0
         scatter_pow16<17>(v, lx + w2, c1, c4);
@@ -244,14 +246,16 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         OTH_STAMP(8);       // second butterfly, W256 twiddles, exchange-2 writes issued
 
         // pass 3: thread (k0,k1) gathers c, DFT over c, accumulate |X|^2
+#if OTH_W4096_DIAG
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] = lx[r2 + c];
-#if OTH_W4096_DIAG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         OTH_STAMP(9);       // exchange-2 writes + reads landed
-#endif
         prio_compute();
         dft16(v);
+#else
+        dft16_from_lds<1>(v, lx + r2, [] { prio_compute(); });
+#endif
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             const float2 X = v[r16(k2)];

@@ -61,7 +61,7 @@ namespace {
 #endif
 
 constexpr int TWS = 512;
-constexpr int WS_RED = 32;                 // float2: per image 4 new-half wave sums + 4 first-half wave sums (x2 images)
+constexpr int WS_RED = 32;                 // float2: per image the four producer waves' sums over the segment (8 slots reserved, x2 images)
 constexpr int WS_CTRL = 16;                // ints: item kind per image [0..1], next-chunk ticket [4]
 constexpr size_t WS_LDS_BYTES = (2 * LDS_X + WS_RED) * sizeof(float2) + WS_CTRL * sizeof(int);
 
@@ -186,10 +186,7 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
                 sum.y = wave_total(sum.y);
                 float2 other = prev_new;
                 if (FIRST) other = make_float2(wave_total(sumf.x), wave_total(sumf.y));
-                if ((t & 63) == 0) {
-                    red[q * 8 + wave] = sum;
-                    red[q * 8 + 4 + wave] = other;
-                }
+                if ((t & 63) == 0) red[q * 8 + wave] = cadd(sum, other);
                 prev_new = sum;
             }
             WS_STAMP(1);
@@ -275,35 +272,25 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
         float acc[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        float2 mean = make_float2(0.f, 0.f);
         float2 v[16];
+        float2 mean = make_float2(0.f, 0.f);
         int item = ITEM_BUBBLE;           // nothing to consume in the first step
         for (int it = 0;; ++it) {
             if (item == ITEM_STOP) break; // the producer left after the barrier of the step that published it
             if (item == ITEM_DATA) {      // v holds the exchange-1 reads of image (it - 1) & 1
                 float2 *lx = img + ((it & 1) ^ 1) * LDS_X;
-#if OTH_WS_DIAG
-                WS_STAMP(5);
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                WS_STAMP(0);
-#endif
                 __builtin_amdgcn_s_setprio(OTH_WS_PBC);
                 dft16(v);
-                WS_STAMP(1);
                 __builtin_amdgcn_s_setprio(OTH_WS_PBL);
-                wave_lds_sync();
                 lx[w2] = v[r16(0)];
 #pragma unroll
                 for (int k1 = 1; k1 < 16; ++k1) lx[w2 + k1 * 17] = cmul(v[r16(k1)], tw2[k1]);
                 wave_lds_sync();
-#pragma unroll
-                for (int c = 0; c < 16; ++c) v[c] = lx[r2 + c];
-#if OTH_WS_DIAG
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                WS_STAMP(2);
-#endif
-                __builtin_amdgcn_s_setprio(OTH_WS_PBC);
-                dft16(v);
+                // exchange-2 reads as ordered ds_read_b64, the first butterfly layer on counted waits (-1.7 % kernel
+                // time against the sixteen plain reads, which hipcc pairs into ds_read2_b64 behind one lgkmcnt(0);
+                // the same treatment of the exchange-1 reads, which needs the butterfly before the item word is
+                // looked at, gave 1.3 % back)
+                dft16_from_lds<1>(v, lx + r2, [] { __builtin_amdgcn_s_setprio(OTH_WS_PBC); });
                 if (DETREND) {          // X[k] -= mean * FFT(w)[k] where FFT(w) is not negligible
                     v[r16(0)] = make_float2(v[r16(0)].x - (mean.x * fw.x - mean.y * fw.y),
                                             v[r16(0)].y - (mean.x * fw.y + mean.y * fw.x));
@@ -315,11 +302,9 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
                     const float2 X = v[r16(k2)];
                     acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
                 }
-                WS_STAMP(3);
                 __builtin_amdgcn_s_setprio(OTH_WS_PBL);
             }
             lds_barrier();
-            WS_STAMP(4);
             // what the producer left in image it & 1: the item type and, in the same batch of LDS reads (harmless
             // when it is not a segment), the exchange-1 reads and the half-segment sums
             const int q = it & 1;
@@ -330,7 +315,7 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             if (DETREND) {      // the segment's mean from the eight per-wave half sums the producer left
                 float2 tot = red[q * 8];
 #pragma unroll
-                for (int i = 1; i < 8; ++i) tot = cadd(tot, red[q * 8 + i]);
+                for (int i = 1; i < 4; ++i) tot = cadd(tot, red[q * 8 + i]);
                 mean = make_float2(tot.x * (1.0f / 4096.0f), tot.y * (1.0f / 4096.0f));
             }
         }
