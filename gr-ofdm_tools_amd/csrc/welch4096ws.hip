@@ -274,50 +274,66 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
         float2 v[16];
         float2 mean = make_float2(0.f, 0.f);
-        int item = ITEM_BUBBLE;           // nothing to consume in the first step
-        for (int it = 0;; ++it) {
-            if (item == ITEM_STOP) break; // the producer left after the barrier of the step that published it
-            if (item == ITEM_DATA) {      // v holds the exchange-1 reads of image (it - 1) & 1
-                float2 *lx = img + ((it & 1) ^ 1) * LDS_X;
-                __builtin_amdgcn_s_setprio(OTH_WS_PBC);
-                dft16(v);
-                __builtin_amdgcn_s_setprio(OTH_WS_PBL);
-                lx[w2] = v[r16(0)];
-#pragma unroll
-                for (int k1 = 1; k1 < 16; ++k1) lx[w2 + k1 * 17] = cmul(v[r16(k1)], tw2[k1]);
-                wave_lds_sync();
-                // exchange-2 reads as ordered ds_read_b64, the first butterfly layer on counted waits (-1.7 % kernel
-                // time against the sixteen plain reads, which hipcc pairs into ds_read2_b64 behind one lgkmcnt(0);
-                // the same treatment of the exchange-1 reads, which needs the butterfly before the item word is
-                // looked at, gave 1.3 % back)
-                dft16_from_lds<1>(v, lx + r2, [] { __builtin_amdgcn_s_setprio(OTH_WS_PBC); });
-                if (DETREND) {          // X[k] -= mean * FFT(w)[k] where FFT(w) is not negligible
-                    v[r16(0)] = make_float2(v[r16(0)].x - (mean.x * fw.x - mean.y * fw.y),
-                                            v[r16(0)].y - (mean.x * fw.y + mean.y * fw.x));
-                    v[r16(15)] = make_float2(v[r16(15)].x - (mean.x * fw.z - mean.y * fw.w),
-                                             v[r16(15)].y - (mean.x * fw.w + mean.y * fw.z));
-                }
-#pragma unroll
-                for (int k2 = 0; k2 < 16; ++k2) {
-                    const float2 X = v[r16(k2)];
-                    acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
-                }
-                __builtin_amdgcn_s_setprio(OTH_WS_PBL);
-            }
+        int it = 0;
+        // barrier of step `it`, then what the producer left in image it & 1: the item kind and, in the same batch
+        // of LDS reads (harmless when it is not a segment), the exchange-1 reads and the per-wave sums
+        auto next_item = [&]() -> int {
+            __builtin_amdgcn_s_setprio(OTH_WS_PBL);
             lds_barrier();
-            // what the producer left in image it & 1: the item type and, in the same batch of LDS reads (harmless
-            // when it is not a segment), the exchange-1 reads and the half-segment sums
+            WS_STAMP(4);
             const int q = it & 1;
             const float2 *lq = img + q * LDS_X;
-            item = ctrl[q];
+            const int kind = ctrl[q];
 #pragma unroll
             for (int b = 0; b < 16; ++b) v[b] = lq[r1 + b * 17];
-            if (DETREND) {      // the segment's mean from the eight per-wave half sums the producer left
+            if (DETREND) {      // the segment's mean from the four per-wave sums the producer left
                 float2 tot = red[q * 8];
 #pragma unroll
                 for (int i = 1; i < 4; ++i) tot = cadd(tot, red[q * 8 + i]);
                 mean = make_float2(tot.x * (1.0f / 4096.0f), tot.y * (1.0f / 4096.0f));
             }
+            ++it;
+            return kind;
+        };
+        int item = next_item();           // nothing to consume in step 0
+        for (;;) {
+            // idle steps stay out of the path that updates the accumulators (with both in one conditional the
+            // sixteen accumulators were copied twice per step)
+            while (item == ITEM_BUBBLE) item = next_item();
+            if (item == ITEM_STOP) break; // the producer left after the barrier of the step that published it
+            float2 *lx = img + ((it & 1) ^ 1) * LDS_X;      // v holds the exchange-1 reads of image (it - 1) & 1
+#if OTH_WS_DIAG
+            WS_STAMP(5);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            WS_STAMP(0);
+#endif
+            __builtin_amdgcn_s_setprio(OTH_WS_PBC);
+            dft16(v);
+            WS_STAMP(1);
+            __builtin_amdgcn_s_setprio(OTH_WS_PBL);
+            lx[w2] = v[r16(0)];           // in place: each thread rewrites exactly the sixteen elements it read
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) lx[w2 + k1 * 17] = cmul(v[r16(k1)], tw2[k1]);
+            wave_lds_sync();              // exchange 2 stays inside the wave: program order is enough
+            WS_STAMP(2);
+            // exchange-2 reads as ordered ds_read_b64, the first butterfly layer on counted waits (-1.7 % kernel
+            // time against the sixteen plain reads, which hipcc pairs into ds_read2_b64 behind one lgkmcnt(0);
+            // the same treatment of the exchange-1 reads, which needs the butterfly before the item word is
+            // looked at, gave 1.3 % back)
+            dft16_from_lds<1>(v, lx + r2, [] { __builtin_amdgcn_s_setprio(OTH_WS_PBC); });
+            if (DETREND) {                // X[k] -= mean * FFT(w)[k] where FFT(w) is not negligible
+                v[r16(0)] = make_float2(v[r16(0)].x - (mean.x * fw.x - mean.y * fw.y),
+                                        v[r16(0)].y - (mean.x * fw.y + mean.y * fw.x));
+                v[r16(15)] = make_float2(v[r16(15)].x - (mean.x * fw.z - mean.y * fw.w),
+                                         v[r16(15)].y - (mean.x * fw.w + mean.y * fw.z));
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const float2 X = v[r16(k2)];
+                acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
+            }
+            WS_STAMP(3);
+            item = next_item();
         }
         // bin k0 + 16 k1 + 256 k2 of this workgroup sits at t + 256 k2 (finalize_kernel layout 1)
         float *dst = p.partial + ((size_t)stream * W + wg) * 4096;
