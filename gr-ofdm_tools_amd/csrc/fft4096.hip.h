@@ -171,6 +171,17 @@ __device__ __forceinline__ float wave_total(float v) {
            __int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48));
 }
 
+// Sum over the 64 lanes of a wave, valid in lane 63 only (rows 1, 3 take in the row before them, then rows 2, 3
+// the first half): two DPP adds instead of four v_readlane + their hazard slots when one lane stores the result.
+__device__ __forceinline__ float wave_total_lane63(float v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));   // row_bcast:31
+    return v;
+}
 
 }  // namespace
 }  // namespace oth

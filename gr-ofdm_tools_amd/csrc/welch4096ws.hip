@@ -182,11 +182,11 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
                 load_chunk_head(nsb);
             }
             if (DETREND) {      // per-wave sums of both halves of this segment, side by side for the consumer
-                sum.x = wave_total(sum.x);
-                sum.y = wave_total(sum.y);
+                sum.x = wave_total_lane63(sum.x);      // (these live in lane 63 of each wave only)
+                sum.y = wave_total_lane63(sum.y);
                 float2 other = prev_new;
-                if (FIRST) other = make_float2(wave_total(sumf.x), wave_total(sumf.y));
-                if ((t & 63) == 0) red[q * 8 + wave] = cadd(sum, other);
+                if (FIRST) other = make_float2(wave_total_lane63(sumf.x), wave_total_lane63(sumf.y));
+                if ((t & 63) == 63) red[q * 8 + wave] = cadd(sum, other);
                 prev_new = sum;
             }
             WS_STAMP(1);
