@@ -35,7 +35,7 @@
 #define OTH_WS_PBL 2
 #endif
 #ifndef OTH_WS_PBC
-#define OTH_WS_PBC 0
+#define OTH_WS_PBC 1         // the consumer is the critical path: its butterflies go ahead of the producer's (-4.5 %)
 #endif
 #define OTH_CAT2(a, b) a##b
 #define OTH_CAT(a, b) OTH_CAT2(a, b)
