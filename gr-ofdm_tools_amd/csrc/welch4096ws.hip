@@ -31,6 +31,9 @@
 #ifndef OTH_WS_PAC
 #define OTH_WS_PAC 0
 #endif
+#ifndef OTH_WS_PAS           // producer: twiddles + exchange-1 writes
+#define OTH_WS_PAS OTH_WS_PAL
+#endif
 #ifndef OTH_WS_PBL
 #define OTH_WS_PBL 2
 #endif
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             __builtin_amdgcn_s_setprio(OTH_WS_PAC);
             dft16(v);
             WS_STAMP(2);
-            __builtin_amdgcn_s_setprio(OTH_WS_PAL);
+            __builtin_amdgcn_s_setprio(OTH_WS_PAS);
             scatter_pow16<RS>(v, lx + w1, b1, b4);
 #if OTH_WS_DIAG
             __builtin_amdgcn_s_waitcnt(0xC07F);
