@@ -286,13 +286,14 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             WS_STAMP(4);
             const int q = it & 1;
             const float2 *lq = img + q * LDS_X;
+            // one batch of LDS reads: the item word and the four per-wave sums (used only after the butterfly, so
+            // their wait falls behind it), then pass 2's sixteen reads as full-rate ds_read_b64 on counted waits.
+            // Pass 2 therefore runs before the item word is looked at - on junk in an idle step and in the last.
             const int kind = ctrl[q];
-#pragma unroll
-            for (int b = 0; b < 16; ++b) v[b] = lq[r1 + b * 17];
-            if (DETREND) {      // the segment's mean from the four per-wave sums the producer left
-                float2 tot = red[q * 8];
-#pragma unroll
-                for (int i = 1; i < 4; ++i) tot = cadd(tot, red[q * 8 + i]);
+            const float2 h0 = red[q * 8], h1 = red[q * 8 + 1], h2 = red[q * 8 + 2], h3 = red[q * 8 + 3];
+            dft16_from_lds<17>(v, lq + r1, [] { __builtin_amdgcn_s_setprio(OTH_WS_PBC); });
+            if (DETREND) {
+                const float2 tot = cadd(cadd(h0, h1), cadd(h2, h3));
                 mean = make_float2(tot.x * (1.0f / 4096.0f), tot.y * (1.0f / 4096.0f));
             }
             ++it;
@@ -304,14 +305,12 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             // sixteen accumulators were copied twice per step)
             while (item == ITEM_BUBBLE) item = next_item();
             if (item == ITEM_STOP) break; // the producer left after the barrier of the step that published it
-            float2 *lx = img + ((it & 1) ^ 1) * LDS_X;      // v holds the exchange-1 reads of image (it - 1) & 1
+            float2 *lx = img + ((it & 1) ^ 1) * LDS_X;      // v holds pass 2 of image (it - 1) & 1
 #if OTH_WS_DIAG
             WS_STAMP(5);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             WS_STAMP(0);
 #endif
-            __builtin_amdgcn_s_setprio(OTH_WS_PBC);
-            dft16(v);
             WS_STAMP(1);
             __builtin_amdgcn_s_setprio(OTH_WS_PBL);
             lx[w2] = v[r16(0)];           // in place: each thread rewrites exactly the sixteen elements it read
