@@ -96,28 +96,6 @@ __device__ __forceinline__ void dft16_from_lds(float2 (&v)[16], const float2 *ba
     for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
 }
 
-// Sixteen float2 from LDS at base[STRIDE * i] as plain ds_read_b64 (hipcc pairs them into ds_read2_b64, which moves
-// half as many bytes per LDS cycle on gfx950), in two halves: issue, then - after other reads of the same batch
-// have been issued by ordinary code - land.  LDS returns in order, so the later ordinary reads are correctly
-// waited for by the compiler's own counts.
-template <int STRIDE> __device__ __forceinline__ void lds_issue16(double (&r)[16], const float2 *base) {
-    const unsigned addr = (unsigned)(unsigned long long)base;
-#define OTH_LDS_READ(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[i]) : "v"(addr), "n"(8 * STRIDE * (i)))
-    OTH_LDS_READ(0); OTH_LDS_READ(1); OTH_LDS_READ(2); OTH_LDS_READ(3);
-    OTH_LDS_READ(4); OTH_LDS_READ(5); OTH_LDS_READ(6); OTH_LDS_READ(7);
-    OTH_LDS_READ(8); OTH_LDS_READ(9); OTH_LDS_READ(10); OTH_LDS_READ(11);
-    OTH_LDS_READ(12); OTH_LDS_READ(13); OTH_LDS_READ(14); OTH_LDS_READ(15);
-#undef OTH_LDS_READ
-}
-__device__ __forceinline__ void lds_land16(double (&r)[16], float2 (&v)[16]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
-    asm volatile(""
-                 : "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]));
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = __builtin_bit_cast(float2, r[i]);
-}
-
 // Chunk c of the segment schedule: the first `nbig` chunks have `chunk` segments, the rest `tail_chunk`
 // (smaller chunks for the last round even out the finish of the dynamic schedule).
 __device__ __forceinline__ long long chunk_count(const WelchArgs &p) {

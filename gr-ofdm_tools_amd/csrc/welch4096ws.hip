@@ -101,8 +101,10 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
         float win[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) win[a] = p.win[256 * a + t];
-        const float2 b1 = p.tw[t], b4 = p.tw[4 * t];            // pass-1 twiddle seeds W4096^t, W4096^(4t)
-        float2 kw[8], nxt[8], raw0[8];
+        // pass-1 twiddle seeds W4096^t, W4096^(4t): the fifteen twiddles are multiplied out per segment (keeping
+        // even W^2, W^3, W^8, W^12 in registers as well spills at the 128-VGPR cap)
+        const float2 b1 = p.tw[t], b4 = p.tw[4 * t];
+        float2 kw[8], nxt[8];
         float2 prev_new = make_float2(0.f, 0.f);     // this wave's sum of the previous segment's new half
         int it = 0;
         unsigned ticket = 0;
@@ -120,8 +122,8 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {      // one scalar base per pair of rows: offsets t and t + 256 (immediate)
                 const float2 *xj = xs + 512 * j;
-                raw0[2 * j] = xj[(unsigned)t];
-                raw0[2 * j + 1] = xj[(unsigned)t + 256u];
+                kw[2 * j] = xj[(unsigned)t];         // raw: the chunk's first item windows them in place
+                kw[2 * j + 1] = xj[(unsigned)t + 256u];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -154,9 +156,9 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             float2 sumf = make_float2(0.f, 0.f), sum = make_float2(0.f, 0.f);
             if (FIRST) {
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    sumf = cadd(sumf, raw0[a]);
-                    kw[a] = make_float2(raw0[a].x * win[a], raw0[a].y * win[a]);
+                for (int a = 0; a < 8; ++a) {      // kw still holds the raw first half of the chunk's first segment
+                    sumf = cadd(sumf, kw[a]);
+                    kw[a] = make_float2(kw[a].x * win[a], kw[a].y * win[a]);
                 }
             }
 #pragma unroll
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
                 const float2 r = nxt[a];
                 v[a] = kw[a];
                 v[8 + a] = make_float2(r.x * win[8 + a], r.y * win[8 + a]);
-                kw[a] = make_float2(r.x * win[a], r.y * win[a]);
+                if (MODE == 0) kw[a] = make_float2(r.x * win[a], r.y * win[a]);      // (else kw is reloaded below)
                 sum = cadd(sum, r);
             }
             // dynamic schedule: the ticket of the chunk after this one is drawn with the chunk's first segment and
