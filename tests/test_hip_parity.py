@@ -242,6 +242,31 @@ def test_welch_batched_streams_device_resident(ctx):
         assert relerr(out[i], ref) < RTOL
 
 
+@pytest.mark.parametrize('ns', [64, 65, 130, 700])
+def test_welch_many_streams_tuned_vs_generic(ctx, hip, ns):
+    """Stream counts around and beyond the 64 ticket counters and the resident workgroup count: up to 64 streams
+    draw chunks from per-stream tickets, more fall back to the interleaved schedule, and beyond one workgroup
+    per stream every stream still gets its own."""
+    n = 4096 + 2048 * 10 + 37
+    d_in = ctx.alloc(ns * n * 8)
+    d_a, d_b = ctx.alloc(ns * 4096 * 4), ctx.alloc(ns * 4096 * 4)
+    try:
+        ctx.synth_iq(d_in, ns * n, 900 + ns, R.TONES, R.DC)
+        tuned = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_TUNED)
+        gen = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_GENERIC)
+        assert tuned.exec_dev(d_in, n, d_a, nstreams=ns, stream_stride=n) == 11
+        assert gen.exec_dev(d_in, n, d_b, nstreams=ns, stream_stride=n) == 11
+        a = ctx.d2h(d_a, (ns, 4096), np.float32).astype(np.float64)
+        b = ctx.d2h(d_b, (ns, 4096), np.float32).astype(np.float64)
+        assert np.max(np.abs(a - b) / np.maximum(b, 0.1 * np.median(b))) < 5e-5
+        x0 = ctx.d2h(d_in, (n,), np.complex64)
+        _, ref = R.welch_np(x0, nperseg=4096, nfft=4096)
+        assert relerr(a[0], ref) < RTOL
+    finally:
+        for ptr in (d_in, d_a, d_b):
+            ctx.free(ptr)
+
+
 def test_time_sharded_partials_add_up(ctx):
     """Long-stream sharding: partial sums of halo-overlapped chunks add to the whole."""
     nfft, step = 4096, 2048
