@@ -185,10 +185,11 @@ def main():
 
     # clock ramp (setup, untimed, not a step count): the part idles at its lowest sclk level and needs
     # some tens of ms of load before it holds its sustained clock; then the W warm-up steps
+    # (time-bounded, so every rank runs its own number of iterations: local kernels only, no collective)
     t_ramp = time.perf_counter()
     while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
         for _ in range(8):
-            step()
+            plan.exec_dev(iq.data_ptr(), n, local[0].data_ptr())
         torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
