@@ -109,6 +109,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    # the pool's host driver only supports dmabuf IPC; RCCL needs this before the HIP runtime starts
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import numpy as np
     import torch
     import torch.distributed as dist
