@@ -132,15 +132,19 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # BENCH_FORCE_COLLECTIVE=1: run the N > 1 code path (RCCL init, all-gather, barriers) with whatever world
+    # size the launcher gives, 1 included - a one-GPU box can then exercise the real nccl backend
+    force = os.environ.get('BENCH_FORCE_COLLECTIVE') == '1'
+    if world > 1 or force:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         if rehearse:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     n = 1 << args.log2_samples
-    multi = world > 1
+    multi = world > 1 or force
     trim = 256 if multi else 0
     nbins = NFFT - 2 * trim
 
