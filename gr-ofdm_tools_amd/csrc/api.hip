@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -32,6 +33,7 @@ struct oth_ctx {
     float *sink = nullptr;
     double *acc4 = nullptr;
     unsigned *queue = nullptr;         // 64 chunk tickets for the dynamic segment schedule
+    std::recursive_mutex mu;           // every entry point that takes this context (or a plan / chain of it) holds it
     bool queue_clean = false;          // all zero on the stream's timeline (finalize_kernel re-zeroes what a launch used)
     int queue_used = 0;                // counters the last averaging launch drew from
 };
@@ -88,6 +90,20 @@ int fail(oth_ctx *c, int code, const std::string &msg) {
         g_err = msg;
     return code;
 }
+
+// Serialises the entry points per context: GNU Radio runs each block's work() on its own thread and the
+// blocks of one process share the default context (scratch buffers, ticket counters, timing events).
+struct CtxGuard {
+    oth_ctx *c;
+    explicit CtxGuard(oth_ctx *ctx) : c(ctx) {
+        if (c) c->mu.lock();
+    }
+    ~CtxGuard() {
+        if (c) c->mu.unlock();
+    }
+    CtxGuard(const CtxGuard &) = delete;
+    CtxGuard &operator=(const CtxGuard &) = delete;
+};
 
 #define HIPCHK(c, expr)                                                                                 \
     do {                                                                                                \
@@ -490,24 +506,28 @@ int oth_ctx_destroy(oth_ctx *c) {
 const char *oth_last_error(oth_ctx *c) { return c ? c->err.c_str() : g_err.c_str(); }
 
 int oth_ctx_sync(oth_ctx *c) {
+    CtxGuard guard_(c);
     if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
 }
 
 int oth_ctx_device_name(oth_ctx *c, char *buf, size_t buflen) {
+    CtxGuard guard_(c);
     if (!c || !buf || !buflen) return fail(c, OTH_ERR_INVALID, "bad argument");
     std::snprintf(buf, buflen, "%s", c->name.c_str());
     return OTH_OK;
 }
 
 int oth_ctx_set_timing(oth_ctx *c, int enable) {
+    CtxGuard guard_(c);
     if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
     c->timing = enable != 0;
     return OTH_OK;
 }
 
 int oth_ctx_get_timing(oth_ctx *c, double *total_ms, uint64_t *launches, int reset) {
+    CtxGuard guard_(c);
     if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto &ev : c->events) {
@@ -527,6 +547,7 @@ int oth_ctx_get_timing(oth_ctx *c, double *total_ms, uint64_t *launches, int res
 }
 
 int oth_dev_alloc(oth_ctx *c, size_t bytes, void **dptr) {
+    CtxGuard guard_(c);
     if (!c || !dptr) return fail(c, OTH_ERR_INVALID, "bad argument");
     if (use_device(c)) return OTH_ERR_HIP;
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
@@ -535,6 +556,7 @@ int oth_dev_alloc(oth_ctx *c, size_t bytes, void **dptr) {
 }
 
 int oth_dev_free(oth_ctx *c, void *dptr) {
+    CtxGuard guard_(c);
     if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
     if (!dptr) return OTH_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -543,6 +565,7 @@ int oth_dev_free(oth_ctx *c, void *dptr) {
 }
 
 int oth_memcpy_h2d(oth_ctx *c, void *dst, const void *src, size_t bytes) {
+    CtxGuard guard_(c);
     if (!c || !dst || !src) return fail(c, OTH_ERR_INVALID, "bad argument");
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -550,6 +573,7 @@ int oth_memcpy_h2d(oth_ctx *c, void *dst, const void *src, size_t bytes) {
 }
 
 int oth_memcpy_d2h(oth_ctx *c, void *dst, const void *src, size_t bytes) {
+    CtxGuard guard_(c);
     if (!c || !dst || !src) return fail(c, OTH_ERR_INVALID, "bad argument");
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -558,6 +582,7 @@ int oth_memcpy_d2h(oth_ctx *c, void *dst, const void *src, size_t bytes) {
 
 int oth_synth_iq(oth_ctx *c, void *iq_dev, size_t nsamples, uint64_t seed, int ntones, const float *tone_amp,
                  const float *tone_freq, float dc_re, float dc_im) {
+    CtxGuard guard_(c);
     if (!c || !iq_dev || ntones < 0 || ntones > 8 || (ntones && (!tone_amp || !tone_freq)))
         return fail(c, OTH_ERR_INVALID, "bad argument (at most 8 tones)");
     if (use_device(c)) return OTH_ERR_HIP;
@@ -566,6 +591,7 @@ int oth_synth_iq(oth_ctx *c, void *iq_dev, size_t nsamples, uint64_t seed, int n
 }
 
 int oth_stream_read_probe(oth_ctx *c, const void *dptr, size_t bytes, int repeats, double *ms_per_pass) {
+    CtxGuard guard_(c);
     if (!c || !dptr || bytes < 16 || repeats < 1 || !ms_per_pass) return fail(c, OTH_ERR_INVALID, "bad argument");
     if (use_device(c)) return OTH_ERR_HIP;
     hipEvent_t a, b;
@@ -585,6 +611,7 @@ int oth_stream_read_probe(oth_ctx *c, const void *dptr, size_t bytes, int repeat
 }
 
 int oth_iq_power(oth_ctx *c, const void *iq_dev, size_t nsamples, double *mean_re, double *mean_im, double *var) {
+    CtxGuard guard_(c);
     if (!c || !iq_dev || !nsamples) return fail(c, OTH_ERR_INVALID, "bad argument");
     if (use_device(c)) return OTH_ERR_HIP;
     HIPCHK(c, hipMemsetAsync(c->acc4, 0, 4 * sizeof(double), c->stream));
@@ -603,6 +630,7 @@ int oth_iq_power(oth_ctx *c, const void *iq_dev, size_t nsamples, double *mean_r
 
 int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float *window, int detrend, int scaling,
                    double fs, int fftshift, int trim_bins, oth_plan **out) {
+    CtxGuard guard_(c);
     if (!c || !out) return fail(c, OTH_ERR_INVALID, "ctx/out is NULL");
     *out = nullptr;
     if (!is_pow2(nfft) || !generic_supported(nfft))
@@ -666,6 +694,7 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
 }
 
 int oth_plan_destroy(oth_plan *p) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return OTH_OK;
     oth_ctx *c = p->ctx;
     hipSetDevice(c->device);
@@ -683,12 +712,14 @@ int oth_plan_destroy(oth_plan *p) {
 }
 
 int oth_plan_set_output_db(oth_plan *p, int enable) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     p->db = enable != 0;
     return OTH_OK;
 }
 
 int oth_plan_set_kernel(oth_plan *p, int which) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     if (which < OTH_KERNEL_AUTO || which > OTH_KERNEL_TUNED) return fail(p->ctx, OTH_ERR_INVALID, "unknown kernel id");
     p->kernel = which;
@@ -696,6 +727,7 @@ int oth_plan_set_kernel(oth_plan *p, int which) {
 }
 
 int oth_plan_set_schedule(oth_plan *p, int which) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     if (which < OTH_SCHED_CONTIGUOUS || which > OTH_SCHED_DYNAMIC) return fail(p->ctx, OTH_ERR_INVALID, "unknown schedule");
     p->sched = which;
@@ -703,6 +735,7 @@ int oth_plan_set_schedule(oth_plan *p, int which) {
 }
 
 int oth_plan_out_len(oth_plan *p, int *n) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p || !n) return fail(p ? p->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
     *n = p->nfft - 2 * p->trim;
     return OTH_OK;
@@ -710,6 +743,7 @@ int oth_plan_out_len(oth_plan *p, int *n) {
 
 int oth_welch_exec_dev(oth_plan *p, const void *iq_dev, size_t nsamples, int nstreams, size_t stream_stride,
                        float *psd_out_dev, uint64_t *nseg_out) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
     if (!iq_dev || !psd_out_dev || nstreams < 1) return fail(c, OTH_ERR_INVALID, "bad argument");
@@ -753,6 +787,7 @@ static int stage_host(oth_plan *p, const void *x, const void *y, size_t nsamples
 
 int oth_welch_exec(oth_plan *p, const void *iq, size_t nsamples, int src_is_device, float *psd_out,
                    uint64_t *nseg_out) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
     if (!iq || !psd_out) return fail(c, OTH_ERR_INVALID, "bad argument");
@@ -770,6 +805,7 @@ int oth_welch_exec(oth_plan *p, const void *iq, size_t nsamples, int src_is_devi
 }
 
 int oth_welch_partial_dev(oth_plan *p, const void *iq_dev, size_t nsamples, float *sum_out_dev, uint64_t *nseg_out) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
     if (!iq_dev || !sum_out_dev) return fail(c, OTH_ERR_INVALID, "bad argument");
@@ -794,6 +830,7 @@ int oth_welch_partial_dev(oth_plan *p, const void *iq_dev, size_t nsamples, floa
 }
 
 int oth_welch_scale_dev(oth_plan *p, const float *sum_dev, uint64_t nseg_total, float *psd_out_dev) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
     if (!sum_dev || !psd_out_dev || !nseg_total) return fail(c, OTH_ERR_INVALID, "bad argument");
@@ -804,6 +841,7 @@ int oth_welch_scale_dev(oth_plan *p, const float *sum_dev, uint64_t nseg_total, 
 }
 
 int oth_welch_reset(oth_plan *p) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
     if (use_device(c)) return OTH_ERR_HIP;
@@ -814,6 +852,7 @@ int oth_welch_reset(oth_plan *p) {
 }
 
 int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
     if (!iq_host && nsamples) return fail(c, OTH_ERR_INVALID, "iq is NULL");
@@ -867,6 +906,7 @@ int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
 }
 
 int oth_welch_finalize(oth_plan *p, float *psd_out, uint64_t *nseg_out) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
     if (!psd_out) return fail(c, OTH_ERR_INVALID, "psd_out is NULL");
@@ -885,6 +925,7 @@ int oth_welch_finalize(oth_plan *p, float *psd_out, uint64_t *nseg_out) {
 
 int oth_csd_exec(oth_plan *p, const void *x, const void *y, size_t nsamples, int src_is_device, float *pxx,
                  float *pyy, float *pxy, float *cxy, uint64_t *nseg_out) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
     if (!x || !y) return fail(c, OTH_ERR_INVALID, "x/y is NULL");
@@ -928,6 +969,7 @@ int oth_csd_exec(oth_plan *p, const void *x, const void *y, size_t nsamples, int
 
 int oth_chain_create(oth_ctx *c, int nfft, const float *window, int fftshift, int epilogue, int keep_one_in_n,
                      oth_chain **out) {
+    CtxGuard guard_(c);
     if (!c || !out) return fail(c, OTH_ERR_INVALID, "ctx/out is NULL");
     *out = nullptr;
     if (!is_pow2(nfft) || !generic_supported(nfft))
@@ -967,6 +1009,7 @@ int oth_chain_create(oth_ctx *c, int nfft, const float *window, int fftshift, in
 }
 
 int oth_chain_destroy(oth_chain *h) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return OTH_OK;
     oth_ctx *c = h->ctx;
     hipSetDevice(c->device);
@@ -982,6 +1025,7 @@ int oth_chain_destroy(oth_chain *h) {
 }
 
 int oth_chain_set_keep_one_in_n(oth_chain *h, int n) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     if (n < 1) return fail(h->ctx, OTH_ERR_INVALID, "keep_one_in_n must be >= 1");
     h->keep_n = h->count = n;   // keep_one_in_n::set_n restarts the count
@@ -989,6 +1033,7 @@ int oth_chain_set_keep_one_in_n(oth_chain *h, int n) {
 }
 
 int oth_chain_set_iir_log(oth_chain *h, float alpha, float k_db) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     h->do_iir = alpha > 0.f;
     h->alpha = alpha;
@@ -997,12 +1042,14 @@ int oth_chain_set_iir_log(oth_chain *h, float alpha, float k_db) {
 }
 
 int oth_chain_set_peak_hold(oth_chain *h, int enable) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     h->do_peak = enable != 0;
     return OTH_OK;
 }
 
 int oth_chain_reset(oth_chain *h) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     oth_ctx *c = h->ctx;
     if (use_device(c)) return OTH_ERR_HIP;
@@ -1016,6 +1063,7 @@ int oth_chain_reset(oth_chain *h) {
 
 int oth_chain_push(oth_chain *h, const void *iq, size_t nsamples, int src_is_device, float *rows_out,
                    size_t rows_capacity, uint64_t *nrows_out) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     oth_ctx *c = h->ctx;
     if (nrows_out) *nrows_out = 0;
@@ -1076,6 +1124,7 @@ int oth_chain_push(oth_chain *h, const void *iq, size_t nsamples, int src_is_dev
 }
 
 int oth_chain_get_peak(oth_chain *h, float *peak_out) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h || !peak_out) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
     oth_ctx *c = h->ctx;
     HIPCHK(c, hipMemcpyAsync(peak_out, h->d_peak, sizeof(float) * h->nfft, hipMemcpyDeviceToHost, c->stream));
@@ -1084,6 +1133,7 @@ int oth_chain_get_peak(oth_chain *h, float *peak_out) {
 }
 
 int oth_chain_get_iir(oth_chain *h, float *lin_out) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h || !lin_out) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
     oth_ctx *c = h->ctx;
     HIPCHK(c, hipMemcpyAsync(lin_out, h->d_iir, sizeof(float) * h->nfft, hipMemcpyDeviceToHost, c->stream));
@@ -1092,6 +1142,7 @@ int oth_chain_get_iir(oth_chain *h, float *lin_out) {
 }
 
 int oth_rows_group_mean(oth_ctx *c, const float *rows_host, size_t nrows, int nfft, int group, float *out_host) {
+    CtxGuard guard_(c);
     if (!c || !rows_host || !out_host || nfft < 1 || group < 1 || nrows < (size_t)group)
         return fail(c, OTH_ERR_INVALID, "bad argument");
     if (use_device(c)) return OTH_ERR_HIP;
@@ -1114,6 +1165,7 @@ int oth_rows_group_mean(oth_ctx *c, const float *rows_host, size_t nrows, int nf
 
 int oth_channel_power(oth_ctx *c, const float *psd_host, int nfft, double srch_bins, int nch, const int *lo,
                       const int *hi, float *power_out, float *movavg_out) {
+    CtxGuard guard_(c);
     if (!c || !psd_host || !lo || !hi || !power_out || nfft < 1 || nch < 1 || !(srch_bins >= 1.0))
         return fail(c, OTH_ERR_INVALID, "bad argument (srch_bins must be >= 1)");
     for (int i = 0; i < nch; ++i)
@@ -1143,6 +1195,7 @@ int oth_channel_power(oth_ctx *c, const float *psd_host, int nfft, double srch_b
 
 int oth_bin_threshold(oth_ctx *c, const float *psd_host, int nrows, int nfft, double srch_bins, float thr_leveler,
                       unsigned char *mask_out, float *noise_out) {
+    CtxGuard guard_(c);
     if (!c || !psd_host || !mask_out || nrows < 1 || nfft < 1 || !(srch_bins >= 1.0))
         return fail(c, OTH_ERR_INVALID, "bad argument (srch_bins must be >= 1)");
     if (use_device(c)) return OTH_ERR_HIP;
@@ -1185,11 +1238,13 @@ static int xcorr_impl(oth_ctx *c, const void *a, size_t na, const void *b, size_
 }
 
 int oth_xcorr(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, int L, float *out) {
+    CtxGuard guard_(c);
     return xcorr_impl(c, a, na, b, nb, L, out, 0);
 }
 
 // Not part of the ABI (not in the header): raw bytes behind the partial sums (diagnostic kernel builds).
 int oth__debug_tail(oth_plan *p, void *out, size_t nbytes, int *nwg) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p || !out || !nwg) return OTH_ERR_INVALID;
     oth_ctx *c = p->ctx;
     if (nbytes > 1024 * (size_t)p->last_W) return OTH_ERR_INVALID;
@@ -1201,6 +1256,7 @@ int oth__debug_tail(oth_plan *p, void *out, size_t nbytes, int *nwg) {
 
 // Not part of the ABI (not in the header): reads the per-workgroup stamps of the diagnostic kernel build.
 int oth__debug_stamps(oth_plan *p, unsigned long long *out, int max_wg, int *nwg) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p || !out || !nwg) return OTH_ERR_INVALID;
     oth_ctx *c = p->ctx;
     const int n = p->last_W < max_wg ? p->last_W : max_wg;
@@ -1213,6 +1269,7 @@ int oth__debug_stamps(oth_plan *p, unsigned long long *out, int max_wg, int *nwg
 }
 
 int oth_fac(oth_ctx *c, const void *data, size_t n, int L, float *out) {
+    CtxGuard guard_(c);
     return xcorr_impl(c, data, n, nullptr, 0, L, out, 1);
 }
 

@@ -127,7 +127,8 @@ def _fptr(a):
 
 
 class Context(object):
-    """One device + one HIP stream (oth_ctx).  Not thread-safe; serialise per context."""
+    """One device + one HIP stream (oth_ctx).  The library serialises calls per context, so blocks
+    running on different scheduler threads may share one."""
 
     def __init__(self, device=0, stream=None):
         self.lib = load()

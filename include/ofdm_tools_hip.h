@@ -17,8 +17,13 @@
  *     on that context (or a static string for a NULL context).
  *   - IQ data is interleaved float32 (re, im) = numpy.complex64 = gr_complex.
  *   - The caller owns every buffer it passes.  The library owns contexts, plans
- *     and their device scratch.  A context wraps one device + one HIP stream; a
- *     context (and its plans) must not be used from two threads at once.
+ *     and their device scratch.  A context wraps one device + one HIP stream.
+ *     Entry points that take a context, or a plan / chain made from it, hold
+ *     that context's lock for the duration of the call, so the blocks of one
+ *     flowgraph (one scheduler thread each) may share a context; calls are then
+ *     serialised and their kernels run in call order on its stream.
+ *     oth_last_error() reports the context's most recent failure, whichever
+ *     thread caused it.  oth_ctx_destroy() must not race with other calls.
  *   - "_dev" entry points take device pointers, are asynchronous on the
  *     context's stream and never synchronise; the others take host pointers
  *     (or a device source when src_is_device != 0), and return with the host

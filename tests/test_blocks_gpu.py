@@ -327,3 +327,38 @@ def test_flanck_detector_edges(ctx, tmp_path):
     ch20 = [e for e in blk.events if e[0] == subj[1]]
     assert (subj[1], +1) in ch20 and ch20[-1] == (subj[1], -1)
     assert blk._logger.cumulative_statistics == ref.cumulative_statistics
+
+
+def test_two_threads_share_one_context():
+    """GNU Radio gives every block its own scheduler thread and the blocks of a process share the default
+    context: two threads hammer one context with different plans (ctypes drops the GIL during the calls);
+    every result must equal the single-threaded one."""
+    import threading
+    from ofdm_tools import _hip, windows
+    ctx = _hip.Context(0)
+    try:
+        xa = R.synth_iq(4096 + 2048 * 400, 501)
+        xb = R.synth_iq(2048 * 300, 502)
+        pa = ctx.welch_plan(4096, window=windows.get_window('hann', 4096))
+        pb = ctx.welch_plan(2048, window=windows.get_window('flattop', 2048), fs=2e6, fftshift=True)
+        want_a, want_b = pa.exec(xa).copy(), pb.exec(xb).copy()
+        errors = []
+
+        def worker(plan, x, want):
+            try:
+                for _ in range(150):
+                    got = plan.exec(x)
+                    if float(np.max(np.abs(got - want) / want)) > 2e-5:
+                        errors.append('mismatch')
+                        return
+            except Exception as e:      # noqa: BLE001 - report anything from the worker thread
+                errors.append(repr(e))
+
+        ts = [threading.Thread(target=worker, args=a) for a in ((pa, xa, want_a), (pb, xb, want_b))]
+        for th in ts:
+            th.start()
+        for th in ts:
+            th.join()
+        assert not errors, errors
+    finally:
+        ctx.close()
