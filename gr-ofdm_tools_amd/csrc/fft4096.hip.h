@@ -96,6 +96,13 @@ __device__ __forceinline__ void dft16_from_lds(float2 (&v)[16], const float2 *ba
     for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
 }
 
+// Non-temporal load of a sample that is read once: it does not displace the tables and partial sums in L2.
+__device__ __forceinline__ float2 load_once(const float2 *p) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 r = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p));
+    return make_float2(r.x, r.y);
+}
+
 // Chunk c of the segment schedule: the first `nbig` chunks have `chunk` segments, the rest `tail_chunk`
 // (smaller chunks for the last round even out the finish of the dynamic schedule).
 __device__ __forceinline__ long long chunk_count(const WelchArgs &p) {

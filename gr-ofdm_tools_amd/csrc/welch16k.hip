@@ -15,6 +15,15 @@
 // 16 waves = 4 per SIMD at <= 128 VGPRs.  Four workgroup barriers per segment.
 #include "fft4096.hip.h"
 
+#ifndef OTH_16K_NT
+#define OTH_16K_NT 1           // segments do not overlap: every sample is read once
+#endif
+#if OTH_16K_NT
+#define OTH_16K_LOAD(p) load_once(p)
+#else
+#define OTH_16K_LOAD(p) (*(p))
+#endif
+
 namespace oth {
 namespace {
 
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int a = 0; a < 4; ++a) v[4 * j + a] = xs[4096 * a + 1024 * j];
+                for (int a = 0; a < 4; ++a) v[4 * j + a] = OTH_16K_LOAD(xs + 4096 * a + 1024 * j);
             float2 mean = make_float2(0.f, 0.f);
             if (DETREND) {
                 float2 sum = v[0];

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         if (s + 1 < se) {   // the half the NEXT segment adds; lands while this segment is transformed
             const float2 *xn = xb + (s + 2) * 2048 + t;
 #pragma unroll
-            for (int a = 0; a < 8; ++a) nxt[a] = xn[256 * a];
+            for (int a = 0; a < 8; ++a) nxt[a] = load_once(xn + 256 * a);      // read once: non-temporal
         }
 #else
         const float2 *xs = xb + s * p.step + t;

@@ -27,12 +27,12 @@
 #define OTH_WS_NT_LOADS 1
 #endif
 #if OTH_WS_NT_LOADS
-#define OTH_WS_LOAD(p) ws_nt_load(p)
+#define OTH_WS_LOAD(p) load_once(p)
 #else
 #define OTH_WS_LOAD(p) (*(p))
 #endif
 #if OTH_WS_NT_LOADS > 1
-#define OTH_WS_LOAD_HEAD(p) ws_nt_load(p)
+#define OTH_WS_LOAD_HEAD(p) load_once(p)
 #else
 #define OTH_WS_LOAD_HEAD(p) (*(p))
 #endif
@@ -77,12 +77,6 @@ namespace {
 #else
 #define WS_STAMP(i)
 #endif
-
-__device__ __forceinline__ float2 ws_nt_load(const float2 *p) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 r = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p));
-    return make_float2(r.x, r.y);
-}
 
 constexpr int TWS = 512;
 constexpr int WS_RED = 32;                 // float2: per image the four producer waves' sums over the segment (8 slots reserved, x2 images)
