@@ -7,17 +7,20 @@
 // (window, both twiddle sets, accumulators, the kept half and the prefetch) and has to rebuild both
 // twiddle sets every segment to stay at 128 VGPRs.  Split by role, the producer holds window + data
 // pipeline and rebuilds only its twiddles, the consumer holds its 15 twiddles and the accumulators in
-// registers: about 100 fewer VALU instructions per segment, one workgroup barrier per segment instead of
-// two, and the loads of the producer overlap the butterflies of the consumer by construction.
+// registers: 9 % fewer VALU instructions per segment, one workgroup barrier per segment instead of two,
+// and the loads of the producer overlap the butterflies of the consumer by construction.
 //
 // The constant detrend runs in the frequency domain: FFT((x - m) w) = FFT(x w) - m FFT(w).  For every
 // window whose spectrum is confined to bins [0,256) U [3840,4096) (host check at plan time; exact for the
 // periodic cosine-sum windows scipy.signal.welch builds) those are the k2 = 0 and k2 = 15 outputs of
 // pass 3, so each consumer thread fixes two of its sixteen bins with its own pair of FFT(w) values
-// (WelchArgs.fd).  The producer therefore never needs the mean: it publishes the per-wave sums of the raw
-// half-segments next to the image, and windows samples as soon as they arrive.
+// (WelchArgs.fd).  The producer therefore never needs the mean: it publishes per-wave sums of the raw
+// samples next to the image, and windows samples as soon as they arrive.
 //
-// Per step `it` (one barrier):  producer: segment it -> image[it & 1];  consumer: image[(it-1) & 1].
+// Per step `it` (one LDS-only barrier):  producer: segment it -> image[it & 1];  consumer: right behind the
+// barrier pass 2 of image[it & 1] (its LDS reads in one batch with the item word), then, once the item word
+// says it is a segment, exchange 2, pass 3 and the accumulation.  The consumer is the critical path (443
+// VALU instructions per step against the producer's 336): its butterflies run at a higher wave priority.
 #ifndef OTH_WS_TAG
 #define OTH_WS_TAG ws
 #endif
@@ -79,20 +82,19 @@ namespace {
 #endif
 
 constexpr int TWS = 512;
-constexpr int WS_RED = 32;                 // float2: per image the four producer waves' sums over the segment (8 slots reserved, x2 images)
+constexpr int WS_RED = 32;                 // float2: per image the four producer waves' segment sums (8 slots each)
 constexpr int WS_CTRL = 16;                // ints: item kind per image [0..1], next-chunk ticket [4]
 constexpr size_t WS_LDS_BYTES = (2 * LDS_X + WS_RED) * sizeof(float2) + WS_CTRL * sizeof(int);
 
 enum { ITEM_STOP = 0, ITEM_DATA = 1, ITEM_BUBBLE = 2 };
-
 
 template <bool DETREND>
 __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *img = reinterpret_cast<float2 *>(smem);             // two images of LDS_X float2
     float2 *red = img + 2 * LDS_X;                              // [2][8]
-    int *ctrl = reinterpret_cast<int *>(red + WS_RED);          // item[0..1], first[2..3], next ticket [4]; re-read after
-                                                                // every lds_barrier() (it is a compiler memory barrier)
+    int *ctrl = reinterpret_cast<int *>(red + WS_RED);          // item kind [0..1], next ticket [4]; re-read after every
+                                                                // lds_barrier() (it is a compiler memory barrier)
 
     const int tid = threadIdx.x;
     const bool producer = tid < 256;
@@ -143,8 +145,8 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float2 *xj = xs + 2048 + 512 * j;
-                nxt[2 * j] = xj[(unsigned)t];
-                nxt[2 * j + 1] = xj[(unsigned)t + 256u];
+                nxt[2 * j] = OTH_WS_LOAD(xj + (unsigned)t);
+                nxt[2 * j + 1] = OTH_WS_LOAD(xj + ((unsigned)t + 256u));
             }
         };
         auto step_end = [&](int item) {
