@@ -19,7 +19,16 @@ arrays that are tagged scipy/numpy below; rows that have no library call behind
 them (GNU Radio chains, scanner state machines, framing) are produced by the
 restatement and tagged ``restated`` - they pin regressions, not the reference.
 
-Run from the repo root:  python tests/golden/make_golden.py
+Rows tagged ``reference`` (files ``ref_*.npz``) are different: ``reference_fixtures()`` runs the
+reference's OWN function bodies - cut out of /root/reference/python/{ofdm_cr_tools,spectrum_sweeper}.py at
+generation time by ``ref_extract.py`` and exec'd against the real numpy / scipy.signal - on inputs for which
+Python-2 and Python-3 ``/`` agree (float or even-int Sf).  They pin rows a4, a6, a7 and a14 to the reference
+itself.  Not run that way (they do not execute unmodified under Python 3 / SciPy 1.15): ``xcorr`` / ``fac``
+(a12, ``len(h)/2`` index) and ``src_power_fft`` (``sg.flattop``), which stay NumPy-pinned; the GNU Radio
+chains a1-a3 stay unpinned.  Only numbers are written; no reference text is stored in any form.
+
+Run from the repo root:  python tests/golden/make_golden.py            (everything)
+                         python tests/golden/make_golden.py --reference  (only the ref_*.npz files)
 """
 import os
 import sys
@@ -41,9 +50,145 @@ def save(name, **kw):
     print('wrote', name, {k: getattr(v, 'shape', None) for k, v in kw.items()})
 
 
+def reference_fixtures():
+    """ref_*.npz: outputs of the reference's own functions (see the module docstring)."""
+    import warnings
+    warnings.simplefilter('ignore')
+    sys.path.insert(0, HERE)
+    import ref_extract as E
+    if not E.available():
+        raise SystemExit('/root/reference is not present: the reference-tagged fixtures can only be made in '
+                         'the build container')
+    T, S = E.cr_tools(), E.sweeper()
+    c128 = lambda v: np.asarray(v).astype(np.complex128)      # noqa: E731
+
+    # a6 - welch_plot_dB (:321-326) and welch_power_estimate (:341-345): default Hann, 50 %, nperseg = nfft
+    x = np.load(os.path.join(HERE, 'welch_hann_4096_50.npz'))['x']
+    Sf, fc, nfft = 2000000, 433.0e6, 4096
+    axis, db = T['welch_plot_dB'](c128(x), Sf, fc, nfft)
+    save('ref_welch_hann_4096.npz', source=np.array('reference'), input_from=np.array('welch_hann_4096_50.npz'),
+         Sf=Sf, fc=fc, nfft=nfft, expected_axis=np.array(axis), expected_db=np.array(db),
+         expected_power=T['welch_power_estimate'](c128(x), nfft, Sf),
+         expected_power_fs1=T['welch_power_estimate'](c128(x), nfft, 1.0),
+         expected_clc_power_freq=T['clc_power_freq'](c128(x[:4096]), 4096, Sf))
+
+    # a6 / a14 - src_power_welch (:213-230) and fast_spectrum_scan(method='welch') (:471-537)
+    x = np.load(os.path.join(HERE, 'welch_flattop_2048.npz'))['x']
+    Sf, N, cs, sbw = 1000000, 2048, 50e3, 25e3
+    Fr = float(Sf) / N
+    bb = T['frange'](-Sf / 2, Sf / 2, cs)
+    psd, ax, plc = T['src_power_welch'](c128(x), len(x), N, Fr, Sf, bb, sbw / Fr)
+    scans, ne = [], 1e-11
+    for lo, hi in ((0, 16384), (8192, 32768), (0, 32768)):      # the noise estimate carries over between scans
+        thr, plc_s, ne, occ = T['fast_spectrum_scan'](c128(x[lo:hi]), 100.0e6, cs, sbw, N, Sf, 'welch', 4, ne,
+                                                     0.5, False)
+        scans.append((thr, plc_s, ne, occ))
+    ax_ch = T['frange'](100.0e6 - Sf / 2, 100.0e6 + Sf / 2, cs)
+    save('ref_src_power_welch_2048.npz', source=np.array('reference'),
+         input_from=np.array('welch_flattop_2048.npz'), Sf=Sf, nfft=N, channel_rate=cs, srch_bw=sbw,
+         bb_freqs=np.array(bb), expected_psd=np.array(psd), expected_axis=np.array(ax), expected_plc=np.array(plc),
+         scan_ranges=np.array([(0, 16384), (8192, 32768), (0, 32768)]), scan_fc=100.0e6, scan_thr_leveler=4,
+         scan_alpha=0.5, scan_noise0=1e-11, ax_ch=np.array(ax_ch),
+         scan_thr=np.array([s[0] for s in scans]), scan_plc=np.array([s[1] for s in scans]),
+         scan_noise=np.array([s[2] for s in scans]),
+         scan_occupied=np.array([[1.0 if a in s[3] else 0.0 for a in ax_ch] for s in scans]))
+
+    # a4 - spectrum_sweeper._src_power (:260-276) and the sweeper's inclusive frange (:37-42)
+    g = np.load(os.path.join(HERE, 'welch_flattop_nperseg_quarter.npz'))
+    x, nfft, ex, fs = g['x'], int(g['nfft']), int(g['excess_bins']), float(g['fs'])
+    save('ref_sweeper_src_power.npz', source=np.array('reference'),
+         input_from=np.array('welch_flattop_nperseg_quarter.npz'), nfft=nfft, excess_bins=ex, fs=fs,
+         expected_db=T_db(S['_src_power'](c128(x), nfft, fs, ex)),
+         expected_db_notrim=T_db(S['_src_power'](c128(x[:9000]), 1024, 250000.0, 0)),
+         frange_le_a=np.array(S['frange'](88.0e6 + 1.0e6, 108.0e6, 2.0e6)),
+         frange_le_b=np.array(S['frange'](0, 1, 0.25)), frange_le_c=np.array(S['frange'](0.0, 1.0, 0.1)))
+
+    # a7 - frange (:136-141), movingaverage (:168-170), src_power (:232-249) on the committed PSD cases
+    g = np.load(os.path.join(HERE, 'src_power_cases.npz'))
+    out = {}
+    for i in range(int(g['n'])):
+        Sf, N = int(g['Sf_%d' % i]), int(g['N_%d' % i])
+        cs, sbw = float(g['cs_%d' % i]), float(g['sbw_%d' % i])
+        psd = g['psd_%d' % i]
+        Fr = float(Sf) / N
+        bb = T['frange'](-Sf / 2, Sf / 2, cs)          # even-int Sf: Python-2 and Python-3 '/' agree
+        sb = sbw / Fr
+        out['bb_%d' % i] = np.array(bb)
+        out['ma_%d' % i] = T['movingaverage'](psd, 1 * sb)
+        out['plc_%d' % i] = np.array(T['src_power'](psd, N, Fr, Sf, bb, sb))
+        out['plc_f32_%d' % i] = np.array(T['src_power'](psd.astype(np.float32), N, Fr, Sf, bb, sb))
+    save('ref_src_power_cases.npz', source=np.array('reference'), input_from=np.array('src_power_cases.npz'),
+         n=int(g['n']), frange_a=np.array(T['frange'](0, 1, 0.25)), frange_b=np.array(T['frange'](0, 1, 0.1)),
+         frange_c=np.array(T['frange'](-500000.0, 500000.0, 25e3)), **out)
+
+
+    # a11 - coherence_detector.watcher.scanner (:254-274) + find_nearest_index (:276-278), run on a stand-in
+    # object that carries the attributes the method reads (its __init__ needs gnuradio)
+    from types import SimpleNamespace as NS
+    g = np.load(os.path.join(HERE, 'coherence_scanner.npz'))
+    scanner = E.load_method('coherence_detector.py', 'watcher', 'scanner')
+    fni = E.load('coherence_detector.py', ['find_nearest_index'])['find_nearest_index']
+    N, Sf, tune = int(g['N']), int(g['sample_rate']), int(g['tune_freq'])
+    ax = np.array(range(-N // 2, N // 2)) * (float(Sf) / N) + tune          # coherence_detector.py:188
+    idx = [int(fni(ax, c)) for c in g['subject_channels']]
+    valve, outcome, sent = [], [], []
+    me = NS(n_chans=len(idx), idx_subject_channels=idx, subject_channels_coherence=[0] * len(idx), threshold=10,
+            threshold_mtm=0.2, valve_callback=valve.append, set_subject_channels_outcome=outcome.append,
+            data_queue0=NS(put=lambda v: sent.append(list(v))))
+    scanner(me, g['d0'], g['d1'], g['d2'])
+    save('ref_coherence_scanner.npz', source=np.array('reference'), input_from=np.array('coherence_scanner.npz'),
+         idx=np.array(idx), threshold=10, threshold_mtm=0.2, coherence=np.array(sent[0], np.float64),
+         outcome=np.array(outcome[0]), valve=np.array(valve))
+
+    # a8 (truncation + 0.6/0.4 EMA) and a9 (top-4): spectrum_sensor_v2.basic_spectrum_watcher.spectrum_scanner
+    # (:533-544), spectrum_sensor_v2.output_data.publish (:228-237), multichannel_scanner
+    # basic_spectrum_watcher.spectrum_scanner / publish (:214-239) over the 16 committed PSD rows.  The stand-in's
+    # attributes follow the classes' __init__ lines (spectrum_sensor_v2.py:368-385) with Python-2 integer '/'.
+    g = np.load(os.path.join(HERE, 'scanner_state_seq.npz'))
+    fft_len, Sf, cs, sbw, tune, trunc_band = 1024, 1000000, 25e3, 12.5e3, 100000000, 800000
+    Fr = float(Sf) / fft_len
+    trunc = Sf - trunc_band
+    trunc_ch = int(trunc / cs) // 2
+    ax_ch = T['frange'](tune - Sf // 2, tune + Sf // 2, cs)[trunc_ch:-trunc_ch]
+    assert np.allclose(ax_ch, g['ax_ch'])
+    sent = []
+    me = NS(fft_len=fft_len, Fr=Fr, sample_rate=Sf, bb_freqs=T['frange'](-Sf // 2, Sf // 2, cs), srch_bins=sbw / Fr,
+            trunc=trunc, trunc_ch=trunc_ch, plc=np.array([0.0] * len(ax_ch)),
+            data_queue=NS(put=lambda v: sent.append(np.array(v))))
+    scan_v2 = E.load_method('spectrum_sensor_v2.py', 'basic_spectrum_watcher', 'spectrum_scanner',
+                            {'src_power': T['src_power']})
+    scan_mc = E.load_method('multichannel_scanner.py', 'basic_spectrum_watcher', 'spectrum_scanner',
+                            {'src_power': T['src_power']})
+    me_mc = NS(**{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in vars(me).items()})
+    for r in g['rows']:
+        scan_v2(me, r.astype(np.float32))
+        scan_mc(me_mc, r.astype(np.float32))
+    assert np.array_equal(me.plc, me_mc.plc)
+    subj = [float(v) for v in g['subject_channels']]
+    idx = [ax_ch.index(c) for c in subj]                                      # spectrum_sensor_v2.py:218-220
+    freqs = []
+    od = NS(data_queue=NS(get=lambda: sent[-1]), idx_subject_channels=idx, subject_channels=subj,
+            subject_channels_pwr=np.array([1.0] * len(subj)), set_freqs=lambda *f: freqs.append(list(f)))
+    E.load_method('spectrum_sensor_v2.py', 'output_data', 'publish')(od)
+    me_mc.idx_subject_channels, me_mc.subject_channels = idx, subj
+    me_mc.subject_channels_pwr = np.array([1.0] * len(subj))
+    me_mc.set_freqs = lambda *f: freqs.append(list(f))
+    me_mc.output_data = NS()
+    E.load_method('multichannel_scanner.py', 'basic_spectrum_watcher', 'publish')(me_mc)
+    assert freqs[0] == freqs[1] == me_mc.output_data.top4
+    save('ref_scanner_seq.npz', source=np.array('reference'), input_from=np.array('scanner_state_seq.npz'),
+         plc_seq=np.array(sent), subject_pwr=od.subject_channels_pwr, top4=np.array(freqs[0]))
+
+
+def T_db(v):
+    return np.asarray(v, np.float64)
+
+
 def main():
     import warnings
     warnings.simplefilter('ignore')
+    if '--reference' in sys.argv:
+        return reference_fixtures()
 
     # a6 - default Hann / 50 % overlap Welch, the BASELINE config-2 call pattern
     x = R.synth_iq(65536, 1002)
@@ -190,6 +335,10 @@ def main():
                 fh.write(np.uint32(len(fr)).tobytes())
                 fh.write(fr)
     print('wrote fragments.bin')
+    sys.path.insert(0, HERE)
+    import ref_extract
+    if ref_extract.available():
+        reference_fixtures()
 
 
 if __name__ == '__main__':

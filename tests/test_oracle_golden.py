@@ -180,3 +180,118 @@ def test_known_answers():
     # x == y -> coherence 1
     _, c, *_ = R.coherence_np(x[:16384], x[:16384], nperseg=1024, nfft=1024)
     assert np.allclose(c, 1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Fixtures tagged source='reference' (tests/golden/ref_*.npz): outputs of the reference's OWN function
+# bodies, cut out of /root/reference/python/*.py and exec'd by tests/golden/ref_extract.py in the build
+# container.  These pin the restatement to the reference itself, not to a re-reading of it.
+# ---------------------------------------------------------------------------------------------
+
+def test_reference_fixtures_are_tagged(golden):
+    import glob
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'ref_*.npz')))
+    assert names == ['ref_coherence_scanner.npz', 'ref_scanner_seq.npz', 'ref_src_power_cases.npz',
+                     'ref_src_power_welch_2048.npz', 'ref_sweeper_src_power.npz', 'ref_welch_hann_4096.npz']
+    for n in names:
+        g = golden(n)
+        assert str(g['source']) == 'reference' and os.path.exists(
+            os.path.join(os.path.dirname(__file__), 'golden', str(g['input_from'])))
+
+
+def test_ref_welch_plot_db_and_power_estimate(golden):
+    """a6: ofdm_cr_tools.py:321-326 (welch_plot_dB) and :341-345 (welch_power_estimate)."""
+    g = golden('ref_welch_hann_4096.npz')
+    x = golden(str(g['input_from']))['x']
+    Sf, fc, nfft = int(g['Sf']), float(g['fc']), int(g['nfft'])
+    axis, db = R.welch_plot_dB(x, Sf, fc, nfft)
+    assert np.allclose(axis, g['expected_axis'], rtol=0, atol=1e-6)
+    assert relerr(10 ** (np.array(db) / 10), 10 ** (g['expected_db'] / 10)) < RTOL
+    assert abs(R.welch_power_estimate(x, nfft, Sf) - float(g['expected_power'])) < RTOL * float(g['expected_power'])
+    assert abs(R.welch_power_estimate(x, nfft, 1.0) - float(g['expected_power_fs1'])) < RTOL * float(g['expected_power_fs1'])
+    assert abs(R.clc_power_freq(x[:4096].astype(np.complex128), 4096, Sf) - float(g['expected_clc_power_freq'])) < \
+        RTOL * float(g['expected_clc_power_freq'])
+    # the SciPy-tagged fixture of the same call agrees with what the reference's own lines returned
+    lin = np.fft.fftshift(golden('welch_hann_4096_50.npz')['expected_psd']) / Sf       # fs = 1 there
+    assert relerr(lin, 10 ** (g['expected_db'] / 10) - 1e-20) < 1e-9
+
+
+def test_ref_src_power_welch_and_fast_spectrum_scan(golden):
+    """a6/a14: ofdm_cr_tools.py:213-230 (src_power_welch), :471-537 (fast_spectrum_scan, method 'welch')."""
+    g = golden('ref_src_power_welch_2048.npz')
+    x = golden(str(g['input_from']))['x']
+    Sf, N, cs, sbw = int(g['Sf']), int(g['nfft']), float(g['channel_rate']), float(g['srch_bw'])
+    Fr = float(Sf) / N
+    bb = R.frange(-Sf // 2, Sf // 2, cs)
+    assert np.array_equal(bb, g['bb_freqs'])
+    psd, ax, plc = R.src_power_welch(x, len(x), N, Fr, Sf, bb, sbw / Fr)
+    assert relerr(psd, g['expected_psd']) < RTOL and np.allclose(ax, g['expected_axis'])
+    assert relerr(plc, g['expected_plc']) < RTOL
+    ne = float(g['scan_noise0'])
+    for i, (lo, hi) in enumerate(g['scan_ranges']):
+        thr, plc, ne, occ = R.fast_spectrum_scan(x[lo:hi], float(g['scan_fc']), cs, sbw, N, Sf, 'welch',
+                                                 int(g['scan_thr_leveler']), ne, float(g['scan_alpha']))
+        assert abs(thr - g['scan_thr'][i]) < RTOL * g['scan_thr'][i]
+        assert abs(ne - g['scan_noise'][i]) < RTOL * g['scan_noise'][i]
+        assert relerr(plc, g['scan_plc'][i]) < RTOL
+        assert [1.0 if a in occ else 0.0 for a in g['ax_ch']] == list(g['scan_occupied'][i])
+    assert 0 < g['scan_occupied'].sum() < g['scan_occupied'].size      # both outcomes present
+
+
+def test_ref_sweeper_src_power_and_frange(golden):
+    """a4: spectrum_sweeper.py:260-276 (_src_power), :37-42 (inclusive frange)."""
+    g = golden('ref_sweeper_src_power.npz')
+    x = golden(str(g['input_from']))['x']
+    db = R.sweeper_src_power(x, int(g['nfft']), float(g['fs']), int(g['excess_bins']))
+    assert db.shape == g['expected_db'].shape and np.max(np.abs(db - g['expected_db'])) < 1e-9
+    db2 = R.sweeper_src_power(x[:9000], 1024, 250000.0, 0)
+    assert np.max(np.abs(db2 - g['expected_db_notrim'])) < 1e-9
+    assert np.array_equal(R.frange_le(88.0e6 + 1.0e6, 108.0e6, 2.0e6), g['frange_le_a'])
+    assert np.array_equal(R.frange_le(0, 1, 0.25), g['frange_le_b'])
+    assert np.array_equal(R.frange_le(0.0, 1.0, 0.1), g['frange_le_c'])
+
+
+def test_ref_src_power_movingaverage_frange(golden):
+    """a7: ofdm_cr_tools.py:136-141 (frange), :168-170 (movingaverage), :232-249 (src_power)."""
+    g = golden('ref_src_power_cases.npz')
+    c = golden(str(g['input_from']))
+    assert np.array_equal(R.frange(0, 1, 0.25), g['frange_a']) and np.array_equal(R.frange(0, 1, 0.1), g['frange_b'])
+    assert np.array_equal(R.frange(-500000.0, 500000.0, 25e3), g['frange_c'])
+    for i in range(int(g['n'])):
+        Sf, N = int(c['Sf_%d' % i]), int(c['N_%d' % i])
+        cs, sbw = float(c['cs_%d' % i]), float(c['sbw_%d' % i])
+        Fr = float(Sf) / N
+        psd = c['psd_%d' % i]
+        bb = R.frange(-Sf // 2, Sf // 2, cs)
+        assert np.array_equal(bb, g['bb_%d' % i])
+        assert np.allclose(R.movingaverage(psd, sbw / Fr), g['ma_%d' % i], rtol=1e-12, atol=0)
+        assert np.allclose(R.src_power(psd, N, Fr, Sf, bb, sbw / Fr), g['plc_%d' % i], rtol=1e-12, atol=0)
+        assert np.allclose(R.src_power(psd.astype(np.float32), N, Fr, Sf, bb, sbw / Fr), g['plc_f32_%d' % i],
+                           rtol=1e-6, atol=0)      # float32 rows: the order of np.convolve's float32 sums
+
+
+def test_ref_coherence_scanner(golden):
+    """a11: coherence_detector.py:254-274 (watcher.scanner), :276-278 (find_nearest_index)."""
+    g = golden('ref_coherence_scanner.npz')
+    c = golden(str(g['input_from']))
+    ax = R.coherence_axis(int(c['N']), int(c['sample_rate']), int(c['tune_freq']))
+    idx = [R.find_nearest_index(ax, f) for f in c['subject_channels']]
+    assert idx == list(g['idx'])
+    coh, outcome, valve = R.coherence_scanner(c['d0'], c['d1'], c['d2'], idx, int(g['threshold']),
+                                              float(g['threshold_mtm']))
+    assert np.array_equal(np.array(coh, np.float64), g['coherence'])
+    assert outcome == list(g['outcome']) and valve == list(g['valve'])
+
+
+def test_ref_scanner_ema_and_top4(golden):
+    """a8 (edge truncation + 0.6/0.4 EMA) and a9 (top-4): spectrum_sensor_v2.py:533-544, :228-237;
+    multichannel_scanner.py:214-239."""
+    g = golden('ref_scanner_seq.npz')
+    c = golden(str(g['input_from']))
+    st = R.ScannerState(1024, 1000000, 25e3, 12.5e3, tune_freq=100000000, trunc_band=800000,
+                        thr_leveler=4, alpha_avg=0.5)
+    for i, r in enumerate(c['rows']):
+        st.scan(r.astype(np.float32))
+        assert np.allclose(st.plc, g['plc_seq'][i], rtol=1e-12, atol=0)
+    pwr, top4 = R.publish_top4(st.plc, st.ax_ch, list(c['subject_channels']))
+    assert np.allclose(pwr, g['subject_pwr'], rtol=1e-12) and top4 == list(g['top4'])
