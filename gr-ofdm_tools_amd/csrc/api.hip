@@ -36,6 +36,8 @@ struct oth_ctx {
     std::recursive_mutex mu;           // every entry point that takes this context (or a plan / chain of it) holds it
     bool queue_clean = false;          // all zero on the stream's timeline (finalize_kernel re-zeroes what a launch used)
     int queue_used = 0;                // counters the last averaging launch drew from
+    unsigned char *scratch = nullptr;  // device scratch of the small ops (channel power, decision stage, xcorr): grown on
+    size_t scratch_cap = 0;            // demand, never freed per call
 };
 
 struct oth_plan {
@@ -61,6 +63,16 @@ struct oth_plan {
     size_t carry = 0;                  // samples kept at the front of d_stream
     float2 *d_stream = nullptr;
     size_t stream_cap = 0;
+    // launch tuning (A/B tools and the parity suite): the OTH_W4096_* environment variables are read ONCE, when
+    // the plan is created; oth_plan_set_tuning() changes them afterwards.  0 / -1 / empty = library default.
+    std::string tune_variant;
+    int tune_sched = -1, tune_chunk = 0, tune_tail = 0;
+    // pinned staging ring of the streaming form (oth_welch_accumulate): the caller's buffer is copied here, the
+    // H2D copy and the kernels are enqueued, and the call returns without waiting for the GPU
+    void *h_ring[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t h_ring_cap[4] = {0, 0, 0, 0};
+    hipEvent_t h_ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned h_ring_next = 0;
 };
 
 struct oth_chain {
@@ -77,6 +89,20 @@ struct oth_chain {
     float alpha = 0.f, kdb = 0.f;
     float *d_iir = nullptr, *d_peak = nullptr;
     int *d_peak_init = nullptr;
+    float2 *d_stage = nullptr;         // host input lands here (H2D), then feeds the kernels
+    size_t stage_cap = 0;
+    float *d_out = nullptr;            // rows handed back by the host-output forms
+    size_t out_cap = 0;
+    // asynchronous work() form (oth_chain_push_async): pinned input ring + pinned latest-row ring.  A slot is
+    // reused kRing pushes later; the push waits only if the GPU is still that far behind.
+    static constexpr int kRing = 4;
+    void *h_in[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    size_t h_in_cap[kRing] = {0, 0, 0, 0};
+    float *h_row[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[kRing] = {nullptr, nullptr, nullptr, nullptr};      // recorded behind the D2H of the slot's row
+    uint64_t ticket_of[kRing] = {0, 0, 0, 0};
+    uint64_t nrows_of[kRing] = {0, 0, 0, 0};
+    uint64_t next_ticket = 1;
 };
 
 namespace {
@@ -216,9 +242,9 @@ struct W4096Variant {
 const W4096Variant kVariants[] = {
     {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp, 8, 1, false},            // any step
     {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe, 16, 1, false},        // step 2048 (50 % overlap)
-    {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16, 1, false},
     {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 20, 1, true},     // step 2048, confined window spectrum
 #ifdef OTH_EXPERIMENTS
+    {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16, 1, false},      // stamped build (tools/diag_stamps.py)
     {"exp1", launch_welch_tuned4096_exp1, tuned4096_blocks_per_cu_exp1, 16, 1, false},
     {"exp2", launch_welch_tuned4096_exp2, tuned4096_blocks_per_cu_exp2, 16, 1, false},
     {"exp3", launch_welch_tuned4096_exp3, tuned4096_blocks_per_cu_exp3, 16, 1, false},
@@ -229,12 +255,11 @@ const W4096Variant kVariants[] = {
     {"wsx4", launch_welch_tuned4096_wsx4, tuned4096_blocks_per_cu_wsx4, 32, 1, true},
 #endif
 };
-const W4096Variant *w4096_variant(int step, bool fd_ok) {
-    const char *e = getenv("OTH_W4096_VARIANT");
-    const W4096Variant *pick = (step == 2048) ? (fd_ok ? &kVariants[3] : &kVariants[1]) : &kVariants[0];
-    if (e)
+const W4096Variant *w4096_variant(int step, bool fd_ok, const std::string &want) {
+    const W4096Variant *pick = (step == 2048) ? (fd_ok ? &kVariants[2] : &kVariants[1]) : &kVariants[0];
+    if (!want.empty())
         for (const auto &v : kVariants)
-            if (!strcmp(e, v.tag)) pick = &v;
+            if (want == v.tag) pick = &v;
     // the wave-specialised build detrends in the frequency domain: only with a confined window spectrum
     if (pick->fd && !fd_ok) pick = &kVariants[1];
     // the pipelined builds keep the overlapped half in registers: only for step = nperseg / 2
@@ -318,7 +343,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
     const W4096Variant *var =
         tuned ? w4096_variant(p->nperseg == 4096 ? p->step : 0,
-                              (p->detrend == OTH_DETREND_NONE || p->d_fd) && nseg < (1LL << 30))   // ws: 32-bit segment indices
+                              (p->detrend == OTH_DETREND_NONE || p->d_fd) && nseg < (1LL << 30),   // ws: 32-bit segment indices
+                              p->tune_variant)
               : nullptr;
     int W = generic_wg(c, p->nfft, nseg, nstreams);
     if (tuned || tuned_csd || tuned_16k) {
@@ -355,10 +381,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.queue = nullptr;
     a.fd = p->d_fd;
     if (tuned || tuned_csd || tuned_16k) {
-        const char *e = getenv("OTH_W4096_SCHED");
-        const char *ec = getenv("OTH_W4096_CHUNK");
-        a.sched = e ? atoi(e) : p->sched;
-        a.chunk = ec ? atoi(ec) : (tuned_16k ? 2 : (tuned ? var->chunk : 8));
+        a.sched = p->tune_sched >= 0 ? p->tune_sched : p->sched;
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? 2 : (tuned ? var->chunk : 8));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;
@@ -368,8 +392,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
             else {
                 a.queue = c->queue;
                 // guided tail: the last half round of work goes out in quarter-size chunks
-                const char *et = getenv("OTH_W4096_TAIL");
-                a.tail_chunk = et ? atoi(et) : (a.chunk >= 4 ? a.chunk / 4 : 1);
+                a.tail_chunk = p->tune_tail > 0 ? p->tune_tail : (a.chunk >= 4 ? a.chunk / 4 : 1);
                 if (a.tail_chunk < 1) a.tail_chunk = 1;
                 const long long tail_segs = (long long)W * a.chunk / 2;
                 a.nbig = nseg > tail_segs ? (nseg - tail_segs) / a.chunk : 0;
@@ -498,6 +521,7 @@ int oth_ctx_destroy(oth_ctx *c) {
     if (c->sink) hipFree(c->sink);
     if (c->acc4) hipFree(c->acc4);
     if (c->queue) hipFree(c->queue);
+    if (c->scratch) hipFree(c->scratch);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return OTH_OK;
@@ -655,6 +679,10 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     p->fs = fs;
     p->fftshift = fftshift != 0;
     p->trim = trim_bins;
+    if (const char *e = getenv("OTH_W4096_VARIANT")) p->tune_variant = e;      // read once, here
+    if (const char *e = getenv("OTH_W4096_SCHED")) p->tune_sched = atoi(e);
+    if (const char *e = getenv("OTH_W4096_CHUNK")) p->tune_chunk = atoi(e);
+    if (const char *e = getenv("OTH_W4096_TAIL")) p->tune_tail = atoi(e);
     std::vector<float> w(nfft, 0.f);   // zero-extended so that kernels may index [0, nfft)
     double s1 = 0.0, s2 = 0.0;
     for (int i = 0; i < nperseg; ++i) {
@@ -707,6 +735,10 @@ int oth_plan_destroy(oth_plan *p) {
     if (p->d_stage) hipFree(p->d_stage);
     if (p->d_sum) hipFree(p->d_sum);
     if (p->d_stream) hipFree(p->d_stream);
+    for (int i = 0; i < 4; ++i) {
+        if (p->h_ring[i]) hipHostFree(p->h_ring[i]);
+        if (p->h_ring_ev[i]) hipEventDestroy(p->h_ring_ev[i]);
+    }
     delete p;
     return OTH_OK;
 }
@@ -731,6 +763,23 @@ int oth_plan_set_schedule(oth_plan *p, int which) {
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     if (which < OTH_SCHED_CONTIGUOUS || which > OTH_SCHED_DYNAMIC) return fail(p->ctx, OTH_ERR_INVALID, "unknown schedule");
     p->sched = which;
+    return OTH_OK;
+}
+
+int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, int tail_chunk) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    if (sched < -1 || sched > OTH_SCHED_DYNAMIC || chunk < 0 || tail_chunk < 0)
+        return fail(p->ctx, OTH_ERR_INVALID, "bad tuning value");
+    if (variant && *variant) {
+        bool known = false;
+        for (const auto &v : kVariants) known = known || !strcmp(variant, v.tag);
+        if (!known) return fail(p->ctx, OTH_ERR_UNSUPPORTED, std::string("unknown kernel build: ") + variant);
+    }
+    p->tune_variant = variant ? variant : "";
+    p->tune_sched = sched;
+    p->tune_chunk = chunk;
+    p->tune_tail = tail_chunk;
     return OTH_OK;
 }
 
@@ -861,10 +910,25 @@ int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
     const size_t total = p->carry + nsamples;
     int rc = ensure_keep(c, &p->d_stream, &p->stream_cap, total * sizeof(float2), p->carry * sizeof(float2));
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(p->d_stream + p->carry, iq_host, nsamples * sizeof(float2), hipMemcpyHostToDevice,
-                             c->stream));
-    // the caller's buffer is only valid during the call (sync_block.work contract)
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        // the caller's buffer is only valid during the call (sync_block.work contract): it is copied into a pinned
+        // slot, the H2D copy is enqueued from there and the call returns without waiting for the GPU (a slot is
+        // reused four calls later; only then, if the GPU is still that far behind, does the call wait)
+        const unsigned slot = p->h_ring_next++ & 3u;
+        const size_t bytes = nsamples * sizeof(float2);
+        if (!p->h_ring_ev[slot]) HIPCHK(c, hipEventCreateWithFlags(&p->h_ring_ev[slot], hipEventDisableTiming));
+        else HIPCHK(c, hipEventSynchronize(p->h_ring_ev[slot]));
+        if (p->h_ring_cap[slot] < bytes) {
+            if (p->h_ring[slot]) HIPCHK(c, hipHostFree(p->h_ring[slot]));
+            p->h_ring[slot] = nullptr;
+            p->h_ring_cap[slot] = 0;
+            HIPCHK(c, hipHostMalloc(&p->h_ring[slot], bytes + bytes / 2 + 4096, hipHostMallocDefault));
+            p->h_ring_cap[slot] = bytes + bytes / 2 + 4096;
+        }
+        memcpy(p->h_ring[slot], iq_host, bytes);
+        HIPCHK(c, hipMemcpyAsync(p->d_stream + p->carry, p->h_ring[slot], bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(p->h_ring_ev[slot], c->stream));
+    }
     if (total < (size_t)p->nperseg) {
         p->carry = total;
         return OTH_OK;
@@ -923,6 +987,73 @@ int oth_welch_finalize(oth_plan *p, float *psd_out, uint64_t *nseg_out) {
     return oth_welch_reset(p);
 }
 
+// Averaging launch + cross-workgroup reduction of the two-channel path.  raw: unscaled sums in natural
+// order (no shift / trim), the time-sharded form; else the plan's scale, shift and trim.
+static int csd_run(oth_plan *p, const float2 *dx, const float2 *dy, size_t nsamples, bool raw, float *o_xx,
+                   float *o_yy, float *o_xy, float *o_c, uint64_t *nseg_out) {
+    oth_ctx *c = p->ctx;
+    long long nseg = 0;
+    int W = 0, layout = 0;
+    int rc = run_average(p, dx, dy, nsamples, 1, nsamples, &nseg, &W, &layout);
+    if (rc) return rc;
+    FinalizeArgs f{};
+    f.partial = p->d_partial;
+    f.scratch = p->d_reduce;
+    f.out0 = o_xx;
+    f.out1 = o_yy;
+    f.out2 = o_xy;
+    f.out3 = o_c;
+    f.scale = raw ? 1.0 : p->scale / (double)nseg;
+    f.W = W;
+    f.nfft = p->nfft;
+    f.nch = 4;
+    f.layout = layout;
+    f.fftshift = raw ? 0 : p->fftshift;
+    f.trim = raw ? 0 : p->trim;
+    f.nout = raw ? p->nfft : p->nfft - 2 * p->trim;
+    if (int frc = finalize_and_rearm(c, f, 1)) return frc;
+    if (nseg_out) *nseg_out = (uint64_t)nseg;
+    return OTH_OK;
+}
+
+int oth_csd_exec_dev(oth_plan *p, const void *x_dev, const void *y_dev, size_t nsamples, float *pxx_dev,
+                     float *pyy_dev, float *pxy_dev, float *cxy_dev, uint64_t *nseg_out) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (!x_dev || !y_dev) return fail(c, OTH_ERR_INVALID, "x/y is NULL");
+    if (p->db) return fail(c, OTH_ERR_UNSUPPORTED, "dB output is not defined for the cross spectrum");
+    if (nsamples < (size_t)p->nperseg) return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
+    if (use_device(c)) return OTH_ERR_HIP;
+    return csd_run(p, (const float2 *)x_dev, (const float2 *)y_dev, nsamples, false, pxx_dev, pyy_dev, pxy_dev,
+                   cxy_dev, nseg_out);
+}
+
+int oth_csd_partial_dev(oth_plan *p, const void *x_dev, const void *y_dev, size_t nsamples, float *sums_out_dev,
+                        uint64_t *nseg_out) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (!x_dev || !y_dev || !sums_out_dev) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (nsamples < (size_t)p->nperseg) return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
+    if (use_device(c)) return OTH_ERR_HIP;
+    const int N = p->nfft;
+    return csd_run(p, (const float2 *)x_dev, (const float2 *)y_dev, nsamples, true, sums_out_dev, sums_out_dev + N,
+                   sums_out_dev + 2 * N, nullptr, nseg_out);
+}
+
+int oth_csd_scale_dev(oth_plan *p, const float *sums_dev, uint64_t nseg_total, float *pxx_dev, float *pyy_dev,
+                      float *pxy_dev, float *cxy_dev) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    oth_ctx *c = p->ctx;
+    if (!sums_dev || !nseg_total) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (use_device(c)) return OTH_ERR_HIP;
+    HIPCHK(c, launch_csd_scale(sums_dev, p->nfft, p->scale / (double)nseg_total, p->fftshift, p->trim, pxx_dev,
+                               pyy_dev, pxy_dev, cxy_dev, c->stream));
+    return OTH_OK;
+}
+
 int oth_csd_exec(oth_plan *p, const void *x, const void *y, size_t nsamples, int src_is_device, float *pxx,
                  float *pyy, float *pxy, float *cxy, uint64_t *nseg_out) {
     CtxGuard guard_(p ? p->ctx : nullptr);
@@ -935,33 +1066,15 @@ int oth_csd_exec(oth_plan *p, const void *x, const void *y, size_t nsamples, int
     const float2 *dx = (const float2 *)x, *dy = (const float2 *)y;
     int rc;
     if (!src_is_device && (rc = stage_host(p, x, y, nsamples, &dx, &dy))) return rc;
-    long long nseg = 0;
-    int W = 0, layout = 0;
-    if ((rc = run_average(p, dx, dy, nsamples, 1, nsamples, &nseg, &W, &layout))) return rc;
     if ((rc = ensure(c, &p->d_out, &p->out_cap, sizeof(float) * 5 * p->nfft))) return rc;
     const int nout = p->nfft - 2 * p->trim;
-    FinalizeArgs f{};
-    f.partial = p->d_partial;
-    f.scratch = p->d_reduce;
-    f.out0 = p->d_out;
-    f.out1 = p->d_out + p->nfft;
-    f.out2 = p->d_out + 2 * p->nfft;
-    f.out3 = p->d_out + 4 * p->nfft;
-    f.scale = p->scale / (double)nseg;
-    f.W = W;
-    f.nfft = p->nfft;
-    f.nch = 4;
-    f.layout = layout;
-    f.fftshift = p->fftshift;
-    f.trim = p->trim;
-    f.nout = nout;
-    if (int frc = finalize_and_rearm(c, f, 1)) return frc;
-    if (pxx) HIPCHK(c, hipMemcpyAsync(pxx, f.out0, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
-    if (pyy) HIPCHK(c, hipMemcpyAsync(pyy, f.out1, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
-    if (pxy) HIPCHK(c, hipMemcpyAsync(pxy, f.out2, sizeof(float) * 2 * nout, hipMemcpyDeviceToHost, c->stream));
-    if (cxy) HIPCHK(c, hipMemcpyAsync(cxy, f.out3, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+    float *o0 = p->d_out, *o1 = p->d_out + p->nfft, *o2 = p->d_out + 2 * p->nfft, *o3 = p->d_out + 4 * p->nfft;
+    if ((rc = csd_run(p, dx, dy, nsamples, false, o0, o1, o2, o3, nseg_out))) return rc;
+    if (pxx) HIPCHK(c, hipMemcpyAsync(pxx, o0, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+    if (pyy) HIPCHK(c, hipMemcpyAsync(pyy, o1, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+    if (pxy) HIPCHK(c, hipMemcpyAsync(pxy, o2, sizeof(float) * 2 * nout, hipMemcpyDeviceToHost, c->stream));
+    if (cxy) HIPCHK(c, hipMemcpyAsync(cxy, o3, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (nseg_out) *nseg_out = (uint64_t)nseg;
     return OTH_OK;
 }
 
@@ -1020,6 +1133,13 @@ int oth_chain_destroy(oth_chain *h) {
     if (h->d_iir) hipFree(h->d_iir);
     if (h->d_peak) hipFree(h->d_peak);
     if (h->d_peak_init) hipFree(h->d_peak_init);
+    if (h->d_stage) hipFree(h->d_stage);
+    if (h->d_out) hipFree(h->d_out);
+    for (int i = 0; i < oth_chain::kRing; ++i) {
+        if (h->h_in[i]) hipHostFree(h->h_in[i]);
+        if (h->h_row[i]) hipHostFree(h->h_row[i]);
+        if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    }
     delete h;
     return OTH_OK;
 }
@@ -1061,6 +1181,104 @@ int oth_chain_reset(oth_chain *h) {
     return OTH_OK;
 }
 
+// `nrows` kept vectors of x, vector index first_vec + r * keep_n (r = 0 .. nrows-1), through FFT + epilogue in
+// time order (IIR / peak state advance); the LAST `give` post-epilogue rows land in rows_last (device).
+static int chain_launch(oth_chain *h, const float2 *x, long long first_vec, long long nrows, float *rows_last,
+                        long long give) {
+    oth_ctx *c = h->ctx;
+    const int N = h->nfft;
+    int rc = ensure(c, &h->d_rows, &h->rows_cap, sizeof(float) * (size_t)nrows * N);
+    if (rc) return rc;
+    PgramArgs a;
+    a.x = x;
+    a.win = h->d_win;
+    a.tw = h->d_tw;
+    a.rows = h->d_rows;
+    a.first_vec = first_vec;
+    a.nrows = nrows;
+    a.keep_n = h->keep_n;
+    a.fftshift = h->fftshift;
+    a.epilogue = h->epilogue;
+    a.scale = h->epilogue == OTH_EPI_MAG2_OVER_N2 ? (float)(1.0 / ((double)N * (double)N)) : 1.0f;
+    {
+        Timed tm(c);
+        HIPCHK(c, launch_pgram(N, a, c->stream));
+    }
+    if (h->do_iir || h->do_peak)
+        HIPCHK(c, launch_rows_epilogue(h->d_rows, nrows, N, h->alpha, h->kdb, h->d_iir, h->d_peak, h->d_peak_init,
+                                       h->do_iir, h->do_peak, c->stream));
+    if (rows_last && give > 0)
+        HIPCHK(c, hipMemcpyAsync(rows_last, h->d_rows + (size_t)(nrows - give) * N, sizeof(float) * (size_t)give * N,
+                                 hipMemcpyDeviceToDevice, c->stream));
+    return OTH_OK;
+}
+
+// Feed nsamples device-resident samples: completes the vector left over from the previous call, runs the full
+// vectors straight from `src`, keeps the incomplete tail.  Asynchronous on the context's stream.  rows_dev (may
+// be NULL) receives the last min(rows, capacity) rows of this call in time order.
+static int chain_feed(oth_chain *h, const float2 *src, size_t nsamples, float *rows_dev, size_t capacity,
+                      uint64_t *nrows_out) {
+    oth_ctx *c = h->ctx;
+    const int N = h->nfft;
+    int rc = ensure(c, &h->d_buf, &h->buf_cap, sizeof(float2) * (size_t)N);
+    if (rc) return rc;
+    bool head = false;           // a vector completed in d_buf
+    if (h->leftover) {
+        const size_t take = nsamples < (size_t)N - h->leftover ? nsamples : (size_t)N - h->leftover;
+        HIPCHK(c, hipMemcpyAsync(h->d_buf + h->leftover, src, take * sizeof(float2), hipMemcpyDeviceToDevice,
+                                 c->stream));
+        h->leftover += take;
+        src += take;
+        nsamples -= take;
+        if (h->leftover == (size_t)N) {
+            head = true;
+            h->leftover = 0;
+        }
+    }
+    const long long nvec = (long long)(nsamples / N);
+    // keep_one_in_n: `count` vectors to go until the next kept one (GNU Radio keeps the LAST of every n)
+    long long k_head = 0;
+    if (head) {
+        if (--h->count == 0) {
+            k_head = 1;
+            h->count = h->keep_n;
+        }
+    }
+    long long k_body = 0, first = h->count - 1;
+    if (nvec > first) k_body = 1 + (nvec - 1 - first) / h->keep_n;
+    if (k_body == 0) {
+        h->count -= (int)nvec;
+    } else {
+        const long long last = first + (k_body - 1) * h->keep_n;
+        h->count = h->keep_n - (int)(nvec - 1 - last);
+    }
+    const long long give_body = k_body < (long long)capacity ? k_body : (long long)capacity;
+    const long long give_head = k_head < (long long)capacity - give_body ? k_head : (long long)capacity - give_body;
+    if (k_head && (rc = chain_launch(h, h->d_buf, 0, 1, rows_dev, rows_dev ? give_head : 0))) return rc;
+    if (k_body && (rc = chain_launch(h, src, first, k_body, rows_dev ? rows_dev + (size_t)give_head * N : nullptr,
+                                     rows_dev ? give_body : 0)))
+        return rc;
+    const size_t used = (size_t)nvec * N, keep = nsamples - used;
+    if (keep) {      // d_buf is free again: a completed head vector has been consumed by the launch above (stream order)
+        HIPCHK(c, hipMemcpyAsync(h->d_buf, src + used, keep * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+        h->leftover = keep;
+    }
+    if (nrows_out) *nrows_out = (uint64_t)(k_head + k_body);
+    return OTH_OK;
+}
+
+int oth_chain_push_dev(oth_chain *h, const void *iq_dev, size_t nsamples, float *rows_out_dev, size_t rows_capacity,
+                       uint64_t *nrows_out) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
+    if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
+    oth_ctx *c = h->ctx;
+    if (nrows_out) *nrows_out = 0;
+    if (!iq_dev && nsamples) return fail(c, OTH_ERR_INVALID, "iq is NULL");
+    if (!nsamples) return OTH_OK;
+    if (use_device(c)) return OTH_ERR_HIP;
+    return chain_feed(h, (const float2 *)iq_dev, nsamples, rows_out_dev, rows_out_dev ? rows_capacity : 0, nrows_out);
+}
+
 int oth_chain_push(oth_chain *h, const void *iq, size_t nsamples, int src_is_device, float *rows_out,
                    size_t rows_capacity, uint64_t *nrows_out) {
     CtxGuard guard_(h ? h->ctx : nullptr);
@@ -1071,56 +1289,114 @@ int oth_chain_push(oth_chain *h, const void *iq, size_t nsamples, int src_is_dev
     if (!nsamples) return OTH_OK;
     if (use_device(c)) return OTH_ERR_HIP;
     const int N = h->nfft;
-    const size_t total = h->leftover + nsamples;
-    int rc = ensure_keep(c, &h->d_buf, &h->buf_cap, total * sizeof(float2), h->leftover * sizeof(float2));
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(h->d_buf + h->leftover, iq, nsamples * sizeof(float2),
-                             src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    if (!src_is_device) HIPCHK(c, hipStreamSynchronize(c->stream));
-    const long long nvec = (long long)(total / N);
-    long long nrows = 0, first = h->count - 1;
-    if (nvec > first) nrows = 1 + (nvec - 1 - first) / h->keep_n;
-    if (nrows == 0) {
-        h->count -= (int)nvec;
-    } else {
-        const long long last = first + (nrows - 1) * h->keep_n;
-        h->count = h->keep_n - (int)(nvec - 1 - last);
-        if ((rc = ensure(c, &h->d_rows, &h->rows_cap, sizeof(float) * (size_t)nrows * N))) return rc;
-        PgramArgs a;
-        a.x = h->d_buf;
-        a.win = h->d_win;
-        a.tw = h->d_tw;
-        a.rows = h->d_rows;
-        a.first_vec = first;
-        a.nrows = nrows;
-        a.keep_n = h->keep_n;
-        a.fftshift = h->fftshift;
-        a.epilogue = h->epilogue;
-        a.scale = h->epilogue == OTH_EPI_MAG2_OVER_N2 ? (float)(1.0 / ((double)N * (double)N)) : 1.0f;
-        {
-            Timed tm(c);
-            HIPCHK(c, launch_pgram(N, a, c->stream));
-        }
-        if (h->do_iir || h->do_peak)
-            HIPCHK(c, launch_rows_epilogue(h->d_rows, nrows, N, h->alpha, h->kdb, h->d_iir, h->d_peak,
-                                           h->d_peak_init, h->do_iir, h->do_peak, c->stream));
-        if (rows_out && rows_capacity) {
-            const size_t give = (size_t)nrows < rows_capacity ? (size_t)nrows : rows_capacity;
-            HIPCHK(c, hipMemcpyAsync(rows_out, h->d_rows + ((size_t)nrows - give) * N, sizeof(float) * give * N,
-                                     hipMemcpyDeviceToHost, c->stream));
-        }
+    const float2 *src = (const float2 *)iq;
+    int rc;
+    if (!src_is_device) {
+        if ((rc = ensure(c, &h->d_stage, &h->stage_cap, nsamples * sizeof(float2)))) return rc;
+        HIPCHK(c, hipMemcpyAsync(h->d_stage, iq, nsamples * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+        src = h->d_stage;
     }
-    // carry the samples of the incomplete vector
-    const size_t used = (size_t)nvec * N;
-    const size_t keep = total - used;
-    if (keep && used) {
-        // keep < N <= used, so source and destination do not overlap
-        HIPCHK(c, hipMemcpyAsync(h->d_buf, h->d_buf + used, keep * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
-    }
-    h->leftover = keep;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (nrows_out) *nrows_out = (uint64_t)nrows;
+    // rows this call can produce at most: one completed leftover vector + the full vectors of the new samples
+    size_t cap = rows_out ? rows_capacity : 0;
+    const size_t most = nsamples / N + 2;
+    if (cap > most) cap = most;
+    if (cap && (rc = ensure(c, &h->d_out, &h->out_cap, sizeof(float) * cap * N))) return rc;
+    uint64_t nrows = 0;
+    if ((rc = chain_feed(h, src, nsamples, cap ? h->d_out : nullptr, cap, &nrows))) return rc;
+    const size_t give = nrows < cap ? (size_t)nrows : cap;
+    if (give) HIPCHK(c, hipMemcpyAsync(rows_out, h->d_out, sizeof(float) * give * N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller's buffer and rows_out are the caller's again
+    if (nrows_out) *nrows_out = nrows;
     return OTH_OK;
+}
+
+// sync_block.work() form: copy the scheduler's buffer into a pinned slot, enqueue H2D + kernels + the D2H of the
+// latest row, record an event and return.  The watcher collects the row with oth_chain_poll / oth_chain_wait.
+int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uint64_t *ticket_out) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
+    if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
+    oth_ctx *c = h->ctx;
+    if (!ticket_out) return fail(c, OTH_ERR_INVALID, "ticket_out is NULL");
+    *ticket_out = 0;
+    if (!iq_host && nsamples) return fail(c, OTH_ERR_INVALID, "iq is NULL");
+    if (use_device(c)) return OTH_ERR_HIP;
+    const int N = h->nfft;
+    const uint64_t ticket = h->next_ticket;
+    const int slot = (int)(ticket % oth_chain::kRing);
+    if (!h->ev[slot]) {
+        HIPCHK(c, hipEventCreateWithFlags(&h->ev[slot], hipEventDisableTiming));
+        HIPCHK(c, hipHostMalloc((void **)&h->h_row[slot], sizeof(float) * N, hipHostMallocDefault));
+    } else if (h->ticket_of[slot]) {
+        HIPCHK(c, hipEventSynchronize(h->ev[slot]));      // only when the GPU is kRing pushes behind
+    }
+    const size_t bytes = nsamples * sizeof(float2);
+    if (h->h_in_cap[slot] < bytes) {
+        if (h->h_in[slot]) HIPCHK(c, hipHostFree(h->h_in[slot]));
+        h->h_in[slot] = nullptr;
+        h->h_in_cap[slot] = 0;
+        const size_t cap = bytes + bytes / 2 + 4096;
+        HIPCHK(c, hipHostMalloc(&h->h_in[slot], cap, hipHostMallocDefault));
+        h->h_in_cap[slot] = cap;
+    }
+    int rc;
+    uint64_t nrows = 0;
+    if (nsamples) {
+        memcpy(h->h_in[slot], iq_host, bytes);      // the scheduler's buffer dies when work() returns
+        if ((rc = ensure(c, &h->d_stage, &h->stage_cap, bytes))) return rc;
+        if ((rc = ensure(c, &h->d_out, &h->out_cap, sizeof(float) * N))) return rc;
+        HIPCHK(c, hipMemcpyAsync(h->d_stage, h->h_in[slot], bytes, hipMemcpyHostToDevice, c->stream));
+        if ((rc = chain_feed(h, h->d_stage, nsamples, h->d_out, 1, &nrows))) return rc;
+        if (nrows)
+            HIPCHK(c, hipMemcpyAsync(h->h_row[slot], h->d_out, sizeof(float) * N, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(h->ev[slot], c->stream));
+    h->ticket_of[slot] = ticket;
+    h->nrows_of[slot] = nrows;
+    h->next_ticket = ticket + 1;
+    *ticket_out = ticket;
+    return OTH_OK;
+}
+
+static int chain_collect(oth_chain *h, uint64_t ticket, float *row_out, uint64_t *nrows_out, int *ready, bool wait) {
+    oth_ctx *c = h->ctx;
+    const int slot = (int)(ticket % oth_chain::kRing);
+    if (!ticket || h->ticket_of[slot] != ticket)
+        return fail(c, OTH_ERR_STATE, "ticket unknown or overwritten (the ring keeps the last 4 pushes: latest wins)");
+    hipError_t e = wait ? hipEventSynchronize(h->ev[slot]) : hipEventQuery(h->ev[slot]);
+    if (e == hipErrorNotReady) {
+        if (ready) *ready = 0;
+        return OTH_OK;
+    }
+    if (e != hipSuccess) return fail(c, OTH_ERR_HIP, std::string("event: ") + hipGetErrorString(e));
+    if (ready) *ready = 1;
+    if (nrows_out) *nrows_out = h->nrows_of[slot];
+    if (row_out && h->nrows_of[slot]) memcpy(row_out, h->h_row[slot], sizeof(float) * h->nfft);
+    return OTH_OK;
+}
+
+int oth_chain_poll(oth_chain *h, uint64_t ticket, float *row_out, uint64_t *nrows_out, int *ready) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
+    if (!h || !ready) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
+    *ready = 0;
+    return chain_collect(h, ticket, row_out, nrows_out, ready, false);
+}
+
+int oth_chain_wait(oth_chain *h, uint64_t ticket, float *row_out, uint64_t *nrows_out) {
+    // the wait itself runs WITHOUT the context lock: work() on the scheduler thread must be able to enqueue meanwhile
+    hipEvent_t ev = nullptr;
+    {
+        CtxGuard guard_(h ? h->ctx : nullptr);
+        if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
+        const int slot = (int)(ticket % oth_chain::kRing);
+        if (!ticket || h->ticket_of[slot] != ticket)
+            return fail(h->ctx, OTH_ERR_STATE, "ticket unknown or overwritten (the ring keeps the last 4 pushes: latest wins)");
+        ev = h->ev[slot];
+    }
+    hipError_t e = hipEventSynchronize(ev);
+    if (e != hipSuccess) return fail(h->ctx, OTH_ERR_HIP, std::string("event: ") + hipGetErrorString(e));
+    CtxGuard guard_(h->ctx);
+    int ready = 0;
+    return chain_collect(h, ticket, row_out, nrows_out, &ready, false);
 }
 
 int oth_chain_get_peak(oth_chain *h, float *peak_out) {
@@ -1147,21 +1423,18 @@ int oth_rows_group_mean(oth_ctx *c, const float *rows_host, size_t nrows, int nf
         return fail(c, OTH_ERR_INVALID, "bad argument");
     if (use_device(c)) return OTH_ERR_HIP;
     const size_t ngroups = nrows / group;
-    float *d_in = nullptr, *d_out = nullptr;
     const size_t in_bytes = sizeof(float) * ngroups * group * nfft, out_bytes = sizeof(float) * ngroups * nfft;
-    if (hipMalloc(&d_in, in_bytes) != hipSuccess || hipMalloc(&d_out, out_bytes) != hipSuccess) {
-        if (d_in) hipFree(d_in);
-        return fail(c, OTH_ERR_NOMEM, "hipMalloc failed");
-    }
-    hipError_t e = hipMemcpyAsync(d_in, rows_host, in_bytes, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = launch_group_mean(d_in, (long long)ngroups, nfft, group, d_out, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_in);
-    hipFree(d_out);
-    if (e != hipSuccess) return fail(c, OTH_ERR_HIP, std::string("group_mean: ") + hipGetErrorString(e));
+    int rc = ensure(c, &c->scratch, &c->scratch_cap, in_bytes + out_bytes);
+    if (rc) return rc;
+    float *d_in = (float *)c->scratch, *d_out = (float *)(c->scratch + in_bytes);
+    HIPCHK(c, hipMemcpyAsync(d_in, rows_host, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_group_mean(d_in, (long long)ngroups, nfft, group, d_out, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out_host, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
 }
+
+static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 int oth_channel_power(oth_ctx *c, const float *psd_host, int nfft, double srch_bins, int nch, const int *lo,
                       const int *hi, float *power_out, float *movavg_out) {
@@ -1171,25 +1444,22 @@ int oth_channel_power(oth_ctx *c, const float *psd_host, int nfft, double srch_b
     for (int i = 0; i < nch; ++i)
         if (lo[i] < 0 || hi[i] > nfft) return fail(c, OTH_ERR_INVALID, "channel slice outside [0, nfft]");
     if (use_device(c)) return OTH_ERR_HIP;
-    unsigned char *d = nullptr;
-    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t o_psd = 0, o_ma = up(o_psd + sizeof(float) * nfft), o_maf = up(o_ma + sizeof(double) * nfft),
-                 o_lo = up(o_maf + sizeof(float) * nfft), o_hi = up(o_lo + sizeof(int) * nch),
-                 o_pw = up(o_hi + sizeof(int) * nch), bytes = up(o_pw + sizeof(float) * nch);
-    if (hipMalloc(&d, bytes) != hipSuccess) return fail(c, OTH_ERR_NOMEM, "hipMalloc failed");
-    hipError_t e = hipMemcpyAsync(d + o_psd, psd_host, sizeof(float) * nfft, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_lo, lo, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_hi, hi, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess)
-        e = launch_channel_power((const float *)(d + o_psd), nfft, srch_bins, nch, (const int *)(d + o_lo),
-                                 (const int *)(d + o_hi), (double *)(d + o_ma), (float *)(d + o_pw),
-                                 (float *)(d + o_maf), c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(power_out, d + o_pw, sizeof(float) * nch, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && movavg_out)
-        e = hipMemcpyAsync(movavg_out, d + o_maf, sizeof(float) * nfft, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
-    if (e != hipSuccess) return fail(c, OTH_ERR_HIP, std::string("channel_power: ") + hipGetErrorString(e));
+    const size_t o_psd = 0, o_ma = up16(o_psd + sizeof(float) * nfft), o_maf = up16(o_ma + sizeof(double) * nfft),
+                 o_lo = up16(o_maf + sizeof(float) * nfft), o_hi = up16(o_lo + sizeof(int) * nch),
+                 o_pw = up16(o_hi + sizeof(int) * nch), bytes = up16(o_pw + sizeof(float) * nch);
+    int rc = ensure(c, &c->scratch, &c->scratch_cap, bytes);
+    if (rc) return rc;
+    unsigned char *d = c->scratch;
+    HIPCHK(c, hipMemcpyAsync(d + o_psd, psd_host, sizeof(float) * nfft, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + o_lo, lo, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + o_hi, hi, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_channel_power((const float *)(d + o_psd), 1, nfft, srch_bins, nch, (const int *)(d + o_lo),
+                                   (const int *)(d + o_hi), (double *)(d + o_ma), (float *)(d + o_pw),
+                                   (float *)(d + o_maf), c->stream));
+    HIPCHK(c, hipMemcpyAsync(power_out, d + o_pw, sizeof(float) * nch, hipMemcpyDeviceToHost, c->stream));
+    if (movavg_out)
+        HIPCHK(c, hipMemcpyAsync(movavg_out, d + o_maf, sizeof(float) * nfft, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
 }
 
@@ -1200,19 +1470,52 @@ int oth_bin_threshold(oth_ctx *c, const float *psd_host, int nrows, int nfft, do
         return fail(c, OTH_ERR_INVALID, "bad argument (srch_bins must be >= 1)");
     if (use_device(c)) return OTH_ERR_HIP;
     const size_t nb = (size_t)nrows * nfft;
-    unsigned char *d = nullptr;
-    const size_t o_mask = sizeof(float) * nb, o_noise = (o_mask + nb + 15) & ~(size_t)15;
-    if (hipMalloc(&d, o_noise + sizeof(float) * nrows) != hipSuccess) return fail(c, OTH_ERR_NOMEM, "hipMalloc failed");
-    hipError_t e = hipMemcpyAsync(d, psd_host, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess)
-        e = launch_bin_threshold((const float *)d, nrows, nfft, srch_bins, thr_leveler, d + o_mask,
-                                 (float *)(d + o_noise), c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(mask_out, d + o_mask, nb, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && noise_out)
-        e = hipMemcpyAsync(noise_out, d + o_noise, sizeof(float) * nrows, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
-    if (e != hipSuccess) return fail(c, OTH_ERR_HIP, std::string("bin_threshold: ") + hipGetErrorString(e));
+    const size_t o_mask = sizeof(float) * nb, o_noise = up16(o_mask + nb);
+    int rc = ensure(c, &c->scratch, &c->scratch_cap, o_noise + sizeof(float) * nrows);
+    if (rc) return rc;
+    unsigned char *d = c->scratch;
+    HIPCHK(c, hipMemcpyAsync(d, psd_host, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_bin_threshold((const float *)d, nrows, nfft, srch_bins, thr_leveler, d + o_mask,
+                                   (float *)(d + o_noise), c->stream));
+    HIPCHK(c, hipMemcpyAsync(mask_out, d + o_mask, nb, hipMemcpyDeviceToHost, c->stream));
+    if (noise_out)
+        HIPCHK(c, hipMemcpyAsync(noise_out, d + o_noise, sizeof(float) * nrows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OTH_OK;
+}
+
+// Decision stage of the batched scanner on PSD rows that are already in HBM (BASELINE config 5): one launch
+// sequence, context-owned scratch, no copy of the rows.  Host results: mask (nullable), noise[nrows],
+// power[nrows][nch] (nullable when nch == 0).
+int oth_scan_decide_dev(oth_ctx *c, const float *psd_rows_dev, int nrows, int nfft, double srch_bins, float thr_leveler,
+                        int nch, const int *lo, const int *hi, unsigned char *mask_out, float *noise_out,
+                        float *power_out) {
+    CtxGuard guard_(c);
+    if (!c || !psd_rows_dev || nrows < 1 || nfft < 1 || nch < 0 || !(srch_bins >= 1.0) || (nch && (!lo || !hi || !power_out)))
+        return fail(c, OTH_ERR_INVALID, "bad argument (srch_bins must be >= 1)");
+    for (int i = 0; i < nch; ++i)
+        if (lo[i] < 0 || hi[i] > nfft) return fail(c, OTH_ERR_INVALID, "channel slice outside [0, nfft]");
+    if (use_device(c)) return OTH_ERR_HIP;
+    const size_t nb = (size_t)nrows * nfft;
+    const size_t o_ma = 0, o_mask = up16(o_ma + sizeof(double) * nb), o_noise = up16(o_mask + nb),
+                 o_pw = up16(o_noise + sizeof(float) * nrows), o_lo = up16(o_pw + sizeof(float) * nrows * (nch + 1)),
+                 o_hi = up16(o_lo + sizeof(int) * (nch + 1)), bytes = up16(o_hi + sizeof(int) * (nch + 1));
+    int rc = ensure(c, &c->scratch, &c->scratch_cap, bytes);
+    if (rc) return rc;
+    unsigned char *d = c->scratch;
+    if (nch) {
+        HIPCHK(c, hipMemcpyAsync(d + o_lo, lo, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d + o_hi, hi, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, launch_scan_decide(psd_rows_dev, nrows, nfft, srch_bins, thr_leveler, nch, (const int *)(d + o_lo),
+                                 (const int *)(d + o_hi), (double *)(d + o_ma), mask_out ? d + o_mask : nullptr,
+                                 (float *)(d + o_noise), nch ? (float *)(d + o_pw) : nullptr, c->stream));
+    if (mask_out) HIPCHK(c, hipMemcpyAsync(mask_out, d + o_mask, nb, hipMemcpyDeviceToHost, c->stream));
+    if (noise_out)
+        HIPCHK(c, hipMemcpyAsync(noise_out, d + o_noise, sizeof(float) * nrows, hipMemcpyDeviceToHost, c->stream));
+    if (nch)
+        HIPCHK(c, hipMemcpyAsync(power_out, d + o_pw, sizeof(float) * nrows * nch, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
 }
 
@@ -1224,16 +1527,14 @@ static int xcorr_impl(oth_ctx *c, const void *a, size_t na, const void *b, size_
     const float2 *tw = nullptr;
     int rc = get_twiddles(c, L, &tw);
     if (rc) return rc;
-    float2 *d = nullptr;
-    if (hipMalloc(&d, sizeof(float2) * 3 * L) != hipSuccess) return fail(c, OTH_ERR_NOMEM, "hipMalloc failed");
-    hipError_t e = hipMemsetAsync(d, 0, sizeof(float2) * 3 * L, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d, a, sizeof(float2) * na, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && mode == 0) e = hipMemcpyAsync(d + L, b, sizeof(float2) * nb, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = launch_xcorr(L, d, d + L, tw, (float *)(d + 2 * L), mode, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d + 2 * L, sizeof(float) * (L - L / 2), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
-    if (e != hipSuccess) return fail(c, OTH_ERR_HIP, std::string("xcorr: ") + hipGetErrorString(e));
+    if ((rc = ensure(c, &c->scratch, &c->scratch_cap, sizeof(float2) * 3 * (size_t)L))) return rc;
+    float2 *d = (float2 *)c->scratch;
+    HIPCHK(c, hipMemsetAsync(d, 0, sizeof(float2) * 3 * L, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d, a, sizeof(float2) * na, hipMemcpyHostToDevice, c->stream));
+    if (mode == 0) HIPCHK(c, hipMemcpyAsync(d + L, b, sizeof(float2) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_xcorr(L, d, d + L, tw, (float *)(d + 2 * L), mode, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, d + 2 * L, sizeof(float) * (L - L / 2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
 }
 

@@ -178,6 +178,32 @@ hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, in
     return hipGetLastError();
 }
 
+// Summed partials of the two-channel path (time-sharded form): sums = [sum|X|^2][sum|Y|^2][sum conj(X)Y re,im]
+// in natural bin order -> scaled Pxx, Pyy, Pxy, Cxy with the plan's shift / trim.
+__global__ void csd_scale_kernel(const float *sums, int nfft, double scale, int fftshift, int trim, int nout,
+                                 float *pxx, float *pyy, float *pxy, float *cxy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nout) return;
+    const int ks = i + trim;
+    const int k = fftshift ? ((ks + nfft / 2) & (nfft - 1)) : ks;
+    const double xx = sums[k], yy = sums[nfft + k], re = sums[2 * nfft + 2 * k], im = sums[2 * nfft + 2 * k + 1];
+    if (pxx) pxx[i] = (float)(xx * scale);
+    if (pyy) pyy[i] = (float)(yy * scale);
+    if (pxy) {
+        pxy[2 * i] = (float)(re * scale);
+        pxy[2 * i + 1] = (float)(im * scale);
+    }
+    if (cxy) cxy[i] = (float)((re * re + im * im) / (xx * yy));
+}
+
+hipError_t launch_csd_scale(const float *sums, int nfft, double scale, int fftshift, int trim, float *pxx, float *pyy,
+                            float *pxy, float *cxy, hipStream_t s) {
+    const int nout = nfft - 2 * trim;
+    hipLaunchKernelGGL(csd_scale_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, sums, nfft, scale, fftshift, trim,
+                       nout, pxx, pyy, pxy, cxy);
+    return hipGetLastError();
+}
+
 // One thread per bin walks the rows in time order.
 __global__ void rows_epilogue_kernel(float *rows, long long nrows, int nfft, float alpha, float kdb,
                                      float *iir_state, float *peak_state, int *peak_init, int do_iir, int do_peak) {
@@ -225,35 +251,38 @@ hipError_t launch_group_mean(const float *rows, long long ngroups, int nfft, int
 
 // movingaverage(): np.convolve(psd, ones(M)/sb, 'same'), M = int(sb):
 // same[i] = (1/sb) * sum_{j<M} psd[i + (M-1)/2 - j]  (terms outside [0,N) dropped), then abs.
+// blockIdx.y = PSD row (batched scanner: one row per channel stream).
 __global__ void movavg_kernel(const float *psd, int nfft, double srch_bins, double *movavg, float *movavg_f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfft) return;
+    const size_t row = (size_t)blockIdx.y * nfft;
     const int M = (int)srch_bins;
     const int top = i + (M - 1) / 2;
     double s = 0.0;
     for (int j = 0; j < M; ++j) {
         const int n = top - j;
-        if (n >= 0 && n < nfft) s += (double)psd[n];
+        if (n >= 0 && n < nfft) s += (double)psd[row + n];
     }
     s = fabs(s / srch_bins);
-    movavg[i] = s;
-    if (movavg_f) movavg_f[i] = (float)s;
+    movavg[row + i] = s;
+    if (movavg_f) movavg_f[row + i] = (float)s;
 }
 
-__global__ void channel_sum_kernel(const double *movavg, int nch, const int *lo, const int *hi, float *power) {
+__global__ void channel_sum_kernel(const double *movavg, int nfft, int nch, const int *lo, const int *hi, float *power) {
     const int c = blockIdx.x;
+    const double *row = movavg + (size_t)blockIdx.y * nfft;
     double s = 0.0;
-    for (int i = lo[c] + threadIdx.x; i < hi[c]; i += 64) s += movavg[i];
+    for (int i = lo[c] + threadIdx.x; i < hi[c]; i += 64) s += row[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (threadIdx.x == 0) power[c] = (float)s;
+    if (threadIdx.x == 0) power[(size_t)blockIdx.y * nch + c] = (float)s;
 }
 
-hipError_t launch_channel_power(const float *psd, int nfft, double srch_bins, int nch, const int *lo, const int *hi,
-                                double *movavg, float *power, float *movavg_f, hipStream_t s) {
-    hipLaunchKernelGGL(movavg_kernel, dim3((nfft + 255) / 256), dim3(256), 0, s, psd, nfft, srch_bins, movavg,
+hipError_t launch_channel_power(const float *psd, int nrows, int nfft, double srch_bins, int nch, const int *lo,
+                                const int *hi, double *movavg, float *power, float *movavg_f, hipStream_t s) {
+    hipLaunchKernelGGL(movavg_kernel, dim3((nfft + 255) / 256, nrows), dim3(256), 0, s, psd, nfft, srch_bins, movavg,
                        movavg_f);
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(nch), dim3(64), 0, s, movavg, nch, lo, hi, power);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(nch, nrows), dim3(64), 0, s, movavg, nfft, nch, lo, hi, power);
     return hipGetLastError();
 }
 
@@ -281,6 +310,37 @@ __global__ __launch_bounds__(256) void bin_threshold_kernel(const float *psd, in
     if (threadIdx.x == 0 && noise_out) noise_out[blockIdx.x] = noise;
     const float level = noise * thr;
     for (int i = threadIdx.x; i < nfft; i += 256) mask[(size_t)blockIdx.x * nfft + i] = row[i] > level ? 1 : 0;
+}
+
+// Same decision from an already computed moving average (the batched decision stage runs movavg_kernel once for the
+// channel sums and the noise floor): noise = min_k movavg[k], mask[k] = psd[k] > thr * noise.
+__global__ __launch_bounds__(256) void bin_threshold_ma_kernel(const float *psd, const double *movavg, int nfft, float thr,
+                                                               unsigned char *mask, float *noise_out) {
+    __shared__ float red[4];
+    const float *row = psd + (size_t)blockIdx.x * nfft;
+    const double *ma = movavg + (size_t)blockIdx.x * nfft;
+    float mn = 3.4e38f;
+    for (int i = threadIdx.x; i < nfft; i += 256) mn = fminf(mn, (float)ma[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    const float noise = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    if (threadIdx.x == 0 && noise_out) noise_out[blockIdx.x] = noise;
+    if (!mask) return;
+    const float level = noise * thr;
+    for (int i = threadIdx.x; i < nfft; i += 256) mask[(size_t)blockIdx.x * nfft + i] = row[i] > level ? 1 : 0;
+}
+
+hipError_t launch_scan_decide(const float *psd, int nrows, int nfft, double srch_bins, float thr, int nch, const int *lo,
+                              const int *hi, double *movavg, unsigned char *mask, float *noise, float *power,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(movavg_kernel, dim3((nfft + 255) / 256, nrows), dim3(256), 0, s, psd, nfft, srch_bins, movavg,
+                       (float *)nullptr);
+    if (nch > 0 && power)
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(nch, nrows), dim3(64), 0, s, movavg, nfft, nch, lo, hi, power);
+    hipLaunchKernelGGL(bin_threshold_ma_kernel, dim3(nrows), dim3(256), 0, s, psd, movavg, nfft, thr, mask, noise);
+    return hipGetLastError();
 }
 
 hipError_t launch_bin_threshold(const float *psd, int nrows, int nfft, double srch_bins, float thr,

@@ -74,8 +74,8 @@ hipError_t launch_welch_generic(int nfft, const WelchArgs &a, hipStream_t s);
     hipError_t launch_welch_tuned4096_##tag(const WelchArgs &a, hipStream_t s); \
     int tuned4096_blocks_per_cu_##tag();
 OTH_DECL_W4096(dpp)
-OTH_DECL_W4096(diag)
 #ifdef OTH_EXPERIMENTS
+OTH_DECL_W4096(diag)
 OTH_DECL_W4096(exp1)
 OTH_DECL_W4096(exp2)
 OTH_DECL_W4096(exp3)
@@ -100,11 +100,16 @@ hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s);
 hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,
                         hipStream_t s);
+hipError_t launch_csd_scale(const float *sums, int nfft, double scale, int fftshift, int trim, float *pxx, float *pyy,
+                            float *pxy, float *cxy, hipStream_t s);
 hipError_t launch_rows_epilogue(float *rows, long long nrows, int nfft, float alpha, float kdb, float *iir_state,
                                 float *peak_state, int *peak_init, int do_iir, int do_peak, hipStream_t s);
 hipError_t launch_group_mean(const float *rows, long long ngroups, int nfft, int group, float *out, hipStream_t s);
-hipError_t launch_channel_power(const float *psd, int nfft, double srch_bins, int nch, const int *lo, const int *hi,
-                                double *movavg, float *power, float *movavg_f, hipStream_t s);
+hipError_t launch_channel_power(const float *psd, int nrows, int nfft, double srch_bins, int nch, const int *lo,
+                                const int *hi, double *movavg, float *power, float *movavg_f, hipStream_t s);
+hipError_t launch_scan_decide(const float *psd, int nrows, int nfft, double srch_bins, float thr, int nch, const int *lo,
+                              const int *hi, double *movavg, unsigned char *mask, float *noise, float *power,
+                              hipStream_t s);
 hipError_t launch_bin_threshold(const float *psd, int nrows, int nfft, double srch_bins, float thr,
                                 unsigned char *mask, float *noise, hipStream_t s);
 hipError_t launch_xcorr(int L, const float2 *a, const float2 *b, const float2 *tw, float *out, int mode,

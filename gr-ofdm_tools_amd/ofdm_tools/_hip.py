@@ -65,6 +65,7 @@ SIGNATURES = {
     'oth_plan_set_kernel': (C.c_int, [_p, C.c_int]),
     'oth_plan_set_schedule': (C.c_int, [_p, C.c_int]),
     'oth_plan_out_len': (C.c_int, [_p, C.POINTER(C.c_int)]),
+    'oth_plan_set_tuning': (C.c_int, [_p, C.c_char_p, C.c_int, C.c_int, C.c_int]),
     'oth_welch_exec': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f, _u64p]),
     'oth_welch_exec_dev': (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_size_t, _p, _u64p]),
     'oth_welch_partial_dev': (C.c_int, [_p, _p, C.c_size_t, _p, _u64p]),
@@ -73,6 +74,9 @@ SIGNATURES = {
     'oth_welch_finalize': (C.c_int, [_p, _f, _u64p]),
     'oth_welch_reset': (C.c_int, [_p]),
     'oth_csd_exec': (C.c_int, [_p, _p, _p, C.c_size_t, C.c_int, _f, _f, _f, _f, _u64p]),
+    'oth_csd_exec_dev': (C.c_int, [_p, _p, _p, C.c_size_t, _p, _p, _p, _p, _u64p]),
+    'oth_csd_partial_dev': (C.c_int, [_p, _p, _p, C.c_size_t, _p, _u64p]),
+    'oth_csd_scale_dev': (C.c_int, [_p, _p, C.c_uint64, _p, _p, _p, _p]),
     'oth_chain_create': (C.c_int, [_p, C.c_int, _f, C.c_int, C.c_int, C.c_int, _pp]),
     'oth_chain_destroy': (C.c_int, [_p]),
     'oth_chain_set_keep_one_in_n': (C.c_int, [_p, C.c_int]),
@@ -80,12 +84,18 @@ SIGNATURES = {
     'oth_chain_set_peak_hold': (C.c_int, [_p, C.c_int]),
     'oth_chain_reset': (C.c_int, [_p]),
     'oth_chain_push': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f, C.c_size_t, _u64p]),
+    'oth_chain_push_dev': (C.c_int, [_p, _p, C.c_size_t, _p, C.c_size_t, _u64p]),
+    'oth_chain_push_async': (C.c_int, [_p, _p, C.c_size_t, _u64p]),
+    'oth_chain_poll': (C.c_int, [_p, C.c_uint64, _f, _u64p, C.POINTER(C.c_int)]),
+    'oth_chain_wait': (C.c_int, [_p, C.c_uint64, _f, _u64p]),
     'oth_chain_get_peak': (C.c_int, [_p, _f]),
     'oth_chain_get_iir': (C.c_int, [_p, _f]),
     'oth_rows_group_mean': (C.c_int, [_p, _f, C.c_size_t, C.c_int, C.c_int, _f]),
     'oth_channel_power': (C.c_int, [_p, _f, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     _f, _f]),
     'oth_bin_threshold': (C.c_int, [_p, _f, C.c_int, C.c_int, C.c_double, C.c_float, C.POINTER(C.c_ubyte), _f]),
+    'oth_scan_decide_dev': (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_double, C.c_float, C.c_int, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_ubyte), _f, _f]),
     'oth_xcorr': (C.c_int, [_p, _p, C.c_size_t, _p, C.c_size_t, C.c_int, _f]),
     'oth_fac': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f]),
 }
@@ -254,6 +264,23 @@ class Context(object):
                    'oth_bin_threshold')
         return mask, noise
 
+    def scan_decide_dev(self, rows_dptr, nrows, nfft, srch_bins, thr_leveler, lo=(), hi=(), want_mask=True):
+        """Decision stage on device-resident PSD rows -> (mask uint8[nrows][nfft] or None, noise[nrows],
+        power[nrows][nch])."""
+        lo = np.ascontiguousarray(lo, np.int32)
+        hi = np.ascontiguousarray(hi, np.int32)
+        nch = len(lo)
+        mask = np.empty((nrows, nfft), np.uint8) if want_mask else None
+        noise = np.empty(nrows, np.float32)
+        power = np.empty((nrows, nch), np.float32)
+        ip = C.POINTER(C.c_int)
+        self.check(self.lib.oth_scan_decide_dev(self.h, C.c_void_p(rows_dptr), int(nrows), int(nfft), float(srch_bins),
+                                                float(thr_leveler), nch, lo.ctypes.data_as(ip) if nch else None,
+                                                hi.ctypes.data_as(ip) if nch else None,
+                                                mask.ctypes.data_as(C.POINTER(C.c_ubyte)) if want_mask else None,
+                                                _fptr(noise), _fptr(power) if nch else None), 'oth_scan_decide_dev')
+        return mask, noise, power
+
     def xcorr(self, a, b, length):
         a, b = _c64(a)[:length], _c64(b)[:length]
         out = np.empty(length - length // 2, np.float32)
@@ -306,6 +333,13 @@ class WelchPlan(object):
 
     def set_kernel(self, which):
         self.ctx.check(self.ctx.lib.oth_plan_set_kernel(self.h, int(which)), 'oth_plan_set_kernel')
+
+    def set_tuning(self, variant=None, sched=-1, chunk=0, tail=0):
+        """A/B tools and the parity suite: pick a build of the 4096-point kernel ('dpp', 'pipe', 'ws'), override the
+        schedule, set the segments per chunk / tail chunk.  Defaults restore the library's choices."""
+        v = variant.encode() if variant else None
+        self.ctx.check(self.ctx.lib.oth_plan_set_tuning(self.h, v, int(sched), int(chunk), int(tail)),
+                       'oth_plan_set_tuning')
 
     def set_schedule(self, which):
         self.ctx.check(self.ctx.lib.oth_plan_set_schedule(self.h, int(which)), 'oth_plan_set_schedule')
@@ -380,6 +414,49 @@ class WelchPlan(object):
         return pxx, pyy, pxy.view(np.complex64), cxy
 
 
+def _csd_device_src(self, dx, dy, nsamples):
+    """-> pxx, pyy, pxy (complex64), cxy for device inputs."""
+    m = self.out_len
+    pxx, pyy, cxy = (np.empty(m, np.float32) for _ in range(3))
+    pxy = np.empty(2 * m, np.float32)
+    n = C.c_uint64()
+    self.ctx.check(self.ctx.lib.oth_csd_exec(self.h, C.c_void_p(dx), C.c_void_p(dy), nsamples, 1, _fptr(pxx),
+                                             _fptr(pyy), _fptr(pxy), _fptr(cxy), C.byref(n)), 'oth_csd_exec')
+    self.last_nseg = n.value
+    return pxx, pyy, pxy.view(np.complex64), cxy
+
+
+WelchPlan.csd_device_src = _csd_device_src
+
+
+def _csd_exec_dev(self, dx, dy, nsamples, pxx=0, pyy=0, pxy=0, cxy=0):
+    """Asynchronous: device in, device out (any output pointer may be 0)."""
+    n = C.c_uint64()
+    vp = lambda v: C.c_void_p(v) if v else None      # noqa: E731
+    self.ctx.check(self.ctx.lib.oth_csd_exec_dev(self.h, C.c_void_p(dx), C.c_void_p(dy), nsamples, vp(pxx), vp(pyy),
+                                                 vp(pxy), vp(cxy), C.byref(n)), 'oth_csd_exec_dev')
+    return n.value
+
+
+def _csd_partial_dev(self, dx, dy, nsamples, sums_dptr):
+    """Raw sums [sum|X|^2 | sum|Y|^2 | sum conj(X)Y re,im] (4 * nfft floats, natural order) of this time chunk."""
+    n = C.c_uint64()
+    self.ctx.check(self.ctx.lib.oth_csd_partial_dev(self.h, C.c_void_p(dx), C.c_void_p(dy), nsamples,
+                                                    C.c_void_p(sums_dptr), C.byref(n)), 'oth_csd_partial_dev')
+    return n.value
+
+
+def _csd_scale_dev(self, sums_dptr, nseg_total, pxx=0, pyy=0, pxy=0, cxy=0):
+    vp = lambda v: C.c_void_p(v) if v else None      # noqa: E731
+    self.ctx.check(self.ctx.lib.oth_csd_scale_dev(self.h, C.c_void_p(sums_dptr), int(nseg_total), vp(pxx), vp(pyy),
+                                                  vp(pxy), vp(cxy)), 'oth_csd_scale_dev')
+
+
+WelchPlan.csd_exec_dev = _csd_exec_dev
+WelchPlan.csd_partial_dev = _csd_partial_dev
+WelchPlan.csd_scale_dev = _csd_scale_dev
+
+
 class Chain(object):
     """stream_to_vector -> keep_one_in_n -> fft_vcc -> |.|/|.|^2 [-> IIR -> log] with GNU Radio's
     streaming state kept on the device (oth_chain)."""
@@ -432,6 +509,38 @@ class Chain(object):
                                                    C.byref(n)), 'oth_chain_push')
         got = min(int(n.value), cap)
         return rows[:got], int(n.value)
+
+    def push_dev(self, dptr, nsamples, rows_dptr=0, capacity=0):
+        """Asynchronous: device-resident samples in, the last `capacity` rows to rows_dptr (device).  -> rows produced."""
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_chain_push_dev(self.h, C.c_void_p(dptr), nsamples,
+                                                       C.c_void_p(rows_dptr) if rows_dptr else None, int(capacity),
+                                                       C.byref(n)), 'oth_chain_push_dev')
+        return int(n.value)
+
+    def push_async(self, x):
+        """work() form: enqueue and return a ticket; the latest row is collected with poll() / wait()."""
+        x = _c64(x)
+        t = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_chain_push_async(self.h, x.ctypes.data_as(_p), len(x), C.byref(t)),
+                       'oth_chain_push_async')
+        return int(t.value)
+
+    def poll(self, ticket):
+        """-> None while the GPU is still working, else (row or None, rows produced by that push)."""
+        row = np.empty(self.nfft, np.float32)
+        n, ready = C.c_uint64(), C.c_int()
+        self.ctx.check(self.ctx.lib.oth_chain_poll(self.h, int(ticket), _fptr(row), C.byref(n), C.byref(ready)),
+                       'oth_chain_poll')
+        if not ready.value:
+            return None
+        return (row if n.value else None), int(n.value)
+
+    def wait(self, ticket):
+        row = np.empty(self.nfft, np.float32)
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_chain_wait(self.h, int(ticket), _fptr(row), C.byref(n)), 'oth_chain_wait')
+        return (row if n.value else None), int(n.value)
 
     def peak(self):
         out = np.empty(self.nfft, np.float32)

@@ -6,12 +6,13 @@ import math
 import numpy as np
 
 from . import _hip, packets, windows
+from .chain_block import ChainBlockMixin
 from .gr_compat import pdu, sync_block
 from .ofdm_cr_tools import _py2div
 
 
-class local_worker(sync_block):
-    def __init__(self, fft_len, sample_rate, average, rate, max_tu, data_precision, ctx=None):
+class local_worker(ChainBlockMixin, sync_block):
+    def __init__(self, fft_len, sample_rate, average, rate, max_tu, data_precision, ctx=None, threaded=False):
         sync_block.__init__(self, 'local_worker', [np.complex64], None)
         self.fft_len = fft_len
         self.sample_rate = sample_rate
@@ -21,8 +22,8 @@ class local_worker(sync_block):
         self.data_precision = data_precision
         self.message_port_register_hier_out('pdus')
         self.ctx = ctx or _hip.default_context()
-        self._chain = self.ctx.chain(fft_len, windows.blackmanharris(fft_len), True, _hip.EPI_MAG2,
-                                     self._decimation())
+        self._chain_init(self.ctx.chain(fft_len, windows.blackmanharris(fft_len), True, _hip.EPI_MAG2,
+                                        self._decimation()), threaded)
         # nlog10_ff's constant is fixed at construction in the reference (:67-69)
         self._k = -10 * math.log10(self.fft_len) - 10 * math.log10(self.sample_rate)
         self._set_iir()
@@ -34,13 +35,10 @@ class local_worker(sync_block):
     def _set_iir(self):
         self._chain.set_iir_log(self.average, self._k)
 
-    def work(self, input_items, output_items):
-        in0 = input_items[0]
-        rows, n = self._chain.push(in0, max_rows=1)
-        if n:
-            self.last_db = rows[-1]
-            self.send_packet(self.last_db)
-        return len(in0)
+    def _on_vector(self, row):
+        """main_thread.run body (:126-139): the latest dB row goes out as PDU fragments."""
+        self.last_db = row
+        self.send_packet(row)
 
     def send_packet(self, db_row):
         for frame in packets.worker_fragments(db_row, self.max_tu, self.fft_len, self.data_precision):

@@ -4,15 +4,16 @@ Constructor as multichannel_scanner.py:46-47."""
 import numpy as np
 
 from . import _hip
+from .chain_block import ChainBlockMixin
 from .gr_compat import sync_block, to_msg
 from .message_pdu import message_pdu
 from .ofdm_cr_tools import _py2div
 from .scanner import ChannelScanner, top4
 
 
-class multichannel_scanner(sync_block):
+class multichannel_scanner(ChainBlockMixin, sync_block):
     def __init__(self, fft_len, sens_per_sec, sample_rate, channel_space=1, search_bw=1, tune_freq=0,
-                 trunc_band=1, verbose=False, output=False, subject_channels=[], ctx=None):
+                 trunc_band=1, verbose=False, output=False, subject_channels=[], ctx=None, threaded=False):
         sync_block.__init__(self, 'multichannel_scanner', [np.complex64], None)
         self.fft_len = fft_len
         self.sens_per_sec = sens_per_sec
@@ -30,20 +31,18 @@ class multichannel_scanner(sync_block):
             self.message_port_register_hier_out(port)
         self.ctx = ctx or _hip.default_context()
         self.decimation = max(1, int(_py2div(_py2div(sample_rate, fft_len), sens_per_sec)))
-        self._chain = self.ctx.chain(fft_len, None, True, _hip.EPI_MAG2_OVER_N2, self.decimation)
+        chain = self.ctx.chain(fft_len, None, True, _hip.EPI_MAG2_OVER_N2, self.decimation)
         self.PDU_messages = message_pdu(None)
         self.PDU_messages.msg_connect('out', lambda m: self.message_port_pub('freq_msg_PDU', m))
         self._scanner = ChannelScanner(fft_len, sample_rate, channel_space, search_bw, tune_freq, trunc_band,
                                        ctx=self.ctx)
         self._idx_subject = self._scanner.subject_index(self.subject_channels)
+        self._chain_init(chain, threaded)
 
-    def work(self, input_items, output_items):
-        in0 = input_items[0]
-        rows, n = self._chain.push(in0, max_rows=1)
-        if n:
-            self._scanner.basic_scan(rows[-1])
-            self.publish()
-        return len(in0)
+    def _on_vector(self, row):
+        """basic_spectrum_watcher.run body (:196-210)."""
+        self._scanner.basic_scan(row)
+        self.publish()
 
     def publish(self):
         """basic_spectrum_watcher.publish, :227-239."""

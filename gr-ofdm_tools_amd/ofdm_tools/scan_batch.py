@@ -27,11 +27,53 @@ class BatchScanPlan(object):
         """Device in, device out: [nstreams][fft_len] averaged PSD rows; asynchronous."""
         return self.plan.exec_dev(iq_dptr, nsamples, out_dptr, nstreams=nstreams, stream_stride=stream_stride)
 
+    def _slices(self):
+        from .ofdm_cr_tools import _slice_bounds
+        sc = self.scanner
+        lo, hi = _slice_bounds(self.fft_len, sc.Fr, sc.sample_rate, sc.bb_freqs, sc.srch_bins)
+        if sc.trunc > 0:
+            lo, hi = lo[sc.trunc_ch:-sc.trunc_ch], hi[sc.trunc_ch:-sc.trunc_ch]
+        return lo, hi
+
+    def decide_dev(self, rows_dptr, nstreams, want_mask=True):
+        """The decision stage on the device rows psd_rows_dev() left in HBM (oth_scan_decide_dev: one launch
+        sequence, context-owned scratch, no copy of the rows) -> (mask uint8[nstreams][fft_len] or None,
+        noise floor per stream, channel powers [nstreams][nch])."""
+        lo, hi = self._slices()
+        return self.ctx.scan_decide_dev(rows_dptr, nstreams, self.fft_len, self.scanner.srch_bins, self.thr_leveler,
+                                        lo, hi, want_mask)
+
     def decide(self, rows):
-        """rows: host float32 [nstreams][fft_len] -> (mask, noise floor per stream, channel powers per stream)."""
-        mask, noise = self.ctx.bin_threshold(rows, self.scanner.srch_bins, self.thr_leveler)
-        plc = np.array([self.scanner.channel_powers(r) for r in rows])
-        return mask, noise, plc
+        """Host rows (float32 [nstreams][fft_len]): uploaded once, then decide_dev()."""
+        rows = np.ascontiguousarray(np.atleast_2d(rows), np.float32)
+        d = self.ctx.alloc(rows.nbytes)
+        try:
+            self.ctx.h2d(d, rows)
+            return self.decide_dev(d, rows.shape[0])
+        finally:
+            self.ctx.free(d)
+
+    def scan_sharded(self, iq_dptr, nsamples, stream_stride, nch_total, rank, world, device, group=None):
+        """BASELINE config 5 over `world` ranks: this rank holds channel streams rank, rank + world, ... back to back
+        in HBM.  PSD rows and the decision stage run locally on the device; ONE all-gather returns rows, noise
+        floors and channel powers in channel order on every rank (mask = rows > thr * noise is recomputed from
+        them by whoever needs it).  -> (rows [nch][fft_len], noise [nch], power [nch][nchan]) torch tensors."""
+        import torch
+        from . import sweep
+        mine = sweep.shard_segments(nch_total, rank, world)
+        spr = sweep.segments_per_rank(nch_total, world)
+        nchan = len(self._slices()[0])
+        width = self.fft_len + 1 + nchan
+        local = torch.zeros((spr, width), dtype=torch.float32, device=device)
+        if mine:
+            rows = torch.empty((len(mine), self.fft_len), dtype=torch.float32, device=device)
+            self.psd_rows_dev(iq_dptr, nsamples, len(mine), stream_stride, rows.data_ptr())
+            _, noise, power = self.decide_dev(rows.data_ptr(), len(mine), want_mask=False)
+            local[:len(mine), :self.fft_len] = rows
+            local[:len(mine), self.fft_len] = torch.from_numpy(noise).to(device)
+            local[:len(mine), self.fft_len + 1:] = torch.from_numpy(power).to(device)
+        allr = sweep.gather_rows(local, nch_total, rank, world, group)
+        return allr[:, :self.fft_len], allr[:, self.fft_len], allr[:, self.fft_len + 1:]
 
 
 def shard_channels(nch, rank, world):

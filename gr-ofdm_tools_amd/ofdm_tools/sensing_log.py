@@ -4,10 +4,13 @@ Holds the cumulative / periodic PSD peaks, per-channel max powers, occupancy
 statistics and waterfall rows that the watchers of spectrum_sensor_v2 update, and
 can write them in the reference's on-disk formats (np.save for arrays, ``str(dict)``
 for statistics, ``%1.2e`` rows for the waterfall; ofdm_cr_tools.py:2029-2046) with
-:meth:`flush`.  The background file_logger thread of the reference is not started
-here: a host calls flush() when it wants the files.
+:meth:`flush`.  :meth:`start_file_logger` runs the reference's periodic ``file_logger`` thread
+(ofdm_cr_tools.py:1958-2107): write everything, start a new period, sleep ``periodicity`` seconds, stop
+after ``test_duration`` with one last write; a host loop can instead call flush() when it wants the files.
 """
+import datetime
 import os
+import threading
 import time
 
 import numpy as np
@@ -27,6 +30,38 @@ class logger(object):
         self.cumulative_max_power = None
         self.cumulative_waterfall = []
         self.reset_periodic_vars()
+        self._fl_thread = None
+        self._fl_stop = threading.Event()
+        self.files_written = 0
+
+    # -- file_logger thread (ofdm_cr_tools.py:1906, 1958-2107) ---------------------------------------------
+    def start_file_logger(self):
+        if self._fl_thread is not None:
+            return
+        if self.directory is None:       # ~/sensing-<yymmdd>-<HHMM>/ (ofdm_cr_tools.py:1855-1859)
+            self.directory = os.path.join(os.path.expanduser('~'), 'sensing-%s-%s' % (self.start_dat,
+                                                                                         time.strftime('%H%M')))
+        self.stop_time = datetime.datetime.now() + datetime.timedelta(seconds=self.test_duration)
+        self._fl_stop.clear()
+        self._fl_thread = threading.Thread(target=self._file_logger_run, daemon=True)
+        self._fl_thread.start()
+
+    def _file_logger_run(self):
+        while True:                      # file_logger.run (:2010-2071)
+            self.flush()
+            self.files_written += 1
+            if self._fl_stop.wait(self.periodicity):
+                break
+            if datetime.datetime.now() > self.stop_time:
+                break
+        self.flush(new_period=False)     # "saves data for the last time" (:2073-2106): no reset afterwards
+        self.files_written += 1
+
+    def stop_file_logger(self):
+        self._fl_stop.set()
+        if self._fl_thread is not None:
+            self._fl_thread.join(5.0)
+            self._fl_thread = None
 
     def reset_periodic_vars(self):
         self.periodic_psd_peaks = None
@@ -73,7 +108,7 @@ class logger(object):
                 fh.write('settings ' + str(settings) + '\n')
                 fh.write('statistics ' + str(statistics) + '\n')
 
-    def flush(self, directory=None):
+    def flush(self, directory=None, new_period=True):
         """One pass of file_logger.run (ofdm_cr_tools.py:2010-2058): rewrite the cumulative files, write the
         periodic ones, append the waterfall rows, then start a new period (new periodic file names, periodic
         state and waterfall buffer reset).  Returns the paths written."""
@@ -101,6 +136,7 @@ class logger(object):
         with open(out['waterfall'], 'ab') as fh:
             if len(self.cumulative_waterfall):
                 np.savetxt(fh, np.array(self.cumulative_waterfall), fmt='%1.2e', delimiter=',')
-        self._period_stamp = (time.strftime('%y%m%d'), time.strftime('%H%M%S'))
-        self.reset_periodic_vars()
+        if new_period:
+            self._period_stamp = (time.strftime('%y%m%d'), time.strftime('%H%M%S'))
+            self.reset_periodic_vars()
         return out

@@ -13,18 +13,19 @@ import time
 import numpy as np
 
 from . import _hip
-from .gr_compat import LossyQueue, sync_block, to_msg
+from .chain_block import ChainBlockMixin, MessageStrobe
+from .gr_compat import sync_block, to_msg
 from .message_pdu import message_pdu
 from .ofdm_cr_tools import _py2div
 from .scanner import ChannelScanner, top4
 from .sensing_log import logger
 
 
-class spectrum_sensor_v2(sync_block):
+class spectrum_sensor_v2(ChainBlockMixin, sync_block):
     def __init__(self, fft_len, sens_per_sec, sample_rate, channel_space=1, search_bw=1, thr_leveler=10,
                  tune_freq=0, alpha_avg=1, test_duration=1, period=3600, trunc_band=1, verbose=False,
                  stats=False, psd=False, waterfall=False, output=False, subject_channels=[],
-                 ctx=None, threaded=False, log_directory=None):
+                 ctx=None, threaded=False, log_directory=None, strobe_period_ms=1000):
         sync_block.__init__(self, 'spectrum_sensor_v2', [np.complex64], None)
         self.fft_len = fft_len
         self.sens_per_sec = sens_per_sec
@@ -48,8 +49,10 @@ class spectrum_sensor_v2(sync_block):
 
         self.ctx = ctx or _hip.default_context()
         self.decimation = max(1, int(_py2div(_py2div(sample_rate, fft_len), sens_per_sec)))   # :86-87
-        self._chain = self.ctx.chain(fft_len, None, True, _hip.EPI_MAG2_OVER_N2, self.decimation)
-        self.msgq0 = LossyQueue(2)
+        chain = self.ctx.chain(fft_len, None, True, _hip.EPI_MAG2_OVER_N2, self.decimation)
+        # message_strobe x 4, 1000 ms (:108-111): set_freqs() only changes their message; start() runs them
+        self._strobes = [MessageStrobe(lambda m, i=i: self.message_port_pub('freq_out_%d' % i, m),
+                                       to_msg('freq', 0), strobe_period_ms) for i in range(4)]
         self.PDU_messages = message_pdu(None)
         self.PDU_messages.msg_connect('out', lambda m: self.message_port_pub('freq_msg_PDU', m))
 
@@ -61,34 +64,23 @@ class spectrum_sensor_v2(sync_block):
         self.subject_channels_pwr = np.array([1.0] * len(self.subject_channels))
         self._waterfall_count = 0
         self._lock = threading.Lock()
-        self._threaded = threaded
-        self._thread = None
-        if threaded:
-            self.keep_running = True
-            self._thread = threading.Thread(target=self._watch, daemon=True)
-            self._thread.start()
+        self._chain_init(chain, threaded)      # work() / watcher plumbing: chain_block.ChainBlockMixin
 
-    # -- gr.sync_block ----------------------------------------------------------
-    def work(self, input_items, output_items):
-        in0 = input_items[0]
-        rows, n = self._chain.push(in0, max_rows=1)
-        if n:
-            if self._threaded:
-                self.msgq0.insert_tail(rows[-1].copy())      # dropped when the watcher lags (dont_block)
-            else:
-                self._on_vector(rows[-1])
-        return len(in0)
-
-    def _watch(self):
-        while self.keep_running:
-            row = self.msgq0.delete_head(timeout=0.1)
-            if row is not None:
-                self._on_vector(row)
+    def start(self):
+        """What top_block.start() sets going besides the stream: the four 1 Hz strobes (:108-111,125-129) and
+        the periodic file_logger thread (ofdm_cr_tools.py:1906, 2010-2107)."""
+        for st in self._strobes:
+            st.start()
+        if self._logger is not None:
+            self._logger.start_file_logger()
+        return True
 
     def stop(self):
-        self.keep_running = False
-        if self._thread:
-            self._thread.join(1.0)
+        for st in self._strobes:
+            st.stop()
+        if self._logger is not None:
+            self._logger.stop_file_logger()
+        return ChainBlockMixin.stop(self)
 
     # -- watchers ---------------------------------------------------------------
     def _on_vector(self, float_data):
@@ -140,7 +132,10 @@ class spectrum_sensor_v2(sync_block):
         """:157-165 - the strobes carry the differential frequency."""
         for i, f in enumerate((freq0, freq1, freq2, freq3)):
             self.top4[i] = f
-            self.message_port_pub('freq_out_%d' % i, to_msg('freq', f - self.tune_freq))
+            msg = to_msg('freq', f - self.tune_freq)
+            self._strobes[i].set_msg(msg)
+            if not self._strobes[i].running:      # host-loop mode (no start()): emit now instead of at the next tick
+                self.message_port_pub('freq_out_%d' % i, msg)
 
     def send_PDU_data(self):
         """send_PDU_data.run body, :178-183 (one round)."""

@@ -153,14 +153,22 @@ class spectrum_sweeper(sync_block):
         return self._blend_and_send(psd)
 
     def sweep_once_sharded(self, capture, rank, world, device, group=None):
-        """The same sweep with segment i on rank i mod world and one all-gather.
-        ``capture(i, f)`` returns the complex64 samples observed at tune frequency f."""
+        """The same sweep with segment i on rank i mod world and one all-gather (RCCL over xGMI on GPUs).
+        ``capture(i, f)`` returns what was observed at tune frequency f: host complex64 samples, or a torch
+        complex64 / float32 [n][2] tensor already on ``device``.  Each segment goes through the HIP plan straight
+        into this rank's row of the gather buffer (device in, device out); only the stitched wideband PSD
+        comes back to the host, for the PDU fragments."""
         import torch
         from . import sweep
         nbins = self.fft_len - 2 * self.excess_bins
 
         def compute(iq, out_row):
-            out_row.copy_(torch.from_numpy(self._src_power(iq)))
+            if not torch.is_tensor(iq):
+                iq = torch.from_numpy(np.ascontiguousarray(iq, np.complex64).view(np.float32)).to(device)
+                torch.cuda.current_stream(device).synchronize()      # the copy ran on torch's stream
+            nsamples = iq.numel() // 2 if iq.dtype == torch.float32 else iq.numel()
+            self._plan.exec_dev(iq.data_ptr(), nsamples, out_row.data_ptr())
+            self.ctx.sync()          # the all-gather runs on torch's stream, the plan on the context's
 
         wide = sweep.sweep_psd(lambda i: capture(i, self.tune_frequencies[i]), compute,
                                len(self.tune_frequencies), nbins, device, rank, world, group)

@@ -47,3 +47,107 @@ def sweep_psd(segment_iq, compute_psd, nseg_total, nbins, device, rank, world, g
     for j, i in enumerate(shard_segments(nseg_total, rank, world)):
         compute_psd(segment_iq(i), local[j])
     return gather_wideband(local, nseg_total, rank, world, group)
+
+
+# --------------------------------------------------------------------------------------------
+# Long-stream sharding: segment sums are associative, so a stream is cut
+# into contiguous runs of segments, one per rank; run g needs samples
+# [s0 * step, (s1 - 1) * step + nperseg) - i.e. its neighbour's first nperseg - step samples again (the
+# halo).  Every rank reduces its run to raw sums (oth_welch_partial_dev: sum |X|^2, nfft floats;
+# oth_csd_partial_dev: sum |X|^2, sum |Y|^2, sum conj(X) Y, 4 * nfft floats), ONE all-gather moves the
+# partials + segment counts, every rank adds them in rank order (bit-identical result everywhere) and
+# applies the scaling for the total segment count (oth_welch_scale_dev / oth_csd_scale_dev).
+# --------------------------------------------------------------------------------------------
+
+def time_shard(nsamples, nperseg, step, rank, world):
+    """-> (first_sample, nsamples_local, first_segment, nseg_local) of rank's contiguous run of segments
+    (ceil(nseg / world) segments per rank; trailing ranks may get none)."""
+    nseg = (nsamples - (nperseg - step)) // step if nsamples >= nperseg else 0
+    per = -(-nseg // world) if nseg else 0
+    s0 = min(rank * per, nseg)
+    s1 = min(s0 + per, nseg)
+    if s1 <= s0:
+        return s0 * step, 0, s0, 0
+    return s0 * step, (s1 - s0 - 1) * step + nperseg, s0, s1 - s0
+
+
+def reduce_partials(local_sums, nseg_local, rank=None, world=None, group=None):
+    """local_sums: 1-D float32 tensor of raw sums (zeros when this rank has no segment).  Returns
+    (sums float32 tensor, nseg_total) - the same bits on every rank (fixed summation order)."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_sums, int(nseg_local)
+    n = local_sums.numel()
+    packed = torch.empty(n + 2, dtype=torch.float32, device=local_sums.device)
+    packed[:n] = local_sums
+    packed[n] = float(int(nseg_local) >> 16)          # the count travels exactly in two floats
+    packed[n + 1] = float(int(nseg_local) & 0xFFFF)
+    out = torch.empty(world * (n + 2), dtype=torch.float32, device=local_sums.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    out = out.view(world, n + 2)
+    total = torch.zeros(n, dtype=torch.float64, device=local_sums.device)
+    for r in range(world):                            # rank order: deterministic, identical everywhere
+        total += out[r, :n].to(torch.float64)
+    counts = out[:, n:].to(torch.float64).cpu()
+    nseg = int(sum(int(counts[r, 0]) * 65536 + int(counts[r, 1]) for r in range(world)))
+    return total.to(torch.float32), nseg
+
+
+def welch_time_sharded(partial, scale, nsamples, nperseg, step, nsums, device, rank, world, group=None):
+    """One long stream over `world` ranks.  partial(first_sample, n, out) reduces samples
+    [first_sample, first_sample + n) to raw sums in the float32 tensor `out` (nsums floats) and returns
+    its segment count; scale(sums, nseg_total) turns the summed partials into the result."""
+    first, n, _, nseg_local = time_shard(nsamples, nperseg, step, rank, world)
+    local = torch.zeros(nsums, dtype=torch.float32, device=device)
+    got = partial(first, n, local) if nseg_local else 0
+    assert got == nseg_local, (got, nseg_local)
+    sums, nseg = reduce_partials(local, nseg_local, rank, world, group)
+    return scale(sums, nseg), nseg
+
+
+def gather_rows(local_rows, nrows_total, rank=None, world=None, group=None):
+    """Batched scanner (8e row 3): channel stream c lives on rank c mod world; -> rows in channel order."""
+    nbins = local_rows.shape[1]
+    return gather_wideband(local_rows, nrows_total, rank, world, group).view(nrows_total, nbins)
+
+
+# ---- the same two paths on HIP plans (device pointers; ofdm_tools._hip.WelchPlan) ---------------------------
+
+def welch_long_stream(plan, local_dptr, local_first_sample, nsamples_total, device, rank, world, group=None):
+    """Welch PSD of one stream of nsamples_total samples spread over the ranks in time order.  This rank's HBM
+    buffer at local_dptr starts at stream sample local_first_sample and must cover its run + halo
+    (time_shard()).  -> (psd float32 tensor [plan.out_len] on `device`, nseg_total), identical on every rank."""
+    def partial(first, n, out):
+        nseg = plan.partial_dev(local_dptr + 8 * (first - local_first_sample), n, out.data_ptr())
+        plan.ctx.sync()                      # the collective runs on torch's stream
+        return nseg
+
+    def scale(sums, nseg):
+        out = torch.empty(plan.out_len, dtype=torch.float32, device=device)
+        plan.scale_dev(sums.contiguous().data_ptr(), nseg, out.data_ptr())
+        plan.ctx.sync()
+        return out
+    return welch_time_sharded(partial, scale, nsamples_total, plan.nperseg, plan.step, plan.nfft, device, rank, world,
+                              group)
+
+
+def csd_long_stream(plan, x_dptr, y_dptr, local_first_sample, nsamples_total, device, rank, world, group=None):
+    """Two-channel cross spectrum / coherence of one long stream pair over the ranks (partials: sum |X|^2,
+    sum |Y|^2, sum conj(X) Y = 4 * nfft floats per rank).  -> ((pxx, pyy, pxy [out_len][2], cxy), nseg_total)."""
+    def partial(first, n, out):
+        off = 8 * (first - local_first_sample)
+        nseg = plan.csd_partial_dev(x_dptr + off, y_dptr + off, n, out.data_ptr())
+        plan.ctx.sync()
+        return nseg
+
+    def scale(sums, nseg):
+        m = plan.out_len
+        pxx, pyy, cxy = (torch.empty(m, dtype=torch.float32, device=device) for _ in range(3))
+        pxy = torch.empty((m, 2), dtype=torch.float32, device=device)
+        plan.csd_scale_dev(sums.contiguous().data_ptr(), nseg, pxx.data_ptr(), pyy.data_ptr(), pxy.data_ptr(),
+                           cxy.data_ptr())
+        plan.ctx.sync()
+        return pxx, pyy, pxy, cxy
+    return welch_time_sharded(partial, scale, nsamples_total, plan.nperseg, plan.step, 4 * plan.nfft, device, rank,
+                              world, group)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OTH_ABI_VERSION 1
+#define OTH_ABI_VERSION 2
 
 #define OTH_OK               0
 #define OTH_ERR_INVALID     -1   /* bad argument */
@@ -137,6 +137,11 @@ int oth_plan_set_output_db(oth_plan *plan, int enable);      /* 10*log10 in the 
 int oth_plan_set_kernel(oth_plan *plan, int which);           /* OTH_KERNEL_* */
 int oth_plan_set_schedule(oth_plan *plan, int which);         /* OTH_SCHED_* */
 int oth_plan_out_len(oth_plan *plan, int *n);
+/* Launch tuning for A/B tools and the parity suite: which build of the 4096-point kernel ("dpp", "pipe", "ws";
+ * NULL or "" = the library's choice), a schedule override (-1 = the plan's), segments per chunk and per tail chunk
+ * (0 = default).  The OTH_W4096_VARIANT / _SCHED / _CHUNK / _TAIL environment variables give the initial values
+ * and are read once, in oth_welch_plan(). */
+int oth_plan_set_tuning(oth_plan *plan, const char *variant, int sched, int chunk, int tail_chunk);
 
 /* one-shot: nsamples complex64 -> psd_out[nfft - 2*trim] (host) */
 int oth_welch_exec(oth_plan *plan, const void *iq, size_t nsamples, int src_is_device,
@@ -152,7 +157,9 @@ int oth_welch_partial_dev(oth_plan *plan, const void *iq_dev, size_t nsamples,
 int oth_welch_scale_dev(oth_plan *plan, const float *sum_dev, uint64_t nseg_total, float *psd_out_dev);
 
 /* streaming form used by the sync_block work() host (python/spectrum_sensor.py:71-75
- * contract): chunks of any length; the overlap tail is carried between calls. */
+ * contract): chunks of any length; the overlap tail is carried between calls.  accumulate() copies the
+ * caller's buffer into a pinned staging slot, enqueues the H2D copy and the kernels, and returns without
+ * waiting for the GPU (it waits only if the GPU is still four calls behind); finalize() synchronises. */
 int oth_welch_accumulate(oth_plan *plan, const void *iq_host, size_t nsamples);
 int oth_welch_finalize(oth_plan *plan, float *psd_out, uint64_t *nseg_out);   /* then resets */
 int oth_welch_reset(oth_plan *plan);
@@ -164,6 +171,18 @@ int oth_welch_reset(oth_plan *plan);
  * cxy are float[nfft]; pxy is interleaved re,im float[2*nfft].  Any may be NULL. */
 int oth_csd_exec(oth_plan *plan, const void *x, const void *y, size_t nsamples, int src_is_device,
                  float *pxx, float *pyy, float *pxy, float *cxy, uint64_t *nseg_out);
+
+/* Device forms of the same (asynchronous on the context's stream; any output pointer may be NULL). */
+int oth_csd_exec_dev(oth_plan *plan, const void *x_dev, const void *y_dev, size_t nsamples, float *pxx_dev,
+                     float *pyy_dev, float *pxy_dev, float *cxy_dev, uint64_t *nseg_out);
+/* Raw sums over segments for time-sharded multi-GPU coherence: sums_out_dev is
+ * float[4 * nfft] = sum |X|^2 [nfft], sum |Y|^2 [nfft], sum conj(X) Y [nfft] interleaved re,im; natural bin order,
+ * no scale / shift / trim.  Partial sums of ranks add; oth_csd_scale_dev() then applies the plan's scaling for
+ * nseg_total segments, its fftshift / trim, and forms Cxy = |Pxy|^2 / (Pxx Pyy). */
+int oth_csd_partial_dev(oth_plan *plan, const void *x_dev, const void *y_dev, size_t nsamples, float *sums_out_dev,
+                        uint64_t *nseg_out);
+int oth_csd_scale_dev(oth_plan *plan, const float *sums_dev, uint64_t nseg_total, float *pxx_dev, float *pyy_dev,
+                      float *pxy_dev, float *cxy_dev);
 
 /* ---- per-vector periodogram chain ----------------------------------------
  * Replaces the GNU Radio chain
@@ -188,6 +207,18 @@ int oth_chain_reset(oth_chain *chain);
  * stage is on); nrows_out = rows produced by this call. */
 int oth_chain_push(oth_chain *chain, const void *iq, size_t nsamples, int src_is_device,
                    float *rows_out, size_t rows_capacity, uint64_t *nrows_out);
+/* device in, device out ([rows_capacity][nfft], may be NULL), asynchronous, never synchronises */
+int oth_chain_push_dev(oth_chain *chain, const void *iq_dev, size_t nsamples, float *rows_out_dev,
+                       size_t rows_capacity, uint64_t *nrows_out);
+/* The sync_block.work() form (python/spectrum_sensor.py:71-75: must not block; input valid only during the
+ * call; consumers behind message_sink(dont_block) + msg_queue(2) see the latest vector,
+ * spectrum_sensor_v2.py:71-72,97,404-414): the samples are copied into a pinned ring slot, H2D copy + kernels +
+ * the D2H copy of the LATEST row are enqueued, an event is recorded and the call returns a ticket.  poll() is
+ * non-blocking (ready = 0 while the GPU is still working); wait() blocks without holding the context.  The ring
+ * keeps the last four tickets: an older one returns OTH_ERR_STATE (it lost against newer vectors). */
+int oth_chain_push_async(oth_chain *chain, const void *iq_host, size_t nsamples, uint64_t *ticket_out);
+int oth_chain_poll(oth_chain *chain, uint64_t ticket, float *row_out, uint64_t *nrows_out, int *ready);
+int oth_chain_wait(oth_chain *chain, uint64_t ticket, float *row_out, uint64_t *nrows_out);
 int oth_chain_get_peak(oth_chain *chain, float *peak_out);    /* float[nfft] */
 int oth_chain_get_iir(oth_chain *chain, float *lin_out);      /* float[nfft], linear IIR state */
 /* mean of each `group` consecutive rows (BASELINE config 1 "8-seg avg") */
@@ -207,6 +238,15 @@ int oth_channel_power(oth_ctx *ctx, const float *psd_host, int nfft, double srch
  * uint8[nrows][nfft], noise_out float[nrows] (nullable). */
 int oth_bin_threshold(oth_ctx *ctx, const float *psd_host, int nrows, int nfft, double srch_bins,
                       float thr_leveler, unsigned char *mask_out, float *noise_out);
+
+/* Decision stage of the batched scanner on PSD rows that are already in HBM (oth_welch_exec_dev with nstreams
+ * rows): moving average once per row, channel slice sums (src_power, ofdm_cr_tools.py:232-249), noise floor and
+ * per-bin mask (as oth_bin_threshold) in one launch sequence on context-owned scratch - no copy of the rows, no
+ * allocation per call.  Host outputs: mask_out uint8[nrows][nfft] (nullable), noise_out float[nrows] (nullable),
+ * power_out float[nrows][nch] (required when nch > 0). */
+int oth_scan_decide_dev(oth_ctx *ctx, const float *psd_rows_dev, int nrows, int nfft, double srch_bins,
+                        float thr_leveler, int nch, const int *lo, const int *hi, unsigned char *mask_out,
+                        float *noise_out, float *power_out);
 
 /* ---- xcorr (ofdm_cr_tools.py:155-161) ------------------------------------
  * |fftshift(ifft(fft(b,L) * conj(fft(a,L))))[L/2:]|, L a power of two <= 16384;

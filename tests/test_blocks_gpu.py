@@ -362,3 +362,98 @@ def test_two_threads_share_one_context():
         assert not errors, errors
     finally:
         ctx.close()
+
+
+# ---- asynchronous work() and the lossy depth-2 transport (SURVEY.md 8a row a15, 8b contract row) --------------
+
+def test_work_returns_before_the_gpu_is_done_and_results_match_the_sync_path(ctx):
+    """oth_chain_push_async: work() enqueues (pinned copy, H2D, kernels, D2H of the latest row, event) and
+    returns; poll() is non-blocking; the collected rows equal the synchronous oth_chain_push path."""
+    from ofdm_tools import _hip, windows
+    N = 2048
+    x = R.synth_iq(N * 4096, 71)                       # 64 MiB per push: the copy alone takes > 1 ms
+    k = -10 * np.log10(N) - 10 * np.log10(2.0e6)
+    ref = ctx.chain(N, windows.blackmanharris(N), True, _hip.EPI_MAG2, 1)
+    ref.set_iir_log(0.8, k)
+    want = [ref.push(x, max_rows=1)[0][-1].copy() for _ in range(3)]
+    ch = ctx.chain(N, windows.blackmanharris(N), True, _hip.EPI_MAG2, 1)
+    ch.set_iir_log(0.8, k)
+    tickets = [ch.push_async(x) for _ in range(3)]     # three pushes back to back: the GPU is busy for several ms
+    assert ch.poll(tickets[-1]) is None                # the call returned before its event completed
+    for t, w in zip(tickets, want):
+        row, n = ch.wait(t)
+        assert n == 4096 and relerr(10 ** (row / 10.0), 10 ** (w / 10.0)) < 1e-5
+    assert ch.poll(tickets[-1]) is not None
+    # the ring keeps four tickets: the oldest of six is gone (latest wins)
+    more = [ch.push_async(x[:N * 8]) for _ in range(6)]
+    with pytest.raises(_hip.HipError) as ei:
+        ch.wait(more[0])
+    assert ei.value.code == -5
+    assert ch.wait(more[-1])[1] == 8
+
+
+def test_threaded_watcher_drops_when_stalled_and_never_back_pressures(ctx, golden):
+    """threaded=True: work() hands tickets to a depth-2 lossy queue; a stalled watcher loses vectors
+    (LossyQueue.dropped > 0) while work() keeps returning at once; what the watcher does process equals the
+    inline path's result for the same vector."""
+    import threading
+    import time
+    import ofdm_tools
+    g = golden('scanner_state_seq.npz')
+    kw = dict(channel_space=25e3, search_bw=12.5e3, thr_leveler=4, tune_freq=100000000, alpha_avg=0.5,
+              trunc_band=800000, stats=True, ctx=ctx)
+    x = g['x']
+    inline = ofdm_tools.spectrum_sensor_v2(1024, 1000, 1000000, **kw)
+    inline.work([x[:1024]], [])
+    blk = ofdm_tools.spectrum_sensor_v2(1024, 1000, 1000000, threaded=True, **kw)
+    gate = threading.Event()
+    seen = []
+    real = blk._on_vector
+
+    def slow(row):
+        seen.append(row.copy())
+        gate.wait(5.0)                                  # the watcher is stuck in its first vector
+        real(row)
+    blk._on_vector = slow
+    t0 = time.perf_counter()
+    for i in range(16):
+        assert blk.work([x[i * 1024:(i + 1) * 1024]], []) == 1024
+    dt = time.perf_counter() - t0
+    assert dt < 1.0, dt                                 # sixteen calls, none waited for the stalled watcher
+    assert blk.msgq0.dropped >= 12                      # depth 2: at most the one in progress + two queued survive
+    gate.set()
+    deadline = time.time() + 5.0
+    while blk.msgq0.count() and time.time() < deadline:
+        time.sleep(0.01)
+    time.sleep(0.1)
+    blk.stop()
+    assert 1 <= len(seen) <= 3 and len(seen) + blk.vectors_lost + blk.msgq0.dropped >= 16 - 2
+    assert relerr(seen[0], R.chain_sensor_v2(x[:1024], 1024)[0]) < RTOL
+    # the first processed vector gave the same scanner state as the inline block's
+    assert blk._scanner.n_measurements == len(seen) - blk.vectors_lost or blk._scanner.n_measurements >= 1
+
+
+def test_strobes_reemit_and_file_logger_thread(ctx, golden, tmp_path):
+    """What start() adds (spectrum_sensor_v2.py:108-111,125-129; ofdm_cr_tools.py:1906,2010-2107): the top-4
+    frequencies are re-emitted every strobe period, and the file_logger thread writes the logs periodically
+    and once more when it stops."""
+    import time
+    import ofdm_tools
+    g = golden('scanner_state_seq.npz')
+    subj = list(g['subject_channels'])
+    blk = ofdm_tools.spectrum_sensor_v2(1024, 1000, 1000000, channel_space=25e3, search_bw=12.5e3, thr_leveler=4,
+                                        tune_freq=100000000, alpha_avg=0.5, trunc_band=800000, stats=True, psd=True,
+                                        output='o', subject_channels=subj, ctx=ctx, log_directory=str(tmp_path),
+                                        period=0.05, test_duration=0.2, strobe_period_ms=20)
+    msgs = []
+    blk.msg_connect('freq_out_0', msgs.append)
+    blk.start()
+    blk.feed(g['x'], max_items=1024)
+    time.sleep(0.3)
+    blk.stop()
+    assert blk.top4 == list(g['top4'])
+    assert len(msgs) >= 5 and msgs[-1][1] == g['top4'][0] - 100000000      # re-emitted, not only once
+    assert blk._logger.files_written >= 3                                   # periodic passes + the last write
+    import glob
+    assert glob.glob(str(tmp_path / 'sdr_psd_cumulative_log-*.matz')) and \
+        len(glob.glob(str(tmp_path / 'sdr_ss_periodic_log-*.log'))) >= 1

@@ -525,13 +525,11 @@ def test_randomized_welch_plans_vs_oracle(ctx, hip):
 
 
 @pytest.mark.parametrize('variant', ['', 'ws', 'pipe', 'dpp'])
-def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip, monkeypatch, variant):
+def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip, variant):
     """Chunked schedules at the edges: segment counts around multiples of the chunk size and of the
     resident workgroup count, one to three streams, all three schedules, default and tiny chunks
     (one- and two-segment chunks take their own paths in the wave-specialised kernel) - every build of
     the tuned kernel vs the independent generic kernel on device-resident data."""
-    if variant:
-        monkeypatch.setenv('OTH_W4096_VARIANT', variant)
     rng = np.random.default_rng(7)
     nmax = 4096 + 2048 * 9000
     d_in = ctx.alloc(3 * nmax * 8)
@@ -547,10 +545,7 @@ def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip, monkeypatch, varia
             ns = int(rng.integers(1, 4))
             sched = int(rng.integers(0, 3))
             chunk = int(rng.integers(0, 6))
-            if chunk:
-                monkeypatch.setenv('OTH_W4096_CHUNK', str(chunk))
-            else:
-                monkeypatch.delenv('OTH_W4096_CHUNK', raising=False)
+            tuned.set_tuning(variant or None, chunk=chunk)
             tuned.set_schedule(sched)
             assert tuned.exec_dev(d_in, n, d_a, nstreams=ns, stream_stride=nmax) == nseg
             assert gen.exec_dev(d_in, n, d_b, nstreams=ns, stream_stride=nmax) == nseg
@@ -566,16 +561,15 @@ def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip, monkeypatch, varia
 
 
 @pytest.mark.parametrize('variant', ['', 'pipe'])
-def test_welch4096_large_dc_offset(ctx, hip, monkeypatch, variant):
+def test_welch4096_large_dc_offset(ctx, hip, variant):
     """A DC offset 30x the noise level (uncalibrated SDR front end): the default build removes the mean in
     the frequency domain (X - mean * FFT(w)), the fallback in the time domain; both must hold 1e-4 on every
     bin, the ones under the removed DC line included."""
-    if variant:
-        monkeypatch.setenv('OTH_W4096_VARIANT', variant)
     rng = np.random.default_rng(11)
     n = 4096 + 2048 * 63
     x = (rng.standard_normal(n) + 1j * rng.standard_normal(n) + (30.0 - 18.0j)).astype(np.complex64)
     plan = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_TUNED)
+    plan.set_tuning(variant or None)
     got = plan.exec(x)
     plan.close()
     _, want = R.welch_np(x, fs=1.0, window=hann(4096), nperseg=4096, noverlap=2048, nfft=4096)
@@ -597,7 +591,7 @@ def test_welch4096_window_with_wide_spectrum_takes_the_time_domain_detrend(ctx, 
     assert relerr(got, want) < RTOL
 
 
-def test_tuned_kernels_repeat_without_drift(ctx, hip, monkeypatch):
+def test_tuned_kernels_repeat_without_drift(ctx, hip):
     """300 launches of the tuned builds on one input, schedules and chunk sizes drawn at random: every result
     must stay within rounding of the generic kernel's (a missed barrier or a stale ticket shows up as an
     occasional outlier, not as a steady error)."""
@@ -613,8 +607,7 @@ def test_tuned_kernels_repeat_without_drift(ctx, hip, monkeypatch):
         want = ctx.d2h(d_b, (2, 4096), np.float32).astype(np.float64)
         worst = 0.0
         for it in range(300):
-            monkeypatch.setenv('OTH_W4096_VARIANT', ('ws', 'pipe', 'dpp')[it % 3])
-            monkeypatch.setenv('OTH_W4096_CHUNK', str(int(rng.choice([1, 2, 3, 5, 8, 16, 32, 64]))))
+            tuned.set_tuning(('ws', 'pipe', 'dpp')[it % 3], chunk=int(rng.choice([1, 2, 3, 5, 8, 16, 32, 64])))
             tuned.set_schedule(int(rng.integers(0, 3)))
             assert tuned.exec_dev(d_in, n, d_a, nstreams=2, stream_stride=n) == 2047
             got = ctx.d2h(d_a, (2, 4096), np.float32)
@@ -670,7 +663,8 @@ def test_ref_a6_a14_src_power_welch_and_fast_spectrum_scan(ctx, golden):
 def test_ref_a4_sweeper_src_power(ctx, golden):
     """spectrum_sweeper.py:260-276 through the product's spectrum_sweeper block (flattop, nperseg = nfft/4
     zero-padded, shift, trim, dB in one plan) vs the reference's own output."""
-    from ofdm_tools import spectrum_sweeper as SW
+    import importlib
+    SW = importlib.import_module('ofdm_tools.spectrum_sweeper')      # the package re-exports the class under this name
     g = golden('ref_sweeper_src_power.npz')
     x = golden(str(g['input_from']))['x']
     nfft, ex, fs = int(g['nfft']), int(g['excess_bins']), float(g['fs'])
@@ -726,3 +720,104 @@ def test_ref_a8_a9_a11_host_state_machines(ctx, golden):
     subj = [float(v) for v in c['subject_channels']]
     pwr, top = S.top4(st.plc, st.subject_index(subj), subj)
     assert np.allclose(pwr, g['subject_pwr'], atol=1e-4) and top == list(g['top4'])
+
+
+# ------------------------------------------- device / partial forms added in ABI 2 ----
+
+def test_csd_partial_sums_of_time_chunks_add_up_and_device_form(ctx, hip, golden):
+    """raw sums (sum|X|^2, sum|Y|^2, sum conj(X)Y) of halo-overlapped time chunks add to the
+    whole; oth_csd_scale_dev turns them into Pxx, Pyy, Pxy, Cxy; oth_csd_exec_dev equals oth_csd_exec."""
+    from ofdm_tools import sweep
+    g = golden('coherence_csd_4096.npz')
+    x, y = g['x'], g['y']
+    nfft, step, n = 4096, 2048, len(g['x'])
+    plan = ctx.welch_plan(nfft, window=hann(nfft), fs=1.0, fftshift=True, trim_bins=64)
+    want = plan.csd(x, y)
+    dx, dy = ctx.alloc(x.nbytes), ctx.alloc(y.nbytes)
+    d_sum, d_o = ctx.alloc(4 * nfft * 4), ctx.alloc(5 * nfft * 4)
+    m = plan.out_len
+    try:
+        ctx.h2d(dx, x)
+        ctx.h2d(dy, y)
+        tot = np.zeros(4 * nfft, np.float64)
+        nseg = 0
+        for r in range(3):                               # three "ranks"
+            first, cnt, s0, k = sweep.time_shard(n, nfft, step, r, 3)
+            assert plan.csd_partial_dev(dx + 8 * first, dy + 8 * first, cnt, d_sum) == k
+            tot += ctx.d2h(d_sum, (4 * nfft,), np.float32)
+            nseg += k
+        assert nseg == 31
+        ctx.h2d(d_sum, tot.astype(np.float32))
+        plan.csd_scale_dev(d_sum, nseg, d_o, d_o + 4 * nfft, d_o + 8 * nfft, d_o + 16 * nfft)
+        got = [ctx.d2h(d_o, (m,), np.float32), ctx.d2h(d_o + 4 * nfft, (m,), np.float32),
+               ctx.d2h(d_o + 8 * nfft, (2 * m,), np.float32).view(np.complex64), ctx.d2h(d_o + 16 * nfft, (m,), np.float32)]
+        assert relerr(got[0], want[0]) < 2e-6 and relerr(got[1], want[1]) < 2e-6
+        assert np.max(np.abs(got[2] - want[2]) / np.sqrt(want[0] * want[1])) < 2e-6
+        assert np.max(np.abs(got[3] - want[3])) < 1e-5
+        # asynchronous device form, only Cxy requested
+        assert plan.csd_exec_dev(dx, dy, n, cxy=d_o) == 31
+        assert np.max(np.abs(ctx.d2h(d_o, (m,), np.float32) - want[3])) < 1e-6
+        e = np.fft.fftshift(g['expected_cxy'])[64:-64]
+        assert np.max(np.abs(want[3] - e)) < RTOL
+    finally:
+        for p in (dx, dy, d_sum, d_o):
+            ctx.free(p)
+
+
+def test_chain_push_dev_matches_host_push_across_ragged_chunks(ctx, hip, golden):
+    """oth_chain_push_dev (device in, device rows out, asynchronous): same rows as the host form when the stream
+    arrives in chunks that split vectors, keep_one_in_n = 3, IIR + log epilogue."""
+    g = golden('gr_chain_bh_iir_log_2048.npz')
+    N, x = 2048, g['x']
+    k = -10 * np.log10(N) - 10 * np.log10(int(g['sample_rate']))
+    a = ctx.chain(N, g['window'], True, hip.EPI_MAG2, 3)
+    b = ctx.chain(N, g['window'], True, hip.EPI_MAG2, 3)
+    for ch in (a, b):
+        ch.set_iir_log(float(g['average']), k)
+    d_x, d_rows = ctx.alloc(x.nbytes), ctx.alloc(16 * N * 4)
+    try:
+        ctx.h2d(d_x, x)
+        for lo, hi_ in ((0, 3000), (3000, 3001), (3001, 20000), (20000, 20480), (20480, len(x))):
+            rows, n = a.push(x[lo:hi_])
+            nd = b.push_dev(d_x + 8 * lo, hi_ - lo, d_rows, 16)
+            assert nd == n
+            if n:
+                got = ctx.d2h(d_rows, (n, N), np.float32)
+                assert np.array_equal(got, rows)
+        assert np.array_equal(a.iir(), b.iir())
+    finally:
+        ctx.free(d_x)
+        ctx.free(d_rows)
+    ref = R.chain_local_worker(x, N, int(g['sample_rate']), float(g['average']), decim=3)[0]
+    assert relerr(a.iir(), ref[-1]) < RTOL
+
+
+def test_scan_decide_dev_on_device_rows(ctx, hip):
+    """BASELINE config 5 decision stage on the rows oth_welch_exec_dev left in HBM: mask / noise floor equal
+    oth_bin_threshold, channel sums equal src_power (the oracle's, ofdm_cr_tools.py:232-249) per stream."""
+    from ofdm_tools.scan_batch import BatchScanPlan
+    N, ns, n = 16384, 5, 16384 * 6
+    Sf = 1000000
+    bp = BatchScanPlan(ctx, N, Sf, 15625.0, 10e3, thr_leveler=3.0)
+    xs = [R.synth_iq(n, 3000 + i) for i in range(ns)]
+    d_in, d_rows = ctx.alloc(ns * n * 8), ctx.alloc(ns * N * 4)
+    try:
+        ctx.h2d(d_in, np.concatenate(xs))
+        assert bp.psd_rows_dev(d_in, n, ns, n, d_rows) == 6
+        mask, noise, plc = bp.decide_dev(d_rows, ns)
+        rows = ctx.d2h(d_rows, (ns, N), np.float32)
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_rows)
+    mask2, noise2 = ctx.bin_threshold(rows, bp.scanner.srch_bins, 3.0)
+    assert np.array_equal(mask, mask2) and np.array_equal(noise, noise2)
+    st = R.ScannerState(N, Sf, 15625.0, 10e3, trunc_band=Sf)
+    for i in range(ns):
+        want = R.src_power(rows[i], N, st.Fr, Sf, st.bb_freqs, st.srch_bins)
+        assert plc.shape == (ns, len(want)) and np.allclose(plc[i], want, rtol=1e-5)
+        ma = R.movingaverage(rows[i], st.srch_bins)
+        assert np.isclose(noise[i], ma.min(), rtol=1e-5)
+        assert np.array_equal(mask[i], (rows[i] > np.float32(3.0) * noise[i]).astype(np.uint8))
+    # host-row convenience form goes through the same entry point
+    m3, n3, p3 = bp.decide(rows)
+    assert np.array_equal(m3, mask) and np.array_equal(p3, plc)

@@ -211,3 +211,114 @@ def test_sensing_log_file_formats(tmp_path):
     out2 = lg.flush()
     assert open(out2['waterfall']).read() == '1.23e-05,6.50e-07\n2.00e+00,3.00e+00\n'
     assert np.load(out2['periodic_psd'], allow_pickle=True).item() is None
+
+
+# ---- multi-rank long-stream Welch / coherence and the batched scanner over gloo ----
+
+GLOO_LONG_STREAM = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'gr-ofdm_tools_amd'))
+import numpy as np, torch, torch.distributed as dist
+from ofdm_tools import sweep
+from oracle import ref_cpu as R
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+nfft, step, fs = 1024, 512, 2.0e6
+n = %(nsamples)d
+x = R.synth_iq(n, 1002)
+y = (0.7 * np.roll(x, 5) + 0.5 * R.synth_iq(n, 1004)).astype(np.complex64)
+win = R.get_window('hann', nfft)
+scale = 1.0 / (fs * (win * win).sum())
+nseg_all = (n - (nfft - step)) // step
+calls = []
+
+# the oracle stands in for oth_welch_partial_dev / oth_csd_partial_dev on the CPU ranks: raw sums of one run
+def welch_partial(first, cnt, out):
+    calls.append((first, cnt))
+    xs = x[first:first + cnt]
+    k = (cnt - (nfft - step)) // step
+    _, p = R.welch_np(xs, nperseg=nfft, nfft=nfft, scaling='none')
+    out.copy_(torch.from_numpy((p * k).astype(np.float32)))
+    return k
+
+def csd_partial(first, cnt, out):
+    xs, ys = x[first:first + cnt], y[first:first + cnt]
+    k = (cnt - (nfft - step)) // step
+    _, pxx = R.welch_np(xs, nperseg=nfft, nfft=nfft, scaling='none')
+    _, pyy = R.welch_np(ys, nperseg=nfft, nfft=nfft, scaling='none')
+    _, pxy = R.csd_np(xs, ys, nperseg=nfft, nfft=nfft, scaling='none')
+    v = np.concatenate([pxx * k, pyy * k, np.stack([pxy.real, pxy.imag], 1).reshape(-1) * k]).astype(np.float32)
+    out.copy_(torch.from_numpy(v))
+    return k
+
+dev = torch.device('cpu')
+psd, nseg = sweep.welch_time_sharded(welch_partial, lambda s, k: s.to(torch.float64) * (scale / k), n, nfft, step,
+                                     nfft, dev, rank, world)
+assert nseg == nseg_all, (nseg, nseg_all)
+_, ref = R.welch_np(x, fs=fs, nperseg=nfft, nfft=nfft)
+err = float(np.max(np.abs(psd.numpy() - ref) / ref))
+assert err < 2e-6, err
+# every rank holds the same bits
+mine = psd.to(torch.float64).clone()
+both = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(both, mine)
+assert all(torch.equal(both[0], b) for b in both)
+first, cnt, s0, k = sweep.time_shard(n, nfft, step, rank, world)
+assert calls == ([(first, cnt)] if k else []), (calls, first, cnt)
+
+def csd_scale(s, k):
+    s = s.to(torch.float64).numpy()
+    pxx, pyy, pxy = s[:nfft], s[nfft:2 * nfft], s[2 * nfft:].reshape(-1, 2)
+    pxy = pxy[:, 0] + 1j * pxy[:, 1]
+    return pxx * scale / k, pyy * scale / k, pxy * scale / k, np.abs(pxy) ** 2 / (pxx * pyy)
+(pxx, pyy, pxy, cxy), nseg = sweep.welch_time_sharded(csd_partial, csd_scale, n, nfft, step, 4 * nfft, dev, rank, world)
+_, rc, rxx, ryy, rxy = R.coherence_np(x, y, fs=fs, nperseg=nfft, nfft=nfft)
+assert nseg == nseg_all
+assert np.max(np.abs(pxx - rxx) / rxx) < 2e-6 and np.max(np.abs(pyy - ryy) / ryy) < 2e-6
+assert np.max(np.abs(pxy - rxy) / np.sqrt(rxx * ryy)) < 2e-6 and np.max(np.abs(cxy - rc)) < 1e-5
+
+# batched scanner: channel c on rank c mod world, rows come back in channel order
+nch, nbins = %(nch)d, 48
+mine = sweep.shard_segments(nch, rank, world)
+local = torch.zeros((sweep.segments_per_rank(nch, world), nbins))
+for j, c in enumerate(mine):
+    local[j] = torch.arange(nbins, dtype=torch.float32) + 1000.0 * c
+rows = sweep.gather_rows(local, nch, rank, world)
+assert rows.shape == (nch, nbins)
+assert torch.equal(rows[:, 0], 1000.0 * torch.arange(nch, dtype=torch.float32))
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'ok', nseg, k)
+'''
+
+
+@pytest.mark.parametrize('nsamples,nch', [(512 * 40 + 512, 8), (512 * 37 + 512 + 99, 5), (1024, 3)])
+def test_long_stream_and_channel_sharding_world_size_2_gloo(nsamples, nch, tmp_path):
+    """Welch and coherence of one long stream cut into contiguous time runs with a halo (even, ragged, and a
+    stream with a single segment so that rank 1 owns nothing), partial sums + counts all-gathered and summed
+    in rank order; batched-scanner rows gathered back into channel order."""
+    script = tmp_path / 'worker.py'
+    script.write_text(GLOO_LONG_STREAM % {'root': ROOT, 'nsamples': nsamples, 'nch': nch})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29600 + nch), WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    nseg = (nsamples - 512) // 512
+    per = -(-nseg // 2)
+    assert 'ok %d %d' % (nseg, min(per, nseg)) in outs[0] and 'ok %d %d' % (nseg, nseg - min(per, nseg)) in outs[1]
+
+
+def test_time_shard_covers_every_segment_once():
+    from ofdm_tools import sweep
+    for n, nper, step, world in [(2 ** 20, 4096, 2048, 8), (100000, 4096, 2048, 3), (4096, 4096, 2048, 4),
+                                 (4095, 4096, 2048, 2), (50000, 1024, 1024, 5), (9000, 1024, 300, 7)]:
+        nseg = (n - (nper - step)) // step if n >= nper else 0
+        seen = []
+        for r in range(world):
+            first, cnt, s0, k = sweep.time_shard(n, nper, step, r, world)
+            assert first == s0 * step and (cnt == 0) == (k == 0)
+            if k:
+                assert cnt == (k - 1) * step + nper and first + cnt <= n
+            seen += list(range(s0, s0 + k))
+        assert seen == list(range(nseg))

@@ -47,12 +47,7 @@ else:
 def select(v):
     f = v.split(':')
     sched, chunk, tail = f + ['2', '8', ''][len(f):]
-    os.environ['OTH_W4096_SCHED'] = sched
-    os.environ['OTH_W4096_CHUNK'] = chunk
-    if tail:
-        os.environ['OTH_W4096_TAIL'] = tail
-    else:
-        os.environ.pop('OTH_W4096_TAIL', None)
+    plan.set_tuning(None, int(sched), int(chunk), int(tail) if tail else 0)
 
 
 for _ in range(100):

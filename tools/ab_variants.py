@@ -18,13 +18,7 @@ variants = sys.argv[3:] or ['dpp:0:8', 'dpp:2:8', 'pipe:0:8', 'pipe:2:8', 'pipe:
 def select(v):
     f = v.split(':')
     tag, sched, chunk, tail = f + ['', '0', '8', ''][len(f):]
-    os.environ['OTH_W4096_VARIANT'] = tag
-    os.environ['OTH_W4096_SCHED'] = sched
-    os.environ['OTH_W4096_CHUNK'] = chunk
-    if tail:
-        os.environ['OTH_W4096_TAIL'] = tail
-    else:
-        os.environ.pop('OTH_W4096_TAIL', None)
+    plan.set_tuning(tag or None, int(sched), int(chunk), int(tail) if tail else 0)
 
 
 n = 1 << log2n

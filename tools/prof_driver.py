@@ -1,6 +1,17 @@
 #!/usr/bin/env python3
-"""Profiling driver: a few launches of the Welch kernel on the C2 workload, nothing else
-(run under rocprofv3 --kernel-trace or --pmc).  usage: prof_driver.py [log2_samples] [reps] [kernel]"""
+"""Profiling driver: a few launches of ONE configuration's kernels on device-resident synthetic IQ, nothing
+else (run under rocprofv3 --kernel-trace or --pmc; the python program goes directly after `--`).
+
+usage: prof_driver.py <config> [reps] [log2_samples]
+  C2        4096-pt Hann Welch, 50 % overlap, one 2^28 stream            (welch4096ws_kernel)
+  C3        two-channel csd/coherence, 2 x 2^26                          (csd4096 kernel)
+  C4        sweep 8 x 2^25, Hann 4096, shift + trim + dB                 (welch4096ws_kernel, 8 streams)
+  C4ref     reference-faithful sweep: flattop nperseg 1024 -> nfft 4096  (welch4096_kernel<NA=4>)
+  C5        64 channels x 2^22, 16384-pt rect |X|^2/N^2 mean             (welch16k_kernel)
+  w1024 / w2048      Hann Welch 50 % at nfft 1024 / 2048, 2^27 samples
+  chain1024 / chain2048 / chain4096   periodogram chain (BH window, shift, |X|^2, IIR + log), 2^26 samples
+Prints the HIP-event average of the FFT kernel and the algorithmic GB/s.
+"""
 import os
 import sys
 
@@ -8,20 +19,91 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'gr-ofdm_tools_amd'))
 from ofdm_tools import _hip, windows  # noqa: E402
 
-log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'C2'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-kernel = int(sys.argv[3]) if len(sys.argv) > 3 else _hip.KERNEL_AUTO
-n = 1 << log2n
+TONES = ((0.5, 0.1234), (0.05, -0.31), (2.0, 0.4071))
+DC = 0.1 + 0.05j
 ctx = _hip.Context(0)
-d_in = ctx.alloc(n * 8)
-d_out = ctx.alloc(4096 * 4)
-ctx.synth_iq(d_in, n, 1002, ((0.5, 0.1234), (0.05, -0.31), (2.0, 0.4071)), 0.1 + 0.05j)
-plan = ctx.welch_plan(4096, window=windows.get_window('hann', 4096), fs=1.0, kernel=kernel)
+hann = lambda n: windows.get_window('hann', n)      # noqa: E731
+bufs = []
+
+
+def dev(nbytes):
+    p = ctx.alloc(nbytes)
+    bufs.append(p)
+    return p
+
+
+if cfg in ('28', '26'):          # old calling convention: prof_driver.py <log2n> <reps>
+    cfg, sys.argv = 'C2', sys.argv[:1] + ['C2', sys.argv[2] if len(sys.argv) > 2 else '3', cfg]
+log2n = int(sys.argv[3]) if len(sys.argv) > 3 else None
+nbytes = 0
+if cfg == 'C2':
+    n = 1 << (log2n or 28)
+    d, o = dev(n * 8), dev(4096 * 4)
+    ctx.synth_iq(d, n, 1002, TONES, DC)
+    plan = ctx.welch_plan(4096, window=hann(4096), fs=1.0)
+    run = lambda: plan.exec_dev(d, n, o)      # noqa: E731
+    nbytes = 8 * n
+elif cfg == 'C3':
+    n = 1 << (log2n or 26)
+    dx, dy = dev(n * 8), dev(n * 8)
+    ctx.synth_iq(dx, n, 1003, TONES, DC)
+    ctx.synth_iq(dy, n, 1004, TONES, DC)
+    plan = ctx.welch_plan(4096, window=hann(4096), fs=1.0)
+    run = lambda: plan.csd_device_src(dx, dy, n)      # noqa: E731
+    nbytes = 16 * n
+elif cfg in ('C4', 'C4ref'):
+    S, nrf = 1 << (log2n or 25), 8
+    d, o = dev(nrf * S * 8), dev(nrf * 3584 * 4)
+    for i in range(nrf):
+        ctx.synth_iq(d + i * S * 8, S, 2000 + i, TONES, DC)
+    kw = dict(window=hann(4096)) if cfg == 'C4' else dict(nperseg=1024, window=windows.get_window('flattop', 1024))
+    plan = ctx.welch_plan(4096, fs=2.0e6, fftshift=True, trim_bins=256, db=True, **kw)
+    run = lambda: plan.exec_dev(d, S, o, nstreams=nrf, stream_stride=S)      # noqa: E731
+    nbytes = 8 * nrf * S
+elif cfg == 'C5':
+    nch, S, N = 64, 1 << (log2n or 22), 16384
+    d, o = dev(nch * S * 8), dev(nch * N * 4)
+    for i in range(nch):
+        ctx.synth_iq(d + i * S * 8, S, 3000 + i, TONES, DC)
+    plan = ctx.welch_plan(N, noverlap=0, window=None, detrend=_hip.DETREND_NONE, scaling=_hip.SCALE_OVER_N2,
+                          fftshift=True)
+    run = lambda: plan.exec_dev(d, S, o, nstreams=nch, stream_stride=S)      # noqa: E731
+    nbytes = 8 * nch * S
+elif cfg in ('w1024', 'w2048', 'w512', 'w256'):
+    N = int(cfg[1:])
+    n = 1 << (log2n or 27)
+    d, o = dev(n * 8), dev(N * 4)
+    ctx.synth_iq(d, n, 1002, TONES, DC)
+    plan = ctx.welch_plan(N, window=hann(N), fs=1.0)
+    run = lambda: plan.exec_dev(d, n, o)      # noqa: E731
+    nbytes = 8 * n
+elif cfg.startswith('chain'):
+    N = int(cfg[5:])
+    n = 1 << (log2n or 26)
+    d = dev(n * 8)
+    ctx.synth_iq(d, n, 1001, TONES, DC)
+    ch = ctx.chain(N, windows.blackmanharris(N), True, _hip.EPI_MAG2, 1)
+    ch.set_iir_log(0.8, -10.0)
+    run = lambda: ch.push_dev(d, n)      # noqa: E731
+    nbytes = 8 * n
+else:
+    sys.exit('unknown config ' + cfg)
+
+run()
+ctx.sync()
 ctx.set_timing(True)
+ctx.get_timing()
 for _ in range(reps):
-    plan.exec_dev(d_in, n, d_out)
+    run()
 ms, k = ctx.get_timing()
-probe = ctx.stream_read_probe(d_in, n * 8, 2)
-print('kernel avg ms %.4f over %d launches -> %.1f GB/s; read probe %.1f GB/s' % (ms / k, k, 8.0 * n / (ms / k) / 1e6, 8.0 * n / probe / 1e6))
-ctx.free(d_in)
-ctx.free(d_out)
+ctx.set_timing(False)
+per_call = ms / reps
+print('%s: FFT kernel %.4f ms per call (%d launches / %d calls) -> %.1f GB/s algorithmic = %.1f %% of 8 TB/s'
+      % (cfg, per_call, k, reps, nbytes / per_call / 1e6, nbytes / per_call / 1e6 / 80.0))
+if cfg == 'C2':
+    probe = ctx.stream_read_probe(bufs[0], nbytes, 2)
+    print('read probe %.1f GB/s' % (nbytes / probe / 1e6))
+for p in bufs:
+    ctx.free(p)

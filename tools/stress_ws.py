@@ -28,13 +28,10 @@ while time.time() - t0 < secs:
     n = 4096 + 2048 * (nseg - 1) + int(rng.integers(0, 2048))
     ns = int(rng.integers(1, 5))
     det = _hip.DETREND_CONSTANT if rng.random() < 0.7 else _hip.DETREND_NONE
-    os.environ['OTH_W4096_VARIANT'] = str(rng.choice(['ws', 'ws', 'pipe', 'dpp']))
+    variant = str(rng.choice(['ws', 'ws', 'pipe', 'dpp']))
     chunk = int(rng.choice([0, 1, 2, 3, 4, 7, 20, 33]))
-    if chunk:
-        os.environ['OTH_W4096_CHUNK'] = str(chunk)
-    else:
-        os.environ.pop('OTH_W4096_CHUNK', None)
     tuned, gen = plans[det]
+    tuned.set_tuning(variant, chunk=chunk)
     tuned.set_schedule(int(rng.integers(0, 3)))
     assert tuned.exec_dev(d_in, n, d_a, nstreams=ns, stream_stride=nmax) == nseg
     assert gen.exec_dev(d_in, n, d_b, nstreams=ns, stream_stride=nmax) == nseg
@@ -42,7 +39,7 @@ while time.time() - t0 < secs:
     b = ctx.d2h(d_b, (ns, 4096), np.float32).astype(np.float64)
     err = float(np.max(np.abs(a - b) / np.maximum(b, 0.1 * np.median(b))))
     worst = max(worst, err)
-    assert err < 5e-5, (nseg, ns, det, os.environ['OTH_W4096_VARIANT'], chunk, err)
+    assert err < 5e-5, (nseg, ns, det, variant, chunk, err)
     n_cases += 1
     if n_cases % 200 == 0:
         print('%d cases, worst %.2e' % (n_cases, worst), flush=True)
