@@ -110,6 +110,15 @@ def load():
     with _lib_lock:
         if _lib is not None:
             return _lib
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 and finds no GPU if another copy
+        # (the system ROCm's, which this library would pull in) was loaded first.  Multi-GPU hosts use torch for
+        # device tensors and torch.distributed, so when torch is installed its runtime goes in first and this
+        # library binds to it (same SONAME).  OFDM_TOOLS_HIP_STANDALONE=1 skips the import.
+        if os.environ.get('OFDM_TOOLS_HIP_STANDALONE') != '1':
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         if not os.path.exists(LIB_PATH):
             raise HipUnavailable('%s not found - build it with `make -C gr-ofdm_tools_amd` '
                                  '(or __graft_entry__.build()); this package has no CPU fallback' % LIB_PATH)

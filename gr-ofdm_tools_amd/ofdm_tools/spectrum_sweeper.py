@@ -160,6 +160,9 @@ class spectrum_sweeper(sync_block):
         comes back to the host, for the PDU fragments."""
         import torch
         from . import sweep
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise ValueError('sweep_once_sharded computes on the GPU: pass the rank\'s cuda device')
         nbins = self.fft_len - 2 * self.excess_bins
 
         def compute(iq, out_row):

@@ -168,7 +168,12 @@ def test_spectrum_sweeper_sweep_and_wire_format(ctx):
     assert frames == R.sweeper_fragments(struct.pack('<%df' % len(psd), *psd), 1470)
     # the sharded sweep (one process here: rank 0 of 1) gives the same wideband PSD
     import torch
-    wide = blk.sweep_once_sharded(lambda i, f: vectors[i], 0, 1, torch.device('cpu'))
+    dev = torch.device('cuda', 0)
+    wide = blk.sweep_once_sharded(lambda i, f: vectors[i], 0, 1, dev)
+    assert np.allclose(wide, psd, rtol=1e-6)
+    # captures that are already device tensors (complex64) take the same path without the upload
+    tv = [torch.from_numpy(v).to(dev) for v in vectors]
+    wide = blk.sweep_once_sharded(lambda i, f: tv[i], 0, 1, dev)
     assert np.allclose(wide, psd, rtol=1e-6)
     # flowgraph side: work() keeps the last complete capture
     blk2 = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 1e9, 0.0, 8, 0, 1472, ctx=ctx)
