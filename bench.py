@@ -4,30 +4,33 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of synthetic IQ that is already
-resident in HBM: the radix-16 welch4096 kernel + the cross-workgroup finalize
-kernel (scale, fftshift, trim); at N > 1 also the all-gather (RCCL) that
-reassembles the wideband PSD of the sweep on every rank (issued asynchronously so that it
-overlaps the next sweep's kernel; all gathers are complete before the clock stops).
+A step = one pass of the hot path over one batch of synthetic IQ that is already resident in HBM.
 
-N = 1  workload "C2": one 2^28-sample complex64 stream (2 GiB), Hann, nperseg =
-       nfft = 4096, 50 % overlap, detrend constant, density scaling (BASELINE
-       config 2 = the welch() call of ofdm_cr_tools.py:342).
-N > 1  workload "C4-weak": one 2^28-sample RF segment PER RANK with the same Welch
-       parameters + fftshift + 256-bin trim (spectrum_sweeper.py:260-276), then
-       all_gather of the 3584-bin rows in tune order (spectrum_sweeper.py:223).
-       Weak scaling: per-GPU work is fixed.
+N = 1  workload "C2" (the configuration BASELINE.json's metric is quoted on): one 2^28-sample complex64
+       stream (2 GiB), Hann, nperseg = nfft = 4096, 50 % overlap, detrend constant, density scaling
+       (the welch() call of ofdm_cr_tools.py:342): welch4096ws kernel + the cross-workgroup finalize.
+       Extra keys on the same line: `sweep_c4` (the N > 1 workload run on this one GPU, so that the N-GPU
+       speed-up is a plain division), `h2d_inclusive` (host buffer -> PSD through the streaming entry point).
+N > 1  workload "C4" (BASELINE config 4 = the north star's 8-segment sweep), STRONG scaling: a FIXED sweep of
+       8 RF segments x 2^27 samples, segment i on rank i mod N, the same Welch parameters + fftshift + 256-bin
+       trim + dB (spectrum_sweeper.py:260-276), then ONE all-gather (RCCL) of the 3584-bin rows into tune order
+       (spectrum_sweeper.py:223).  It runs the shipped path, ofdm_tools.sweep.SweepPipeline (what
+       spectrum_sweeper's sharded sweep is built on): device in, device out, the gather of sweep i overlapping
+       the kernels of sweep i + 1, all gathers complete before the clock stops.  value = 8 * 2^27 samples
+       per sweep / time per sweep.
 
-Before the W warm-up steps the same step runs untimed for --ramp-ms (default 150 ms) so that
-the device has left its idle clock level; the K timed steps are bracketed by barrier +
-torch.cuda.synchronize() on both sides as the contract says.
+Timing: W warm-up steps, then exactly K timed steps bracketed by barrier + torch.cuda.synchronize() on both
+sides; every step is also bracketed by events on the compute stream.  `ms_per_step` is the MEDIAN of the K
+per-step event times (max over ranks), `value` follows from it; `wall_ms_per_step` is the bracketed wall time
+/ K (max over ranks).  Before the warm-up the same step runs untimed for --ramp-ms so that the device has left
+its idle clock level.
 
-Prints ONE JSON line on rank 0.  `value` = samples processed by all ranks / the
-max-over-ranks wall time of the K timed steps.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -38,6 +41,8 @@ for p in (ROOT, os.path.join(ROOT, 'gr-ofdm_tools_amd')):
 
 NFFT = 4096
 LOG2_SAMPLES = 28
+SWEEP_SEGMENTS = 8
+SWEEP_LOG2_SAMPLES = 27
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 TONES = ((0.5, 0.1234), (0.05, -0.31), (2.0, 0.4071))
 DC = 0.1 + 0.05j
@@ -72,9 +77,15 @@ def cpu_baseline(nfft):
                         'samples of the C2 recipe, median of 3, host has %d cores (%s)' % (os.cpu_count(), model)}
     # the same call split over threads (SciPy's FFT and NumPy's elementwise kernels release the GIL): contiguous
     # runs of segments with a 2048-sample halo, per-run mean x segment count summed - what a user of the
-    # reference could do on this host without changing its arithmetic.  Informational, second object.
+    # reference could do on this host without changing its arithmetic.  Informational, second object.  The
+    # worker count is the CPU share this job may use (scheduler affinity, at most the 16 a one-GPU box grants),
+    # not os.cpu_count(): the host's other cores belong to other jobs.
     from concurrent.futures import ThreadPoolExecutor
-    threads = max(1, min(16, os.cpu_count() or 1))
+    try:
+        share = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        share = os.cpu_count() or 1
+    threads = max(1, min(16, share))
     nseg = (n - nfft // 2) // (nfft // 2)
     bounds = [nseg * i // threads for i in range(threads + 1)]
 
@@ -93,9 +104,30 @@ def cpu_baseline(nfft):
     ref = R.welch_reference_call(x, nfft, 1.0)
     dev = float(np.max(np.abs(total - ref) / ref))
     parallel = {'value': n / sorted(ptimes)[1] / 1e6, 'unit': 'Msamples/s', 'cores': threads, 'kind': 'port',
-                'sample': 'same call and samples, %d threads over contiguous segment runs (2048-sample halo), '
-                          'median of 3, max rel deviation from the one-thread result %.1e' % (threads, dev)}
+                'sample': 'same call and samples, %d threads (this job\'s CPU share; the host has %d cores) over '
+                          'contiguous segment runs (2048-sample halo), median of 3, max rel deviation from the '
+                          'one-thread result %.1e' % (threads, os.cpu_count() or 0, dev)}
     return single, parallel
+
+
+def timed_steps(torch, dist, dev, step, fence, steps, multi):
+    """K steps between two fences; per-step events on the compute stream.  -> (wall seconds max over ranks,
+    per-step ms list max-reduced over ranks)."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i].record()
+        step()
+    ev[steps].record()
+    fence()
+    t1 = time.perf_counter()
+    per = torch.tensor([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)], dtype=torch.float64, device=dev)
+    wall = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if multi:
+        dist.all_reduce(per, op=dist.ReduceOp.MAX)
+        dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    return float(wall.item()), [float(v) for v in per.cpu()]
 
 
 def main():
@@ -105,8 +137,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--ramp-ms', type=float, default=150.0,
                     help='untimed device clock ramp before the warm-up steps (an idle MI355X sits at 775 MHz sclk)')
-    ap.add_argument('--log2-samples', type=int, default=LOG2_SAMPLES)
+    ap.add_argument('--log2-samples', type=int, default=LOG2_SAMPLES, help='C2 stream length (N = 1)')
+    ap.add_argument('--sweep-log2-samples', type=int, default=SWEEP_LOG2_SAMPLES,
+                    help='samples per RF segment of the 8-segment sweep (N > 1, and the sweep_c4 key at N = 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='N = 1: skip the sweep_c4 and h2d_inclusive keys')
     args = ap.parse_args()
 
     # the pool's host driver only supports dmabuf IPC; RCCL needs this before the HIP runtime starts
@@ -114,7 +149,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ofdm_tools import _hip, windows
+    from ofdm_tools import _hip, sweep, windows
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -135,7 +170,8 @@ def main():
     # BENCH_FORCE_COLLECTIVE=1: run the N > 1 code path (RCCL init, all-gather, barriers) with whatever world
     # size the launcher gives, 1 included - a one-GPU box can then exercise the real nccl backend
     force = os.environ.get('BENCH_FORCE_COLLECTIVE') == '1'
-    if world > 1 or force:
+    multi = world > 1 or force
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         if rehearse:
@@ -143,81 +179,134 @@ def main():
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    n = 1 << args.log2_samples
-    multi = world > 1 or force
-    trim = 256 if multi else 0
-    nbins = NFFT - 2 * trim
-
     # a dedicated non-blocking stream, made torch's current stream: the library's kernels, torch's fills and the
     # event dependencies of the NCCL collectives all refer to it (the legacy null stream would serialise
     # against every blocking stream in the process)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = _hip.Context(local_rank, stream=stream.cuda_stream)
-    iq = torch.empty((n, 2), dtype=torch.float32, device=dev)               # the IQ ring buffer in HBM
-    ctx.synth_iq(iq.data_ptr(), n, (2000 + rank) if multi else 1002, TONES, DC)
-    plan = ctx.welch_plan(NFFT, window=windows.get_window('hann', NFFT), fs=1.0, fftshift=multi, trim_bins=trim)
-    nseg = plan.nseg(n)
-    # two sets of buffers: the all-gather of sweep i overlaps the Welch kernel of sweep i+1
-    local = [torch.zeros((1, nbins), dtype=torch.float32, device=dev) for _ in range(2)]
-    gathered = [torch.empty((world, nbins), dtype=torch.float32, device=dev) for _ in range(2)] if multi else None
-    pending = [None, None]
-    count = [0]
-
-    def step():
-        i = count[0] & 1
-        count[0] += 1
-        if multi and pending[i] is not None:
-            pending[i].wait()                     # sweep i-2 has been gathered: its buffers are free again
-            pending[i] = None
-        plan.exec_dev(iq.data_ptr(), n, local[i].data_ptr())
-        if multi:
-            pending[i] = dist.all_gather_into_tensor(gathered[i], local[i], async_op=True)
-            return gathered[i]
-        return local[i][0]
-
-    def drain():
-        for i in range(2):
-            if multi and pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
+    assert ctx.on_torch_stream()
+    hann = windows.get_window('hann', NFFT)
 
     def fence():
-        drain()
         torch.cuda.synchronize(dev)
         if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # clock ramp (setup, untimed, not a step count): the part idles at its lowest sclk level and needs
-    # some tens of ms of load before it holds its sustained clock; then the W warm-up steps
-    # (time-bounded, so every rank runs its own number of iterations: local kernels only, no collective)
-    t_ramp = time.perf_counter()
-    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-        for _ in range(8):
-            plan.exec_dev(iq.data_ptr(), n, local[0].data_ptr())
-        torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ctx.set_timing(True)
-    ctx.get_timing(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wide = step()
-    fence()
-    t1 = time.perf_counter()
-    kern_ms, launches = ctx.get_timing(reset=True)
-    ctx.set_timing(False)
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if multi:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    def ramp(fn):
+        # clock ramp (setup, untimed, not a step count): the part idles at its lowest sclk level and needs some
+        # tens of ms of load before it holds its sustained clock (local kernels only, no collective)
+        t_ramp = time.perf_counter()
+        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+            for _ in range(8):
+                fn()
+            torch.cuda.synchronize(dev)
+
+    # ---------------------------------------------------------------- the 8-segment sweep (C4) ----------
+    def sweep_bench(steps, warmup):
+        S = 1 << args.sweep_log2_samples
+        trim = 256
+        nbins = NFFT - 2 * trim
+        mine = sweep.shard_segments(SWEEP_SEGMENTS, rank, world)
+        seg = {}
+        for i in mine:                                   # this rank's RF segments, resident in HBM
+            seg[i] = torch.empty((S, 2), dtype=torch.float32, device=dev)
+            ctx.synth_iq(seg[i].data_ptr(), S, 2000 + i, TONES, DC)
+        plan = ctx.welch_plan(NFFT, window=hann, fs=2.0e6, fftshift=True, trim_bins=trim, db=True)
+        pipe = sweep.SweepPipeline(SWEEP_SEGMENTS, nbins, dev, rank, world)
+
+        def compute(i, out_row):
+            plan.exec_dev(seg[i].data_ptr(), S, out_row.data_ptr())
+
+        last = [0]
+
+        def step():
+            last[0] = pipe.run(compute)
+
+        def full_fence():
+            pipe.drain()
+            fence()
+
+        if mine:
+            ramp(lambda: plan.exec_dev(seg[mine[0]].data_ptr(), S, pipe.local[0][0].data_ptr()))
+        for _ in range(warmup):
+            step()
+        ctx.set_timing(True)
+        ctx.get_timing(reset=True)
+        wall, per = timed_steps(torch, dist, dev, step, full_fence, steps, multi)
+        kern_ms, launches = ctx.get_timing(reset=True)
+        ctx.set_timing(False)
+        wide = pipe.wideband(last[0])
+        assert int(wide.numel()) == SWEEP_SEGMENTS * nbins and bool(torch.isfinite(wide).all())
+        # parity of this rank's first segment on a prefix, against the oracle (outside the timed region)
+        err = None
+        if rank == 0:
+            from oracle import ref_cpu as R
+            pre = seg[0][:1 << 20].cpu().numpy().view(np.complex64).reshape(-1)
+            _, ref = R.welch_np(pre, fs=2.0e6, nperseg=NFFT, nfft=NFFT)
+            ref = np.fft.fftshift(ref)[trim:-trim]
+            chk = ctx.welch_plan(NFFT, window=hann, fs=2.0e6, fftshift=True, trim_bins=trim, db=True)
+            err = float(np.max(np.abs(10 ** (chk.exec(pre).astype(np.float64) / 10) - ref) / ref))
+        med = statistics.median(per)
+        total = SWEEP_SEGMENTS * S
+        out = {'value': total / (med * 1e-3) / 1e6, 'unit': 'Msamples/s', 'ms_per_sweep': med,
+               'wall_ms_per_sweep': 1e3 * wall / steps, 'segments': SWEEP_SEGMENTS, 'samples_per_segment': S,
+               'segments_on_rank0': len(mine), 'steps': steps,
+               'kernel_avg_ms': kern_ms / max(launches, 1), 'launches': int(launches),
+               'parity_prefix_max_rel_err': err}
+        del seg
+        return out, S
 
     result = None
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = world * n / (elapsed / args.steps) / 1e6
+    if multi:
+        sw, S = sweep_bench(args.steps, args.warmup)
+        if rank == 0:
+            kavg = sw['kernel_avg_ms']
+            achieved = 8.0 * S / (kavg * 1e-3) / 1e9 if kavg else 0.0
+            result = {
+                'metric': 'IQ Msamples/s Welch-PSD (4096-pt, 50% ovlp)',
+                'value': sw['value'], 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': sw['ms_per_sweep'], 'wall_ms_per_step': sw['wall_ms_per_sweep'],
+                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+                'data': 'synthetic',
+                'config': {'workload': 'C4: fixed sweep of %d RF segments x 2^%d samples, segment i on rank i mod %d, '
+                                       '4096-pt Hann Welch 50%% overlap, fftshift + 256-bin trim + dB, all_gather of '
+                                       '3584-bin rows into tune order (ofdm_tools.sweep.SweepPipeline)'
+                                       % (SWEEP_SEGMENTS, args.sweep_log2_samples, world),
+                           'nfft': NFFT, 'noverlap': NFFT // 2, 'window': 'hann', 'segments': SWEEP_SEGMENTS,
+                           'samples_per_segment': S, 'parallelism': 'segment-per-gpu x%d' % world},
+                'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                             'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'welch4096ws_kernel',
+                             'kernel_avg_ms': kavg, 'launches': sw['launches'],
+                             'algorithmic_bytes_per_launch': 8 * S},
+                'parity_prefix_max_rel_err': sw['parity_prefix_max_rel_err'],
+                'cpu_baseline': None, 'device': ctx.device_name(),
+            }
+    else:
+        n = 1 << args.log2_samples
+        iq = torch.empty((n, 2), dtype=torch.float32, device=dev)               # the IQ ring buffer in HBM
+        ctx.synth_iq(iq.data_ptr(), n, 1002, TONES, DC)
+        plan = ctx.welch_plan(NFFT, window=hann, fs=1.0)
+        nseg = plan.nseg(n)
+        out = [torch.zeros(NFFT, dtype=torch.float32, device=dev) for _ in range(2)]
+        count = [0]
+
+        def step():
+            count[0] += 1
+            plan.exec_dev(iq.data_ptr(), n, out[count[0] & 1].data_ptr())
+
+        ramp(step)
+        for _ in range(args.warmup):
+            step()
+        ctx.set_timing(True)
+        ctx.get_timing(reset=True)
+        wall, per = timed_steps(torch, dist, dev, step, fence, args.steps, False)
+        kern_ms, launches = ctx.get_timing(reset=True)
+        ctx.set_timing(False)
+        psd = out[count[0] & 1]
+        assert bool(torch.isfinite(psd).all())
+        med = statistics.median(per)
         kavg_ms = kern_ms / max(launches, 1)
         achieved = 8.0 * n / (kavg_ms * 1e-3) / 1e9
         traffic = None
@@ -232,22 +321,20 @@ def main():
         # sanity / parity on a prefix, outside the timed region
         from oracle import ref_cpu as R
         pre = iq[:1 << 20].cpu().numpy().view(np.complex64).reshape(-1)
-        chk = ctx.welch_plan(NFFT, window=windows.get_window('hann', NFFT), fs=1.0)
+        chk = ctx.welch_plan(NFFT, window=hann, fs=1.0)
         _, ref = R.welch_np(pre, fs=1.0, nperseg=NFFT, nfft=NFFT)
         err = float(np.max(np.abs(chk.exec(pre) - ref) / ref))
         probe_ms = ctx.stream_read_probe(iq.data_ptr(), n * 8, 5)
         result = {
             'metric': 'IQ Msamples/s Welch-PSD (4096-pt, 50% ovlp)',
-            'value': value, 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('C4-weak: one 2^%d-sample RF segment per GPU, 4096-pt Hann Welch 50%% overlap, '
-                                    'fftshift + 256-bin trim, all_gather of %d-bin rows' % (args.log2_samples, nbins))
-                       if multi else
-                       ('C2: 2^%d-sample complex64 stream, 4096-pt Hann Welch, 50%% overlap, detrend constant, '
-                        'density' % args.log2_samples),
+            'value': n / (med * 1e-3) / 1e6, 'unit': 'Msamples/s', 'n_gpus': 1, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': med, 'wall_ms_per_step': 1e3 * wall / args.steps,
+            'ms_per_step_min_max': [min(per), max(per)],
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C2: 2^%d-sample complex64 stream, 4096-pt Hann Welch, 50%% overlap, detrend '
+                                   'constant, density' % args.log2_samples,
                        'nfft': NFFT, 'noverlap': NFFT // 2, 'window': 'hann', 'samples_per_gpu': n,
-                       'segments_per_gpu': nseg, 'parallelism': 'segment-per-gpu x%d' % world},
+                       'segments_per_gpu': nseg, 'parallelism': 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'kernel': 'welch4096ws_kernel', 'kernel_avg_ms': kavg_ms, 'launches': int(launches),
@@ -256,12 +343,34 @@ def main():
             'parity_prefix_max_rel_err': err,
             'device': ctx.device_name(),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_extras:
+            # host buffer -> PSD on the host through the streaming entry point (pinned staging ring, asynchronous
+            # H2D + kernels): the PCIe-inclusive rate; never `value`
+            m, chunk = 1 << 26, 1 << 22
+            host = np.empty(chunk, np.complex64)
+            host.real = np.random.default_rng(5).standard_normal(chunk).astype(np.float32)
+            host.imag = 0.25
+            sp = ctx.welch_plan(NFFT, window=hann, fs=1.0)
+            for _ in range(4):
+                sp.accumulate(host)
+            sp.finalize()
+            t0 = time.perf_counter()
+            for _ in range(m // chunk):
+                sp.accumulate(host)
+            sp.finalize()
+            dt = time.perf_counter() - t0
+            result['h2d_inclusive'] = {'value': m / dt / 1e6, 'unit': 'Msamples/s', 'GBps': 8.0 * m / dt / 1e9,
+                                       'sample': '2^26 samples from a pageable host buffer in 2^22-sample work() '
+                                                 'chunks through oth_welch_accumulate (pinned ring, async H2D + '
+                                                 'kernels) + oth_welch_finalize'}
+            del iq
+            torch.cuda.empty_cache()
+            sw, _ = sweep_bench(max(10, args.steps // 4), max(3, args.warmup // 4))
+            result['sweep_c4'] = sw
+        if not args.no_cpu_baseline:
             result['cpu_baseline'], result['cpu_baseline_parallel'] = cpu_baseline(NFFT)
         else:
             result['cpu_baseline'] = None
-        assert int(wide.numel()) == world * nbins
-        assert bool(torch.isfinite(wide).all())
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -160,6 +160,15 @@ class Context(object):
             raise HipError(rc, 'oth_ctx_create', self.lib.oth_last_error(None).decode())
         self.h = h
         self.device = int(device)
+        self.stream = None if stream is None else int(stream)      # the adopted hipStream_t, if any
+
+    def on_torch_stream(self):
+        """True when this context runs on torch's current stream of its device: kernels and torch ops
+        (collectives included) are then ordered by the stream and need no host synchronisation between them."""
+        if self.stream is None:
+            return False
+        import torch
+        return int(torch.cuda.current_stream(self.device).cuda_stream) == self.stream
 
     def check(self, rc, where):
         if rc != OK:

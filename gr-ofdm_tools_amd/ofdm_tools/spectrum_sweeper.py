@@ -171,7 +171,8 @@ class spectrum_sweeper(sync_block):
                 torch.cuda.current_stream(device).synchronize()      # the copy ran on torch's stream
             nsamples = iq.numel() // 2 if iq.dtype == torch.float32 else iq.numel()
             self._plan.exec_dev(iq.data_ptr(), nsamples, out_row.data_ptr())
-            self.ctx.sync()          # the all-gather runs on torch's stream, the plan on the context's
+            if not self.ctx.on_torch_stream():
+                self.ctx.sync()      # the all-gather runs on torch's stream, the plan on the context's own
 
         wide = sweep.sweep_psd(lambda i: capture(i, self.tune_frequencies[i]), compute,
                                len(self.tune_frequencies), nbins, device, rank, world, group)

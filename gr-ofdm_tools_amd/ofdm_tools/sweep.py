@@ -120,13 +120,15 @@ def welch_long_stream(plan, local_dptr, local_first_sample, nsamples_total, devi
     (time_shard()).  -> (psd float32 tensor [plan.out_len] on `device`, nseg_total), identical on every rank."""
     def partial(first, n, out):
         nseg = plan.partial_dev(local_dptr + 8 * (first - local_first_sample), n, out.data_ptr())
-        plan.ctx.sync()                      # the collective runs on torch's stream
+        if not plan.ctx.on_torch_stream():
+            plan.ctx.sync()                  # the collective runs on torch's stream
         return nseg
 
     def scale(sums, nseg):
         out = torch.empty(plan.out_len, dtype=torch.float32, device=device)
         plan.scale_dev(sums.contiguous().data_ptr(), nseg, out.data_ptr())
-        plan.ctx.sync()
+        if not plan.ctx.on_torch_stream():
+            plan.ctx.sync()
         return out
     return welch_time_sharded(partial, scale, nsamples_total, plan.nperseg, plan.step, plan.nfft, device, rank, world,
                               group)
@@ -138,7 +140,8 @@ def csd_long_stream(plan, x_dptr, y_dptr, local_first_sample, nsamples_total, de
     def partial(first, n, out):
         off = 8 * (first - local_first_sample)
         nseg = plan.csd_partial_dev(x_dptr + off, y_dptr + off, n, out.data_ptr())
-        plan.ctx.sync()
+        if not plan.ctx.on_torch_stream():
+            plan.ctx.sync()
         return nseg
 
     def scale(sums, nseg):
@@ -147,7 +150,55 @@ def csd_long_stream(plan, x_dptr, y_dptr, local_first_sample, nsamples_total, de
         pxy = torch.empty((m, 2), dtype=torch.float32, device=device)
         plan.csd_scale_dev(sums.contiguous().data_ptr(), nseg, pxx.data_ptr(), pyy.data_ptr(), pxy.data_ptr(),
                            cxy.data_ptr())
-        plan.ctx.sync()
+        if not plan.ctx.on_torch_stream():
+            plan.ctx.sync()
         return pxx, pyy, pxy, cxy
     return welch_time_sharded(partial, scale, nsamples_total, plan.nperseg, plan.step, 4 * plan.nfft, device, rank,
                               world, group)
+
+
+class SweepPipeline(object):
+    """Continuous sweeping (spectrum_stitcher.run loops forever, python/spectrum_sweeper.py:207-231): the
+    all-gather of sweep i is issued asynchronously and overlaps the kernels of sweep i + 1 on `depth` sets of
+    row buffers.  ``run(compute)`` computes this rank's segments (``compute(i, out_row)`` writes nbins float32
+    of tune index i into the device row, asynchronously on torch's current stream) and starts the gather;
+    ``wideband(slot)`` waits for it and returns the stitched PSD in tune order."""
+
+    def __init__(self, nseg_total, nbins, device, rank, world, group=None, depth=2):
+        self.nseg_total, self.nbins, self.rank, self.world, self.group = nseg_total, nbins, rank, world, group
+        self.mine = shard_segments(nseg_total, rank, world)
+        self.spr = segments_per_rank(nseg_total, world)
+        self.local = [torch.zeros((self.spr, nbins), dtype=torch.float32, device=device) for _ in range(depth)]
+        self.gathered = [torch.empty((world * self.spr, nbins), dtype=torch.float32, device=device)
+                         for _ in range(depth)] if world > 1 else None
+        self.pending = [None] * depth
+        self.count = 0
+
+    def run(self, compute):
+        slot = self.count % len(self.local)
+        self.count += 1
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()            # the sweep that used these buffers has been gathered
+            self.pending[slot] = None
+        for j, i in enumerate(self.mine):
+            compute(i, self.local[slot][j])
+        if self.world > 1:
+            self.pending[slot] = dist.all_gather_into_tensor(self.gathered[slot], self.local[slot], group=self.group,
+                                                             async_op=True)
+        return slot
+
+    def wideband(self, slot):
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+        if self.world == 1:
+            return self.local[slot][:self.nseg_total].reshape(-1)
+        g = self.gathered[slot]
+        return g.view(self.world, self.spr, self.nbins).permute(1, 0, 2).reshape(-1, self.nbins)[:self.nseg_total] \
+            .reshape(-1)
+
+    def drain(self):
+        for s in range(len(self.pending)):
+            if self.pending[s] is not None:
+                self.pending[s].wait()
+                self.pending[s] = None
