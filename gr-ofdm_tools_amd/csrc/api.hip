@@ -91,6 +91,9 @@ struct oth_chain {
     int *d_peak_init = nullptr;
     float2 *d_stage = nullptr;         // host input lands here (H2D), then feeds the kernels
     size_t stage_cap = 0;
+    float *d_partial = nullptr;        // per-team accumulator rows of the fused kernel
+    size_t partial_cap = 0;
+    int kernel = OTH_KERNEL_AUTO;      // OTH_KERNEL_GENERIC forces the coverage kernels (parity tests)
     float *d_out = nullptr;            // rows handed back by the host-output forms
     size_t out_cap = 0;
     // asynchronous work() form (oth_chain_push_async): pinned input ring + pinned latest-row ring.  A slot is
@@ -338,8 +341,13 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     bool tuned = p->nfft == 4096 && p->nperseg >= 256 && (p->nperseg & (p->nperseg - 1)) == 0 && !csd;
     const bool tuned_csd = csd && p->nfft == 4096 && p->nperseg == 4096 && p->kernel != OTH_KERNEL_GENERIC;
     const bool tuned_16k = !csd && p->nfft == 16384 && p->nperseg == 16384 && p->kernel != OTH_KERNEL_GENERIC;
+    // segfft.hip: nperseg = nfft = 1024 / 2048, any step (team of nfft / 16 threads per segment)
+    const bool tuned_seg = !csd && (p->nfft == 1024 || p->nfft == 2048) && p->nperseg == p->nfft &&
+                           p->kernel != OTH_KERNEL_GENERIC;
+    const int seg_kind = p->step == p->nfft / 2 ? 0 : 1;
+    const bool seg_wps4 = p->tune_variant == "seg4";
     if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
-    if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd && !tuned_16k)
+    if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd && !tuned_16k && !tuned_seg)
         return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
     const W4096Variant *var =
         tuned ? w4096_variant(p->nperseg == 4096 ? p->step : 0,
@@ -347,9 +355,11 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
                               p->tune_variant)
               : nullptr;
     int W = generic_wg(c, p->nfft, nseg, nstreams);
-    if (tuned || tuned_csd || tuned_16k) {
+    if (tuned || tuned_csd || tuned_16k || tuned_seg) {
         // exactly the resident workgroups: one wave of workgroups, no tail round
-        const int bpc = tuned ? var->blocks_per_cu() : (tuned_csd ? csd4096_blocks_per_cu() : 1);
+        const int bpc = tuned ? var->blocks_per_cu()
+                              : (tuned_csd ? csd4096_blocks_per_cu()
+                                           : (tuned_seg ? seg_teams_per_cu(p->nfft, seg_kind, seg_wps4) : 1));
         long long w = ((long long)c->cu_count * bpc + nstreams - 1) / nstreams;
         W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
     }
@@ -380,9 +390,9 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.nbig = 0;
     a.queue = nullptr;
     a.fd = p->d_fd;
-    if (tuned || tuned_csd || tuned_16k) {
+    if (tuned || tuned_csd || tuned_16k || tuned_seg) {
         a.sched = p->tune_sched >= 0 ? p->tune_sched : p->sched;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? 2 : (tuned ? var->chunk : 8));
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? 2 : (tuned ? var->chunk : (tuned_seg ? 16 : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;
@@ -402,7 +412,28 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
             }
         }
     }
-    {
+    if (tuned_seg) {
+        SegArgs g{};
+        g.x = x;
+        g.stream_stride = stride;
+        g.nstreams = nstreams;
+        g.win = p->d_win;
+        g.tw = p->d_tw;
+        g.first = 0;
+        g.step = p->step;
+        g.nseg = nseg;
+        g.detrend = p->detrend;
+        g.chain = 0;
+        g.partial = p->d_partial;
+        g.wg_per_stream = W;
+        g.sched = a.sched;
+        g.chunk = a.chunk;
+        g.tail_chunk = a.tail_chunk;
+        g.nbig = a.nbig;
+        g.queue = a.queue;
+        Timed tm(c);
+        HIPCHK(c, launch_seg(p->nfft, g, seg_kind, seg_wps4, c->stream));
+    } else {
         Timed tm(c);
         HIPCHK(c, tuned ? var->launch(a, c->stream)
                         : (tuned_csd ? launch_csd_tuned4096(a, c->stream)
@@ -772,7 +803,7 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
     if (sched < -1 || sched > OTH_SCHED_DYNAMIC || chunk < 0 || tail_chunk < 0)
         return fail(p->ctx, OTH_ERR_INVALID, "bad tuning value");
     if (variant && *variant) {
-        bool known = false;
+        bool known = !strcmp(variant, "seg3") || !strcmp(variant, "seg4");      // builds of the 1024 / 2048 kernel
         for (const auto &v : kVariants) known = known || !strcmp(variant, v.tag);
         if (!known) return fail(p->ctx, OTH_ERR_UNSUPPORTED, std::string("unknown kernel build: ") + variant);
     }
@@ -1134,6 +1165,7 @@ int oth_chain_destroy(oth_chain *h) {
     if (h->d_peak) hipFree(h->d_peak);
     if (h->d_peak_init) hipFree(h->d_peak_init);
     if (h->d_stage) hipFree(h->d_stage);
+    if (h->d_partial) hipFree(h->d_partial);
     if (h->d_out) hipFree(h->d_out);
     for (int i = 0; i < oth_chain::kRing; ++i) {
         if (h->h_in[i]) hipHostFree(h->h_in[i]);
@@ -1168,6 +1200,14 @@ int oth_chain_set_peak_hold(oth_chain *h, int enable) {
     return OTH_OK;
 }
 
+int oth_chain_set_kernel(oth_chain *h, int which) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
+    if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
+    if (which < OTH_KERNEL_AUTO || which > OTH_KERNEL_TUNED) return fail(h->ctx, OTH_ERR_INVALID, "unknown kernel id");
+    h->kernel = which;
+    return OTH_OK;
+}
+
 int oth_chain_reset(oth_chain *h) {
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
@@ -1181,12 +1221,94 @@ int oth_chain_reset(oth_chain *h) {
     return OTH_OK;
 }
 
+// The fused path (segfft.hip): FFT + epilogue + IIR / peak accumulation in one launch over all kept vectors, a
+// small tail kernel for the state and the rows the caller wants.  Covers nfft 1024 / 2048 / 4096 with at most one
+// of {IIR + log, peak hold} and up to kTailRows rows handed back.
+constexpr long long kTailRows = 256;
+
+static bool chain_fused_ok(const oth_chain *h, long long give) {
+    if (h->kernel == OTH_KERNEL_GENERIC || !seg_supported(h->nfft)) return false;
+    if (h->do_iir && h->do_peak) return false;
+    if (h->do_iir && !(h->alpha > 0.f && h->alpha <= 1.f)) return false;
+    return give <= kTailRows;
+}
+
+static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec, long long nrows, float *rows_last,
+                              long long give) {
+    oth_ctx *c = h->ctx;
+    const int N = h->nfft;
+    SegArgs a{};
+    a.x = x;
+    a.stream_stride = 0;
+    a.nstreams = 1;
+    a.win = h->d_win;
+    a.tw = h->d_tw;
+    a.step = (long long)h->keep_n * N;
+    a.first = first_vec * N;
+    a.nseg = nrows;
+    a.detrend = 0;
+    a.chain = 1;
+    a.epilogue = h->epilogue;
+    a.scale = h->epilogue == OTH_EPI_MAG2_OVER_N2 ? (float)(1.0 / ((double)N * (double)N)) : 1.0f;
+    a.fftshift = h->fftshift;
+    a.store_from = nrows - give;
+    int rc;
+    if (h->do_iir) {
+        a.acc_mode = 1;
+        a.acc_end = a.store_from;
+        a.l2 = h->alpha >= 1.f ? -INFINITY : log2f(1.0f - h->alpha);
+        if (give) {
+            if ((rc = ensure(c, &h->d_rows, &h->rows_cap, sizeof(float) * (size_t)give * N))) return rc;
+            a.rows = h->d_rows;      // raw |X|^2 rows; the tail kernel turns them into dB rows
+        }
+    } else if (h->do_peak) {
+        a.acc_mode = 2;
+        a.acc_end = nrows;
+        a.rows = rows_last;
+    } else {
+        // no state: rows nobody asked for are not computed at all (latest wins)
+        if (!give) return OTH_OK;
+        a.acc_mode = 3;
+        a.acc_end = 0;
+        a.first += a.store_from * a.step;
+        a.nseg = give;
+        a.store_from = 0;
+        a.rows = rows_last;
+    }
+    const int tpc = seg_teams_per_cu(N, 2, false);
+    a.chunk = 4;
+    long long nchunks = (a.nseg + a.chunk - 1) / a.chunk;
+    long long W = (long long)c->cu_count * tpc;
+    if (W > nchunks) W = nchunks;
+    if (W < 1) W = 1;
+    a.wg_per_stream = (int)W;
+    a.sched = 1;                     // interleaved chunks: chunk c = team, team + W, ...
+    a.tail_chunk = a.chunk;
+    a.nbig = a.nseg / a.chunk;
+    a.queue = nullptr;
+    if (a.acc_mode != 3) {
+        if ((rc = ensure(c, &h->d_partial, &h->partial_cap, sizeof(float) * (size_t)W * N))) return rc;
+        a.partial = h->d_partial;
+    }
+    {
+        Timed tm(c);
+        HIPCHK(c, launch_seg(N, a, 2, false, c->stream));
+    }
+    if (a.acc_mode != 3)
+        HIPCHK(c, launch_chain_tail(h->d_partial, (int)W, N, h->fftshift, a.acc_mode, a.acc_end, h->alpha, h->kdb,
+                                    h->d_iir, h->d_peak, h->d_peak_init, h->d_rows, h->do_iir ? give : 0, rows_last,
+                                    c->stream));
+    return OTH_OK;
+}
+
 // `nrows` kept vectors of x, vector index first_vec + r * keep_n (r = 0 .. nrows-1), through FFT + epilogue in
 // time order (IIR / peak state advance); the LAST `give` post-epilogue rows land in rows_last (device).
 static int chain_launch(oth_chain *h, const float2 *x, long long first_vec, long long nrows, float *rows_last,
                         long long give) {
     oth_ctx *c = h->ctx;
     const int N = h->nfft;
+    if (!rows_last) give = 0;
+    if (chain_fused_ok(h, give)) return chain_launch_fused(h, x, first_vec, nrows, rows_last, give);
     int rc = ensure(c, &h->d_rows, &h->rows_cap, sizeof(float) * (size_t)nrows * N);
     if (rc) return rc;
     PgramArgs a;

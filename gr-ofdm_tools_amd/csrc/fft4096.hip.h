@@ -119,6 +119,22 @@ __device__ __forceinline__ void chunk_range(const WelchArgs &p, long long c, lon
     }
 }
 
+// the same schedule for kernels that do not take a WelchArgs (segfft.hip)
+__device__ __forceinline__ long long chunk_count_of(long long nseg, long long nbig, int chunk, int tail_chunk) {
+    const long long rest = nseg - nbig * chunk;
+    return nbig + (rest + tail_chunk - 1) / tail_chunk;
+}
+__device__ __forceinline__ void chunk_range_of(long long nseg, long long nbig, int chunk, int tail_chunk, long long c,
+                                               long long &sb, long long &se) {
+    if (c < nbig) {
+        sb = c * chunk;
+        se = sb + chunk;
+    } else {
+        sb = nbig * chunk + (c - nbig) * tail_chunk;
+        se = sb + tail_chunk < nseg ? sb + tail_chunk : nseg;
+    }
+}
+
 // Wave priority.  Everything that starts long-latency work or releases other waves (global loads, the
 // segment sum, LDS exchanges, barriers) runs at raised priority so that it is issued as early as
 // possible; the three 16-point butterflies, pure VALU, run at base priority and fill the gaps of the

@@ -226,6 +226,45 @@ __global__ void rows_epilogue_kernel(float *rows, long long nrows, int nfft, flo
 
 __global__ void set_flag_kernel(int *flag, int v) { *flag = v; }
 
+// Closes a fused chain launch (segfft.hip): the per-team accumulator rows (natural bin order) become the new IIR /
+// peak state (kept in ROW order, i.e. after the optional fftshift), and the raw rows the launch stored for the
+// caller go through the last steps of the recursion in time order.
+//   acc_mode 1  y = (1-alpha)^nbase y0 + alpha sum_w partial[w][k];  per raw row: y = alpha x + (1-alpha) y,
+//               rows_out = 10 log10(y) + kdb      (single_pole_iir_filter_ff + nlog10_ff, local_worker.py:66-69)
+//   acc_mode 2  peak = max(state, max_w partial[w][k])                (psd_logger.py:85); rows were written raw
+__global__ void chain_tail_kernel(const float *partial, int W, int nfft, int fftshift, int acc_mode, long long nbase,
+                                  float alpha, float kdb, float *iir_state, float *peak_state, const int *peak_init,
+                                  const float *raw_rows, long long nraw, float *rows_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // row position
+    if (i >= nfft) return;
+    const int k = fftshift ? ((i + nfft / 2) & (nfft - 1)) : i;
+    if (acc_mode == 1) {
+        double s = 0.0;
+        for (int w = 0; w < W; ++w) s += (double)partial[(size_t)w * nfft + k];
+        float y = iir_state[i];
+        if (nbase > 0) y = (float)((double)y * pow(1.0 - (double)alpha, (double)nbase) + (double)alpha * s);
+        for (long long r = 0; r < nraw; ++r) {
+            y = fmaf(alpha, raw_rows[(size_t)r * nfft + i], (1.0f - alpha) * y);
+            rows_out[(size_t)r * nfft + i] = 10.0f * log10f(y) + kdb;
+        }
+        iir_state[i] = y;
+    } else if (acc_mode == 2) {
+        float pk = 0.f;
+        for (int w = 0; w < W; ++w) pk = fmaxf(pk, partial[(size_t)w * nfft + k]);
+        if (*peak_init) pk = fmaxf(pk, peak_state[i]);
+        peak_state[i] = pk;
+    }
+}
+
+hipError_t launch_chain_tail(const float *partial, int W, int nfft, int fftshift, int acc_mode, long long nbase,
+                             float alpha, float kdb, float *iir_state, float *peak_state, int *peak_init,
+                             const float *raw_rows, long long nraw, float *rows_out, hipStream_t s) {
+    hipLaunchKernelGGL(chain_tail_kernel, dim3((nfft + 255) / 256), dim3(256), 0, s, partial, W, nfft, fftshift, acc_mode,
+                       nbase, alpha, kdb, iir_state, peak_state, peak_init, raw_rows, nraw, rows_out);
+    if (acc_mode == 2) hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, s, peak_init, 1);
+    return hipGetLastError();
+}
+
 hipError_t launch_rows_epilogue(float *rows, long long nrows, int nfft, float alpha, float kdb, float *iir_state,
                                 float *peak_state, int *peak_init, int do_iir, int do_peak, hipStream_t s) {
     hipLaunchKernelGGL(rows_epilogue_kernel, dim3((nfft + 255) / 256), dim3(256), 0, s, rows, nrows, nfft, alpha,

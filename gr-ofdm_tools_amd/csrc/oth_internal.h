@@ -31,6 +31,38 @@ struct WelchArgs {
     const float4 *fd;
 };
 
+// Launch description of segfft.hip: segment transforms of 1024 / 2048 / 4096 points by teams of nfft / 16
+// threads, Welch average or periodogram chain (see the file header).
+struct SegArgs {
+    const float2 *x;        // device IQ, stream 0
+    size_t stream_stride;   // samples between streams
+    int nstreams;
+    const float *win;       // nfft floats
+    const float2 *tw;       // W_nfft^k, nfft entries
+    long long first;        // sample index of segment 0 (chain: first kept vector)
+    long long step;         // samples between segment starts (chain: keep_n * nfft)
+    long long nseg;         // segments per stream
+    int detrend;
+    int chain;              // 0: Welch average (sum |X|^2 of every segment); 1: periodogram chain
+    float *partial;         // [nstreams][wg_per_stream][nfft] accumulator rows, natural bin order (or nullptr)
+    // chain only
+    int acc_mode;           // 1 weighted sum (IIR), 2 max (peak hold), 3 none
+    long long acc_end;      // segments s < acc_end take part in the accumulation
+    float l2;               // log2(1 - alpha): weight of segment s is 2^(l2 (acc_end - 1 - s))
+    float *rows;            // [nstreams][nseg - store_from][nfft]: epilogue values of segments s >= store_from
+    long long store_from;
+    int epilogue;           // OTH_EPI_*
+    float scale;            // applied to |X|^2 (MAG2_OVER_N2)
+    int fftshift;
+    // schedule (as WelchArgs)
+    int wg_per_stream;
+    int sched;
+    int chunk;
+    int tail_chunk;
+    long long nbig;
+    unsigned *queue;
+};
+
 struct PgramArgs {
     const float2 *x;
     const float *win;       // nfft floats
@@ -97,6 +129,15 @@ int csd4096_blocks_per_cu();
 // welch16k.hip: nfft = nperseg = 16384, one 1024-thread workgroup per CU
 hipError_t launch_welch_tuned16k(const WelchArgs &a, hipStream_t s);
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
+// segfft.hip
+bool seg_supported(int nfft);
+// kind: 0 Welch with step = nfft / 2 (the overlapped half stays in registers), 1 Welch with any step, 2 chain
+int seg_teams_per_cu(int nfft, int kind, bool wps4);
+hipError_t launch_seg(int nfft, const SegArgs &a, int kind, bool wps4, hipStream_t s);
+// partial rows of a chain launch + the stored raw rows -> IIR / peak state and the rows handed back
+hipError_t launch_chain_tail(const float *partial, int W, int nfft, int fftshift, int acc_mode, long long nbase,
+                             float alpha, float kdb, float *iir_state, float *peak_state, int *peak_init,
+                             const float *raw_rows, long long nraw, float *rows_out, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s);
 hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,
                         hipStream_t s);

@@ -1,0 +1,445 @@
+// segfft: segment transforms of N = 256 R points (R = 4, 8, 16 -> N = 1024, 2048, 4096) by one TEAM of 16 R
+// threads, 16 points per thread, with everything that follows the transform fused into the launch:
+//
+//   Welch average          sum over segments of |X|^2, any step (scipy.signal.welch, ofdm_cr_tools.py:214,322,342)
+//   periodogram chain      stream_to_vector -> keep_one_in_n -> fft_vcc -> |.| or |.|^2 [x 1/N^2]
+//                          [-> single_pole_iir -> nlog10] [peak hold]  (spectrum_sensor_v2.py:85-93,
+//                          psd_logger.py:43-53, local_worker.py:58-69, multichannel_scanner.py:78-86):
+//                          the kept vectors are segments with step = keep_n * N; IIR and peak hold become
+//                          weighted-sum / max accumulations over the launch (y_n = (1-a)^n y_0 + sum_s a (1-a)^(n-1-s) x_s),
+//                          only the rows the caller asked for are written.
+//
+// Decomposition N = 16 x 16 x R, decimation in frequency, thread t = R b + c:
+//   sample index  n = 16R a + R b + c                bin index  k = k0 + 16 k1 + 256 k2
+//   pass 1  thread (b, c)  holds a  = 0..15  -> k0, times W_N^(k0 t)
+//   pass 2  thread (k0, c) holds b  = 0..15  -> k1, times W_N^(16 k1 c)
+//   pass 3  thread (k0, j) holds c  = 0..R-1 for k1 = j + R m, m < 16/R  -> k2
+// Exchange 1 (b <-> k0) crosses the team; exchange 2 (c <-> k1) stays inside the R lanes that share k0.  At
+// R = 4 the team is ONE wave: no workgroup barrier anywhere, sixteen independent waves per CU.  At R = 8 (two
+// waves) and R = 16 (four) exchange 1 sits between two LDS-only barriers.
+//
+// LDS image: N float2, NO padding, XOR-swizzled so that every ds_write_b64 (16-lane groups, 32 banks) and
+// ds_read_b64 (32-lane groups, 64 banks) of both exchanges is conflict-free:
+//   idx(k0, row, c) = 512 (k0 >> P) + 32 row + R ((k0 & KP) ^ (row & KM)) + (c ^ (row & (R-1)))
+//   P = 5 - log2 R, KP = 2^P - 1, KM = {R=4: 3, R=8: 1, R=16: 0};  row = b (exchange 1) or k1 (exchange 2).
+// (GF(2) argument: the low address bits are a bijection of the index bits that vary inside a lane group for each
+// of the four access shapes - DESIGN.md "segfft LDS image".)  Per access the address is (lane base ^ constant) +
+// immediate; the constants take 4 / 8 / 16 values, so a segment spends 16 / 26 / 49 v_xor on addressing.
+#include <type_traits>
+#include "fft4096.hip.h"
+
+namespace oth {
+namespace {
+
+template <int R> struct Geo {
+    static constexpr int T = 16 * R, N = 256 * R, Q = 16 / R;
+    static constexpr int LR = (R == 4) ? 2 : (R == 8 ? 3 : 4);
+    static constexpr int P = 5 - LR;
+    static constexpr int KP = (1 << P) - 1;
+    static constexpr int KM = (R == 4) ? 3 : (R == 8 ? 1 : 0);
+    static constexpr int WAVES = T / 64;
+    // 256 B of slack (the image is aligned to 256 B: the swizzle XORs address bits 3..7) + image + per-wave
+    // half-segment sums (2 x 4 float2) + chunk ticket
+    static constexpr size_t LDS_BYTES = 256 + (size_t)N * sizeof(float2) + 16 * sizeof(float2);
+};
+
+enum { LOAD_HALF = 0, LOAD_FULL = 1 };
+enum { ACC_SUM = 0, ACC_WSUM = 1, ACC_MAX = 2, ACC_NONE = 3 };
+
+// Image accesses are explicit ds_read_b64 / ds_write_b64 at (swizzled lane base) + immediate.  A wave's LDS
+// operations execute in program order, so inside one wave (exchange 2 always, exchange 1 at R = 4) a write
+// followed by another lane's read needs no fence; across waves exchange 1 sits between lds_barrier()s.
+
+// the immediate of an asm operand must be a constant expression: template parameter + compile-time loop
+template <int IMM> __device__ __forceinline__ void lds_read_imm(double &dst, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
+}
+template <int IMM> __device__ __forceinline__ void lds_write_imm(unsigned addr, float2 val) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(__builtin_bit_cast(double, val)), "n"(IMM) : "memory");
+}
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// 8-point DFT, natural order in and out
+__device__ __forceinline__ void dft8(float2 (&v)[8]) {
+    dft4<false>(v[0], v[2], v[4], v[6]);
+    dft4<false>(v[1], v[3], v[5], v[7]);
+    const float2 o0 = v[1], o1 = mul_w2(v[3]), o2 = mul_w4(v[5]), o3 = mul_w6(v[7]);      // W8^k = W16^(2k)
+    const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    v[0] = cadd(e0, o0);
+    v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1);
+    v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2);
+    v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3);
+    v[7] = csub(e3, o3);
+}
+
+// v[r16(k)] * W^k for k = 0..15 handed to put(k, value).  W^k = W^(4i) W^j (k = 4i + j) from the six stored
+// powers W, W^2, W^3, W^4, W^8, W^12 (correctly rounded table values): at most ONE complex product per twiddle.
+// Rebuilding all fifteen from W and W^4 (scatter_pow16 of the 4096 kernels) chains up to three products; with a
+// strong off-bin tone in a rectangular-window periodogram that rounding shows in every bin (the tone's bins carry
+// 2 sqrt(N) times the noise amplitude), enough to break 1e-4 on single rows.
+struct Pow6 {
+    float2 j1, j2, j3, i1, i2, i3;      // W^1, W^2, W^3, W^4, W^8, W^12
+};
+template <class F> __device__ __forceinline__ void twiddle_pow16(const float2 (&v)[16], const Pow6 &w6, F put) {
+    float2 wj[4], wi[4];
+    wj[1] = w6.j1;
+    wj[2] = w6.j2;
+    wj[3] = w6.j3;
+    wi[1] = w6.i1;
+    wi[2] = w6.i2;
+    wi[3] = w6.i3;
+    // the products below are loop-invariant: without this the compiler hoists all nine out of the segment loop
+    // and keeps them in registers (+36 VGPRs per pass)
+    asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wj[2].x), "+v"(wj[2].y), "+v"(wj[3].x), "+v"(wj[3].y));
+    asm volatile("" : "+v"(wi[1].x), "+v"(wi[1].y), "+v"(wi[2].x), "+v"(wi[2].y), "+v"(wi[3].x), "+v"(wi[3].y));
+    put(std::integral_constant<int, 0>{}, v[0]);
+    static_for<1, 16>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, i = k >> 2, j = k & 3;
+        const float2 w = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
+        put(kc, cmul(v[r16(k)], w));
+    });
+}
+
+// WPS = waves per SIMD the register allocation is held to (4 -> 128 VGPRs, 3 -> 168)
+template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS>
+__global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
+    using G = Geo<R>;
+    constexpr int T = G::T, N = G::N, Q = G::Q, LR = G::LR, P = G::P, KP = G::KP, KM = G::KM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned img = ((unsigned)(unsigned long long)smem + 255u) & ~255u;      // LDS byte address of the image
+    float2 *red = reinterpret_cast<float2 *>(smem + (img - (unsigned)(unsigned long long)smem)) + N;   // [2][4] half sums
+    int *lnext = reinterpret_cast<int *>(red + 12);                                     // chunk ticket
+
+    const int t = threadIdx.x;
+    const int hi = t >> LR, lo = t & (R - 1);
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const float2 *xb = p.x + (size_t)stream * p.stream_stride + p.first;
+
+    // lane parts of the four LDS access shapes (byte addresses)
+    const unsigned b_rw = img + 8u * (512u * (hi >> P) + R * (hi & KP) + lo);                                    // (k0, c)
+    const unsigned b_w1 = img + 8u * (32u * hi + R * (hi & KM) + (lo ^ (hi & (R - 1))));                        // (b, c)
+    const unsigned b_r2 = img + 8u * (512u * (hi >> P) + 32u * lo + R * ((hi & KP) ^ (lo & KM)) + lo);          // (k0, j)
+
+    float win[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) win[a] = p.win[T * a + t];
+    // W_N^(k t) for pass 1 and W_N^(16 k c) for pass 2, k = 1, 2, 3, 4, 8, 12 (table index mod N)
+    const Pow6 tw1 = {p.tw[t], p.tw[(2 * t) & (N - 1)], p.tw[(3 * t) & (N - 1)], p.tw[(4 * t) & (N - 1)],
+                      p.tw[(8 * t) & (N - 1)], p.tw[(12 * t) & (N - 1)]};
+    const Pow6 tw2 = {p.tw[16 * lo], p.tw[(32 * lo) & (N - 1)], p.tw[(48 * lo) & (N - 1)], p.tw[(64 * lo) & (N - 1)],
+                      p.tw[(128 * lo) & (N - 1)], p.tw[(192 * lo) & (N - 1)]};
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+
+    constexpr int NH = (LOAD == LOAD_HALF) ? 8 : 16;
+    float2 kw[LOAD == LOAD_HALF ? 8 : 1], nxt[NH];
+    float2 prev_tot = make_float2(0.f, 0.f);
+
+    const int sched = p.sched;
+    const long long nchunks = sched ? chunk_count_of(p.nseg, p.nbig, p.chunk, p.tail_chunk) : 1;
+    const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
+    unsigned ticket = 0;
+    for (long long cur = sched ? wg : 0; cur < nchunks;) {
+        long long sb = s0, se = s1;
+        if (sched) chunk_range_of(p.nseg, p.nbig, p.chunk, p.tail_chunk, cur, sb, se);
+        if (sb < se) {      // chunk prologue
+            const float2 *xs = xb + sb * p.step + t;
+            if (LOAD == LOAD_HALF) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) kw[a] = xs[T * a];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) nxt[a] = xs[8 * T + T * a];
+            } else {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) nxt[a] = load_once(xs + T * a);
+            }
+        }
+        for (long long s = sb; s < se; ++s) {
+            float2 v[16];
+            prio_latency();
+            // ---- samples, window, raw sums ------------------------------------------------------------
+            float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
+            if (LOAD == LOAD_HALF) {
+                if (s == sb) {
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) {      // kw holds the raw first half of the chunk's first segment
+                        sumf = cadd(sumf, kw[a]);
+                        kw[a] = make_float2(kw[a].x * win[a], kw[a].y * win[a]);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const float2 r = nxt[a];
+                    v[a] = kw[a];
+                    v[8 + a] = make_float2(r.x * win[8 + a], r.y * win[8 + a]);
+                    kw[a] = make_float2(r.x * win[a], r.y * win[a]);
+                    sum = cadd(sum, r);
+                }
+                if (s + 1 < se) {
+                    const float2 *xn = xb + (s + 2) * (long long)(N / 2) + t;
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) nxt[a] = load_once(xn + T * a);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    const float2 r = nxt[a];
+                    v[a] = make_float2(r.x * win[a], r.y * win[a]);
+                    sum = cadd(sum, r);
+                }
+                if (s + 1 < se) {
+                    const float2 *xn = xb + (s + 1) * p.step + t;
+#pragma unroll
+                    for (int a = 0; a < 16; ++a) nxt[a] = load_once(xn + T * a);
+                }
+            }
+            float2 tot = make_float2(0.f, 0.f);
+            if (DETREND) {
+                sum.x = wave_total(sum.x);
+                sum.y = wave_total(sum.y);
+                if (LOAD == LOAD_HALF && s == sb) {
+                    sumf.x = wave_total(sumf.x);
+                    sumf.y = wave_total(sumf.y);
+                }
+                if (G::WAVES > 1 && (t & 63) == 0) {
+                    red[t >> 6] = sum;
+                    if (LOAD == LOAD_HALF && s == sb) red[4 + (t >> 6)] = sumf;
+                }
+            }
+            if (G::WAVES > 1) lds_barrier();     // A: the previous segment's exchange-2 reads are done everywhere; red[] visible
+            if (sched == 2 && t == 0) {
+                if (s == sb) ticket = atomicAdd(p.queue + stream, 1u);
+                if (s == se - 1) *lnext = (int)ticket;
+            }
+            if (DETREND) {       // totals are read here: barrier B separates them from the next segment's red[] writes;
+                                 // time-domain detrend on the windowed samples: (x - m) w = x w - m w
+                if (G::WAVES > 1) {
+                    float2 nt = red[0];
+#pragma unroll
+                    for (int w = 1; w < G::WAVES; ++w) nt = cadd(nt, red[w]);
+                    if (LOAD == LOAD_HALF && s == sb) {
+                        float2 ft = red[4];
+#pragma unroll
+                        for (int w = 1; w < G::WAVES; ++w) ft = cadd(ft, red[4 + w]);
+                        prev_tot = ft;
+                    }
+                    sum = nt;
+                } else if (LOAD == LOAD_HALF && s == sb) {
+                    prev_tot = sumf;
+                }
+                if (LOAD == LOAD_HALF) {
+                    tot = cadd(prev_tot, sum);
+                    prev_tot = sum;
+                } else {
+                    tot = sum;
+                }
+                const float2 nm = make_float2(tot.x * (-1.0f / N), tot.y * (-1.0f / N));
+#pragma unroll
+                for (int a = 0; a < 16; ++a) v[a] = make_float2(fmaf(nm.x, win[a], v[a].x), fmaf(nm.y, win[a], v[a].y));
+            }
+            // ---- pass 1 -----------------------------------------------------------------------------------
+            prio_compute();
+            dft16(v);
+            prio_latency();
+            twiddle_pow16(v, tw1, [&](auto kc, float2 val) {
+                constexpr int k0 = decltype(kc)::value;
+                lds_write_imm<8 * (512 * (k0 >> P) + R * (k0 & KP & ~KM))>(b_w1 ^ (8u * R * (k0 & KM)), val);
+            });
+            if (G::WAVES > 1) lds_barrier();     // B
+            // ---- pass 2: thread (k0, c) gathers b -----------------------------------------------------------
+            {
+                double r[16];
+                // rows b with equal (b & KM, b & (R-1)) share one swizzled base
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, b = (i >> 2) + 4 * (i & 3);      // issue order 0,4,8,12, 1,5,9,13, ...
+                    lds_read_imm<256 * b>(r[b], b_rw ^ (8u * (R * (b & KM) + (b & (R - 1)))));
+                });
+                prio_compute();
+                float dep = 0.f;
+#define SEG_WAIT(n, a, d) \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r[a]), "+v"(r[a + 4]), "+v"(r[a + 8]), "+v"(r[a + 12]), "+v"(d))
+#pragma unroll
+                for (int a0 = 0; a0 < 4; ++a0) {
+                    if (a0 == 0) SEG_WAIT(12, 0, dep);
+                    else if (a0 == 1) SEG_WAIT(8, 1, v[0].x);
+                    else if (a0 == 2) SEG_WAIT(4, 2, v[1].x);
+                    else SEG_WAIT(0, 3, v[2].x);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = __builtin_bit_cast(float2, r[a0 + 4 * j]);
+                    dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
+                }
+                v[5] = mul_w1(v[5]);
+                v[9] = mul_w2(v[9]);
+                v[13] = mul_w3(v[13]);
+                v[6] = mul_w2(v[6]);
+                v[10] = mul_w4(v[10]);
+                v[14] = mul_w6(v[14]);
+                v[7] = mul_w3(v[7]);
+                v[11] = mul_w6(v[11]);
+                v[15] = mul_w9(v[15]);
+#pragma unroll
+                for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
+            }
+            prio_latency();
+            // in place: the R lanes that share k0 sit in one wave and have issued their reads of region k0 above
+            twiddle_pow16(v, tw2, [&](auto kc, float2 val) {
+                constexpr int k1 = decltype(kc)::value;
+                lds_write_imm<256 * k1>(b_rw ^ (8u * (R * (k1 & KM) + (k1 & (R - 1)))), val);
+            });
+            // ---- pass 3: thread (k0, j) gathers c for k1 = j + R m ---------------------------------------------
+            {
+                double r[16];
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, c = i / Q, m = i % Q;
+                    lds_read_imm<256 * R * m>(r[m * R + c], b_r2 ^ (8u * c));
+                });
+                prio_compute();
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                               "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]),
+                               "+v"(r[15]));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = __builtin_bit_cast(float2, r[i]);
+            }
+            // X[k0 + 16 (lo + R m) + 256 k2] lands in v[m R + k2] (R = 16: v[r16(k2)])
+            if (R == 4) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) dft4<false>(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]);
+            } else if (R == 8) {
+                float2 h0[8], h1[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    h0[i] = v[i];
+                    h1[i] = v[8 + i];
+                }
+                dft8(h0);
+                dft8(h1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = h0[i];
+                    v[8 + i] = h1[i];
+                }
+            } else {
+                dft16(v);
+            }
+            auto at = [&](int m, int k2) -> float2 & { return v[R == 16 ? r16(k2) : m * R + k2]; };
+            if (!CHAIN) {
+#pragma unroll
+                for (int m = 0; m < Q; ++m)
+#pragma unroll
+                    for (int k2 = 0; k2 < R; ++k2) {
+                        const float2 X = at(m, k2);
+                        acc[m * R + k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[m * R + k2]));
+                    }
+            } else {
+                const bool st = s >= p.store_from, ac = s < p.acc_end;
+                float *row = p.rows + ((size_t)stream * (p.nseg - p.store_from) + (size_t)(s - p.store_from)) * N;
+                const int sh = p.fftshift ? N / 2 : 0;
+                float w = 1.0f;
+                if (ac && p.acc_mode == ACC_WSUM) {
+                    const long long kk = p.acc_end - 1 - s;
+                    w = kk == 0 ? 1.0f : exp2f(p.l2 * (float)kk);
+                }
+#pragma unroll
+                for (int m = 0; m < Q; ++m)
+#pragma unroll
+                    for (int k2 = 0; k2 < R; ++k2) {
+                        const float2 X = at(m, k2);
+                        const float pw = fmaf(X.x, X.x, X.y * X.y);
+                        const float val = p.epilogue == 0 ? sqrtf(pw) : pw * p.scale;
+                        if (st) row[(hi + 16 * (lo + R * m) + 256 * k2 + sh) & (N - 1)] = val;
+                        if (ac) {
+                            float &a_ = acc[m * R + k2];
+                            a_ = p.acc_mode == ACC_WSUM ? fmaf(w, val, a_) : (p.acc_mode == ACC_MAX ? fmaxf(a_, val) : a_);
+                        }
+                    }
+            }
+        }
+        if (sched == 0) break;
+        if (sched == 1) {
+            cur += W;
+        } else {
+            if (G::WAVES == 1) wave_lds_sync();   // (WAVES > 1: *lnext was written before barrier B of the last segment)
+            cur = (long long)W + *lnext;
+        }
+    }
+
+    if (p.partial) {      // natural bin order: k = k0 + 16 k1 + 256 k2
+        float *dst = p.partial + ((size_t)stream * W + wg) * N;
+#pragma unroll
+        for (int m = 0; m < Q; ++m)
+#pragma unroll
+            for (int k2 = 0; k2 < R; ++k2) dst[hi + 16 * (lo + R * m) + 256 * k2] = acc[m * R + k2];
+    }
+}
+
+template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS> hipError_t launch_one(const SegArgs &a, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    hipLaunchKernelGGL((seg_kernel<R, LOAD, DETREND, CHAIN, WPS>), grid, dim3(Geo<R>::T), Geo<R>::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS> int occupancy_one() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_kernel<R, LOAD, DETREND, CHAIN, WPS>, Geo<R>::T,
+                                                     Geo<R>::LDS_BYTES) != hipSuccess || n < 1)
+        n = 1;
+    return n;
+}
+
+// kind: 0 Welch step = N/2 (half kept in registers), 1 Welch any step, 2 chain.  wps4: the 128-VGPR build of kind 0.
+template <int R> hipError_t launch_r(const SegArgs &a, int kind, bool wps4, hipStream_t s) {
+    if (kind == 2) return launch_one<R, LOAD_FULL, false, true, 3>(a, s);
+    if constexpr (R == 16) {
+        return hipErrorInvalidValue;      // the Welch average at 4096 has its own kernels (welch4096*.hip)
+    } else {
+        if (kind == 0) {
+            if (wps4) return a.detrend ? launch_one<R, LOAD_HALF, true, false, 4>(a, s) : launch_one<R, LOAD_HALF, false, false, 4>(a, s);
+            return a.detrend ? launch_one<R, LOAD_HALF, true, false, 3>(a, s) : launch_one<R, LOAD_HALF, false, false, 3>(a, s);
+        }
+        return a.detrend ? launch_one<R, LOAD_FULL, true, false, 3>(a, s) : launch_one<R, LOAD_FULL, false, false, 3>(a, s);
+    }
+}
+
+template <int R> int occupancy_r(int kind, bool wps4) {
+    if (kind == 2) return occupancy_one<R, LOAD_FULL, false, true, 3>();
+    if constexpr (R == 16) {
+        return 1;
+    } else {
+        if (kind == 0) return wps4 ? occupancy_one<R, LOAD_HALF, true, false, 4>() : occupancy_one<R, LOAD_HALF, true, false, 3>();
+        return occupancy_one<R, LOAD_FULL, true, false, 3>();
+    }
+}
+
+}  // namespace
+
+bool seg_supported(int nfft) { return nfft == 1024 || nfft == 2048 || nfft == 4096; }
+
+// resident teams per CU (VGPR / LDS / wave-slot limited)
+int seg_teams_per_cu(int nfft, int kind, bool wps4) {
+    static int cache[3][3][2] = {};
+    const int ri = nfft == 1024 ? 0 : (nfft == 2048 ? 1 : 2);
+    int &c = cache[ri][kind][wps4 ? 1 : 0];
+    if (c) return c;
+    return c = nfft == 1024 ? occupancy_r<4>(kind, wps4) : (nfft == 2048 ? occupancy_r<8>(kind, wps4) : occupancy_r<16>(kind, wps4));
+}
+
+hipError_t launch_seg(int nfft, const SegArgs &a, int kind, bool wps4, hipStream_t s) {
+    switch (nfft) {
+        case 1024: return launch_r<4>(a, kind, wps4, s);
+        case 2048: return launch_r<8>(a, kind, wps4, s);
+        case 4096: return launch_r<16>(a, kind, wps4, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace oth

@@ -82,6 +82,7 @@ SIGNATURES = {
     'oth_chain_set_keep_one_in_n': (C.c_int, [_p, C.c_int]),
     'oth_chain_set_iir_log': (C.c_int, [_p, C.c_float, C.c_float]),
     'oth_chain_set_peak_hold': (C.c_int, [_p, C.c_int]),
+    'oth_chain_set_kernel': (C.c_int, [_p, C.c_int]),
     'oth_chain_reset': (C.c_int, [_p]),
     'oth_chain_push': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f, C.c_size_t, _u64p]),
     'oth_chain_push_dev': (C.c_int, [_p, _p, C.c_size_t, _p, C.c_size_t, _u64p]),
@@ -510,6 +511,9 @@ class Chain(object):
     def set_iir_log(self, alpha, k_db):
         self.ctx.check(self.ctx.lib.oth_chain_set_iir_log(self.h, float(alpha), float(k_db)),
                        'oth_chain_set_iir_log')
+
+    def set_kernel(self, which):
+        self.ctx.check(self.ctx.lib.oth_chain_set_kernel(self.h, int(which)), 'oth_chain_set_kernel')
 
     def set_peak_hold(self, on):
         self.ctx.check(self.ctx.lib.oth_chain_set_peak_hold(self.h, 1 if on else 0), 'oth_chain_set_peak_hold')

@@ -68,7 +68,7 @@ extern "C" {
 /* kernel selection (diagnostics / parity tests) */
 #define OTH_KERNEL_AUTO      0
 #define OTH_KERNEL_GENERIC   1   /* radix-4 Stockham, any power of two 16..16384 */
-#define OTH_KERNEL_TUNED     2   /* radix-16x16x16 register/LDS kernel (nfft 4096) */
+#define OTH_KERNEL_TUNED     2   /* register/LDS radix-16 kernels (nfft 1024, 2048, 4096, 16384) */
 
 /* how the welch4096 kernel hands segments to workgroups */
 #define OTH_SCHED_CONTIGUOUS  0   /* fixed contiguous runs: bit-reproducible sums */
@@ -137,8 +137,9 @@ int oth_plan_set_output_db(oth_plan *plan, int enable);      /* 10*log10 in the 
 int oth_plan_set_kernel(oth_plan *plan, int which);           /* OTH_KERNEL_* */
 int oth_plan_set_schedule(oth_plan *plan, int which);         /* OTH_SCHED_* */
 int oth_plan_out_len(oth_plan *plan, int *n);
-/* Launch tuning for A/B tools and the parity suite: which build of the 4096-point kernel ("dpp", "pipe", "ws";
- * NULL or "" = the library's choice), a schedule override (-1 = the plan's), segments per chunk and per tail chunk
+/* Launch tuning for A/B tools and the parity suite: which build of the 4096-point kernel ("dpp", "pipe", "ws") or
+ * of the 1024 / 2048-point kernel ("seg3", "seg4": registers held to 3 / 4 waves per SIMD; NULL or "" = the
+ * library's choice), a schedule override (-1 = the plan's), segments per chunk and per tail chunk
  * (0 = default).  The OTH_W4096_VARIANT / _SCHED / _CHUNK / _TAIL environment variables give the initial values
  * and are read once, in oth_welch_plan(). */
 int oth_plan_set_tuning(oth_plan *plan, const char *variant, int sched, int chunk, int tail_chunk);
@@ -201,6 +202,7 @@ int oth_chain_set_keep_one_in_n(oth_chain *chain, int n);     /* local_worker.py
 /* single_pole_iir_filter_ff(alpha) + nlog10_ff(10, N, k_db); alpha<=0 disables */
 int oth_chain_set_iir_log(oth_chain *chain, float alpha, float k_db);
 int oth_chain_set_peak_hold(oth_chain *chain, int enable);    /* psd_logger.py:85 */
+int oth_chain_set_kernel(oth_chain *chain, int which);         /* OTH_KERNEL_GENERIC: coverage kernels (parity tests) */
 int oth_chain_reset(oth_chain *chain);
 /* feed nsamples (host, or device when src_is_device); rows_out (host, may be
  * NULL) receives up to rows_capacity post-epilogue rows (dB rows when the IIR/log

@@ -190,7 +190,7 @@ def test_welch_bad_plans_are_rejected(ctx, hip):
         with pytest.raises(hip.HipError):
             ctx.welch_plan(**kw)
     with pytest.raises(hip.HipError):       # tuned kernel forced on a size it does not cover
-        ctx.welch_plan(1024, kernel=hip.KERNEL_TUNED).exec(R.synth_iq(4096, 1))
+        ctx.welch_plan(512, kernel=hip.KERNEL_TUNED).exec(R.synth_iq(4096, 1))
 
 
 def test_welch_streaming_chunks_equal_one_shot(ctx):
@@ -343,7 +343,13 @@ def test_chain_sensor_v2_rows_and_mean8(ctx, hip, golden):
     ch = ctx.chain(1024, None, True, hip.EPI_MAG2_OVER_N2, 1)
     rows, n = ch.push(g['x'])
     assert n == 64 and rows.shape == (64, 1024)
-    assert relerr(rows, g['expected_rows']) < RTOL
+    # A single rectangular-window periodogram of noise has bins down to 1e-5 of the mean level; there an fp32
+    # FFT's amplitude rounding (~3e-7 of the rms amplitude, FFTW3f - what fft_vcc runs - included) is 1e-4 of
+    # the bin's power.  Such bins are judged against 1e-3 of the row's typical level; the averaged quantities
+    # (8-row mean here, every Welch PSD elsewhere) keep the plain 1e-4 on every bin.
+    ref = g['expected_rows']
+    assert np.max(np.abs(rows - ref) / np.maximum(ref, 1e-3 * np.median(ref))) < RTOL
+    assert np.mean(np.abs(rows - ref) / ref) < 2e-6
     assert relerr(ctx.rows_group_mean(rows, 8), g['expected_mean8']) < RTOL
 
 
@@ -821,3 +827,100 @@ def test_scan_decide_dev_on_device_rows(ctx, hip):
     # host-row convenience form goes through the same entry point
     m3, n3, p3 = bp.decide(rows)
     assert np.array_equal(m3, mask) and np.array_equal(p3, plc)
+
+
+# ------------------------------------------- segfft.hip: 1024 / 2048 Welch, fused chain ----
+
+@pytest.mark.parametrize('nfft', [1024, 2048])
+@pytest.mark.parametrize('build', ['seg3', 'seg4'])
+def test_seg_welch_vs_oracle_and_generic(ctx, hip, nfft, build):
+    """The team-per-segment kernel (wave-per-segment at 1024) against the float64 oracle and the coverage kernel:
+    50 % overlap (kept half in registers) and other steps, detrend on / off, a DC offset 30x the noise, segment
+    counts around chunk and grid multiples, three streams, all schedules."""
+    rng = np.random.default_rng(nfft)
+    x = R.synth_iq(nfft * 40 + 77, 500 + nfft)
+    for nov, det in ((nfft // 2, True), (nfft // 2, False), (0, True), (nfft - 1, True), (nfft // 4, False)):
+        _, ref = R.welch_np(x[:nfft * 12 + 5], fs=3.0, nperseg=nfft, noverlap=nov, nfft=nfft,
+                            detrend='constant' if det else False)
+        plan = ctx.welch_plan(nfft, noverlap=nov, window=hann(nfft), fs=3.0,
+                              detrend=hip.DETREND_CONSTANT if det else hip.DETREND_NONE, kernel=hip.KERNEL_TUNED)
+        plan.set_tuning(build)
+        assert relerr(plan.exec(x[:nfft * 12 + 5]), ref) < RTOL, (nov, det)
+        plan.close()
+    xdc = (rng.standard_normal(nfft * 30) + 1j * rng.standard_normal(nfft * 30) + (30.0 - 18.0j)).astype(np.complex64)
+    _, ref = R.welch_np(xdc, nperseg=nfft, nfft=nfft)
+    plan = ctx.welch_plan(nfft, window=hann(nfft), kernel=hip.KERNEL_TUNED)
+    plan.set_tuning(build)
+    assert relerr(plan.exec(xdc), ref) < RTOL
+    # device-resident, many segments, 1-3 streams, schedules and chunk sizes vs the coverage kernel
+    step = nfft // 2
+    nmax = nfft + step * 20000
+    d_in = ctx.alloc(3 * nmax * 8)
+    d_a, d_b = ctx.alloc(3 * nfft * 4), ctx.alloc(3 * nfft * 4)
+    try:
+        ctx.synth_iq(d_in, 3 * nmax, 31, R.TONES, R.DC)
+        gen = ctx.welch_plan(nfft, window=hann(nfft), kernel=hip.KERNEL_GENERIC)
+        for nseg in [1, 2, 3, 15, 16, 17, 255, 4095, 4097, 16383, 20000] + [int(v) for v in rng.integers(1, 20000, 5)]:
+            n = nfft + step * (nseg - 1) + int(rng.integers(0, step))
+            ns = int(rng.integers(1, 4))
+            plan.set_schedule(int(rng.integers(0, 3)))
+            plan.set_tuning(build, chunk=int(rng.integers(0, 6)))
+            assert plan.exec_dev(d_in, n, d_a, nstreams=ns, stream_stride=nmax) == nseg
+            assert gen.exec_dev(d_in, n, d_b, nstreams=ns, stream_stride=nmax) == nseg
+            a = ctx.d2h(d_a, (ns, nfft), np.float32)
+            b = ctx.d2h(d_b, (ns, nfft), np.float32)
+            err = np.max(np.abs(a.astype(np.float64) - b) / np.maximum(b, 0.1 * np.median(b)))
+            assert err < 5e-5, (nseg, ns, err)
+    finally:
+        for ptr in (d_in, d_a, d_b):
+            ctx.free(ptr)
+
+
+@pytest.mark.parametrize('nfft', [1024, 2048, 4096])
+def test_fused_chain_many_rows_iir_peak_and_plain(ctx, hip, nfft):
+    """The fused periodogram chain over thousands of kept vectors in one launch (IIR as a weighted sum over the
+    launch, peak hold as a max) against the sequential oracle, against the coverage kernels, across pushes that
+    split vectors, with keep_one_in_n = 3."""
+    from ofdm_tools import windows
+    rows_n, keep = 700, 3
+    x = R.synth_iq(nfft * rows_n * keep + 123, 900 + nfft)
+    w = windows.blackmanharris(nfft)
+    k = -10 * np.log10(nfft) - 10 * np.log10(2.0e6)
+    lin, db = R.chain_local_worker(x, nfft, 2000000, 0.05, decim=keep)          # slow IIR: hundreds of rows matter
+    assert len(db) == rows_n
+    for kern in (hip.KERNEL_AUTO, hip.KERNEL_GENERIC):
+        ch = ctx.chain(nfft, w, True, hip.EPI_MAG2, keep)
+        ch.set_kernel(kern)
+        ch.set_iir_log(0.05, k)
+        cut = nfft * 1000 + 17
+        r1, n1 = ch.push(x[:cut], max_rows=2)
+        r2, n2 = ch.push(x[cut:], max_rows=5)
+        assert n1 + n2 == rows_n and len(r2) == 5
+        assert relerr(10 ** ((r2.astype(np.float64) - k) / 10), lin[-5:]) < RTOL, kern
+        assert relerr(10 ** ((r1.astype(np.float64) - k) / 10), lin[n1 - 2:n1]) < RTOL, kern
+        assert relerr(ch.iir(), lin[-1]) < RTOL
+    # alpha = 1: the filter forgets everything but the last row
+    ch = ctx.chain(nfft, w, True, hip.EPI_MAG2, keep)
+    ch.set_iir_log(1.0, 0.0)
+    r, n = ch.push(x, max_rows=1)
+    last = R.chain_local_worker(x, nfft, 2000000, 1.0, decim=keep)[0][-1]
+    assert relerr(10 ** (r[0].astype(np.float64) / 10), last) < RTOL
+    # peak hold on |X| (psd_logger): natural order
+    mag, peak = R.chain_psd_logger(x[:nfft * 300], nfft, decim=2)
+    ch = ctx.chain(nfft, w, False, hip.EPI_MAG, 2)
+    ch.set_peak_hold(True)
+    r1, n1 = ch.push(x[:nfft * 100 + 5], max_rows=1)
+    assert relerr(ch.peak(), peak[n1 - 1]) < RTOL and relerr(r1[0], mag[n1 - 1]) < RTOL
+    r2, n2 = ch.push(x[nfft * 100 + 5:nfft * 300], max_rows=3)
+    assert n1 + n2 == len(mag) and relerr(r2, mag[-3:]) < RTOL and relerr(ch.peak(), peak[-1]) < RTOL
+    # plain rows (spectrum_sensor_v2): all rows handed back, and the latest-wins form
+    ref = R.chain_sensor_v2(x[:nfft * 64], nfft)
+    ch = ctx.chain(nfft, None, True, hip.EPI_MAG2_OVER_N2, 1)
+    rows, n = ch.push(x[:nfft * 64])
+    # single periodograms have bins 1e-5 of the mean level, where fp32 rounding of the amplitude is 1e-4 of the
+    # power: judge those against the row's typical level
+    floor = 1e-3 * np.median(ref)
+    assert n == 64 and np.max(np.abs(rows - ref) / np.maximum(ref, floor)) < RTOL
+    ch.reset()
+    rows, n = ch.push(x[:nfft * 64], max_rows=1)
+    assert n == 64 and np.max(np.abs(rows[0] - ref[-1]) / np.maximum(ref[-1], floor)) < RTOL
