@@ -392,7 +392,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.fd = p->d_fd;
     if (tuned || tuned_csd || tuned_16k || tuned_seg) {
         a.sched = p->tune_sched >= 0 ? p->tune_sched : p->sched;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? 2 : (tuned ? var->chunk : (tuned_seg ? 16 : 8)));
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? 2 : (tuned ? var->chunk : (tuned_seg ? (p->nfft == 1024 ? 32 : 16) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;

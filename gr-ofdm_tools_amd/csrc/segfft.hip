@@ -98,8 +98,8 @@ template <class F> __device__ __forceinline__ void twiddle_pow16(const float2 (&
     wi[3] = w6.i3;
     // the products below are loop-invariant: without this the compiler hoists all nine out of the segment loop
     // and keeps them in registers (+36 VGPRs per pass)
+    // (every product has a wj factor: making those three opaque is enough, and costs six copies instead of twelve)
     asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wj[2].x), "+v"(wj[2].y), "+v"(wj[3].x), "+v"(wj[3].y));
-    asm volatile("" : "+v"(wi[1].x), "+v"(wi[1].y), "+v"(wi[2].x), "+v"(wi[2].y), "+v"(wi[3].x), "+v"(wi[3].y));
     put(std::integral_constant<int, 0>{}, v[0]);
     static_for<1, 16>([&](auto kc) {
         constexpr int k = decltype(kc)::value, i = k >> 2, j = k & 3;
@@ -184,8 +184,9 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
                     kw[a] = make_float2(r.x * win[a], r.y * win[a]);
                     sum = cadd(sum, r);
                 }
-                if (s + 1 < se) {
-                    const float2 *xn = xb + (s + 2) * (long long)(N / 2) + t;
+                {   // unconditional: a prefetch under `if (s + 1 < se)` makes nxt a phi and costs 32 register copies per
+                    // segment; the chunk's last segment re-reads the half it has just consumed (valid, L2-resident)
+                    const float2 *xn = xb + (s + (s + 1 < se ? 2 : 1)) * (long long)(N / 2) + t;
 #pragma unroll
                     for (int a = 0; a < 8; ++a) nxt[a] = load_once(xn + T * a);
                 }
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
                     v[a] = make_float2(r.x * win[a], r.y * win[a]);
                     sum = cadd(sum, r);
                 }
-                if (s + 1 < se) {
-                    const float2 *xn = xb + (s + 1) * p.step + t;
+                {   // unconditional (see above): the chunk's last segment re-reads itself
+                    const float2 *xn = xb + (s + (s + 1 < se ? 1 : 0)) * p.step + t;
 #pragma unroll
                     for (int a = 0; a < 16; ++a) nxt[a] = load_once(xn + T * a);
                 }

@@ -91,8 +91,12 @@ elif cfg.startswith('chain'):
 else:
     sys.exit('unknown config ' + cfg)
 
-run()
-ctx.sync()
+import time  # noqa: E402
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.2:      # clock ramp: an idle MI355X sits at its lowest sclk level
+    for _ in range(4):
+        run()
+    ctx.sync()
 ctx.set_timing(True)
 ctx.get_timing()
 for _ in range(reps):
