@@ -340,6 +340,9 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     // welch4096 covers nperseg = 256, 512, ..., 4096 (zero-padded to 4096)
     bool tuned = p->nfft == 4096 && p->nperseg >= 256 && (p->nperseg & (p->nperseg - 1)) == 0 && !csd;
     const bool tuned_csd = csd && p->nfft == 4096 && p->nperseg == 4096 && p->kernel != OTH_KERNEL_GENERIC;
+    // wave-specialised pairs (csd4096ws.hip): 50 % overlap, frequency-domain detrend; "csd1" forces the one-role kernel
+    const bool csd_ws = tuned_csd && p->step == 2048 && (p->detrend == OTH_DETREND_NONE || p->d_fd) &&
+                        nseg < (1LL << 30) && p->tune_variant != "csd1";
     const bool tuned_16k = !csd && p->nfft == 16384 && p->nperseg == 16384 && p->kernel != OTH_KERNEL_GENERIC;
     // segfft.hip: nperseg = nfft = 1024 / 2048, any step (team of nfft / 16 threads per segment)
     const bool tuned_seg = !csd && (p->nfft == 1024 || p->nfft == 2048) && p->nperseg == p->nfft &&
@@ -358,7 +361,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     if (tuned || tuned_csd || tuned_16k || tuned_seg) {
         // exactly the resident workgroups: one wave of workgroups, no tail round
         const int bpc = tuned ? var->blocks_per_cu()
-                              : (tuned_csd ? csd4096_blocks_per_cu()
+                              : (tuned_csd ? (csd_ws ? csd4096ws_blocks_per_cu() : csd4096_blocks_per_cu())
                                            : (tuned_seg ? seg_teams_per_cu(p->nfft, seg_kind, seg_wps4) : 1));
         long long w = ((long long)c->cu_count * bpc + nstreams - 1) / nstreams;
         W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
@@ -392,6 +395,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.fd = p->d_fd;
     if (tuned || tuned_csd || tuned_16k || tuned_seg) {
         a.sched = p->tune_sched >= 0 ? p->tune_sched : p->sched;
+        // one 1024-thread workgroup per CU and equal work per segment: contiguous runs beat the ticket queue (+3 %)
+        if (csd_ws && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC) a.sched = OTH_SCHED_CONTIGUOUS;
         a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? 2 : (tuned ? var->chunk : (tuned_seg ? (p->nfft == 1024 ? 32 : 16) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
@@ -436,7 +441,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     } else {
         Timed tm(c);
         HIPCHK(c, tuned ? var->launch(a, c->stream)
-                        : (tuned_csd ? launch_csd_tuned4096(a, c->stream)
+                        : (tuned_csd ? (csd_ws ? launch_csd_tuned4096ws(a, c->stream) : launch_csd_tuned4096(a, c->stream))
                                      : (tuned_16k ? launch_welch_tuned16k(a, c->stream)
                                                   : launch_welch_generic(p->nfft, a, c->stream))));
     }
@@ -803,7 +808,8 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
     if (sched < -1 || sched > OTH_SCHED_DYNAMIC || chunk < 0 || tail_chunk < 0)
         return fail(p->ctx, OTH_ERR_INVALID, "bad tuning value");
     if (variant && *variant) {
-        bool known = !strcmp(variant, "seg3") || !strcmp(variant, "seg4");      // builds of the 1024 / 2048 kernel
+        bool known = !strcmp(variant, "seg3") || !strcmp(variant, "seg4") ||    // builds of the 1024 / 2048 kernel
+                     !strcmp(variant, "csd1");                                  // the one-role two-channel kernel
         for (const auto &v : kVariants) known = known || !strcmp(variant, v.tag);
         if (!known) return fail(p->ctx, OTH_ERR_UNSUPPORTED, std::string("unknown kernel build: ") + variant);
     }

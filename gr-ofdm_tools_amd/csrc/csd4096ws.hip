@@ -1,0 +1,335 @@
+// csd4096ws: two-channel Welch cross spectrum for nperseg = nfft = 4096, 50 % overlap (BASELINE config 3) as TWO
+// wave-specialised pairs in one 1024-thread workgroup per CU.
+//
+// Semantics of scipy.signal.csd / coherence with the Welch parameters of ofdm_cr_tools.py:322,342 (SURVEY.md 8a
+// row a13: the producer of coherence_detector's first input, coherence_detector.py:45):
+//     Pxx += |X|^2    Pyy += |Y|^2    Pxy += conj(X) Y
+//
+// Threads   0..255  Px  producer of stream x: loads, window, pass 1, exchange-1 writes        (as welch4096ws.hip)
+//         256..511  Py  producer of stream y
+//         512..1023 C   eight consumer waves; in each, lanes 0..31 consume x and lanes 32..63 consume y FOR THE SAME
+//                       BINS (consumer index t = 32 wave + lane % 32 on the lane half's own pair of LDS images):
+//                       pass 2, exchange 2, pass 3; x lanes accumulate |X|^2 and Re conj(X) Y, y lanes |Y|^2 and Im.
+// Each stream's pair of images works exactly as in the headline kernel (one LDS-only barrier per step, the consumers
+// one segment behind the producers).  What is new is the exchange of spectra: X[k] and Y[k] of one bin sit in
+// lanes l and l + 32 of one wave, so thirty-two ds_bpermute_b32 (the LDS crossbar, no memory, no barrier) hand
+// each lane its partner's sixteen bins.  Every thread carries 32 accumulators (the one-role csd4096 kernel: 64,
+// which held it at three waves per SIMD with no room to keep the overlapped halves or to prefetch): both streams
+// are read once, the halves stay in registers, the next halves are prefetched, four waves per SIMD.
+//
+// The two pairs run the same chunk schedule (Px draws the tickets, Py reads them), so x_s and y_s are always in
+// the same step.  Frequency-domain detrend as in welch4096ws.hip (needs WelchArgs.fd).
+#include <type_traits>
+#include "fft4096.hip.h"
+
+#ifndef OTH_CSDWS_STORED_TW
+#define OTH_CSDWS_STORED_TW 0      // 1: the consumer keeps its fifteen pass-2 twiddles in registers (A/B switch)
+#endif
+
+namespace oth {
+namespace {
+
+constexpr int TCS = 1024;
+constexpr int CS_RED = 32;                 // float2 per pair: per image the four producer waves' segment sums
+constexpr int CS_CTRL = 16;                // ints per pair: item kind per image [0..1], next-chunk ticket [4] (pair 0)
+constexpr size_t CS_PAIR_BYTES = (2 * LDS_X + CS_RED) * sizeof(float2) + CS_CTRL * sizeof(int);
+constexpr size_t CS_LDS_BYTES = 2 * CS_PAIR_BYTES;
+
+enum { CS_STOP = 0, CS_DATA = 1, CS_BUBBLE = 2 };
+
+template <bool DETREND>
+__global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const bool producer = tid < 512;
+    const int cidx = tid - 512;                                   // consumers: x in lanes 0..31, y in lanes 32..63
+    // producers: one stream per team, wave-uniform (scalar base addresses); consumers: per lane half
+    const int pair = producer ? __builtin_amdgcn_readfirstlane(tid >> 8) : ((cidx >> 5) & 1);
+    unsigned char *base = smem + pair * CS_PAIR_BYTES;
+    float2 *img = reinterpret_cast<float2 *>(base);             // two images of LDS_X float2
+    float2 *red = img + 2 * LDS_X;
+    int *ctrl = reinterpret_cast<int *>(red + CS_RED);
+    int *ctrl0 = reinterpret_cast<int *>(reinterpret_cast<float2 *>(smem) + 2 * LDS_X + CS_RED);   // pair 0's: the ticket
+
+    const int t = producer ? (tid & 255) : (((cidx >> 6) << 5) | (cidx & 31));
+    const int hi = t >> 4, lo = t & 15;
+    const int wave = t >> 6;
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const float2 *xb = (pair ? p.y : p.x) + (size_t)stream * p.stream_stride;
+    const int sched = p.sched;
+    const long long nchunks = sched ? chunk_count(p) : 1;
+    const int w1 = hi * 17 + lo, r1 = hi * RS + lo, w2 = hi * RS + lo, r2 = hi * RS + lo * 17;
+
+    if (producer) {
+        // ------------------------------------------------------------------ producer (welch4096ws.hip)
+        float win[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) win[a] = p.win[256 * a + t];
+        const float2 b1 = p.tw[t], b4 = p.tw[4 * t];
+        float2 kw[8], nxt[8];
+        float2 prev_new = make_float2(0.f, 0.f);
+        int it = 0;
+        unsigned ticket = 0;
+        using std::false_type;
+        using std::true_type;
+        using mid = std::integral_constant<int, 0>;
+        using head = std::integral_constant<int, 1>;
+        using none = std::integral_constant<int, 2>;
+        auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        auto load_chunk_head = [&](int first_seg) {
+            const float2 *xs = xb + (size_t)uni(first_seg) * 2048;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 *xj = xs + 512 * j;
+                kw[2 * j] = xj[(unsigned)t];
+                kw[2 * j + 1] = xj[(unsigned)t + 256u];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 *xj = xs + 2048 + 512 * j;
+                nxt[2 * j] = load_once(xj + (unsigned)t);
+                nxt[2 * j + 1] = load_once(xj + ((unsigned)t + 256u));
+            }
+        };
+        auto step_end = [&](int item) {
+            if (t == 0) ctrl[it & 1] = item;
+            lds_barrier();
+            ++it;
+        };
+        auto item = [&](auto first_, auto mode_, int s, int nsb, bool publish) {
+            constexpr bool FIRST = decltype(first_)::value;
+            constexpr int MODE = decltype(mode_)::value;
+            const int q = it & 1;
+            float2 *lx = img + q * LDS_X;
+            __builtin_amdgcn_s_setprio(2);
+            float2 v[16];
+            float2 sumf = make_float2(0.f, 0.f), sum = make_float2(0.f, 0.f);
+            if (FIRST) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    sumf = cadd(sumf, kw[a]);
+                    kw[a] = make_float2(kw[a].x * win[a], kw[a].y * win[a]);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const float2 r = nxt[a];
+                v[a] = kw[a];
+                v[8 + a] = make_float2(r.x * win[8 + a], r.y * win[8 + a]);
+                if (MODE == 0) kw[a] = make_float2(r.x * win[a], r.y * win[a]);
+                sum = cadd(sum, r);
+            }
+            if (sched == 2 && t == 0 && pair == 0) {      // one ticket stream for both pairs
+                if (FIRST) ticket = atomicAdd(p.queue + stream, 1u);
+                if (publish) ctrl0[4] = (int)ticket;
+            }
+            if (MODE == 0) {
+                const float2 *xn = xb + (size_t)uni(s + 2) * 2048;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float2 *xj = xn + 512 * j;
+                    nxt[2 * j] = load_once(xj + (unsigned)t);
+                    nxt[2 * j + 1] = load_once(xj + ((unsigned)t + 256u));
+                }
+            } else if (MODE == 1) {
+                load_chunk_head(nsb);
+            }
+            if (DETREND) {
+                sum.x = wave_total_lane63(sum.x);
+                sum.y = wave_total_lane63(sum.y);
+                float2 other = prev_new;
+                if (FIRST) other = make_float2(wave_total_lane63(sumf.x), wave_total_lane63(sumf.y));
+                if ((t & 63) == 63) red[q * 8 + wave] = cadd(sum, other);
+                prev_new = sum;
+            }
+            __builtin_amdgcn_s_setprio(0);
+            dft16(v);
+            __builtin_amdgcn_s_setprio(2);
+            scatter_pow16<RS>(v, lx + w1, b1, b4);
+            step_end(CS_DATA);
+        };
+
+        int cur = 0, sb = 0, se = 0;
+        auto range = [&](int c, int &b, int &e) {
+            long long lb, le;
+            chunk_range(p, c, lb, le);
+            b = uni((int)lb);
+            e = uni((int)le);
+        };
+        auto open_chunk = [&](int c) -> bool {
+            cur = c;
+            if (sched) {
+                if (cur >= nchunks) return false;
+                range(cur, sb, se);
+                return true;
+            }
+            sb = uni((int)((p.nseg * wg) / W));
+            se = uni((int)((p.nseg * (wg + 1)) / W));
+            return sb < se;
+        };
+        bool have = open_chunk(sched ? wg : 0);
+        if (have) load_chunk_head(sb);
+        while (have) {
+            const int n = se - sb;
+            int ncur = 0;
+            if (n >= 2) {
+                item(true_type{}, mid{}, sb, 0, n == 2);
+                int s = sb + 1;
+                if (s < se - 1) item(false_type{}, mid{}, s++, 0, true);
+                for (; s + 1 < se - 1; s += 2) {
+                    item(false_type{}, mid{}, s, 0, false);
+                    item(false_type{}, mid{}, s + 1, 0, false);
+                }
+                if (s < se - 1) item(false_type{}, mid{}, s, 0, false);
+                ncur = (sched == 1) ? cur + W : W + uni(ctrl0[4]);
+                int nsb = 0, nse = 0;
+                const bool have_next = sched && ncur < nchunks;
+                if (have_next) {
+                    range(ncur, nsb, nse);
+                    item(false_type{}, head{}, se - 1, nsb, false);
+                    cur = ncur;
+                    sb = nsb;
+                    se = nse;
+                    continue;
+                }
+                item(false_type{}, none{}, se - 1, 0, false);
+                break;
+            }
+            item(true_type{}, none{}, sb, 0, true);
+            if (sched == 0) break;
+            if (sched == 2) {
+                step_end(CS_BUBBLE);
+                ncur = W + uni(ctrl0[4]);
+            } else {
+                ncur = cur + W;
+            }
+            have = open_chunk(ncur);
+            if (have) load_chunk_head(sb);
+        }
+        step_end(CS_STOP);
+    } else {
+        // ------------------------------------------------------------------ consumer
+        // W256^c, W256^(4c): the fifteen pass-2 twiddles are multiplied out per item (32 accumulators leave no room
+        // for the thirty registers the headline kernel's consumer spends on them)
+#if OTH_CSDWS_STORED_TW
+        float2 tw2[16];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tw2[k] = p.tw[16 * lo * k];
+#else
+        const float2 c1 = p.tw[16 * lo], c4 = p.tw[64 * lo];
+#endif
+        float4 fw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DETREND) fw = p.fd[t];
+        float acs[16], acx[16];       // own power |X|^2 (or |Y|^2); cross term Re (pair 0) or Im (pair 1) of conj(X) Y
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acs[k] = acx[k] = 0.f;
+        float2 v[16];
+        float2 mean = make_float2(0.f, 0.f);
+        int it = 0;
+
+        // barrier A of step `it`, then what the producer left in image it & 1: item word, sums, pass 2
+        auto next_item = [&]() -> int {
+            __builtin_amdgcn_s_setprio(2);
+            lds_barrier();
+            const int q = it & 1;
+            const float2 *lq = img + q * LDS_X;
+            const int kind = __builtin_amdgcn_readfirstlane(ctrl0[q]);      // both streams run the same schedule
+            const float2 h0 = red[q * 8], h1 = red[q * 8 + 1], h2 = red[q * 8 + 2], h3 = red[q * 8 + 3];
+            dft16_from_lds<17>(v, lq + r1, [] { __builtin_amdgcn_s_setprio(1); });
+            if (DETREND) {
+                const float2 tot = cadd(cadd(h0, h1), cadd(h2, h3));
+                mean = make_float2(tot.x * (1.0f / 4096.0f), tot.y * (1.0f / 4096.0f));
+            }
+            ++it;
+            return kind;
+        };
+        const int partner = ((tid & 63) ^ 32) << 2;      // ds_bpermute address of the lane that holds the other stream's bin
+        int item = next_item();
+        for (;;) {
+            while (item == CS_BUBBLE) item = next_item();
+            if (item == CS_STOP) break;
+            const int q = (it & 1) ^ 1;   // the image whose pass 2 sits in v
+            float2 *lx = img + q * LDS_X;
+            __builtin_amdgcn_s_setprio(2);
+#if OTH_CSDWS_STORED_TW
+            lx[w2] = v[r16(0)];
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) lx[w2 + k1 * 17] = cmul(v[r16(k1)], tw2[k1]);
+#else
+            scatter_pow16<17>(v, lx + w2, c1, c4);
+#endif
+            wave_lds_sync();
+            dft16_from_lds<1>(v, lx + r2, [] { __builtin_amdgcn_s_setprio(1); });
+            if (DETREND) {
+                v[r16(0)] = make_float2(v[r16(0)].x - (mean.x * fw.x - mean.y * fw.y),
+                                        v[r16(0)].y - (mean.x * fw.y + mean.y * fw.x));
+                v[r16(15)] = make_float2(v[r16(15)].x - (mean.x * fw.z - mean.y * fw.w),
+                                         v[r16(15)].y - (mean.x * fw.w + mean.y * fw.z));
+            }
+            __builtin_amdgcn_s_setprio(2);
+            // conj(X) Y with own = this lane's bin, o = the partner lane's:  x lanes  Re = Xr Yr + Xi Yi = own.x o.x + own.y o.y
+            //                                                                y lanes  Im = Xr Yi - Xi Yr = own.y o.x - own.x o.y
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float2 o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float2 m = v[r16(4 * g + j)];
+                    o[j].x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(m.x)));
+                    o[j].y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(m.y)));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k2 = 4 * g + j;
+                    const float2 m = v[r16(k2)];
+                    const float u = pair ? m.y : m.x, w = pair ? -m.x : m.y;
+                    acx[k2] = fmaf(u, o[j].x, fmaf(w, o[j].y, acx[k2]));
+                    acs[k2] = fmaf(m.x, m.x, fmaf(m.y, m.y, acs[k2]));
+                }
+            }
+            item = next_item();
+        }
+        // channels xx, yy, re, im; bin k0 + 16 k1 + 256 k2 at t + 256 k2 (finalize_kernel layout 1)
+        float *dst = p.partial + ((size_t)stream * W + wg) * 4 * 4096;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            dst[(pair ? 4096 : 0) + 256 * k2 + t] = acs[k2];
+            dst[(pair ? 12288 : 8192) + 256 * k2 + t] = acx[k2];
+        }
+    }
+}
+
+}  // namespace
+
+int csd4096ws_blocks_per_cu() {
+    static int cached = 0;
+    if (cached) return cached;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, csd4096ws_kernel<true>, TCS, CS_LDS_BYTES) != hipSuccess || n < 1)
+        n = 1;
+    return cached = n;
+}
+
+hipError_t launch_csd_tuned4096ws(const WelchArgs &a, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    static bool armed[64] = {};        // 140 KiB of dynamic LDS needs the opt-in, once per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63, armed[63] = false;
+    bool &big_lds = armed[dev];
+    if (!big_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(csd4096ws_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(csd4096ws_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        big_lds = true;
+    }
+    if (a.detrend)
+        hipLaunchKernelGGL((csd4096ws_kernel<true>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
+    else
+        hipLaunchKernelGGL((csd4096ws_kernel<false>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace oth

@@ -126,6 +126,9 @@ OTH_DECL_W4096(wsx4)
 // csd4096.hip: two-channel cross spectrum, nfft = nperseg = 4096
 hipError_t launch_csd_tuned4096(const WelchArgs &a, hipStream_t s);
 int csd4096_blocks_per_cu();
+// csd4096ws.hip: the same as two wave-specialised pairs in one 1024-thread workgroup; step 2048, WelchArgs.fd for detrend
+hipError_t launch_csd_tuned4096ws(const WelchArgs &a, hipStream_t s);
+int csd4096ws_blocks_per_cu();
 // welch16k.hip: nfft = nperseg = 16384, one 1024-thread workgroup per CU
 hipError_t launch_welch_tuned16k(const WelchArgs &a, hipStream_t s);
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);

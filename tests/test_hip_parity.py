@@ -924,3 +924,38 @@ def test_fused_chain_many_rows_iir_peak_and_plain(ctx, hip, nfft):
     ch.reset()
     rows, n = ch.push(x[:nfft * 64], max_rows=1)
     assert n == 64 and np.max(np.abs(rows[0] - ref[-1]) / np.maximum(ref[-1], floor)) < RTOL
+
+
+@pytest.mark.parametrize('build', ['', 'csd1'])
+def test_csd_tuned_vs_generic_on_awkward_segment_counts(ctx, hip, build):
+    """The two-channel kernels (wave-specialised pairs with the lane-half spectrum exchange; the one-role build)
+    against the coverage kernel on device-resident streams: segment counts around chunk and grid multiples,
+    one- and two-segment chunks, all schedules, detrend on and off."""
+    rng = np.random.default_rng(17)
+    nmax = 4096 + 2048 * 5000
+    dx, dy = ctx.alloc(nmax * 8), ctx.alloc(nmax * 8)
+    outs = [ctx.alloc(5 * 4096 * 4) for _ in range(2)]
+    try:
+        ctx.synth_iq(dx, nmax, 61, R.TONES, R.DC)
+        ctx.synth_iq(dy, nmax, 62, ((0.5, 0.1234), (1.0, 0.2)), 0.3 - 0.2j)
+        for det in (hip.DETREND_CONSTANT, hip.DETREND_NONE):
+            tuned = ctx.welch_plan(4096, window=hann(4096), detrend=det, kernel=hip.KERNEL_TUNED)
+            gen = ctx.welch_plan(4096, window=hann(4096), detrend=det, kernel=hip.KERNEL_GENERIC)
+            for nseg in [1, 2, 3, 7, 8, 9, 255, 256, 257, 511, 2047, 2049, 5000] + [int(v) for v in rng.integers(1, 5000, 4)]:
+                n = 4096 + 2048 * (nseg - 1) + int(rng.integers(0, 2048))
+                tuned.set_tuning(build or None, sched=int(rng.integers(-1, 3)), chunk=int(rng.integers(0, 6)))
+                res = []
+                for plan, o in ((tuned, outs[0]), (gen, outs[1])):
+                    assert plan.csd_exec_dev(dx, dy, n, o, o + 4 * 4096, o + 8 * 4096, o + 16 * 4096) == nseg
+                    res.append(ctx.d2h(o, (5, 4096), np.float32).astype(np.float64))
+                a, b = res
+                lvl = np.sqrt(np.maximum(b[0], 0.1 * np.median(b[0])) * np.maximum(b[1], 0.1 * np.median(b[1])))
+                assert np.max(np.abs(a[0] - b[0]) / np.maximum(b[0], 0.1 * np.median(b[0]))) < 5e-5, (det, nseg)
+                assert np.max(np.abs(a[1] - b[1]) / np.maximum(b[1], 0.1 * np.median(b[1]))) < 5e-5, (det, nseg)
+                pa, pb = (r[2:4].reshape(-1, 2) for r in (a, b))           # Pxy interleaved re, im over rows 2-3
+                assert np.max(np.abs(pa - pb) / lvl[:, None]) < 5e-5, (det, nseg)
+                if nseg >= 8:
+                    assert np.max(np.abs(a[4] - b[4])) < 1e-4, (det, nseg)        # coherence
+    finally:
+        for ptr in (dx, dy) + tuple(outs):
+            ctx.free(ptr)
