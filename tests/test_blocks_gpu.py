@@ -462,3 +462,65 @@ def test_strobes_reemit_and_file_logger_thread(ctx, golden, tmp_path):
     import glob
     assert glob.glob(str(tmp_path / 'sdr_psd_cumulative_log-*.matz')) and \
         len(glob.glob(str(tmp_path / 'sdr_ss_periodic_log-*.log'))) >= 1
+
+
+# ---- multi-GPU host paths on one GPU (world 1 and ranks simulated one after another) -------------------------
+
+def test_long_stream_welch_and_coherence_through_the_hip_plans(ctx, golden):
+    """ofdm_tools.sweep.welch_long_stream / csd_long_stream on device buffers: with
+    world = 1 they equal the one-shot plan; with three ranks run one after another (each given only its time run +
+    halo, partials summed the way reduce_partials does) they equal it too."""
+    import torch
+    from ofdm_tools import sweep, windows
+    g = golden('coherence_csd_4096.npz')
+    dev = torch.device('cuda', 0)
+    x = torch.from_numpy(g['x'].view(np.float32).reshape(-1, 2)).to(dev)
+    y = torch.from_numpy(g['y'].view(np.float32).reshape(-1, 2)).to(dev)
+    torch.cuda.synchronize()
+    n = x.shape[0]
+    plan = ctx.welch_plan(4096, window=windows.get_window('hann', 4096), fs=1.0)
+    want = plan.exec(g['x'])
+    psd, nseg = sweep.welch_long_stream(plan, x.data_ptr(), 0, n, dev, 0, 1)
+    assert nseg == 31 and relerr(psd.cpu().numpy(), want) < 2e-6
+    (pxx, pyy, pxy, cxy), nseg = sweep.csd_long_stream(plan, x.data_ptr(), y.data_ptr(), 0, n, dev, 0, 1)
+    w = plan.csd(g['x'], g['y'])
+    assert nseg == 31 and relerr(pxx.cpu().numpy(), w[0]) < 2e-6 and relerr(pyy.cpu().numpy(), w[1]) < 2e-6
+    assert np.max(np.abs(cxy.cpu().numpy() - w[3])) < 1e-5
+    assert np.max(np.abs(cxy.cpu().numpy() - g['expected_cxy'])) < RTOL
+    # three ranks, one after another: each sees only its own chunk of the stream
+    world, total, count = 3, torch.zeros(4096, dtype=torch.float64, device=dev), 0
+    for r in range(world):
+        first, cnt, s0, k = sweep.time_shard(n, 4096, 2048, r, world)
+        local = x[first:first + cnt].contiguous()
+        part = torch.zeros(4096, dtype=torch.float32, device=dev)
+        assert plan.partial_dev(local.data_ptr(), cnt, part.data_ptr()) == k
+        ctx.sync()
+        total += part.to(torch.float64)
+        count += k
+    out = torch.empty(4096, dtype=torch.float32, device=dev)
+    plan.scale_dev(total.to(torch.float32).data_ptr(), count, out.data_ptr())
+    ctx.sync()
+    assert count == 31 and relerr(out.cpu().numpy(), want) < 2e-6
+
+
+def test_batched_scanner_sharded_entry_point_world_1(ctx):
+    """BatchScanPlan.scan_sharded with one rank: rows, noise floors and channel powers in
+    channel order equal the unsharded device path."""
+    import torch
+    from ofdm_tools.scan_batch import BatchScanPlan
+    N, nch, n = 16384, 3, 16384 * 4
+    dev = torch.device('cuda', 0)
+    bp = BatchScanPlan(ctx, N, 1000000, 15625.0, 10e3, thr_leveler=3.0)
+    iq = torch.empty((nch * n, 2), dtype=torch.float32, device=dev)
+    ctx.synth_iq(iq.data_ptr(), nch * n, 3000, R.TONES, R.DC)
+    ctx.sync()
+    rows, noise, power = bp.scan_sharded(iq.data_ptr(), n, n, nch, 0, 1, dev)
+    d_rows = ctx.alloc(nch * N * 4)
+    try:
+        bp.psd_rows_dev(iq.data_ptr(), n, nch, n, d_rows)
+        mask, noise2, plc = bp.decide_dev(d_rows, nch)
+        want_rows = ctx.d2h(d_rows, (nch, N), np.float32)
+    finally:
+        ctx.free(d_rows)
+    assert np.array_equal(rows.cpu().numpy(), want_rows)
+    assert np.allclose(noise.cpu().numpy(), noise2) and np.allclose(power.cpu().numpy(), plc)
