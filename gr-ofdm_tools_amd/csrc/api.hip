@@ -310,6 +310,50 @@ bool window_spectrum_table(const std::vector<float> &w, std::vector<float> &fd) 
     return true;
 }
 
+// The same table for the role-split 1024 / 2048 kernel (segfft.hip, segws_kernel<R, 2>): consumer thread
+// t = R k0 + j corrects, for k1 = j + R m (m < 16 / R), the bins k0 + 16 k1 (k2 = 0) and k0 + 16 k1 + 256 (R - 1).
+bool window_spectrum_table_seg(const std::vector<float> &w, int n, std::vector<float> &fd) {
+    const int R = n / 256, Q = 16 / R;
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    std::vector<double> re(n), im(n, 0.0);
+    double s2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        int r = 0;
+        for (int b = 0; b < lg; ++b) r |= ((i >> b) & 1) << (lg - 1 - b);
+        re[r] = (double)w[i];
+        s2 += (double)w[i] * (double)w[i];
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / len;
+        for (int i = 0; i < n; i += len)
+            for (int j = 0; j < len / 2; ++j) {
+                const double c = cos(ang * j), s = sin(ang * j);
+                const int a = i + j, b = a + len / 2;
+                const double tr = re[b] * c - im[b] * s, ti = re[b] * s + im[b] * c;
+                re[b] = re[a] - tr;
+                im[b] = im[a] - ti;
+                re[a] += tr;
+                im[a] += ti;
+            }
+    }
+    for (int k = 256; k < n - 256; ++k)
+        if (re[k] * re[k] + im[k] * im[k] > 1e-10 * s2) return false;
+    fd.assign((size_t)4 * (n / 16) * Q, 0.f);
+    for (int t = 0; t < n / 16; ++t) {
+        const int k0 = t / R, j = t % R;
+        for (int m = 0; m < Q; ++m) {
+            const int lo = k0 + 16 * (j + R * m), hi = lo + 256 * (R - 1);
+            float *o = &fd[4 * ((size_t)Q * t + m)];
+            o[0] = (float)re[lo];
+            o[1] = (float)im[lo];
+            o[2] = (float)re[hi];
+            o[3] = (float)im[hi];
+        }
+    }
+    return true;
+}
+
 int segments(const oth_plan *p, size_t nsamples, long long *nseg) {
     if (nsamples < (size_t)p->nperseg) return OTH_ERR_INVALID;
     *nseg = (long long)((nsamples - (size_t)p->noverlap) / (size_t)p->step);
@@ -349,6 +393,11 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
                            p->kernel != OTH_KERNEL_GENERIC;
     const int seg_kind = p->step == p->nfft / 2 ? 0 : 1;
     const bool seg_wps4 = p->tune_variant == "seg4";
+    // role-split build (segws_kernel): 50 % overlap; detrend in the time domain at 1024 (one producer wave), in the
+    // frequency domain at 2048 (needs the window-spectrum table); "seg3" / "seg4" force the one-role builds
+    const int seg_det = p->detrend == OTH_DETREND_NONE ? 0 : (p->nfft == 1024 ? 1 : 2);
+    const bool seg_ws = tuned_seg && seg_kind == 0 && p->tune_variant != "seg3" && !seg_wps4 &&
+                        (seg_det != 2 || p->d_fd != nullptr);
     if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
     if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd && !tuned_16k && !tuned_seg)
         return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
@@ -362,7 +411,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         // exactly the resident workgroups: one wave of workgroups, no tail round
         const int bpc = tuned ? var->blocks_per_cu()
                               : (tuned_csd ? (csd_ws ? csd4096ws_blocks_per_cu() : csd4096_blocks_per_cu())
-                                           : (tuned_seg ? seg_teams_per_cu(p->nfft, seg_kind, seg_wps4) : 1));
+                                           : (tuned_seg ? (seg_ws ? segws_teams_per_cu(p->nfft) : seg_teams_per_cu(p->nfft, seg_kind, seg_wps4)) : 1));
         long long w = ((long long)c->cu_count * bpc + nstreams - 1) / nstreams;
         W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
     }
@@ -397,7 +446,10 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         a.sched = p->tune_sched >= 0 ? p->tune_sched : p->sched;
         // one 1024-thread workgroup per CU and equal work per segment: contiguous runs beat the ticket queue (+3 %)
         if (csd_ws && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC) a.sched = OTH_SCHED_CONTIGUOUS;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? 2 : (tuned ? var->chunk : (tuned_seg ? (p->nfft == 1024 ? 32 : 16) : 8)));
+        // the role-split 1024 kernel: eight two-wave workgroups per CU even out by themselves (+4 % over the tickets)
+        if (seg_ws && p->nfft == 1024 && nstreams == 1 && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC)
+            a.sched = OTH_SCHED_CONTIGUOUS;
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? 2 : (tuned ? var->chunk : (tuned_seg ? (p->nfft == 1024 && !seg_ws ? 32 : 16) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;
@@ -436,8 +488,9 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         g.tail_chunk = a.tail_chunk;
         g.nbig = a.nbig;
         g.queue = a.queue;
+        g.fd = p->d_fd;
         Timed tm(c);
-        HIPCHK(c, launch_seg(p->nfft, g, seg_kind, seg_wps4, c->stream));
+        HIPCHK(c, seg_ws ? launch_segws(p->nfft, g, seg_det, c->stream) : launch_seg(p->nfft, g, seg_kind, seg_wps4, c->stream));
     } else {
         Timed tm(c);
         HIPCHK(c, tuned ? var->launch(a, c->stream)
@@ -742,8 +795,9 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_win, w.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_sum, 0, sizeof(float) * nfft, c->stream);
     std::vector<float> fd;
-    if (e == hipSuccess && nfft == 4096 && nperseg == 4096 && detrend == OTH_DETREND_CONSTANT &&
-        window_spectrum_table(w, fd)) {
+    if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT &&
+        ((nfft == 4096 && nperseg == 4096 && window_spectrum_table(w, fd)) ||
+         (nfft == 2048 && nperseg == 2048 && window_spectrum_table_seg(w, nfft, fd)))) {
         e = hipMalloc(&p->d_fd, sizeof(float) * fd.size());
         if (e == hipSuccess)
             e = hipMemcpyAsync(p->d_fd, fd.data(), sizeof(float) * fd.size(), hipMemcpyHostToDevice, c->stream);
@@ -808,7 +862,7 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
     if (sched < -1 || sched > OTH_SCHED_DYNAMIC || chunk < 0 || tail_chunk < 0)
         return fail(p->ctx, OTH_ERR_INVALID, "bad tuning value");
     if (variant && *variant) {
-        bool known = !strcmp(variant, "seg3") || !strcmp(variant, "seg4") ||    // builds of the 1024 / 2048 kernel
+        bool known = !strcmp(variant, "seg3") || !strcmp(variant, "seg4") || !strcmp(variant, "segws") ||   // 1024 / 2048
                      !strcmp(variant, "csd1");                                  // the one-role two-channel kernel
         for (const auto &v : kVariants) known = known || !strcmp(variant, v.tag);
         if (!known) return fail(p->ctx, OTH_ERR_UNSUPPORTED, std::string("unknown kernel build: ") + variant);

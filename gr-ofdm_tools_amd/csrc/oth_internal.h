@@ -39,6 +39,7 @@ struct SegArgs {
     int nstreams;
     const float *win;       // nfft floats
     const float2 *tw;       // W_nfft^k, nfft entries
+    const float4 *fd;       // role-split build, frequency-domain detrend: [nfft / 16 threads][16 / R] window-spectrum pairs
     long long first;        // sample index of segment 0 (chain: first kept vector)
     long long step;         // samples between segment starts (chain: keep_n * nfft)
     long long nseg;         // segments per stream
@@ -137,6 +138,8 @@ bool seg_supported(int nfft);
 // kind: 0 Welch with step = nfft / 2 (the overlapped half stays in registers), 1 Welch with any step, 2 chain
 int seg_teams_per_cu(int nfft, int kind, bool wps4);
 hipError_t launch_seg(int nfft, const SegArgs &a, int kind, bool wps4, hipStream_t s);
+int segws_teams_per_cu(int nfft);
+hipError_t launch_segws(int nfft, const SegArgs &a, int det, hipStream_t s);
 // partial rows of a chain launch + the stored raw rows -> IIR / peak state and the rows handed back
 hipError_t launch_chain_tail(const float *partial, int W, int nfft, int fftshift, int acc_mode, long long nbase,
                              float alpha, float kdb, float *iir_state, float *peak_state, int *peak_init,

@@ -383,6 +383,311 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// segws: the Welch average at 50 % overlap with the team split by role, as welch4096ws.hip does for 4096 points:
+// a PRODUCER team of 16 R threads (loads, window, pass 1, exchange-1 writes) and a CONSUMER team of 16 R threads
+// (pass 2, exchange 2, pass 3, |X|^2 accumulation) one segment apart on two LDS images, one LDS-only barrier per
+// segment.  At R = 4 that is one producer wave and one consumer wave per 128-thread workgroup.  Why: the one-role
+// kernel above needs ~155 VGPRs (window, kept half, prefetch, data, accumulators, two sets of twiddle powers), i.e.
+// three waves per SIMD; split by role both halves stay under 128 (four waves per SIMD), the consumer keeps all
+// fifteen pass-2 twiddles in registers, and the producer's loads overlap the consumer's butterflies by construction.
+//
+// DET: 0 none; 1 time domain in the producer (R = 4: the producer is one wave, the sum needs no LDS);
+//      2 frequency domain in the consumer, X -= mean FFT(w) on the bins |k| < 256 (SegArgs.fd; needs a window whose
+//        spectrum is confined to those bins, as welch4096ws.hip).
+enum { WS_STOP = 0, WS_DATA = 1 };
+#ifndef OTH_SEGWS_DEEP
+#define OTH_SEGWS_DEEP 0
+#endif
+#ifndef OTH_SEGWS_STORED_TW1
+#define OTH_SEGWS_STORED_TW1 (!OTH_SEGWS_DEEP)
+#endif
+
+template <int R, int DET>
+__global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
+    using G = Geo<R>;
+    constexpr int T = G::T, N = G::N, Q = G::Q, LR = G::LR, P = G::P, KP = G::KP, KM = G::KM, WV = G::WAVES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned img0 = ((unsigned)(unsigned long long)smem + 255u) & ~255u;      // two images, 8 N bytes each
+    unsigned char *tail = smem + (img0 - (unsigned)(unsigned long long)smem) + 2 * N * sizeof(float2);
+    float2 *red = reinterpret_cast<float2 *>(tail);             // [2][4] per-wave sums of the segment in each image
+    int *ctrl = reinterpret_cast<int *>(red + 8);               // item kind per image [0..1], next-chunk ticket [2]
+
+    const int tid = threadIdx.x;
+    const bool producer = tid < T;
+    const int t = producer ? tid : tid - T;
+    const int hi = t >> LR, lo = t & (R - 1);
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const unsigned b_rw = 8u * (512u * (hi >> P) + R * (hi & KP) + lo);
+    const unsigned b_w1 = 8u * (32u * hi + R * (hi & KM) + (lo ^ (hi & (R - 1))));
+    const unsigned b_r2 = 8u * (512u * (hi >> P) + 32u * lo + R * ((hi & KP) ^ (lo & KM)) + lo);
+
+    if (producer) {
+        const float2 *xb = p.x + (size_t)stream * p.stream_stride + p.first;
+        float win[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) win[a] = p.win[T * a + t];
+#if OTH_SEGWS_STORED_TW1
+        float2 tw1[16];      // all fifteen pass-1 twiddles W_N^(k0 t) in registers: the producer has the room (no accumulators)
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tw1[k] = p.tw[(k * t) & (N - 1)];
+#else
+        const Pow6 tw1 = {p.tw[t], p.tw[(2 * t) & (N - 1)], p.tw[(3 * t) & (N - 1)], p.tw[(4 * t) & (N - 1)],
+                          p.tw[(8 * t) & (N - 1)], p.tw[(12 * t) & (N - 1)]};
+#endif
+        // The new half of segment s is half-block s + 1, requested one segment before it is consumed.  OTH_SEGWS_DEEP:
+        // two buffers alternate and a half-block is requested TWO segments ahead - measured no faster (42-43 % against
+        // 43-45 %: it costs the registers of the stored pass-1 twiddles), although a build without the loads runs 19 %
+        // faster; the loads cost through the memory system, not through their latency.
+        float2 kw[8], nA[8];
+#if OTH_SEGWS_DEEP
+        float2 nB[8];
+#endif
+        float2 prev_new = make_float2(0.f, 0.f);
+        const int sched = p.sched;
+        const long long nchunks = sched ? chunk_count_of(p.nseg, p.nbig, p.chunk, p.tail_chunk) : 1;
+        const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
+        unsigned ticket = 0;
+        int it = 0;
+        long long sb = 0, se = 0;
+        auto half = [&](long long h) { return xb + (h < se ? h : se) * (long long)(N / 2) + t; };      // clamped: valid memory
+        auto segment = [&](long long s, float2(&nxt)[8]) {
+            const int q = it & 1;
+            const unsigned img = img0 + q * (unsigned)(N * sizeof(float2));
+            float2 v[16];
+            prio_latency();
+            float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
+            if (s == sb) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    sumf = cadd(sumf, kw[a]);
+                    kw[a] = make_float2(kw[a].x * win[a], kw[a].y * win[a]);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const float2 r = nxt[a];
+                v[a] = kw[a];
+                v[8 + a] = make_float2(r.x * win[8 + a], r.y * win[8 + a]);
+                kw[a] = make_float2(r.x * win[a], r.y * win[a]);
+                sum = cadd(sum, r);
+            }
+#ifndef OTH_SEGWS_NOLOAD      // (timing experiment: -DOTH_SEGWS_NOLOAD keeps re-using the first loaded halves)
+            {
+                const float2 *xn = half(s + (OTH_SEGWS_DEEP ? 3 : 2));
+#pragma unroll
+                for (int a = 0; a < 8; ++a) nxt[a] = load_once(xn + T * a);
+            }
+#else
+#pragma unroll
+            for (int a = 0; a < 8; ++a) asm volatile("" : "+v"(nxt[a].x), "+v"(nxt[a].y));
+#endif
+            if (sched == 2 && t == 0) {
+                if (s == sb) ticket = atomicAdd(p.queue + stream, 1u);
+                if (s == se - 1) ctrl[2] = (int)ticket;
+            }
+            if (DET == 1) {          // one producer wave: the segment total without LDS
+                sum.x = wave_total(sum.x);
+                sum.y = wave_total(sum.y);
+                if (s == sb) prev_new = make_float2(wave_total(sumf.x), wave_total(sumf.y));
+                const float2 nm = make_float2((prev_new.x + sum.x) * (-1.0f / N), (prev_new.y + sum.y) * (-1.0f / N));
+                prev_new = sum;
+#pragma unroll
+                for (int a = 0; a < 16; ++a) v[a] = make_float2(fmaf(nm.x, win[a], v[a].x), fmaf(nm.y, win[a], v[a].y));
+            } else if (DET == 2) {   // per-wave sums of both halves, side by side for the consumer
+                sum.x = wave_total_lane63(sum.x);
+                sum.y = wave_total_lane63(sum.y);
+                float2 other = prev_new;
+                if (s == sb) other = make_float2(wave_total_lane63(sumf.x), wave_total_lane63(sumf.y));
+                if ((t & 63) == 63) red[q * 4 + (t >> 6)] = cadd(sum, other);
+                prev_new = sum;
+            }
+            prio_compute();
+            dft16(v);
+            prio_latency();
+#if OTH_SEGWS_STORED_TW1
+            static_for<0, 16>([&](auto kc) {
+                constexpr int k0 = decltype(kc)::value;
+                const float2 val = k0 ? cmul(v[r16(k0)], tw1[k0]) : v[0];
+                lds_write_imm<8 * (512 * (k0 >> P) + R * (k0 & KP & ~KM))>((img + b_w1) ^ (8u * R * (k0 & KM)), val);
+            });
+#else
+            twiddle_pow16(v, tw1, [&](auto kc, float2 val) {
+                constexpr int k0 = decltype(kc)::value;
+                lds_write_imm<8 * (512 * (k0 >> P) + R * (k0 & KP & ~KM))>((img + b_w1) ^ (8u * R * (k0 & KM)), val);
+            });
+#endif
+            if (t == 0) ctrl[q] = WS_DATA;
+            lds_barrier();
+            ++it;
+        };
+        for (long long cur = sched ? wg : 0; cur < nchunks;) {
+            sb = s0;
+            se = s1;
+            if (sched) chunk_range_of(p.nseg, p.nbig, p.chunk, p.tail_chunk, cur, sb, se);
+            if (sb < se) {
+                const float2 *x0 = half(sb), *x1 = half(sb + 1), *x2 = half(sb + 2);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) kw[a] = x0[T * a];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) nA[a] = load_once(x1 + T * a);
+#if OTH_SEGWS_DEEP
+#pragma unroll
+                for (int a = 0; a < 8; ++a) nB[a] = load_once(x2 + T * a);
+#else
+                (void)x2;
+#endif
+            }
+#if OTH_SEGWS_DEEP
+            for (long long s = sb; s < se; s += 2) {
+                segment(s, nA);
+                if (s + 1 < se) segment(s + 1, nB);
+            }
+#else
+            for (long long s = sb; s < se; ++s) segment(s, nA);
+#endif
+            if (sched == 0) break;
+            // ctrl[2] was written before the barrier of the chunk's last segment
+            cur = (sched == 1) ? cur + W : (long long)W + __builtin_amdgcn_readfirstlane(ctrl[2]);
+        }
+        if (t == 0) ctrl[it & 1] = WS_STOP;
+        lds_barrier();
+    } else {
+        float2 tw2[16];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tw2[k] = p.tw[(16 * lo * k) & (N - 1)];      // W_N^(16 k1 c)
+        float4 fw[Q];
+#pragma unroll
+        for (int m = 0; m < Q; ++m) fw[m] = DET == 2 ? p.fd[Q * t + m] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        float2 v[16];
+        int it = 0;
+        for (;;) {
+            prio_latency();
+            lds_barrier();
+            const int q = it & 1;
+            ++it;
+            const int kind = __builtin_amdgcn_readfirstlane(ctrl[q]);
+            if (kind == WS_STOP) break;
+            const unsigned img = img0 + q * (unsigned)(N * sizeof(float2));
+            float2 mean = make_float2(0.f, 0.f);
+            if (DET == 2) {
+                float2 tot = red[q * 4];
+#pragma unroll
+                for (int w = 1; w < WV; ++w) tot = cadd(tot, red[q * 4 + w]);
+                mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
+            }
+            {
+                double r[16];
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, b = (i >> 2) + 4 * (i & 3);
+                    lds_read_imm<256 * b>(r[b], (img + b_rw) ^ (8u * (R * (b & KM) + (b & (R - 1)))));
+                });
+                prio_compute();
+                float dep = 0.f;
+#pragma unroll
+                for (int a0 = 0; a0 < 4; ++a0) {
+                    if (a0 == 0) SEG_WAIT(12, 0, dep);
+                    else if (a0 == 1) SEG_WAIT(8, 1, v[0].x);
+                    else if (a0 == 2) SEG_WAIT(4, 2, v[1].x);
+                    else SEG_WAIT(0, 3, v[2].x);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = __builtin_bit_cast(float2, r[a0 + 4 * j]);
+                    dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
+                }
+                v[5] = mul_w1(v[5]);
+                v[9] = mul_w2(v[9]);
+                v[13] = mul_w3(v[13]);
+                v[6] = mul_w2(v[6]);
+                v[10] = mul_w4(v[10]);
+                v[14] = mul_w6(v[14]);
+                v[7] = mul_w3(v[7]);
+                v[11] = mul_w6(v[11]);
+                v[15] = mul_w9(v[15]);
+#pragma unroll
+                for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
+            }
+            prio_latency();
+            lds_write_imm<0>((img + b_rw), v[0]);
+            static_for<1, 16>([&](auto kc) {
+                constexpr int k1 = decltype(kc)::value;
+                lds_write_imm<256 * k1>((img + b_rw) ^ (8u * (R * (k1 & KM) + (k1 & (R - 1)))), cmul(v[r16(k1)], tw2[k1]));
+            });
+            {
+                double r[16];
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, c = i / Q, m = i % Q;
+                    lds_read_imm<256 * R * m>(r[m * R + c], (img + b_r2) ^ (8u * c));
+                });
+                prio_compute();
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                               "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]),
+                               "+v"(r[15]));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = __builtin_bit_cast(float2, r[i]);
+            }
+            if (R == 4) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) dft4<false>(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]);
+            } else if (R == 8) {
+                float2 h0[8], h1[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    h0[i] = v[i];
+                    h1[i] = v[8 + i];
+                }
+                dft8(h0);
+                dft8(h1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = h0[i];
+                    v[8 + i] = h1[i];
+                }
+            } else {
+                dft16(v);
+            }
+            auto at = [&](int m, int k2) -> float2 & { return v[R == 16 ? r16(k2) : m * R + k2]; };
+            if (DET == 2) {
+#pragma unroll
+                for (int m = 0; m < Q; ++m) {
+                    float2 &lo_ = at(m, 0), &hi_ = at(m, R - 1);
+                    lo_ = make_float2(lo_.x - (mean.x * fw[m].x - mean.y * fw[m].y), lo_.y - (mean.x * fw[m].y + mean.y * fw[m].x));
+                    hi_ = make_float2(hi_.x - (mean.x * fw[m].z - mean.y * fw[m].w), hi_.y - (mean.x * fw[m].w + mean.y * fw[m].z));
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < Q; ++m)
+#pragma unroll
+                for (int k2 = 0; k2 < R; ++k2) {
+                    const float2 X = at(m, k2);
+                    acc[m * R + k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[m * R + k2]));
+                }
+        }
+        float *dst = p.partial + ((size_t)stream * W + wg) * N;
+#pragma unroll
+        for (int m = 0; m < Q; ++m)
+#pragma unroll
+            for (int k2 = 0; k2 < R; ++k2) dst[hi + 16 * (lo + R * m) + 256 * k2] = acc[m * R + k2];
+    }
+}
+
+template <int R> constexpr size_t segws_lds_bytes() { return 256 + 2 * (size_t)Geo<R>::N * sizeof(float2) + 8 * sizeof(float2) + 16; }
+
+template <int R, int DET> hipError_t launch_ws_one(const SegArgs &a, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    hipLaunchKernelGGL((segws_kernel<R, DET>), grid, dim3(2 * Geo<R>::T), segws_lds_bytes<R>(), s, a);
+    return hipGetLastError();
+}
+template <int R> int occupancy_ws() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, segws_kernel<R, 2>, 2 * Geo<R>::T, segws_lds_bytes<R>()) != hipSuccess || n < 1)
+        n = 1;
+    return n;
+}
+
 template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS> hipError_t launch_one(const SegArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
     hipLaunchKernelGGL((seg_kernel<R, LOAD, DETREND, CHAIN, WPS>), grid, dim3(Geo<R>::T), Geo<R>::LDS_BYTES, s, a);
@@ -432,6 +737,20 @@ int seg_teams_per_cu(int nfft, int kind, bool wps4) {
     int &c = cache[ri][kind][wps4 ? 1 : 0];
     if (c) return c;
     return c = nfft == 1024 ? occupancy_r<4>(kind, wps4) : (nfft == 2048 ? occupancy_r<8>(kind, wps4) : occupancy_r<16>(kind, wps4));
+}
+
+// the role-split build: Welch, step = nfft / 2; det: 0 none, 1 time domain (1024 only), 2 frequency domain (SegArgs.fd)
+int segws_teams_per_cu(int nfft) {
+    static int cache[2] = {};
+    int &c = cache[nfft == 1024 ? 0 : 1];
+    if (c) return c;
+    return c = nfft == 1024 ? occupancy_ws<4>() : occupancy_ws<8>();
+}
+
+hipError_t launch_segws(int nfft, const SegArgs &a, int det, hipStream_t s) {
+    if (nfft == 1024) return det == 0 ? launch_ws_one<4, 0>(a, s) : (det == 1 ? launch_ws_one<4, 1>(a, s) : launch_ws_one<4, 2>(a, s));
+    if (nfft == 2048) return det == 0 ? launch_ws_one<8, 0>(a, s) : (det == 2 ? launch_ws_one<8, 2>(a, s) : hipErrorInvalidValue);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_seg(int nfft, const SegArgs &a, int kind, bool wps4, hipStream_t s) {

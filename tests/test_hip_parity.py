@@ -832,7 +832,7 @@ def test_scan_decide_dev_on_device_rows(ctx, hip):
 # ------------------------------------------- segfft.hip: 1024 / 2048 Welch, fused chain ----
 
 @pytest.mark.parametrize('nfft', [1024, 2048])
-@pytest.mark.parametrize('build', ['seg3', 'seg4'])
+@pytest.mark.parametrize('build', ['segws', 'seg3', 'seg4'])
 def test_seg_welch_vs_oracle_and_generic(ctx, hip, nfft, build):
     """The team-per-segment kernel (wave-per-segment at 1024) against the float64 oracle and the coverage kernel:
     50 % overlap (kept half in registers) and other steps, detrend on / off, a DC offset 30x the noise, segment

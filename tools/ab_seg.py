@@ -11,7 +11,7 @@ from ofdm_tools import _hip, windows  # noqa: E402
 
 nfft = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-variants = sys.argv[3:] or ['seg3:2:16', 'seg4:2:16', 'seg3:2:8', 'seg3:2:32', 'seg3:0:16']
+variants = sys.argv[3:] or ['segws:2:16', 'segws:2:32', 'seg3:2:32', 'segws:0:16', 'segws:2:8']
 ctx = _hip.Context(0)
 n = 1 << 27
 d, o = ctx.alloc(n * 8), ctx.alloc(nfft * 4)

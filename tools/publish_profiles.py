@@ -1,65 +1,109 @@
 #!/usr/bin/env python3
-"""Copy what tools/collect_profiles.sh left under gpurun_out/profiles_<tag>/ into profiles/ (tracked) and
-derive profiles/traffic.json (HBM bytes per launch of the headline kernel, read by bench.py).
-usage: publish_profiles.py <tag> <round-prefix, e.g. r01>"""
+"""Copy what tools/collect_all_profiles.sh (and tools/collect_profiles.sh for the bench command) left under
+gpurun_out/ into profiles/ (tracked) as one text summary per configuration, with the roofline recomputation
+written next to the counters, and refresh profiles/traffic.json (HBM bytes per launch of the headline kernel, read
+by bench.py).   usage: publish_profiles.py <tag> <round-prefix, e.g. r02>"""
 import collections
 import csv
 import glob
 import json
 import os
-import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
-src = os.path.join(ROOT, 'gpurun_out', 'profiles_' + tag)
 dst = os.path.join(ROOT, 'profiles')
 
+# config -> (kernel-name pattern, algorithmic bytes per launch, description)
+CONFIGS = {
+    'C2': ('welch4096ws', 8 * 2 ** 28, 'C2: 4096-pt Hann Welch, 50 % overlap, one 2^28-sample stream'),
+    'C3': ('csd4096ws', 16 * 2 ** 26, 'C3: two-channel csd / coherence, 2 x 2^26 samples (16 B per sample pair)'),
+    'C4': ('welch4096ws', 8 * 8 * 2 ** 25, 'C4: sweep of 8 x 2^25 samples on one GPU, Hann 4096, shift + trim + dB'),
+    'C4ref': ('welch4096_kernel', 8 * 8 * 2 ** 25, 'C4 reference-faithful: flattop, nperseg 1024 zero-padded to 4096 '
+              '(spectrum_sweeper.py:263): 4 transforms per 2048 new samples'),
+    'C5': ('welch16k', 8 * 64 * 2 ** 22, 'C5: 64 channel streams x 2^22 samples, 16384-pt rect |X|^2/N^2 mean'),
+    'w1024': ('seg_kernel', 8 * 2 ** 27, 'Welch 1024-pt Hann 50 % overlap, 2^27 samples'),
+    'w2048': ('seg_kernel', 8 * 2 ** 27, 'Welch 2048-pt Hann 50 % overlap, 2^27 samples'),
+    'chain1024': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 1024 (BH window, shift, |X|^2, IIR 0.8 + log), 2^26 samples'),
+    'chain2048': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 2048, 2^26 samples'),
+    'chain4096': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 4096, 2^26 samples'),
+}
 
-def one(pattern):
+
+def one(src, pattern):
     hits = sorted(glob.glob(os.path.join(src, pattern)))
-    assert hits, pattern
-    return hits[-1]
+    return hits[-1] if hits else None
 
 
-shutil.copy(one('trace/*/*_kernel_stats.csv'), os.path.join(dst, rnd + '_bench_kernel_stats.csv'))
-shutil.copy(os.path.join(src, 'bench_unprofiled.json'), os.path.join(dst, rnd + '_bench.json'))
-shutil.copy(os.path.join(src, 'bench_under_rocprof.json'), os.path.join(dst, rnd + '_bench_under_rocprof.json'))
-for sub in ('sq1', 'sq2', 'fetch', 'write'):
-    shutil.copy(one(sub + '/*/*_counter_collection.csv'), os.path.join(dst, '%s_pmc_%s_counter_collection.csv' % (rnd, sub)))
-shutil.copy(os.path.join(src, 'summary_welch4096.txt'), os.path.join(dst, rnd + '_pmc_welch4096.txt'))
-shutil.copy(os.path.join(src, 'summary_read_probe.txt'), os.path.join(dst, rnd + '_pmc_read_probe_calibration.txt'))
+def counters(src, pat):
+    vals = {}
+    for sub in ('sq1', 'sq2', 'fetch', 'write'):
+        f = one(src, sub + '/*/*_counter_collection.csv')
+        if not f:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if pat in r['Kernel_Name']:
+                agg[r['Counter_Name']].append(float(r['Counter_Value']))
+                vals['_vgpr'] = r['VGPR_Count']
+                vals['_grid'] = r['Grid_Size']
+                vals['_wg'] = r['Workgroup_Size']
+        for k, v in agg.items():
+            vals[k] = sum(v) / len(v)
+    return vals
 
 
-def mean_counter(sub, counter, kernel):
-    vals = collections.defaultdict(list)
-    for r in csv.DictReader(open(one(sub + '/*/*_counter_collection.csv'))):
-        if kernel in r['Kernel_Name'] and r['Counter_Name'] == counter:
-            vals[r['Kernel_Name']].append(float(r['Counter_Value']))
-    assert len(vals) == 1, (kernel, list(vals))
-    name, v = next(iter(vals.items()))
-    return name, sum(v) / len(v)
-
-
-name, fetch_kb = mean_counter('fetch', 'FETCH_SIZE', 'welch4096')
-_, write_kb = mean_counter('write', 'WRITE_SIZE', 'welch4096')
-_, probe_kb = mean_counter('fetch', 'FETCH_SIZE', 'read_probe')
-read_b, write_b = fetch_kb * 1024 * 2, write_kb * 1024
-bench = json.load(open(os.path.join(src, 'bench_unprofiled.json')))
-alg = bench['roofline']['algorithmic_bytes_per_launch']
-json.dump({
-    'log2_samples': 28,
-    'kernel': name,
-    'hbm_bytes_per_launch': read_b + write_b,
-    'read_bytes': read_b,
-    'write_bytes': write_b,
-    'ratio_to_algorithmic': (read_b + write_b) / alg,
-    'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh); '
-              'FETCH_SIZE [KB] x 1024 x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); '
-              'WRITE_SIZE [KB] x 1024; per-launch mean over the pass',
-    'calibration': 'read_probe_kernel (float4 stream of exactly 2^31 bytes) in the same pass: FETCH_SIZE %.6g KB '
-                   '-> x2048 = %.6g bytes (expected 2147483648)' % (probe_kb, probe_kb * 2048),
-    'algorithmic_bytes_per_launch': alg,
-    'source': 'profiles/%s_pmc_fetch_counter_collection.csv, profiles/%s_pmc_write_counter_collection.csv' % (rnd, rnd),
-}, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
-print(open(os.path.join(dst, 'traffic.json')).read())
+written = []
+for cfg, (pat, alg, desc) in CONFIGS.items():
+    src = os.path.join(ROOT, 'gpurun_out', 'prof_%s_%s' % (tag, cfg))
+    stats = one(src, 'trace/*/*_kernel_stats.csv')
+    if not stats:
+        continue
+    lines = ['%s  (tools/prof_driver.py %s under rocprofv3, separate passes: --kernel-trace --stats | --pmc SQ.. | --pmc '
+             'FETCH_SIZE | --pmc WRITE_SIZE..)' % (desc, cfg), '']
+    avg_ns = None
+    for r in csv.DictReader(open(stats)):
+        lines.append('%-92s calls %5s  avg %10.1f us' % (r['Name'][:92], r['Calls'], float(r['AverageNs']) / 1e3))
+        if pat in r['Name'] and avg_ns is None:
+            avg_ns = float(r['AverageNs'])
+    v = counters(src, pat)
+    lines.append('')
+    for k in sorted(v):
+        if not k.startswith('_'):
+            lines.append('%-24s %.4g' % (k, v[k]))
+    lines.append('VGPR_Count %s  Grid_Size %s  Workgroup_Size %s' % (v.get('_vgpr'), v.get('_grid'), v.get('_wg')))
+    if 'SQ_WAVE_CYCLES' in v:
+        wc = v['SQ_WAVE_CYCLES']
+        lines.append('wave time split: wait_any %.1f%%  wait_inst_any %.1f%%  active %.1f%%' % (
+            100 * v['SQ_WAIT_ANY'] / wc, 100 * v['SQ_WAIT_INST_ANY'] / wc, 100 * v['SQ_ACTIVE_INST_ANY'] / wc))
+    lines.append('')
+    if avg_ns:
+        gbps = alg / avg_ns
+        lines.append('roofline: algorithmic bytes per launch %d / kernel avg %.1f us = %.1f GB/s = %.1f %% of 8000 GB/s'
+                     % (alg, avg_ns / 1e3, gbps, gbps / 80.0))
+    if 'FETCH_SIZE' in v:
+        rd = v['FETCH_SIZE'] * 2048.0
+        wr = v.get('WRITE_SIZE', 0.0) * 1024.0
+        lines.append('HBM traffic per launch: read %.4g B (FETCH_SIZE KB x 1024 x 2, the gfx950 wide-read correction of '
+                     'MI355X_MICROARCH.md) + write %.4g B (WRITE_SIZE KB x 1024) = %.3f x algorithmic'
+                     % (rd, wr, (rd + wr) / alg))
+        if cfg == 'C2':
+            json.dump({'log2_samples': 28, 'kernel': pat, 'hbm_bytes_per_launch': rd + wr, 'read_bytes': rd,
+                       'write_bytes': wr, 'ratio_to_algorithmic': (rd + wr) / alg,
+                       'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes '
+                                 '(tools/pmc_passes.sh); FETCH_SIZE [KB] x 1024 x 2 (gfx950 wide-read correction, '
+                                 'MI355X_MICROARCH.md HBM section); WRITE_SIZE [KB] x 1024; per-launch mean',
+                       'algorithmic_bytes_per_launch': alg,
+                       'source': 'profiles/%s_%s.txt' % (rnd, cfg)}, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+    if 'SQ_INSTS_VALU' in v and avg_ns:
+        # issue slots: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles; the clock from GRBM_GUI_ACTIVE / 8 XCDs
+        clk = v.get('GRBM_GUI_ACTIVE', 0.0) / 8.0 / (avg_ns * 1e-9) if v.get('GRBM_GUI_ACTIVE') else 2.0e9
+        slots = 1024 * clk * avg_ns * 1e-9 / 2.0
+        lines.append('VALU issue: %.4g wave-instructions per launch / %.4g issue slots (1024 SIMDs, 2 cycles each, '
+                     '%.2f GHz from GRBM_GUI_ACTIVE) = %.0f %%' % (v['SQ_INSTS_VALU'], slots, clk / 1e9,
+                                                                   100 * v['SQ_INSTS_VALU'] / slots))
+    out = os.path.join(dst, '%s_%s.txt' % (rnd, cfg))
+    open(out, 'w').write('\n'.join(lines) + '\n')
+    st = one(src, 'trace/*/*_kernel_stats.csv')
+    written.append(out)
+print('\n'.join(written))
