@@ -705,14 +705,18 @@ int oth_synth_iq(oth_ctx *c, void *iq_dev, size_t nsamples, uint64_t seed, int n
 
 int oth_stream_read_probe(oth_ctx *c, const void *dptr, size_t bytes, int repeats, double *ms_per_pass) {
     CtxGuard guard_(c);
-    if (!c || !dptr || bytes < 16 || repeats < 1 || !ms_per_pass) return fail(c, OTH_ERR_INVALID, "bad argument");
+    if (!c || !dptr || bytes < 16 || repeats == 0 || !ms_per_pass) return fail(c, OTH_ERR_INVALID, "bad argument");
     if (use_device(c)) return OTH_ERR_HIP;
     hipEvent_t a, b;
     HIPCHK(c, hipEventCreate(&a));
     HIPCHK(c, hipEventCreate(&b));
-    HIPCHK(c, launch_read_probe(dptr, bytes, c->sink, c->stream));   // warm-up
+    // repeats < 0: the 8-bytes-per-lane variant (the access width of the FFT kernels' sample loads), |repeats| passes
+    const bool narrow = repeats < 0;
+    if (narrow) repeats = -repeats;
+    auto probe = [&]() { return narrow ? launch_read_probe8(dptr, bytes, c->sink, c->stream) : launch_read_probe(dptr, bytes, c->sink, c->stream); };
+    HIPCHK(c, probe());   // warm-up
     HIPCHK(c, hipEventRecord(a, c->stream));
-    for (int i = 0; i < repeats; ++i) HIPCHK(c, launch_read_probe(dptr, bytes, c->sink, c->stream));
+    for (int i = 0; i < repeats; ++i) HIPCHK(c, probe());
     HIPCHK(c, hipEventRecord(b, c->stream));
     HIPCHK(c, hipEventSynchronize(b));
     float ms = 0.f;

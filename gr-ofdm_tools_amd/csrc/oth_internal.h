@@ -164,6 +164,7 @@ hipError_t launch_xcorr(int L, const float2 *a, const float2 *b, const float2 *t
 hipError_t launch_synth(float2 *iq, size_t n, uint64_t seed, int ntones, const float *amp, const float *freq,
                         float dc_re, float dc_im, hipStream_t s);
 hipError_t launch_read_probe(const void *p, size_t bytes, float *sink, hipStream_t s);
+hipError_t launch_read_probe8(const void *p, size_t bytes, float *sink, hipStream_t s);
 hipError_t launch_iq_power(const float2 *iq, size_t n, double *acc4, hipStream_t s);
 
 bool generic_supported(int nfft);

@@ -111,7 +111,8 @@ int oth_synth_iq(oth_ctx *ctx, void *iq_dev, size_t nsamples, uint64_t seed, int
                  const float *tone_amp, const float *tone_freq, float dc_re, float dc_im);
 
 /* Streaming-read probe: a float4 sum over [dptr, dptr+bytes); reports the
- * kernel time so the caller can state the achievable HBM-read peak. */
+ * kernel time so the caller can state the achievable HBM-read peak.  repeats < 0: |repeats| passes of the
+ * 8-bytes-per-lane variant (non-temporal float2 loads, the access the FFT kernels use for samples). */
 int oth_stream_read_probe(oth_ctx *ctx, const void *dptr, size_t bytes, int repeats, double *ms_per_pass);
 
 /* mean(|x - mean(x)|^2) of a device IQ buffer (Parseval check at full size) */

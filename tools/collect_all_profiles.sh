@@ -5,7 +5,7 @@
 set -u
 TAG=$1
 for spec in "C2:welch4096ws" "C3:csd4096ws" "C4:welch4096ws" "C4ref:welch4096_kernel" "C5:welch16k" \
-            "w1024:seg_kernel" "w2048:seg_kernel" "chain1024:seg_kernel" "chain2048:seg_kernel" "chain4096:seg_kernel"; do
+            "w1024:segws_kernel" "w2048:segws_kernel" "chain1024:seg_kernel" "chain2048:seg_kernel" "chain4096:seg_kernel"; do
     cfg=${spec%%:*}; pat=${spec##*:}
     tools/pmc_passes.sh prof_${TAG}_${cfg} $cfg 5 $pat > /dev/null 2>&1
     echo "== $cfg"; grep -E "GB/s" $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${cfg}/trace.log | tail -1

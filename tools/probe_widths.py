@@ -1,0 +1,11 @@
+import sys, os
+sys.path.insert(0, os.path.join(os.getcwd(), 'gr-ofdm_tools_amd'))
+from ofdm_tools import _hip
+ctx = _hip.Context(0)
+n = 1 << 28
+d = ctx.alloc(n * 8)
+ctx.synth_iq(d, n, 1, (), 0j)
+for _ in range(3):
+    a = ctx.stream_read_probe(d, n * 8, 20)
+    b = ctx.stream_read_probe(d, n * 8, -20)
+    print('float4 probe %.1f GB/s   float2-nt probe %.1f GB/s' % (n * 8 / a / 1e6, n * 8 / b / 1e6))

@@ -22,8 +22,8 @@ CONFIGS = {
     'C4ref': ('welch4096_kernel', 8 * 8 * 2 ** 25, 'C4 reference-faithful: flattop, nperseg 1024 zero-padded to 4096 '
               '(spectrum_sweeper.py:263): 4 transforms per 2048 new samples'),
     'C5': ('welch16k', 8 * 64 * 2 ** 22, 'C5: 64 channel streams x 2^22 samples, 16384-pt rect |X|^2/N^2 mean'),
-    'w1024': ('seg_kernel', 8 * 2 ** 27, 'Welch 1024-pt Hann 50 % overlap, 2^27 samples'),
-    'w2048': ('seg_kernel', 8 * 2 ** 27, 'Welch 2048-pt Hann 50 % overlap, 2^27 samples'),
+    'w1024': ('segws_kernel', 8 * 2 ** 27, 'Welch 1024-pt Hann 50 % overlap, 2^27 samples'),
+    'w2048': ('segws_kernel', 8 * 2 ** 27, 'Welch 2048-pt Hann 50 % overlap, 2^27 samples'),
     'chain1024': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 1024 (BH window, shift, |X|^2, IIR 0.8 + log), 2^26 samples'),
     'chain2048': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 2048, 2^26 samples'),
     'chain4096': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 4096, 2^26 samples'),
@@ -107,3 +107,15 @@ for cfg, (pat, alg, desc) in CONFIGS.items():
     st = one(src, 'trace/*/*_kernel_stats.csv')
     written.append(out)
 print('\n'.join(written))
+
+# the bench command itself (tools/collect_profiles.sh <tag>)
+src = os.path.join(ROOT, 'gpurun_out', 'profiles_' + tag)
+if os.path.isdir(src):
+    import shutil
+    for name, out in (('bench_unprofiled.json', rnd + '_bench.json'), ('bench_under_rocprof.json', rnd + '_bench_under_rocprof.json')):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, out))
+    st = one(src, 'trace/*/*_kernel_stats.csv')
+    if st:
+        shutil.copy(st, os.path.join(dst, rnd + '_bench_kernel_stats.csv'))
+        print(os.path.join(dst, rnd + '_bench_kernel_stats.csv'))
