@@ -148,10 +148,18 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
     const long long nchunks = sched ? chunk_count_of(p.nseg, p.nbig, p.chunk, p.tail_chunk) : 1;
     const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
     unsigned ticket = 0;
+    bool primed = false;
     for (long long cur = sched ? wg : 0; cur < nchunks;) {
         long long sb = s0, se = s1;
         if (sched) chunk_range_of(p.nseg, p.nbig, p.chunk, p.tail_chunk, cur, sb, se);
-        if (sb < se) {      // chunk prologue
+        // interleaved static schedule: the chunk after this one is known, so its first segment is prefetched with this
+        // chunk's last one (whole-segment loads only) and the prologue below runs once per team
+        long long sb_next = -1;
+        if (LOAD == LOAD_FULL && sched == 1 && cur + W < nchunks) {
+            long long se_next;
+            chunk_range_of(p.nseg, p.nbig, p.chunk, p.tail_chunk, cur + W, sb_next, se_next);
+        }
+        if (sb < se && !primed) {      // chunk prologue
             const float2 *xs = xb + sb * p.step + t;
             if (LOAD == LOAD_HALF) {
 #pragma unroll
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
                 for (int a = 0; a < 16; ++a) nxt[a] = load_once(xs + T * a);
             }
         }
+        primed = sb_next >= 0;
         for (long long s = sb; s < se; ++s) {
             float2 v[16];
             prio_latency();
@@ -197,8 +206,8 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
                     v[a] = make_float2(r.x * win[a], r.y * win[a]);
                     sum = cadd(sum, r);
                 }
-                {   // unconditional (see above): the chunk's last segment re-reads itself
-                    const float2 *xn = xb + (s + (s + 1 < se ? 1 : 0)) * p.step + t;
+                {   // unconditional (see above): the chunk's last segment fetches the next chunk's first one, or itself
+                    const float2 *xn = xb + (s + 1 < se ? s + 1 : (sb_next >= 0 ? sb_next : s)) * p.step + t;
 #pragma unroll
                     for (int a = 0; a < 16; ++a) nxt[a] = load_once(xn + T * a);
                 }
