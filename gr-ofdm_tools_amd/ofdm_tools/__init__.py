@@ -22,3 +22,4 @@ from .multichannel_scanner import multichannel_scanner  # noqa: F401,E402
 from .local_worker import local_worker  # noqa: F401,E402
 from .spectrum_sweeper import spectrum_sweeper  # noqa: F401,E402
 from .flanck_detector import flanck_detector  # noqa: F401,E402
+from .ascii_plot import ascii_plot, ascii_plotter  # noqa: F401,E402

@@ -608,3 +608,60 @@ class FlankState(object):
                 self.peak_alpha[k] = self.peak_alpha_original
                 events.append((self.ax_ch[channel], -1))
         return events
+
+
+# --------------------------------------------------------------------------
+# python/ascii_plot.py - terminal plot of the latest dB row (consumer of the
+# local_worker-style chain; rectangular window: the window of :61 is not passed)
+# --------------------------------------------------------------------------
+
+
+def chain_ascii_plot(x, fft_len, sample_rate, average, decim=1):
+    """ascii_plot.py:57-70: as chain_local_worker but without a window."""
+    vecs = gr_kept_vectors(x, fft_len, decim)
+    p = np.abs(gr_fft_vcc(vecs, None, True)) ** 2
+    y = np.zeros(fft_len)
+    lin = []
+    for r in p:
+        y = average * r + (1 - average) * y
+        lin.append(y.copy())
+    lin = np.array(lin)
+    k = -10 * math.log10(fft_len) - 10 * math.log10(sample_rate)
+    return lin, 10 * np.log10(lin) + k
+
+
+def ascii_make_plot(fft_data, width, height, tune_freq, sample_rate, fft_len):
+    """ascii_plot.py:154-228 (ascii_plotter.__init__ + make_plot on a fresh matrix), Python-2 integer divisions."""
+    axis = _py2div(sample_rate, 2) * np.linspace(-1, 1, fft_len) + tune_freq
+    widthDens = len(axis) // int(width)
+    matrix = [[' ' for _ in range(height)] for _ in range(width)]
+    minValue, maxValue = min(fft_data), max(fft_data)
+    span = math.floor((maxValue - minValue))
+    out, aux = '', 0
+    for i in range(width):
+        ht = sum(fft_data[aux:aux + widthDens]) / widthDens
+        n = int(math.floor(((ht - minValue) * (height - 1)) / span))
+        for k in range(n + 1, height):
+            matrix[i][k] = ' '
+        matrix[i][n] = '^'
+        for k in range(n):
+            matrix[i][k] = '|'
+        aux += widthDens
+    for i in reversed(range(height)):
+        matrix[width // 2][i] = '*'
+        if i % 5 == 0:
+            out += ('%.3f' % ((((i - 0) * span) / height) + minValue))[:6] + ' '
+        else:
+            out += '------ '
+        for j in range(width):
+            out += matrix[j][i] + ' '
+        out += '\n'
+    out += '------ '
+    for a in range(width):
+        if a % 10 == 0:
+            out += '| ' + ('%.3f' % ((((a - 0) * (axis[-1] - axis[0])) / width) + axis[0]))[:5] + ' ' * (2 * 10 - 5 - 2)
+    out += '\n'
+    out += 'Tune freq: %s MHz, Sample rate: %s MS/s, FFT: %s W:%d L:%d\n' % (tune_freq / 1e6, sample_rate / 1e6,
+                                                                             fft_len, width, height)
+    out += '_ ' * width + '_ _ _ _'
+    return out

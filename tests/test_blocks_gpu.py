@@ -524,3 +524,26 @@ def test_batched_scanner_sharded_entry_point_world_1(ctx):
         ctx.free(d_rows)
     assert np.array_equal(rows.cpu().numpy(), want_rows)
     assert np.allclose(noise.cpu().numpy(), noise2) and np.allclose(power.cpu().numpy(), plc)
+
+
+def test_ascii_plot_block(ctx):
+    """ascii_plot (python/ascii_plot.py): rectangular shifted FFT -> |.|^2 -> IIR -> log chain on the GPU, latest
+    row rendered by make_plot and posted on pkt_out; against the oracle's chain + renderer."""
+    import ofdm_tools
+    N, Sf = 1024, 1024 * 30
+    blk = ofdm_tools.ascii_plot(N, Sf, 433.0e6, 0.3, 10, 64, 20, ctx=ctx)
+    assert blk._decimation() == 3
+    msgs = []
+    blk.msg_connect('pkt_out', msgs.append)
+    x = R.synth_iq(N * 31 + 5, 77)
+    blk.feed(x, max_items=4000)
+    lin, db = R.chain_ascii_plot(x, N, Sf, 0.3, decim=3)
+    assert len(db) == 10
+    assert relerr(blk._chain.iir(), lin[-1]) < RTOL
+    want = R.ascii_make_plot(db[-1].astype(np.float32), 64, 20, 433.0e6, Sf, N)
+    assert msgs and msgs[-1][1] == blk.last_plot
+    # the picture is a quantisation of the dB row: identical up to bars that sit within rounding of a row boundary
+    got_rows, want_rows = blk.last_plot.split('\n'), want.split('\n')
+    assert len(got_rows) == len(want_rows) and got_rows[-2:] == want_rows[-2:]
+    diff = sum(a != b for a, b in zip(blk.last_plot, want))
+    assert diff <= 8, diff

@@ -101,6 +101,8 @@ def test_block_constructor_signatures_match_the_reference():
                                        ('search_bw', 1), ('thr_leveler', 10), ('tune_freq', 0), ('alpha_avg', 1),
                                        ('test_duration', 1), ('period', 3600), ('trunc_band', 1), ('verbose', False),
                                        ('peak_alpha', 0), ('subject_channels', [])])
+    check(ofdm_tools.ascii_plot, [('fft_len', E), ('sample_rate', E), ('tune_freq', E), ('average', E), ('rate', E),
+                                  ('width', E), ('height', E)])
     check(ofdm_tools.spectrum_sensor, [('block_length', E), ('sample_rate', 1), ('fft_len', 1), ('channel_space', 1),
                                        ('search_bw', 1), ('method', 'fft'), ('thr_leveler', 10), ('tune_freq', 0),
                                        ('alpha_avg', 1), ('source', None), ('log', False)])
@@ -322,3 +324,23 @@ def test_time_shard_covers_every_segment_once():
                 assert cnt == (k - 1) * step + nper and first + cnt <= n
             seen += list(range(s0, s0 + k))
         assert seen == list(range(nseg))
+
+
+def test_ascii_plotter_layout_and_oracle():
+    """ascii_plot.py:154-228: the text plot of a dB row (host work; the block's chain is a GPU test)."""
+    from ofdm_tools.ascii_plot import ascii_plotter
+    N, W, H = 1024, 64, 20
+    rng = np.random.default_rng(9)
+    row = (-90 + 25 * np.exp(-0.5 * ((np.arange(N) - 700) / 30.0) ** 2) + rng.random(N)).astype(np.float32)
+    pl = ascii_plotter(W, H, 100.0e6, 2000000, N)
+    txt = pl.make_plot(row)
+    assert txt == R.ascii_make_plot(row, W, H, 100.0e6, 2000000, N)
+    lines = txt.split('\n')
+    assert len(lines) == H + 3 and all(len(ln) == 7 + 2 * W for ln in lines[:H])
+    top = [ln[7::2] for ln in lines[:H]]                         # one character per column, top row first
+    col = 700 // (N // W)                                        # the bump sits in this column: tallest bar
+    peak_row = [i for i, ln in enumerate(top) if ln[col] == '^'][0]
+    assert peak_row == min(i for i, ln in enumerate(top) for c in ln if c == '^')
+    assert all(ln[W // 2] == '*' for ln in top)                  # centre marker
+    assert lines[H + 1].startswith('Tune freq: 100.0 MHz, Sample rate: 2.0 MS/s, FFT: 1024 W:64 L:20')
+    assert pl.make_plot(row) == txt                              # the reused matrix gives the same picture again
