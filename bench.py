@@ -360,9 +360,10 @@ def main():
             sp.finalize()
             dt = time.perf_counter() - t0
             result['h2d_inclusive'] = {'value': m / dt / 1e6, 'unit': 'Msamples/s', 'GBps': 8.0 * m / dt / 1e9,
-                                       'sample': '2^26 samples from a pageable host buffer in 2^22-sample work() '
-                                                 'chunks through oth_welch_accumulate (pinned ring, async H2D + '
-                                                 'kernels) + oth_welch_finalize'}
+                                       'sample': '2^26 samples from a pageable host buffer in 2^22-sample chunks '
+                                                 'through oth_welch_accumulate (asynchronous: chunks above 1 MiB use the '
+                                                 'runtime\'s staged copy from pageable memory, smaller ones a pinned '
+                                                 'ring) + oth_welch_finalize'}
             del iq
             torch.cuda.empty_cache()
             sw, _ = sweep_bench(max(10, args.steps // 4), max(3, args.warmup // 4))

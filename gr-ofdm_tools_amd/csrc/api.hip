@@ -110,6 +110,10 @@ struct oth_chain {
 
 namespace {
 
+// host chunks up to this size go through the pinned staging rings (work()-sized buffers: the copy is trivial and the
+// call returns at once); larger ones use the runtime's staged copy from pageable memory directly
+constexpr size_t kPinnedStageMax = 1u << 20;
+
 thread_local std::string g_err = "no error";
 
 int fail(oth_ctx *c, int code, const std::string &msg) {
@@ -1005,7 +1009,12 @@ int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
     const size_t total = p->carry + nsamples;
     int rc = ensure_keep(c, &p->d_stream, &p->stream_cap, total * sizeof(float2), p->carry * sizeof(float2));
     if (rc) return rc;
-    {
+    if (nsamples * sizeof(float2) > kPinnedStageMax) {
+        // large chunks: the runtime's own staged copy from pageable memory is faster than a host memcpy into a pinned
+        // slot (55 against 33 GB/s at 32 MiB); it returns once the caller's buffer has been read
+        HIPCHK(c, hipMemcpyAsync(p->d_stream + p->carry, iq_host, nsamples * sizeof(float2), hipMemcpyHostToDevice,
+                                 c->stream));
+    } else {
         // the caller's buffer is only valid during the call (sync_block.work contract): it is copied into a pinned
         // slot, the H2D copy is enqueued from there and the call returns without waiting for the GPU (a slot is
         // reused four calls later; only then, if the GPU is still that far behind, does the call wait)
@@ -1516,7 +1525,7 @@ int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uin
         HIPCHK(c, hipEventSynchronize(h->ev[slot]));      // only when the GPU is kRing pushes behind
     }
     const size_t bytes = nsamples * sizeof(float2);
-    if (h->h_in_cap[slot] < bytes) {
+    if (bytes <= kPinnedStageMax && h->h_in_cap[slot] < bytes) {
         if (h->h_in[slot]) HIPCHK(c, hipHostFree(h->h_in[slot]));
         h->h_in[slot] = nullptr;
         h->h_in_cap[slot] = 0;
@@ -1527,10 +1536,14 @@ int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uin
     int rc;
     uint64_t nrows = 0;
     if (nsamples) {
-        memcpy(h->h_in[slot], iq_host, bytes);      // the scheduler's buffer dies when work() returns
         if ((rc = ensure(c, &h->d_stage, &h->stage_cap, bytes))) return rc;
         if ((rc = ensure(c, &h->d_out, &h->out_cap, sizeof(float) * N))) return rc;
-        HIPCHK(c, hipMemcpyAsync(h->d_stage, h->h_in[slot], bytes, hipMemcpyHostToDevice, c->stream));
+        if (bytes > kPinnedStageMax) {      // the runtime's staged copy returns once the caller's buffer has been read
+            HIPCHK(c, hipMemcpyAsync(h->d_stage, iq_host, bytes, hipMemcpyHostToDevice, c->stream));
+        } else {
+            memcpy(h->h_in[slot], iq_host, bytes);      // the scheduler's buffer dies when work() returns
+            HIPCHK(c, hipMemcpyAsync(h->d_stage, h->h_in[slot], bytes, hipMemcpyHostToDevice, c->stream));
+        }
         if ((rc = chain_feed(h, h->d_stage, nsamples, h->d_out, 1, &nrows))) return rc;
         if (nrows)
             HIPCHK(c, hipMemcpyAsync(h->h_row[slot], h->d_out, sizeof(float) * N, hipMemcpyDeviceToHost, c->stream));
