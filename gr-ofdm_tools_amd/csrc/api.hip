@@ -392,15 +392,15 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     const bool csd_ws = tuned_csd && p->step == 2048 && (p->detrend == OTH_DETREND_NONE || p->d_fd) &&
                         nseg < (1LL << 30) && p->tune_variant != "csd1";
     const bool tuned_16k = !csd && p->nfft == 16384 && p->nperseg == 16384 && p->kernel != OTH_KERNEL_GENERIC;
-    // segfft.hip: nperseg = nfft = 1024 / 2048, any step (team of nfft / 16 threads per segment)
-    const bool tuned_seg = !csd && (p->nfft == 1024 || p->nfft == 2048) && p->nperseg == p->nfft &&
+    // segfft.hip: nperseg = nfft = 256 / 512 / 1024 / 2048, any step (team of nfft / 16 threads per segment)
+    const bool tuned_seg = !csd && (p->nfft == 256 || p->nfft == 512 || p->nfft == 1024 || p->nfft == 2048) && p->nperseg == p->nfft &&
                            p->kernel != OTH_KERNEL_GENERIC;
     const int seg_kind = p->step == p->nfft / 2 ? 0 : 1;
     const bool seg_wps4 = p->tune_variant == "seg4";
     // role-split build (segws_kernel): 50 % overlap; detrend in the time domain at 1024 (one producer wave), in the
     // frequency domain at 2048 (needs the window-spectrum table); "seg3" / "seg4" force the one-role builds
     const int seg_det = p->detrend == OTH_DETREND_NONE ? 0 : (p->nfft == 1024 ? 1 : 2);
-    const bool seg_ws = tuned_seg && seg_kind == 0 && p->tune_variant != "seg3" && !seg_wps4 &&
+    const bool seg_ws = tuned_seg && p->nfft >= 1024 && seg_kind == 0 && p->tune_variant != "seg3" && !seg_wps4 &&
                         (seg_det != 2 || p->d_fd != nullptr);
     if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
     if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd && !tuned_16k && !tuned_seg)

@@ -1,5 +1,5 @@
-// segfft: segment transforms of N = 256 R points (R = 4, 8, 16 -> N = 1024, 2048, 4096) by one TEAM of 16 R
-// threads, 16 points per thread, with everything that follows the transform fused into the launch:
+// segfft: segment transforms of N = 256 R points (R = 1, 2, 4, 8, 16 -> N = 256 ... 4096) by one TEAM of
+// 16 R threads, 16 points per thread, with everything that follows the transform fused into the launch:
 //
 //   Welch average          sum over segments of |X|^2, any step (scipy.signal.welch, ofdm_cr_tools.py:214,322,342)
 //   periodogram chain      stream_to_vector -> keep_one_in_n -> fft_vcc -> |.| or |.|^2 [x 1/N^2]
@@ -16,12 +16,15 @@
 //   pass 3  thread (k0, j) holds c  = 0..R-1 for k1 = j + R m, m < 16/R  -> k2
 // Exchange 1 (b <-> k0) crosses the team; exchange 2 (c <-> k1) stays inside the R lanes that share k0.  At
 // R = 4 the team is ONE wave: no workgroup barrier anywhere, sixteen independent waves per CU.  At R = 8 (two
-// waves) and R = 16 (four) exchange 1 sits between two LDS-only barriers.
+// waves) and R = 16 (four) exchange 1 sits between two LDS-only barriers.  At R = 2 the team is HALF a wave:
+// a 64-thread workgroup carries two teams, each on its own segments and its own image (a ds_read_b64 is served
+// 32 lanes at a time and a ds_write_b64 16 at a time, so the two teams never meet in a bank).  At R = 1 (N = 256,
+// four teams per wave) pass 3 and exchange 2 do not exist and pairs of teams interleave their rows in one image.
 //
 // LDS image: N float2, NO padding, XOR-swizzled so that every ds_write_b64 (16-lane groups, 32 banks) and
 // ds_read_b64 (32-lane groups, 64 banks) of both exchanges is conflict-free:
 //   idx(k0, row, c) = 512 (k0 >> P) + 32 row + R ((k0 & KP) ^ (row & KM)) + (c ^ (row & (R-1)))
-//   P = 5 - log2 R, KP = 2^P - 1, KM = {R=4: 3, R=8: 1, R=16: 0};  row = b (exchange 1) or k1 (exchange 2).
+//   P = 5 - log2 R, KP = 2^P - 1, KM = 16/R - 1 = {R=2: 7, R=4: 3, R=8: 1, R=16: 0};  row = b (exchange 1) or k1 (exchange 2).
 // (GF(2) argument: the low address bits are a bijection of the index bits that vary inside a lane group for each
 // of the four access shapes - DESIGN.md "segfft LDS image".)  Per access the address is (lane base ^ constant) +
 // immediate; the constants take 4 / 8 / 16 values, so a segment spends 16 / 26 / 49 v_xor on addressing.
@@ -33,14 +36,16 @@ namespace {
 
 template <int R> struct Geo {
     static constexpr int T = 16 * R, N = 256 * R, Q = 16 / R;
-    static constexpr int LR = (R == 4) ? 2 : (R == 8 ? 3 : 4);
+    static constexpr int LR = (R == 1) ? 0 : ((R == 2) ? 1 : ((R == 4) ? 2 : (R == 8 ? 3 : 4)));
     static constexpr int P = 5 - LR;
     static constexpr int KP = (1 << P) - 1;
-    static constexpr int KM = (R == 4) ? 3 : (R == 8 ? 1 : 0);
-    static constexpr int WAVES = T / 64;
-    // 256 B of slack (the image is aligned to 256 B: the swizzle XORs address bits 3..7) + image + per-wave
-    // half-segment sums (2 x 4 float2) + chunk ticket
-    static constexpr size_t LDS_BYTES = 256 + (size_t)N * sizeof(float2) + 16 * sizeof(float2);
+    static constexpr int KM = 16 / R - 1;
+    static constexpr int WAVES = T < 64 ? 1 : T / 64;      // waves per team
+    static constexpr int TPB = T < 64 ? 64 / T : 1;        // teams per workgroup (sub-wave teams share a wave)
+    static constexpr int BLOCK = T * TPB;
+    // 256 B of slack (the images are aligned to 256 B: the swizzle XORs address bits 3..7) + one image per team +
+    // per-wave half-segment sums (2 x 4 float2) + chunk tickets
+    static constexpr size_t LDS_BYTES = 256 + (size_t)TPB * N * sizeof(float2) + 16 * sizeof(float2);
 };
 
 enum { LOAD_HALF = 0, LOAD_FULL = 1 };
@@ -108,19 +113,40 @@ template <class F> __device__ __forceinline__ void twiddle_pow16(const float2 (&
     });
 }
 
+// Sum over the T lanes of a team that is a wave or part of one; every lane of the team gets the total.
+template <int T> __device__ __forceinline__ float team_total(float v) {
+    if constexpr (T >= 64) {
+        return wave_total(v);
+    } else {
+        v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+        v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+        v = dpp_add<0x141>(v);   // row_half_mirror
+        v = dpp_add<0x140>(v);   // row_mirror: the row-of-16 sum in every lane
+        if constexpr (T == 32)   // the other row of the pair, through the LDS crossbar (no memory)
+            v += __int_as_float(__builtin_amdgcn_ds_bpermute((int)((__lane_id() ^ 16u) << 2), __float_as_int(v)));
+        return v;
+    }
+}
+
 // WPS = waves per SIMD the register allocation is held to (4 -> 128 VGPRs, 3 -> 168)
 template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS>
-__global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
+__global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
     using G = Geo<R>;
-    constexpr int T = G::T, N = G::N, Q = G::Q, LR = G::LR, P = G::P, KP = G::KP, KM = G::KM;
+    constexpr int T = G::T, N = G::N, Q = G::Q, LR = G::LR, P = G::P, KP = G::KP, KM = G::KM, TPB = G::TPB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned img = ((unsigned)(unsigned long long)smem + 255u) & ~255u;      // LDS byte address of the image
-    float2 *red = reinterpret_cast<float2 *>(smem + (img - (unsigned)(unsigned long long)smem)) + N;   // [2][4] half sums
-    int *lnext = reinterpret_cast<int *>(red + 12);                                     // chunk ticket
+    const unsigned img0 = ((unsigned)(unsigned long long)smem + 255u) & ~255u;     // LDS byte address of the first image
+    float2 *red = reinterpret_cast<float2 *>(smem + (img0 - (unsigned)(unsigned long long)smem)) + TPB * N;   // [2][4] half sums
+    const int team = TPB > 1 ? (int)threadIdx.x / T : 0;
+    int *lnext = reinterpret_cast<int *>(red + 12) + team;                              // chunk ticket
+    // R = 1 (N = 256: two passes, no exchange 2): a row holds 16 entries, so teams 2i and 2i+1 interleave their
+    // rows in one 32-entry-per-row image - together they fill the 64 banks of a 32-lane read
+    const unsigned img = R == 1 ? img0 + (unsigned)(team >> 1) * 4096u + (unsigned)(team & 1) * 128u
+                                : img0 + (unsigned)team * (unsigned)(N * sizeof(float2));
 
-    const int t = threadIdx.x;
+    const int t = TPB > 1 ? (int)threadIdx.x % T : (int)threadIdx.x;
     const int hi = t >> LR, lo = t & (R - 1);
-    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const int wg = blockIdx.x * TPB + team, W = p.wg_per_stream, stream = blockIdx.y;
+    if (TPB > 1 && wg >= W) return;      // the odd team of the last workgroup (no workgroup barrier below when TPB > 1)
     const float2 *xb = p.x + (size_t)stream * p.stream_stride + p.first;
 
     // lane parts of the four LDS access shapes (byte addresses)
@@ -174,6 +200,10 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
         primed = sb_next >= 0;
         for (long long s = sb; s < se; ++s) {
             float2 v[16];
+            // R <= 2: the swizzle constants take 8 / 16 values per access shape; hoisted out of this loop the forty
+            // (base ^ constant) addresses would live in registers - keep the bases opaque and pay the v_xor instead
+            unsigned a_w1 = b_w1, a_rw = b_rw, a_r2 = b_r2;
+            if (R <= 2) asm volatile("" : "+v"(a_w1), "+v"(a_rw), "+v"(a_r2));
             prio_latency();
             // ---- samples, window, raw sums ------------------------------------------------------------
             float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
@@ -214,11 +244,11 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
             }
             float2 tot = make_float2(0.f, 0.f);
             if (DETREND) {
-                sum.x = wave_total(sum.x);
-                sum.y = wave_total(sum.y);
+                sum.x = team_total<T>(sum.x);
+                sum.y = team_total<T>(sum.y);
                 if (LOAD == LOAD_HALF && s == sb) {
-                    sumf.x = wave_total(sumf.x);
-                    sumf.y = wave_total(sumf.y);
+                    sumf.x = team_total<T>(sumf.x);
+                    sumf.y = team_total<T>(sumf.y);
                 }
                 if (G::WAVES > 1 && (t & 63) == 0) {
                     red[t >> 6] = sum;
@@ -262,7 +292,7 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
             prio_latency();
             twiddle_pow16(v, tw1, [&](auto kc, float2 val) {
                 constexpr int k0 = decltype(kc)::value;
-                lds_write_imm<8 * (512 * (k0 >> P) + R * (k0 & KP & ~KM))>(b_w1 ^ (8u * R * (k0 & KM)), val);
+                lds_write_imm<8 * (512 * (k0 >> P) + R * (k0 & KP & ~KM))>(a_w1 ^ (8u * R * (k0 & KM)), val);
             });
             if (G::WAVES > 1) lds_barrier();     // B
             // ---- pass 2: thread (k0, c) gathers b -----------------------------------------------------------
@@ -271,7 +301,7 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
                 // rows b with equal (b & KM, b & (R-1)) share one swizzled base
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, b = (i >> 2) + 4 * (i & 3);      // issue order 0,4,8,12, 1,5,9,13, ...
-                    lds_read_imm<256 * b>(r[b], b_rw ^ (8u * (R * (b & KM) + (b & (R - 1)))));
+                    lds_read_imm<256 * b>(r[b], a_rw ^ (8u * (R * (b & KM) + (b & (R - 1)))));
                 });
                 prio_compute();
                 float dep = 0.f;
@@ -299,29 +329,40 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
 #pragma unroll
                 for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
             }
-            prio_latency();
-            // in place: the R lanes that share k0 sit in one wave and have issued their reads of region k0 above
-            twiddle_pow16(v, tw2, [&](auto kc, float2 val) {
-                constexpr int k1 = decltype(kc)::value;
-                lds_write_imm<256 * k1>(b_rw ^ (8u * (R * (k1 & KM) + (k1 & (R - 1)))), val);
-            });
-            // ---- pass 3: thread (k0, j) gathers c for k1 = j + R m ---------------------------------------------
-            {
-                double r[16];
-                static_for<0, 16>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value, c = i / Q, m = i % Q;
-                    lds_read_imm<256 * R * m>(r[m * R + c], b_r2 ^ (8u * c));
+            if constexpr (R > 1) {
+                prio_latency();
+                // in place: the R lanes that share k0 sit in one wave and have issued their reads of region k0 above
+                twiddle_pow16(v, tw2, [&](auto kc, float2 val) {
+                    constexpr int k1 = decltype(kc)::value;
+                    lds_write_imm<256 * k1>(a_rw ^ (8u * (R * (k1 & KM) + (k1 & (R - 1)))), val);
                 });
-                prio_compute();
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
-                               "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]),
-                               "+v"(r[15]));
+                // ---- pass 3: thread (k0, j) gathers c for k1 = j + R m ---------------------------------------------
+                {
+                    double r[16];
+                    static_for<0, 16>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, c = i / Q, m = i % Q;
+                        // row k1 = lo + R m: its (k1 & KM) part beyond lo is (R m) & KM - zero unless R = 2
+                        lds_read_imm<256 * R * m>(r[m * R + c], a_r2 ^ (8u * (c + R * ((R * m) & KM))));
+                    });
+                    prio_compute();
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                                   "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]),
+                                   "+v"(r[15]));
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = __builtin_bit_cast(float2, r[i]);
+                    for (int i = 0; i < 16; ++i) v[i] = __builtin_bit_cast(float2, r[i]);
+                }
             }
-            // X[k0 + 16 (lo + R m) + 256 k2] lands in v[m R + k2] (R = 16: v[r16(k2)])
-            if (R == 4) {
+            // X[k0 + 16 (lo + R m) + 256 k2] lands in v[m R + k2] (R = 16: v[r16(k2)]; R = 1: X[k0 + 16 m] in v[r16(m)])
+            if (R == 1) {
+            } else if (R == 2) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const float2 e = v[2 * m], o = v[2 * m + 1];
+                    v[2 * m] = cadd(e, o);
+                    v[2 * m + 1] = csub(e, o);
+                }
+            } else if (R == 4) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) dft4<false>(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]);
             } else if (R == 8) {
@@ -341,7 +382,7 @@ __global__ __launch_bounds__(16 * R, WPS) void seg_kernel(SegArgs p) {
             } else {
                 dft16(v);
             }
-            auto at = [&](int m, int k2) -> float2 & { return v[R == 16 ? r16(k2) : m * R + k2]; };
+            auto at = [&](int m, int k2) -> float2 & { return v[R == 16 ? r16(k2) : (R == 1 ? r16(m) : m * R + k2)]; };
             if (!CHAIN) {
 #pragma unroll
                 for (int m = 0; m < Q; ++m)
@@ -698,17 +739,17 @@ template <int R> int occupancy_ws() {
 }
 
 template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS> hipError_t launch_one(const SegArgs &a, hipStream_t s) {
-    const dim3 grid(a.wg_per_stream, a.nstreams);
-    hipLaunchKernelGGL((seg_kernel<R, LOAD, DETREND, CHAIN, WPS>), grid, dim3(Geo<R>::T), Geo<R>::LDS_BYTES, s, a);
+    const dim3 grid((a.wg_per_stream + Geo<R>::TPB - 1) / Geo<R>::TPB, a.nstreams);
+    hipLaunchKernelGGL((seg_kernel<R, LOAD, DETREND, CHAIN, WPS>), grid, dim3(Geo<R>::BLOCK), Geo<R>::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
 template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS> int occupancy_one() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_kernel<R, LOAD, DETREND, CHAIN, WPS>, Geo<R>::T,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_kernel<R, LOAD, DETREND, CHAIN, WPS>, Geo<R>::BLOCK,
                                                      Geo<R>::LDS_BYTES) != hipSuccess || n < 1)
         n = 1;
-    return n;
+    return n * Geo<R>::TPB;
 }
 
 // kind: 0 Welch step = N/2 (half kept in registers), 1 Welch any step, 2 chain.  wps4: the 128-VGPR build of kind 0.
@@ -737,15 +778,17 @@ template <int R> int occupancy_r(int kind, bool wps4) {
 
 }  // namespace
 
-bool seg_supported(int nfft) { return nfft == 1024 || nfft == 2048 || nfft == 4096; }
+bool seg_supported(int nfft) { return nfft == 256 || nfft == 512 || nfft == 1024 || nfft == 2048 || nfft == 4096; }
 
 // resident teams per CU (VGPR / LDS / wave-slot limited)
 int seg_teams_per_cu(int nfft, int kind, bool wps4) {
-    static int cache[3][3][2] = {};
-    const int ri = nfft == 1024 ? 0 : (nfft == 2048 ? 1 : 2);
+    static int cache[5][3][2] = {};
+    const int ri = nfft == 1024 ? 0 : (nfft == 2048 ? 1 : (nfft == 4096 ? 2 : (nfft == 512 ? 3 : 4)));
     int &c = cache[ri][kind][wps4 ? 1 : 0];
     if (c) return c;
-    return c = nfft == 1024 ? occupancy_r<4>(kind, wps4) : (nfft == 2048 ? occupancy_r<8>(kind, wps4) : occupancy_r<16>(kind, wps4));
+    return c = nfft == 256 ? occupancy_r<1>(kind, wps4) : nfft == 512 ? occupancy_r<2>(kind, wps4)
+                           : (nfft == 1024 ? occupancy_r<4>(kind, wps4)
+                                           : (nfft == 2048 ? occupancy_r<8>(kind, wps4) : occupancy_r<16>(kind, wps4)));
 }
 
 // the role-split build: Welch, step = nfft / 2; det: 0 none, 1 time domain (1024 only), 2 frequency domain (SegArgs.fd)
@@ -764,6 +807,8 @@ hipError_t launch_segws(int nfft, const SegArgs &a, int det, hipStream_t s) {
 
 hipError_t launch_seg(int nfft, const SegArgs &a, int kind, bool wps4, hipStream_t s) {
     switch (nfft) {
+        case 256: return launch_r<1>(a, kind, wps4, s);
+        case 512: return launch_r<2>(a, kind, wps4, s);
         case 1024: return launch_r<4>(a, kind, wps4, s);
         case 2048: return launch_r<8>(a, kind, wps4, s);
         case 4096: return launch_r<16>(a, kind, wps4, s);

@@ -22,11 +22,14 @@ from .sensing_log import logger
 
 
 class spectrum_sensor_v2(ChainBlockMixin, sync_block):
+    _block_name = 'spectrum_sensor_v2'
+    _message_ports = ('freq_out_0', 'freq_out_1', 'freq_out_2', 'freq_out_3', 'freq_msg_PDU')      # :78-82
+
     def __init__(self, fft_len, sens_per_sec, sample_rate, channel_space=1, search_bw=1, thr_leveler=10,
                  tune_freq=0, alpha_avg=1, test_duration=1, period=3600, trunc_band=1, verbose=False,
                  stats=False, psd=False, waterfall=False, output=False, subject_channels=[],
                  ctx=None, threaded=False, log_directory=None, strobe_period_ms=1000):
-        sync_block.__init__(self, 'spectrum_sensor_v2', [np.complex64], None)
+        sync_block.__init__(self, self._block_name, [np.complex64], None)
         self.fft_len = fft_len
         self.sens_per_sec = sens_per_sec
         self.sample_rate = sample_rate
@@ -44,7 +47,7 @@ class spectrum_sensor_v2(ChainBlockMixin, sync_block):
         self.output = output
         self.subject_channels = list(subject_channels)
         self.top4 = [0, 0, 0, 0]
-        for port in ('freq_out_0', 'freq_out_1', 'freq_out_2', 'freq_out_3', 'freq_msg_PDU'):
+        for port in self._message_ports:
             self.message_port_register_hier_out(port)
 
         self.ctx = ctx or _hip.default_context()
@@ -52,7 +55,7 @@ class spectrum_sensor_v2(ChainBlockMixin, sync_block):
         chain = self.ctx.chain(fft_len, None, True, _hip.EPI_MAG2_OVER_N2, self.decimation)
         # message_strobe x 4, 1000 ms (:108-111): set_freqs() only changes their message; start() runs them
         self._strobes = [MessageStrobe(lambda m, i=i: self.message_port_pub('freq_out_%d' % i, m),
-                                       to_msg('freq', 0), strobe_period_ms) for i in range(4)]
+                                       to_msg('freq', 0), strobe_period_ms) for i in range(4 if self._message_ports else 0)]
         self.PDU_messages = message_pdu(None)
         self.PDU_messages.msg_connect('out', lambda m: self.message_port_pub('freq_msg_PDU', m))
 

@@ -63,6 +63,12 @@ def test_spectrum_sensor_v1_is_the_stats_path(ctx, golden, tmp_path):
     assert np.isclose(blk.noise_estimate, g['noise_seq'][-1], rtol=1e-4)
     assert np.allclose(blk._logger.cumulative_max_power, g['cumulative_max'], rtol=1e-4)
     assert relerr(blk._logger.cumulative_psd, g['peak']) < RTOL
+    # what v1 does not have (python/spectrum_sensor_v1.py:40-104): message ports, strobes, the smoothed copy, set_freqs
+    assert blk.name() == 'spectrum_sensor_v1' and blk._strobes == []
+    assert not any(p.startswith('freq_') for p in blk._out_ports)
+    assert not np.any(blk.power_level_ch)
+    with pytest.raises(AttributeError):
+        blk.set_freqs(1, 2, 3, 4)
 
 
 def test_spectrum_sensor_v2_decimation_and_scheduler_chunks(ctx):

@@ -831,7 +831,7 @@ def test_scan_decide_dev_on_device_rows(ctx, hip):
 
 # ------------------------------------------- segfft.hip: 1024 / 2048 Welch, fused chain ----
 
-@pytest.mark.parametrize('nfft', [1024, 2048])
+@pytest.mark.parametrize('nfft', [256, 512, 1024, 2048])
 @pytest.mark.parametrize('build', ['segws', 'seg3', 'seg4'])
 def test_seg_welch_vs_oracle_and_generic(ctx, hip, nfft, build):
     """The team-per-segment kernel (wave-per-segment at 1024) against the float64 oracle and the coverage kernel:
@@ -876,7 +876,7 @@ def test_seg_welch_vs_oracle_and_generic(ctx, hip, nfft, build):
             ctx.free(ptr)
 
 
-@pytest.mark.parametrize('nfft', [1024, 2048, 4096])
+@pytest.mark.parametrize('nfft', [256, 512, 1024, 2048, 4096])
 def test_fused_chain_many_rows_iir_peak_and_plain(ctx, hip, nfft):
     """The fused periodogram chain over thousands of kept vectors in one launch (IIR as a weighted sum over the
     launch, peak hold as a max) against the sequential oracle, against the coverage kernels, across pushes that
