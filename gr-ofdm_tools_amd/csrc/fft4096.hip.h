@@ -28,10 +28,24 @@ __device__ __forceinline__ float2 mul_w9(float2 a) { return make_float2(-fmaf(a.
 // position of output k of dft16() inside v[]
 __host__ __device__ constexpr int r16(int k) { return 4 * (k & 3) + (k >> 2); }
 
-// Forward 16-point DFT in place: in v[a], a = 0..15; out y[k] at v[r16(k)].
-__device__ __forceinline__ void dft16(float2 (&v)[16]) {
-#pragma unroll
-    for (int a0 = 0; a0 < 4; ++a0) dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
+constexpr float T1 = 0.41421356237309503f;   // tan(pi/8)
+
+// Second butterfly layer of the 16-point DFT with the inner twiddles W16^(kl j) folded into the butterflies.
+// Each twiddled input is written as (real scale) x (cheap combination p): W16^2 u = sqrt(1/2) (x + y, y - x),
+// W16^1 u = cos(pi/8) (x + t y, y - t x), W16^3 u = cos(pi/8) (t x + y, t y - x), t = tan(pi/8), and so on;
+// inside one 4-point butterfly the two odd inputs share their scale, so the scale rides on the fused
+// multiply-adds that replace the butterfly's additions.  144 operations per 16-point DFT instead of 160
+// (64 + 16 + 20 + 22 + 22 against 64 + 16 + 24 + 28 + 28).  `OTH_DFT16_PLAIN` restores the multiply-then-add form.
+__device__ __forceinline__ void dft4_tail(float2 t0, float2 t1, float2 p1, float2 p3, float S, float2 &a0, float2 &a1,
+                                          float2 &a2, float2 &a3) {
+    const float2 q = cadd(p1, p3), r = csub(p1, p3);
+    a0 = make_float2(fmaf(S, q.x, t0.x), fmaf(S, q.y, t0.y));
+    a2 = make_float2(fmaf(-S, q.x, t0.x), fmaf(-S, q.y, t0.y));
+    a1 = make_float2(fmaf(S, r.y, t1.x), fmaf(-S, r.x, t1.y));       // t1 + (-i) S r
+    a3 = make_float2(fmaf(-S, r.y, t1.x), fmaf(S, r.x, t1.y));
+}
+__device__ __forceinline__ void dft16_layer2(float2 (&v)[16]) {
+#ifdef OTH_DFT16_PLAIN
     v[5] = mul_w1(v[5]);
     v[9] = mul_w2(v[9]);
     v[13] = mul_w3(v[13]);
@@ -43,6 +57,42 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     v[15] = mul_w9(v[15]);
 #pragma unroll
     for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
+#else
+    dft4<false>(v[0], v[1], v[2], v[3]);
+    {   // kl = 1: W^1, W^2, W^3 on v[5], v[6], v[7]
+        const float2 u1 = v[5], u2 = v[6], u3 = v[7];
+        const float2 p1 = make_float2(fmaf(T1, u1.y, u1.x), fmaf(-T1, u1.x, u1.y));       // W^1 u = C1 p1
+        const float2 p2 = make_float2(u2.x + u2.y, u2.y - u2.x);                           // W^2 u = RH p2
+        const float2 p3 = make_float2(fmaf(T1, u3.x, u3.y), fmaf(T1, u3.y, -u3.x));        // W^3 u = C1 p3
+        const float2 t0 = make_float2(fmaf(RH, p2.x, v[4].x), fmaf(RH, p2.y, v[4].y));
+        const float2 t1 = make_float2(fmaf(-RH, p2.x, v[4].x), fmaf(-RH, p2.y, v[4].y));
+        dft4_tail(t0, t1, p1, p3, C1, v[4], v[5], v[6], v[7]);
+    }
+    {   // kl = 2: W^2, W^4 = -i, W^6 on v[9], v[10], v[11]
+        const float2 u1 = v[9], u2 = v[10], u3 = v[11];
+        const float2 p1 = make_float2(u1.x + u1.y, u1.y - u1.x);                           // W^2 u = RH p1
+        const float2 p3 = make_float2(u3.y - u3.x, -u3.x - u3.y);                          // W^6 u = RH p3
+        const float2 t0 = make_float2(v[8].x + u2.y, v[8].y - u2.x);
+        const float2 t1 = make_float2(v[8].x - u2.y, v[8].y + u2.x);
+        dft4_tail(t0, t1, p1, p3, RH, v[8], v[9], v[10], v[11]);
+    }
+    {   // kl = 3: W^3, W^6, W^9 = -W^1 on v[13], v[14], v[15]
+        const float2 u1 = v[13], u2 = v[14], u3 = v[15];
+        const float2 p1 = make_float2(fmaf(T1, u1.x, u1.y), fmaf(T1, u1.y, -u1.x));        // W^3 u = C1 p1
+        const float2 p2 = make_float2(u2.y - u2.x, -u2.x - u2.y);                          // W^6 u = RH p2
+        const float2 p3 = make_float2(fmaf(-T1, u3.y, -u3.x), fmaf(T1, u3.x, -u3.y));      // W^9 u = C1 p3
+        const float2 t0 = make_float2(fmaf(RH, p2.x, v[12].x), fmaf(RH, p2.y, v[12].y));
+        const float2 t1 = make_float2(fmaf(-RH, p2.x, v[12].x), fmaf(-RH, p2.y, v[12].y));
+        dft4_tail(t0, t1, p1, p3, C1, v[12], v[13], v[14], v[15]);
+    }
+#endif
+}
+
+// Forward 16-point DFT in place: in v[a], a = 0..15; out y[k] at v[r16(k)].
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+#pragma unroll
+    for (int a0 = 0; a0 < 4; ++a0) dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
+    dft16_layer2(v);
 }
 
 // dft16() of sixteen float2 read from LDS at base[STRIDE * i]: the reads are issued as plain ds_read_b64 in the
@@ -83,17 +133,7 @@ __device__ __forceinline__ void dft16_from_lds(float2 (&v)[16], const float2 *ba
         dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
     }
 #undef OTH_LDS_WAIT
-    v[5] = mul_w1(v[5]);
-    v[9] = mul_w2(v[9]);
-    v[13] = mul_w3(v[13]);
-    v[6] = mul_w2(v[6]);
-    v[10] = mul_w4(v[10]);
-    v[14] = mul_w6(v[14]);
-    v[7] = mul_w3(v[7]);
-    v[11] = mul_w6(v[11]);
-    v[15] = mul_w9(v[15]);
-#pragma unroll
-    for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
+    dft16_layer2(v);
 }
 
 // Non-temporal load of a sample that is read once: it does not displace the tables and partial sums in L2.

@@ -317,17 +317,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                     for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = __builtin_bit_cast(float2, r[a0 + 4 * j]);
                     dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
                 }
-                v[5] = mul_w1(v[5]);
-                v[9] = mul_w2(v[9]);
-                v[13] = mul_w3(v[13]);
-                v[6] = mul_w2(v[6]);
-                v[10] = mul_w4(v[10]);
-                v[14] = mul_w6(v[14]);
-                v[7] = mul_w3(v[7]);
-                v[11] = mul_w6(v[11]);
-                v[15] = mul_w9(v[15]);
-#pragma unroll
-                for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
+                dft16_layer2(v);
             }
             if constexpr (R > 1) {
                 prio_latency();
@@ -647,17 +637,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                     for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = __builtin_bit_cast(float2, r[a0 + 4 * j]);
                     dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
                 }
-                v[5] = mul_w1(v[5]);
-                v[9] = mul_w2(v[9]);
-                v[13] = mul_w3(v[13]);
-                v[6] = mul_w2(v[6]);
-                v[10] = mul_w4(v[10]);
-                v[14] = mul_w6(v[14]);
-                v[7] = mul_w3(v[7]);
-                v[11] = mul_w6(v[11]);
-                v[15] = mul_w9(v[15]);
-#pragma unroll
-                for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
+                dft16_layer2(v);
             }
             prio_latency();
             lds_write_imm<0>((img + b_rw), v[0]);

@@ -21,6 +21,28 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b) / np.abs(b)))
 
 
+def check_single_rows(rows, ref, power=True, ulps=4):
+    """SINGLE periodogram rows (the per-vector outputs of the GNU Radio chains: |X|^2 rows when `power`, |X| rows
+    otherwise).  A single transform of noise + a strong tone has bins down to 1e-6 of the row's peak (Rayleigh
+    nulls, leakage skirts); there the amplitude rounding of ANY fp32 FFT (FFTW3f, which fft_vcc runs, included) -
+    about one ulp of the row's LARGEST amplitude, because the tone's energy passes through every butterfly - is
+    1e-4 or more of the bin's own value.  tools/acc_probe.py measures 1.0-1.5 ulp of the peak as the worst
+    amplitude error over sizes and seeds, the same for both butterfly forms.  So single rows are held to
+      * amplitude error <= 4 ulp (2^-21) of the row's peak amplitude on EVERY bin,
+      * the plain 1e-4 on every bin at or above the row's median level (measured < 2e-5),
+      * mean relative error < 2e-6 (measured 3-4e-7).
+    Averaged quantities (the 8-row mean, peak hold over many rows, every Welch PSD) keep the plain 1e-4 on every bin."""
+    rows = np.atleast_2d(np.asarray(rows, np.float64))
+    ref = np.atleast_2d(np.asarray(ref, np.float64))
+    assert rows.shape == ref.shape
+    amp, amp_ref = (np.sqrt(rows), np.sqrt(ref)) if power else (rows, ref)
+    amp_err = np.abs(amp - amp_ref) / amp_ref.max(axis=1, keepdims=True)
+    assert amp_err.max() <= ulps * 2.0 ** -23, amp_err.max() * 2.0 ** 23
+    upper = ref >= np.median(ref, axis=1, keepdims=True)
+    assert np.max(np.abs(rows - ref)[upper] / ref[upper]) < RTOL
+    assert np.mean(np.abs(rows - ref) / ref) < 2e-6
+
+
 @pytest.fixture(scope='module')
 def hip():
     from ofdm_tools import _hip
@@ -190,7 +212,7 @@ def test_welch_bad_plans_are_rejected(ctx, hip):
         with pytest.raises(hip.HipError):
             ctx.welch_plan(**kw)
     with pytest.raises(hip.HipError):       # tuned kernel forced on a size it does not cover
-        ctx.welch_plan(512, kernel=hip.KERNEL_TUNED).exec(R.synth_iq(4096, 1))
+        ctx.welch_plan(128, kernel=hip.KERNEL_TUNED).exec(R.synth_iq(4096, 1))
 
 
 def test_welch_streaming_chunks_equal_one_shot(ctx):
@@ -343,13 +365,7 @@ def test_chain_sensor_v2_rows_and_mean8(ctx, hip, golden):
     ch = ctx.chain(1024, None, True, hip.EPI_MAG2_OVER_N2, 1)
     rows, n = ch.push(g['x'])
     assert n == 64 and rows.shape == (64, 1024)
-    # A single rectangular-window periodogram of noise has bins down to 1e-5 of the mean level; there an fp32
-    # FFT's amplitude rounding (~3e-7 of the rms amplitude, FFTW3f - what fft_vcc runs - included) is 1e-4 of
-    # the bin's power.  Such bins are judged against 1e-3 of the row's typical level; the averaged quantities
-    # (8-row mean here, every Welch PSD elsewhere) keep the plain 1e-4 on every bin.
-    ref = g['expected_rows']
-    assert np.max(np.abs(rows - ref) / np.maximum(ref, 1e-3 * np.median(ref))) < RTOL
-    assert np.mean(np.abs(rows - ref) / ref) < 2e-6
+    check_single_rows(rows, g['expected_rows'])
     assert relerr(ctx.rows_group_mean(rows, 8), g['expected_mean8']) < RTOL
 
 
@@ -358,11 +374,13 @@ def test_chain_psd_logger_mag_and_peak(ctx, hip, golden):
     ch = ctx.chain(4096, g['window'], False, hip.EPI_MAG, 1)
     ch.set_peak_hold(True)
     rows, n = ch.push(g['x'][:5 * 4096])
-    assert n == 5 and relerr(rows, g['expected_mag'][:5]) < RTOL
-    assert relerr(ch.peak(), g['expected_peak'][4]) < RTOL
+    assert n == 5
+    check_single_rows(rows, g['expected_mag'][:5], power=False)
+    check_single_rows(ch.peak(), g['expected_peak'][4], power=False)          # the max of five rows still has nulls
     rows, n = ch.push(g['x'][5 * 4096:])
-    assert n == 11 and relerr(rows, g['expected_mag'][5:]) < RTOL
-    assert relerr(ch.peak(), g['expected_peak'][-1]) < RTOL
+    assert n == 11
+    check_single_rows(rows, g['expected_mag'][5:], power=False)
+    check_single_rows(ch.peak(), g['expected_peak'][-1], power=False)
 
 
 def test_chain_local_worker_iir_log(ctx, hip, golden):
@@ -394,11 +412,12 @@ def test_chain_keep_one_in_n_matches_gnuradio_rule(ctx, hip):
         got.append(rows)
     got = np.concatenate(got)
     assert got.shape == ref.shape == (4, N)
-    assert relerr(got, ref) < RTOL
+    check_single_rows(got, ref)
     # latest-wins: a small rows_capacity returns the LAST row only
     ch.reset()
     rows, n = ch.push(x, max_rows=1)
-    assert n == 4 and relerr(rows[0], ref[3]) < RTOL
+    assert n == 4
+    check_single_rows(rows[0], ref[3])
 
 
 # ------------------------------------------------------- channel power ----
@@ -904,26 +923,28 @@ def test_fused_chain_many_rows_iir_peak_and_plain(ctx, hip, nfft):
     ch.set_iir_log(1.0, 0.0)
     r, n = ch.push(x, max_rows=1)
     last = R.chain_local_worker(x, nfft, 2000000, 1.0, decim=keep)[0][-1]
-    assert relerr(10 ** (r[0].astype(np.float64) / 10), last) < RTOL
+    # through float32 dB: one ulp of a 66 dB value is 1.7e-6 of the power, 7 ulp of the amplitude
+    check_single_rows(10 ** (r[0].astype(np.float64) / 10), last, ulps=16)
     # peak hold on |X| (psd_logger): natural order
     mag, peak = R.chain_psd_logger(x[:nfft * 300], nfft, decim=2)
     ch = ctx.chain(nfft, w, False, hip.EPI_MAG, 2)
     ch.set_peak_hold(True)
     r1, n1 = ch.push(x[:nfft * 100 + 5], max_rows=1)
-    assert relerr(ch.peak(), peak[n1 - 1]) < RTOL and relerr(r1[0], mag[n1 - 1]) < RTOL
+    assert relerr(ch.peak(), peak[n1 - 1]) < RTOL
+    check_single_rows(r1[0], mag[n1 - 1], power=False)
     r2, n2 = ch.push(x[nfft * 100 + 5:nfft * 300], max_rows=3)
-    assert n1 + n2 == len(mag) and relerr(r2, mag[-3:]) < RTOL and relerr(ch.peak(), peak[-1]) < RTOL
+    assert n1 + n2 == len(mag) and relerr(ch.peak(), peak[-1]) < RTOL
+    check_single_rows(r2, mag[-3:], power=False)
     # plain rows (spectrum_sensor_v2): all rows handed back, and the latest-wins form
     ref = R.chain_sensor_v2(x[:nfft * 64], nfft)
     ch = ctx.chain(nfft, None, True, hip.EPI_MAG2_OVER_N2, 1)
     rows, n = ch.push(x[:nfft * 64])
-    # single periodograms have bins 1e-5 of the mean level, where fp32 rounding of the amplitude is 1e-4 of the
-    # power: judge those against the row's typical level
-    floor = 1e-3 * np.median(ref)
-    assert n == 64 and np.max(np.abs(rows - ref) / np.maximum(ref, floor)) < RTOL
+    assert n == 64
+    check_single_rows(rows, ref)
     ch.reset()
     rows, n = ch.push(x[:nfft * 64], max_rows=1)
-    assert n == 64 and np.max(np.abs(rows[0] - ref[-1]) / np.maximum(ref[-1], floor)) < RTOL
+    assert n == 64
+    check_single_rows(rows[0], ref[-1])
 
 
 @pytest.mark.parametrize('build', ['', 'csd1'])

@@ -97,6 +97,12 @@ while time.perf_counter() - t0 < 0.2:      # clock ramp: an idle MI355X sits at 
     for _ in range(4):
         run()
     ctx.sync()
+hold = float(os.environ.get('PROF_LOOP_SECS', '0'))      # tools/power_probe.sh: keep the kernel running while rocm-smi samples
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < hold:
+    for _ in range(50):
+        run()
+    ctx.sync()
 ctx.set_timing(True)
 ctx.get_timing()
 for _ in range(reps):

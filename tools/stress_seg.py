@@ -89,20 +89,25 @@ while time.time() - t0 < secs:
             outs.append((got + got2, rows, state.astype(np.float64)))
             ch.close()
         assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+        # single rows of two fp32 transforms: amplitude difference in ulps of the row's peak amplitude (each
+        # implementation is within ~1.5 of the float64 result, tools/acc_probe.py; float32 dB adds ~7)
         err = 0.0
+
+        def ulps(a, b, power):
+            a, b = (np.sqrt(a), np.sqrt(b)) if power else (a, b)
+            return float(np.max(np.abs(a - b) / np.max(b, axis=-1, keepdims=True))) * 2.0 ** 23
+
         if outs[0][1].size:
             ra, rb = outs[0][1], outs[1][1]
             if mode == 'iir':
                 ra, rb = 10 ** (ra / 10), 10 ** (rb / 10)
-            err = float(np.max(np.abs(ra - rb) / np.maximum(rb, 1e-3 * np.median(rb))))
+            err = ulps(ra, rb, mode != 'peak')
         if outs[0][0] and mode != 'plain':
-            sa, sb = outs[0][2], outs[1][2]
-            err = max(err, float(np.max(np.abs(sa - sb) / np.maximum(sb, 1e-3 * np.median(sb)))))
+            err = max(err, ulps(outs[0][2], outs[1][2], mode != 'peak'))
+        err *= 1e-4 / (32.0 if mode == 'iir' else 8.0)          # normalised so that the common 1e-4 bound applies
         info = (kind, nfft, keep, mode, nrows, give)
     worst = max(worst, err)
-    # single periodogram rows of two fp32 FFTs differ by a few 1e-4 of a bin that sits 1e-3 below the typical level
-    # (5.0e-4 seen in 4000 cases)
-    assert err < (1e-3 if kind == 'chain' else 1e-4), (info, err)
+    assert err < 1e-4, (info, err)
     cases += 1
     if cases % 100 == 0:
         print('%d cases, worst %.2e' % (cases, worst), flush=True)
