@@ -1,12 +1,15 @@
 #!/bin/bash
-# usage (on the GPU box, repo root): tools/collect_all_profiles.sh <tag>
+# usage (on the GPU box, repo root): tools/collect_all_profiles.sh <tag> [config ...]      (default: all)
 # rocprofv3 kernel-trace + PMC passes (tools/pmc_passes.sh) for every configuration DESIGN.md quotes; leaves
 # gpurun_out/prof_<tag>_<config>/summary.txt.  tools/publish_profiles.py <tag> <round> copies them into profiles/.
 set -u
-TAG=$1
+TAG=$1; shift
+ONLY=" $* "
 for spec in "C2:welch4096ws" "C3:csd4096ws" "C4:welch4096ws" "C4ref:welch4096_kernel" "C5:welch16k" \
-            "w1024:segws_kernel" "w2048:segws_kernel" "chain1024:seg_kernel" "chain2048:seg_kernel" "chain4096:seg_kernel"; do
+            "w256:seg_kernel" "w512:seg_kernel" "w1024:segws_kernel" "w2048:segws_kernel" \
+            "chain256:seg_kernel" "chain512:seg_kernel" "chain1024:seg_kernel" "chain2048:seg_kernel" "chain4096:seg_kernel"; do
     cfg=${spec%%:*}; pat=${spec##*:}
+    if [ "$ONLY" != "  " ] && [[ "$ONLY" != *" $cfg "* ]]; then continue; fi
     tools/pmc_passes.sh prof_${TAG}_${cfg} $cfg 5 $pat > /dev/null 2>&1
     echo "== $cfg"; grep -E "GB/s" $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${cfg}/trace.log | tail -1
 done

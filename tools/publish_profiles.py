@@ -22,8 +22,12 @@ CONFIGS = {
     'C4ref': ('welch4096_kernel', 8 * 8 * 2 ** 25, 'C4 reference-faithful: flattop, nperseg 1024 zero-padded to 4096 '
               '(spectrum_sweeper.py:263): 4 transforms per 2048 new samples'),
     'C5': ('welch16k', 8 * 64 * 2 ** 22, 'C5: 64 channel streams x 2^22 samples, 16384-pt rect |X|^2/N^2 mean'),
+    'w256': ('seg_kernel', 8 * 2 ** 27, 'Welch 256-pt Hann 50 % overlap, 2^27 samples (four 16-thread teams per wave)'),
+    'w512': ('seg_kernel', 8 * 2 ** 27, 'Welch 512-pt Hann 50 % overlap, 2^27 samples (two 32-thread teams per wave)'),
     'w1024': ('segws_kernel', 8 * 2 ** 27, 'Welch 1024-pt Hann 50 % overlap, 2^27 samples'),
     'w2048': ('segws_kernel', 8 * 2 ** 27, 'Welch 2048-pt Hann 50 % overlap, 2^27 samples'),
+    'chain256': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 256, 2^26 samples'),
+    'chain512': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 512, 2^26 samples'),
     'chain1024': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 1024 (BH window, shift, |X|^2, IIR 0.8 + log), 2^26 samples'),
     'chain2048': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 2048, 2^26 samples'),
     'chain4096': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 4096, 2^26 samples'),
