@@ -68,7 +68,7 @@ extern "C" {
 /* kernel selection (diagnostics / parity tests) */
 #define OTH_KERNEL_AUTO      0
 #define OTH_KERNEL_GENERIC   1   /* radix-4 Stockham, any power of two 16..16384 */
-#define OTH_KERNEL_TUNED     2   /* register/LDS radix-16 kernels (nfft 1024, 2048, 4096, 16384) */
+#define OTH_KERNEL_TUNED     2   /* register/LDS radix-16 kernels (nfft 256 ... 4096, 16384) */
 
 /* how the welch4096 kernel hands segments to workgroups */
 #define OTH_SCHED_CONTIGUOUS  0   /* fixed contiguous runs: bit-reproducible sums */
@@ -139,7 +139,7 @@ int oth_plan_set_kernel(oth_plan *plan, int which);           /* OTH_KERNEL_* */
 int oth_plan_set_schedule(oth_plan *plan, int which);         /* OTH_SCHED_* */
 int oth_plan_out_len(oth_plan *plan, int *n);
 /* Launch tuning for A/B tools and the parity suite: which build of the 4096-point kernel ("dpp", "pipe", "ws") or
- * of the 1024 / 2048-point kernel ("seg3", "seg4": registers held to 3 / 4 waves per SIMD; NULL or "" = the
+ * of the 256 ... 2048-point kernels ("seg3", "seg4": registers held to 3 / 4 waves per SIMD; NULL or "" = the
  * library's choice), a schedule override (-1 = the plan's), segments per chunk and per tail chunk
  * (0 = default).  The OTH_W4096_VARIANT / _SCHED / _CHUNK / _TAIL environment variables give the initial values
  * and are read once, in oth_welch_plan(). */
