@@ -1768,6 +1768,17 @@ int oth__debug_stamps(oth_plan *p, unsigned long long *out, int max_wg, int *nwg
     return OTH_OK;
 }
 
+// Not part of the ABI: raw bytes of the plan's partial-sum buffer from a float offset on (diagnostic builds' stamps).
+int oth__debug_partial_raw(oth_plan *p, size_t float_offset, void *out, size_t nbytes) {
+    CtxGuard guard_(p ? p->ctx : nullptr);
+    if (!p || !out) return OTH_ERR_INVALID;
+    oth_ctx *c = p->ctx;
+    if (float_offset * sizeof(float) + nbytes > p->partial_cap) return OTH_ERR_INVALID;
+    HIPCHK(c, hipMemcpyAsync(out, p->d_partial + float_offset, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OTH_OK;
+}
+
 int oth_fac(oth_ctx *c, const void *data, size_t n, int L, float *out) {
     CtxGuard guard_(c);
     return xcorr_impl(c, data, n, nullptr, 0, L, out, 1);

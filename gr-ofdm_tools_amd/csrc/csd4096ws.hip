@@ -33,12 +33,34 @@ constexpr int TCS = 1024;
 constexpr int CS_RED = 32;                 // float2 per pair: per image the four producer waves' segment sums
 constexpr int CS_CTRL = 16;                // ints per pair: item kind per image [0..1], next-chunk ticket [4] (pair 0)
 constexpr size_t CS_PAIR_BYTES = (2 * LDS_X + CS_RED) * sizeof(float2) + CS_CTRL * sizeof(int);
-constexpr size_t CS_LDS_BYTES = 2 * CS_PAIR_BYTES;
+constexpr size_t CS_FW_BYTES = 256 * sizeof(float4);      // window-spectrum entries of the detrend, one per t
+constexpr size_t CS_LDS_BYTES = 2 * CS_PAIR_BYTES + CS_FW_BYTES;
+static_assert((2 * CS_PAIR_BYTES) % 16 == 0, "the detrend table is read as float4");
 
 enum { CS_STOP = 0, CS_DATA = 1, CS_BUBBLE = 2 };
 
+// -DOTH_CSDWS_DIAG=1 (tools/csd_phases.py): per-wave cycle counts of the phases of a step, accumulated in scalar
+// registers and written behind the partial sums (1 KiB per workgroup: 16 waves x 8 counters)
+#ifndef OTH_CSDWS_DIAG
+#define OTH_CSDWS_DIAG 0
+#endif
+#if OTH_CSDWS_DIAG
+#define CS_STAMP(i)                                                 \
+    {                                                               \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+        phase[i] += n_ - last_;                                     \
+        last_ = n_;                                                 \
+    }
+#else
+#define CS_STAMP(i)
+#endif
+
 template <bool DETREND>
 __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
+#if OTH_CSDWS_DIAG
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const bool producer = tid < 512;
@@ -93,7 +115,9 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
         };
         auto step_end = [&](int item) {
             if (t == 0) ctrl[it & 1] = item;
+            CS_STAMP(2);      // pass 1 + twiddles + exchange-1 writes issued
             lds_barrier();
+            CS_STAMP(3);      // barrier (includes the LDS writes landing)
             ++it;
         };
         auto item = [&](auto first_, auto mode_, int s, int nsb, bool publish) {
@@ -103,6 +127,11 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
             float2 *lx = img + q * LDS_X;
             __builtin_amdgcn_s_setprio(2);
             float2 v[16];
+#if OTH_CSDWS_DIAG
+            CS_STAMP(0);      // loop / chunk bookkeeping
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            CS_STAMP(1);      // wait for the prefetched half
+#endif
             float2 sumf = make_float2(0.f, 0.f), sum = make_float2(0.f, 0.f);
             if (FIRST) {
 #pragma unroll
@@ -218,28 +247,28 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
 #else
         const float2 c1 = p.tw[16 * lo], c4 = p.tw[64 * lo];
 #endif
-        float4 fw = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (DETREND) fw = p.fd[t];
+        // The detrend's window-spectrum entries and the segment mean are fetched from LDS where they are used: held in
+        // registers across the step they pushed the allocation past 128 VGPRs, and the one spilled register came
+        // back through scratch memory behind an s_waitcnt vmcnt(0) in every step (42 % of the consumers' time).
+        float4 *fwl = reinterpret_cast<float4 *>(smem + 2 * CS_PAIR_BYTES);
+        if (DETREND && pair == 0) fwl[t] = p.fd[t];      // lanes l and l + 32 (same t) are in one wave: ordered
         float acs[16], acx[16];       // own power |X|^2 (or |Y|^2); cross term Re (pair 0) or Im (pair 1) of conj(X) Y
 #pragma unroll
         for (int k = 0; k < 16; ++k) acs[k] = acx[k] = 0.f;
         float2 v[16];
-        float2 mean = make_float2(0.f, 0.f);
         int it = 0;
 
         // barrier A of step `it`, then what the producer left in image it & 1: item word, sums, pass 2
         auto next_item = [&]() -> int {
             __builtin_amdgcn_s_setprio(2);
+            CS_STAMP(4);      // exchange + accumulation (loop tail)
             lds_barrier();
+            CS_STAMP(0);      // barrier
             const int q = it & 1;
             const float2 *lq = img + q * LDS_X;
             const int kind = __builtin_amdgcn_readfirstlane(ctrl0[q]);      // both streams run the same schedule
-            const float2 h0 = red[q * 8], h1 = red[q * 8 + 1], h2 = red[q * 8 + 2], h3 = red[q * 8 + 3];
             dft16_from_lds<17>(v, lq + r1, [] { __builtin_amdgcn_s_setprio(1); });
-            if (DETREND) {
-                const float2 tot = cadd(cadd(h0, h1), cadd(h2, h3));
-                mean = make_float2(tot.x * (1.0f / 4096.0f), tot.y * (1.0f / 4096.0f));
-            }
+            CS_STAMP(1);      // exchange-1 reads + pass 2
             ++it;
             return kind;
         };
@@ -258,9 +287,19 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
 #else
             scatter_pow16<17>(v, lx + w2, c1, c4);
 #endif
+            CS_STAMP(2);      // pass-2 twiddles + exchange-2 writes issued
             wave_lds_sync();
+            float4 fw = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 h0 = make_float2(0.f, 0.f), h1 = h0, h2 = h0, h3 = h0;
+            if (DETREND) {      // image q's sums stay valid until the barrier of the next step
+                fw = fwl[t];
+                h0 = red[q * 8], h1 = red[q * 8 + 1], h2 = red[q * 8 + 2], h3 = red[q * 8 + 3];
+            }
             dft16_from_lds<1>(v, lx + r2, [] { __builtin_amdgcn_s_setprio(1); });
+            CS_STAMP(3);      // exchange-2 reads + pass 3
             if (DETREND) {
+                const float2 tot = cadd(cadd(h0, h1), cadd(h2, h3));
+                const float2 mean = make_float2(tot.x * (1.0f / 4096.0f), tot.y * (1.0f / 4096.0f));
                 v[r16(0)] = make_float2(v[r16(0)].x - (mean.x * fw.x - mean.y * fw.y),
                                         v[r16(0)].y - (mean.x * fw.y + mean.y * fw.x));
                 v[r16(15)] = make_float2(v[r16(15)].x - (mean.x * fw.z - mean.y * fw.w),
@@ -297,6 +336,14 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
             dst[(pair ? 12288 : 8192) + 256 * k2 + t] = acx[k2];
         }
     }
+#if OTH_CSDWS_DIAG
+    if ((tid & 63) == 0) {
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * 4 * 4096) +
+                                 ((size_t)stream * W + wg) * 128 + (tid >> 6) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st[i] = phase[i];
+    }
+#endif
 }
 
 }  // namespace

@@ -49,6 +49,12 @@ template <int R> struct Geo {
 };
 
 enum { LOAD_HALF = 0, LOAD_FULL = 1 };
+#ifndef OTH_CHAIN_WIN_LDS
+#define OTH_CHAIN_WIN_LDS 1
+#endif
+#ifndef OTH_CHAIN_WPS
+#define OTH_CHAIN_WPS 3      // waves per SIMD of the chain build (2: no spills at all, but half the speed)
+#endif
 enum { ACC_SUM = 0, ACC_WSUM = 1, ACC_MAX = 2, ACC_NONE = 3 };
 
 // Image accesses are explicit ds_read_b64 / ds_write_b64 at (swizzled lane base) + immediate.  A wave's LDS
@@ -148,6 +154,18 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
     const int t = TPB > 1 ? (int)threadIdx.x % T : (int)threadIdx.x;
     const int hi = t >> LR, lo = t & (R - 1);
     const int wg = blockIdx.x * TPB + team, W = p.wg_per_stream, stream = blockIdx.y;
+    // WIN_LDS (the chain build): the sixteen window values of a thread live in LDS as four float4 and are read
+    // per segment - sixteen registers less, which is what keeps the build's spills out of the segment loop (a
+    // spill reload waits on vmcnt and with it on the prefetch in flight)
+    constexpr bool WIN_LDS = CHAIN && (OTH_CHAIN_WIN_LDS != 0);
+    float4 *wl = reinterpret_cast<float4 *>(red + 16) + t;      // [4][T] float4, one table per workgroup
+    if (WIN_LDS) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+            wl[qd * T] = make_float4(p.win[T * (4 * qd) + t], p.win[T * (4 * qd + 1) + t], p.win[T * (4 * qd + 2) + t],
+                                     p.win[T * (4 * qd + 3) + t]);
+        __syncthreads();      // (teams of one workgroup write identical tables)
+    }
     if (TPB > 1 && wg >= W) return;      // the odd team of the last workgroup (no workgroup barrier below when TPB > 1)
     const float2 *xb = p.x + (size_t)stream * p.stream_stride + p.first;
 
@@ -157,8 +175,10 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
     const unsigned b_r2 = img + 8u * (512u * (hi >> P) + 32u * lo + R * ((hi & KP) ^ (lo & KM)) + lo);          // (k0, j)
 
     float win[16];
+    if (!WIN_LDS) {
 #pragma unroll
-    for (int a = 0; a < 16; ++a) win[a] = p.win[T * a + t];
+        for (int a = 0; a < 16; ++a) win[a] = p.win[T * a + t];
+    }
     // W_N^(k t) for pass 1 and W_N^(16 k c) for pass 2, k = 1, 2, 3, 4, 8, 12 (table index mod N)
     const Pow6 tw1 = {p.tw[t], p.tw[(2 * t) & (N - 1)], p.tw[(3 * t) & (N - 1)], p.tw[(4 * t) & (N - 1)],
                       p.tw[(8 * t) & (N - 1)], p.tw[(12 * t) & (N - 1)]};
@@ -232,6 +252,13 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                     for (int a = 0; a < 8; ++a) nxt[a] = load_once(xn + T * a);
                 }
             } else {
+                if (WIN_LDS) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const float4 w4 = wl[qd * T];
+                        win[4 * qd] = w4.x, win[4 * qd + 1] = w4.y, win[4 * qd + 2] = w4.z, win[4 * qd + 3] = w4.w;
+                    }
+                }
 #pragma unroll
                 for (int a = 0; a < 16; ++a) {
                     const float2 r = nxt[a];
@@ -720,23 +747,30 @@ template <int R> int occupancy_ws() {
     return n;
 }
 
+// image(s) + sums + tickets, and for the chain build the window table (4 x T float4)
+template <int R, bool CHAIN> constexpr size_t seg_lds_bytes() {
+    return Geo<R>::LDS_BYTES + ((CHAIN && OTH_CHAIN_WIN_LDS) ? 4 * Geo<R>::T * sizeof(float4) : 0);
+}
+
 template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS> hipError_t launch_one(const SegArgs &a, hipStream_t s) {
     const dim3 grid((a.wg_per_stream + Geo<R>::TPB - 1) / Geo<R>::TPB, a.nstreams);
-    hipLaunchKernelGGL((seg_kernel<R, LOAD, DETREND, CHAIN, WPS>), grid, dim3(Geo<R>::BLOCK), Geo<R>::LDS_BYTES, s, a);
+    constexpr size_t lds = seg_lds_bytes<R, CHAIN>();
+    hipLaunchKernelGGL((seg_kernel<R, LOAD, DETREND, CHAIN, WPS>), grid, dim3(Geo<R>::BLOCK), lds, s, a);
     return hipGetLastError();
 }
 
 template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS> int occupancy_one() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_kernel<R, LOAD, DETREND, CHAIN, WPS>, Geo<R>::BLOCK,
-                                                     Geo<R>::LDS_BYTES) != hipSuccess || n < 1)
+    constexpr size_t lds = seg_lds_bytes<R, CHAIN>();
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_kernel<R, LOAD, DETREND, CHAIN, WPS>, Geo<R>::BLOCK, lds) != hipSuccess ||
+        n < 1)
         n = 1;
     return n * Geo<R>::TPB;
 }
 
 // kind: 0 Welch step = N/2 (half kept in registers), 1 Welch any step, 2 chain.  wps4: the 128-VGPR build of kind 0.
 template <int R> hipError_t launch_r(const SegArgs &a, int kind, bool wps4, hipStream_t s) {
-    if (kind == 2) return launch_one<R, LOAD_FULL, false, true, 3>(a, s);
+    if (kind == 2) return launch_one<R, LOAD_FULL, false, true, OTH_CHAIN_WPS>(a, s);
     if constexpr (R == 16) {
         return hipErrorInvalidValue;      // the Welch average at 4096 has its own kernels (welch4096*.hip)
     } else {
@@ -749,7 +783,7 @@ template <int R> hipError_t launch_r(const SegArgs &a, int kind, bool wps4, hipS
 }
 
 template <int R> int occupancy_r(int kind, bool wps4) {
-    if (kind == 2) return occupancy_one<R, LOAD_FULL, false, true, 3>();
+    if (kind == 2) return occupancy_one<R, LOAD_FULL, false, true, OTH_CHAIN_WPS>();
     if constexpr (R == 16) {
         return 1;
     } else {
