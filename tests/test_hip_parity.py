@@ -327,7 +327,7 @@ def test_csd_coherence_golden(ctx, hip, golden, kernel):
     assert relerr(pxx, g['expected_pxx']) < RTOL
     assert relerr(pyy, g['expected_pyy']) < RTOL
     e = g['expected_pxy']
-    assert np.max(np.abs(pxy.astype(np.complex128) - e) / np.abs(e)) < 1e-3   # complex: relative to |Pxy|
+    assert np.max(np.abs(pxy.astype(np.complex128) - e) / np.abs(e)) < RTOL   # relative to |Pxy| (coherence >= 0.35 here; measured 2e-6)
     assert np.max(np.abs(pxy.astype(np.complex128) - e) / np.sqrt(g['expected_pxx'] * g['expected_pyy'])) < RTOL
     assert np.max(np.abs(cxy - g['expected_cxy'])) < RTOL
 
