@@ -391,7 +391,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     // wave-specialised pairs (csd4096ws.hip): 50 % overlap, frequency-domain detrend; "csd1" forces the one-role kernel
     const bool csd_ws = tuned_csd && p->step == 2048 && (p->detrend == OTH_DETREND_NONE || p->d_fd) &&
                         nseg < (1LL << 30) && p->tune_variant != "csd1";
-    const bool tuned_16k = !csd && p->nfft == 16384 && p->nperseg == 16384 && p->kernel != OTH_KERNEL_GENERIC;
+    const bool tuned_16k = !csd && (p->nfft == 16384 || p->nfft == 8192) && p->nperseg == p->nfft &&
+                           p->kernel != OTH_KERNEL_GENERIC;
     // segfft.hip: nperseg = nfft = 256 / 512 / 1024 / 2048, any step (team of nfft / 16 threads per segment)
     const bool tuned_seg = !csd && (p->nfft == 256 || p->nfft == 512 || p->nfft == 1024 || p->nfft == 2048) && p->nperseg == p->nfft &&
                            p->kernel != OTH_KERNEL_GENERIC;
@@ -415,7 +416,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         // exactly the resident workgroups: one wave of workgroups, no tail round
         const int bpc = tuned ? var->blocks_per_cu()
                               : (tuned_csd ? (csd_ws ? csd4096ws_blocks_per_cu() : csd4096_blocks_per_cu())
-                                           : (tuned_seg ? (seg_ws ? segws_teams_per_cu(p->nfft) : seg_teams_per_cu(p->nfft, seg_kind, seg_wps4)) : 1));
+                                           : (tuned_seg ? (seg_ws ? segws_teams_per_cu(p->nfft) : seg_teams_per_cu(p->nfft, seg_kind, seg_wps4))
+                                                        : (p->nfft == 8192 ? 2 : 1)));      // welch16k: 139 / 70 KiB of LDS
         long long w = ((long long)c->cu_count * bpc + nstreams - 1) / nstreams;
         W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
     }
@@ -499,12 +501,12 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         Timed tm(c);
         HIPCHK(c, tuned ? var->launch(a, c->stream)
                         : (tuned_csd ? (csd_ws ? launch_csd_tuned4096ws(a, c->stream) : launch_csd_tuned4096(a, c->stream))
-                                     : (tuned_16k ? launch_welch_tuned16k(a, c->stream)
+                                     : (tuned_16k ? launch_welch_tuned16k(p->nfft, a, c->stream)
                                                   : launch_welch_generic(p->nfft, a, c->stream))));
     }
     *nseg_out = nseg;
     *W_out = W * rows;
-    *layout_out = (tuned || tuned_csd) ? 1 : (tuned_16k ? 2 : 0);
+    *layout_out = (tuned || tuned_csd) ? 1 : (tuned_16k ? (p->nfft == 16384 ? 2 : 3) : 0);
     return OTH_OK;
 }
 

@@ -10,12 +10,12 @@ namespace oth {
 // bin held at position `pos` of a partial-sum row
 //   layout 0: natural order (generic kernels)
 //   layout 1: welch4096 / csd4096 leave bin k0 + 16 k1 + 256 k2 at 16 k0 + k1 + 256 k2
-//   layout 2: welch16k leaves bin k' + 4 q at 4096 k' + (layout-1 position of q)
+//   layout 2: welch16k leaves bin k' + 4 q at 4096 k' + (layout-1 position of q); layout 3 (8192 points): k' + 2 q
 __device__ __forceinline__ int bin_pos(int pos, int layout) {
     if (layout == 0) return pos;
     const int r = pos & 4095;
     const int q = ((r & 15) << 4) | ((r >> 4) & 15) | (r & ~255);
-    return layout == 1 ? q : (pos >> 12) + 4 * q;
+    return layout == 1 ? q : (pos >> 12) + (layout == 2 ? 4 : 2) * q;
 }
 
 // 256 threads = 32 consecutive bins x 8 slices of the workgroup axis; the 8 slice sums are

@@ -90,7 +90,7 @@ struct FinalizeArgs {
     int W;
     int nfft;
     int nch;                // 1 or 4
-    int layout;             // 0 natural, 1 welch4096 digit order, 2 welch16k order (kernels_misc.hip bin_pos)
+    int layout;             // 0 natural, 1 welch4096 digit order, 2 / 3 welch16k order at 16384 / 8192 (kernels_misc.hip bin_pos)
     int fftshift;
     int trim;
     int db;
@@ -130,8 +130,8 @@ int csd4096_blocks_per_cu();
 // csd4096ws.hip: the same as two wave-specialised pairs in one 1024-thread workgroup; step 2048, WelchArgs.fd for detrend
 hipError_t launch_csd_tuned4096ws(const WelchArgs &a, hipStream_t s);
 int csd4096ws_blocks_per_cu();
-// welch16k.hip: nfft = nperseg = 16384, one 1024-thread workgroup per CU
-hipError_t launch_welch_tuned16k(const WelchArgs &a, hipStream_t s);
+// welch16k.hip: nfft = nperseg = 16384 (one 1024-thread workgroup per CU) or 8192 (two 512-thread workgroups)
+hipError_t launch_welch_tuned16k(int nfft, const WelchArgs &a, hipStream_t s);
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
 // segfft.hip
 bool seg_supported(int nfft);

@@ -1,18 +1,18 @@
-// welch16k: segment-averaged |FFT_16384(detrend(x) * w)|^2 for nperseg = nfft = 16384
+// welch16k: segment-averaged |FFT_N(detrend(x) * w)|^2 for nperseg = nfft = N = 4096 F, F = 4 (16384) or 2 (8192)
 // (BASELINE config 5: multichannel_scanner, 64 channel streams x 16384-point PSD,
 // python/multichannel_scanner.py:78-86 chain averaged over the kept vectors; also any
-// scipy.signal.welch call with nperseg = nfft = 16384).
+// scipy.signal.welch call with nperseg = nfft = 8192 / 16384).
 //
-// 16384 = 4 x 4096, decimation in frequency.  One 1024-thread workgroup per segment, 16 points
+// N = F x 4096, decimation in frequency.  One workgroup of T = 256 F threads per segment, 16 points
 // per thread:
 //
-//   pass 0  n = 4096 a' + m: thread tid holds a' = 0..3 for m = tid + 1024 j (j = 0..3), radix-4 over
-//           a' -> k' = k mod 4, times W16384^(k' m); scattered to the LDS region of sub-FFT k'
+//   pass 0  n = 4096 a' + m: thread tid holds a' = 0..F-1 for m = tid + T j (j = 0..16/F-1), radix-F over
+//           a' -> k' = k mod F, times W_N^(k' m); scattered to the LDS region of sub-FFT k'
 //   then    the 256 threads tid >> 8 == k' run the radix-16 x 16 x 16 scheme of welch4096.hip on
-//           their 4096 points (same LDS image, inside region k') -> bins k = k' + 4 q.
+//           their 4096 points (same LDS image, inside region k') -> bins k = k' + F q.
 //
-// LDS: 4 regions of 16 x 272 float2 (139 KiB) + the shared W256 table; one workgroup per CU,
-// 16 waves = 4 per SIMD at <= 128 VGPRs.  Four workgroup barriers per segment.
+// LDS: F regions of 16 x 272 float2 (139 KiB at F = 4: one workgroup per CU; 70 KiB at F = 2: two);
+// 16 waves per CU = 4 per SIMD at <= 128 VGPRs.  Four workgroup barriers per segment.
 #include "fft4096.hip.h"
 
 #ifndef OTH_16K_NT
@@ -27,36 +27,49 @@
 namespace oth {
 namespace {
 
-constexpr int T16 = 1024;
 constexpr int REGION = 16 * RS;                     // float2 per sub-FFT image
-constexpr int LDS16_RED = 32;                       // 16 wave sums + ticket
-constexpr size_t LDS16_BYTES = (4 * REGION + LDS16_RED) * sizeof(float2);
+constexpr int LDS16_RED = 32;                       // up to 16 wave sums + ticket
+template <int F> constexpr size_t lds16_bytes() { return (F * REGION + LDS16_RED) * sizeof(float2); }
 
-// multiply by exp(-2 pi i q / 16), q a compile-time constant 0..9 (the products j * k' that occur)
+// multiply by exp(-2 pi i q / 16), q a compile-time constant (the products j * k' that occur: 0..7 and 9)
 template <int Q> __device__ __forceinline__ float2 mul_w16(float2 a) {
     if constexpr (Q == 0) return a;
     else if constexpr (Q == 1) return mul_w1(a);
     else if constexpr (Q == 2) return mul_w2(a);
     else if constexpr (Q == 3) return mul_w3(a);
     else if constexpr (Q == 4) return mul_w4(a);
+    else if constexpr (Q == 5) return mul_w4(mul_w1(a));
     else if constexpr (Q == 6) return mul_w6(a);
-    else return mul_w9(a);
+    else if constexpr (Q == 7) return mul_w4(mul_w3(a));
+    else {
+        static_assert(Q == 9, "twiddle power not provided");
+        return mul_w9(a);
+    }
 }
 
-template <int J> __device__ __forceinline__ void pass0_scatter(float2 (&v)[16], const float2 (&wt)[4], float2 *l0) {
-    // v[4 J + a'] -> radix-4 over a' -> k' = 0..3, times W16384^(k' (1024 J + tid)) = wt[k'] * W16^(J k')
-    dft4<false>(v[4 * J], v[4 * J + 1], v[4 * J + 2], v[4 * J + 3]);
-    l0[0 * REGION + 1024 * J] = v[4 * J];
-    l0[1 * REGION + 1024 * J] = mul_w16<J>(cmul(v[4 * J + 1], wt[1]));
-    l0[2 * REGION + 1024 * J] = mul_w16<2 * J>(cmul(v[4 * J + 2], wt[2]));
-    l0[3 * REGION + 1024 * J] = mul_w16<3 * J>(cmul(v[4 * J + 3], wt[3]));
+// radix-F butterfly over a' of the points v[F J + a'] (m = T J + tid), times W_N^(k' m) = wt[k'] * W16^(J k')
+// (T / N = 1 / 16 for both sizes), scattered to element m of region k'
+template <int J, int F> __device__ __forceinline__ void pass0_scatter(float2 (&v)[16], const float2 (&wt)[4], float2 *l0) {
+    constexpr int T = 256 * F;
+    if constexpr (F == 4) {
+        dft4<false>(v[4 * J], v[4 * J + 1], v[4 * J + 2], v[4 * J + 3]);
+        l0[0 * REGION + T * J] = v[4 * J];
+        l0[1 * REGION + T * J] = mul_w16<J>(cmul(v[4 * J + 1], wt[1]));
+        l0[2 * REGION + T * J] = mul_w16<2 * J>(cmul(v[4 * J + 2], wt[2]));
+        l0[3 * REGION + T * J] = mul_w16<3 * J>(cmul(v[4 * J + 3], wt[3]));
+    } else {
+        const float2 u0 = v[2 * J], u1 = v[2 * J + 1];
+        l0[0 * REGION + T * J] = cadd(u0, u1);
+        l0[1 * REGION + T * J] = mul_w16<J>(cmul(csub(u0, u1), wt[1]));
+    }
 }
 
-template <bool DETREND>
-__global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
+template <bool DETREND, int F>
+__global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
+    constexpr int T16 = 256 * F, N = 4096 * F, NJ = 16 / F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
-    float2 *red = lds + 4 * REGION;
+    float2 *red = lds + F * REGION;
 
     const int tid = threadIdx.x;
     const int kp = tid >> 8, t = tid & 255;          // sub-FFT k', thread inside it
@@ -65,18 +78,18 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
     const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
     const float2 *xb = p.x + (size_t)stream * p.stream_stride;
 
-    // thread-constant tables: window for n = 4096 a' + 1024 j + tid (stored at [4 j + a']),
-    // W16384^(k' tid) for k' = 1..3, and for the sub-FFT W4096^t, W4096^(4t) = W16384^(4t), W16384^(16t)
+    // thread-constant tables: window for n = 4096 a' + T j + tid (stored at [F j + a']),
+    // W_N^(k' tid) for k' = 1..F-1, and for the sub-FFT W4096^t = W_N^(F t), W4096^(4t)
     float win[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) win[4 * j + a] = p.win[4096 * a + 1024 * j + tid];
-    float2 wt[4];
+        for (int a = 0; a < F; ++a) win[F * j + a] = p.win[4096 * a + T16 * j + tid];
+    float2 wt[4] = {};
 #pragma unroll
-    for (int k = 1; k < 4; ++k) wt[k] = p.tw[k * tid];
-    const float2 b1 = p.tw[4 * t], b4 = p.tw[16 * t];
-    const float2 c1 = p.tw[64 * lo], c4 = p.tw[256 * lo];   // W256^c = W16384^(64 c), W256^(4c)
+    for (int k = 1; k < F; ++k) wt[k] = p.tw[k * tid];
+    const float2 b1 = p.tw[F * t], b4 = p.tw[4 * F * t];
+    const float2 c1 = p.tw[16 * F * lo], c4 = p.tw[64 * F * lo];   // W256^c = W_N^(16 F c), W256^(4c)
 
     float acc[16];
 #pragma unroll
@@ -98,9 +111,9 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
             prio_latency();
             const float2 *xs = xb + s * p.step + tid;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int a = 0; a < 4; ++a) v[4 * j + a] = OTH_16K_LOAD(xs + 4096 * a + 1024 * j);
+                for (int a = 0; a < F; ++a) v[F * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
             float2 mean = make_float2(0.f, 0.f);
             if (DETREND) {
                 float2 sum = v[0];
@@ -119,16 +132,22 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
             if (DETREND) {
                 float2 tot = red[0];
 #pragma unroll
-                for (int w = 1; w < 16; ++w) tot = cadd(tot, red[w]);
-                mean = make_float2(tot.x * (1.0f / 16384.0f), tot.y * (1.0f / 16384.0f));
+                for (int w = 1; w < T16 / 64; ++w) tot = cadd(tot, red[w]);
+                mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
             }
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
             prio_latency();
-            pass0_scatter<0>(v, wt, l0);
-            pass0_scatter<1>(v, wt, l0);
-            pass0_scatter<2>(v, wt, l0);
-            pass0_scatter<3>(v, wt, l0);
+            pass0_scatter<0, F>(v, wt, l0);
+            pass0_scatter<1, F>(v, wt, l0);
+            pass0_scatter<2, F>(v, wt, l0);
+            pass0_scatter<3, F>(v, wt, l0);
+            if constexpr (F == 2) {
+                pass0_scatter<4, F>(v, wt, l0);
+                pass0_scatter<5, F>(v, wt, l0);
+                pass0_scatter<6, F>(v, wt, l0);
+                pass0_scatter<7, F>(v, wt, l0);
+            }
             lds_barrier();   // B0
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = lx[256 * a + t];
@@ -156,29 +175,28 @@ __global__ __launch_bounds__(T16) void welch16k_kernel(WelchArgs p) {
         cur = (sched == 1) ? cur + W : (long long)W + *lnext;
     }
 
-    // bin k' + 4 (k0 + 16 k1 + 256 k2) sits at 4096 k' + 16 k0 + k1 + 256 k2 (finalize_kernel layout 2)
-    float *dst = p.partial + ((size_t)stream * W + wg) * 16384 + 4096 * kp;
+    // bin k' + F (k0 + 16 k1 + 256 k2) sits at 4096 k' + 16 k0 + k1 + 256 k2 (finalize_kernel layout 2 / 3)
+    float *dst = p.partial + ((size_t)stream * W + wg) * N + 4096 * kp;
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) dst[256 * k2 + t] = acc[k2];
 }
 
 }  // namespace
 
-hipError_t launch_welch_tuned16k(const WelchArgs &a, hipStream_t s) {
+template <bool DETREND, int F> hipError_t launch16k(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
-    hipError_t e = hipSuccess;
-    if (a.detrend) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(welch16k_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS16_BYTES);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((welch16k_kernel<true>), grid, dim3(T16), LDS16_BYTES, s, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(welch16k_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS16_BYTES);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((welch16k_kernel<false>), grid, dim3(T16), LDS16_BYTES, s, a);
-    }
+    constexpr size_t lds = lds16_bytes<F>();
+    const void *fn = reinterpret_cast<const void *>(welch16k_kernel<DETREND, F>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((welch16k_kernel<DETREND, F>), grid, dim3(256 * F), lds, s, a);
     return hipGetLastError();
+}
+
+hipError_t launch_welch_tuned16k(int nfft, const WelchArgs &a, hipStream_t s) {
+    if (nfft == 16384) return a.detrend ? launch16k<true, 4>(a, s) : launch16k<false, 4>(a, s);
+    if (nfft == 8192) return a.detrend ? launch16k<true, 2>(a, s) : launch16k<false, 2>(a, s);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace oth

@@ -68,7 +68,7 @@ extern "C" {
 /* kernel selection (diagnostics / parity tests) */
 #define OTH_KERNEL_AUTO      0
 #define OTH_KERNEL_GENERIC   1   /* radix-4 Stockham, any power of two 16..16384 */
-#define OTH_KERNEL_TUNED     2   /* register/LDS radix-16 kernels (nfft 256 ... 4096, 16384) */
+#define OTH_KERNEL_TUNED     2   /* register/LDS radix-16 kernels (nfft 256 ... 16384) */
 
 /* how the welch4096 kernel hands segments to workgroups */
 #define OTH_SCHED_CONTIGUOUS  0   /* fixed contiguous runs: bit-reproducible sums */

@@ -155,10 +155,12 @@ def test_welch_all_sizes_vs_oracle(ctx, nfft):
     assert relerr(psd, ref) < RTOL
 
 
+@pytest.mark.parametrize('N', [8192, 16384])
 @pytest.mark.parametrize('kernel', ['tuned', 'generic'])
-def test_welch16k_scanner_config_batched(ctx, hip, kernel):
-    """BASELINE config 5 shape: channel streams x 16384-point, rect window, no overlap, |X|^2/N^2 mean."""
-    N, ns, n = 16384, 6, 16384 * 9 + 100
+def test_welch16k_scanner_config_batched(ctx, hip, kernel, N):
+    """BASELINE config 5 shape: channel streams x 16384-point (and the 8192-point build of the same kernel), rect
+    window, no overlap, |X|^2/N^2 mean."""
+    ns, n = 6, N * 9 + 100
     xs = [R.synth_iq(n, 3000 + i) for i in range(ns)]
     buf = np.concatenate(xs)
     d_in, d_out = ctx.alloc(buf.nbytes), ctx.alloc(ns * N * 4)
@@ -176,13 +178,23 @@ def test_welch16k_scanner_config_batched(ctx, hip, kernel):
         assert relerr(out[i], ref) < RTOL
 
 
-def test_welch16k_hann_overlap_detrend_many_segments(ctx, hip):
-    x = R.synth_iq(16384 + 4096 * 700, 16)            # 701 segments at 75 % overlap > resident workgroups
-    _, ref = R.welch_np(x, fs=4.0, nperseg=16384, noverlap=12288, nfft=16384)
-    for sched in (hip.SCHED_DYNAMIC, hip.SCHED_CONTIGUOUS):
-        plan = ctx.welch_plan(16384, noverlap=12288, window=hann(16384), fs=4.0, kernel=hip.KERNEL_TUNED)
+@pytest.mark.parametrize('N', [8192, 16384])
+def test_welch16k_hann_overlap_detrend_many_segments(ctx, hip, N):
+    nseg = 701 if N == 16384 else 1403                # at 75 % overlap: more segments than resident workgroups
+    x = R.synth_iq(N + (N // 4) * (nseg - 1), 16)
+    _, ref = R.welch_np(x, fs=4.0, nperseg=N, noverlap=3 * N // 4, nfft=N)
+    for sched in (hip.SCHED_DYNAMIC, hip.SCHED_CONTIGUOUS, hip.SCHED_INTERLEAVED):
+        plan = ctx.welch_plan(N, noverlap=3 * N // 4, window=hann(N), fs=4.0, kernel=hip.KERNEL_TUNED)
         plan.set_schedule(sched)
-        assert relerr(plan.exec(x), ref) < RTOL and plan.last_nseg == 701
+        assert relerr(plan.exec(x), ref) < RTOL and plan.last_nseg == nseg
+    # 50 % overlap, DC offset 30x the noise, no detrend / detrend
+    rng = np.random.default_rng(N)
+    xdc = (rng.standard_normal(N * 12) + 1j * rng.standard_normal(N * 12) + (30.0 - 18.0j)).astype(np.complex64)
+    for det in (True, False):
+        _, ref = R.welch_np(xdc, nperseg=N, nfft=N, detrend='constant' if det else False)
+        plan = ctx.welch_plan(N, window=hann(N), detrend=hip.DETREND_CONSTANT if det else hip.DETREND_NONE,
+                              kernel=hip.KERNEL_TUNED)
+        assert relerr(plan.exec(xdc), ref) < RTOL
 
 
 def test_welch_no_detrend_rect_raw_scaling(ctx, hip):

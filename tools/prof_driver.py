@@ -71,7 +71,7 @@ elif cfg == 'C5':
                           fftshift=True)
     run = lambda: plan.exec_dev(d, S, o, nstreams=nch, stream_stride=S)      # noqa: E731
     nbytes = 8 * nch * S
-elif cfg in ('w1024', 'w2048', 'w512', 'w256'):
+elif cfg in ('w1024', 'w2048', 'w512', 'w256', 'w8192', 'w16384'):
     N = int(cfg[1:])
     n = 1 << (log2n or 27)
     d, o = dev(n * 8), dev(N * 4)
