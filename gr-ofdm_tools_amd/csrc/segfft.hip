@@ -229,6 +229,13 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
             prio_latency();
             // ---- samples, window, raw sums ------------------------------------------------------------
             float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
+            if (WIN_LDS) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float4 w4 = wl[qd * T];
+                    win[4 * qd] = w4.x, win[4 * qd + 1] = w4.y, win[4 * qd + 2] = w4.z, win[4 * qd + 3] = w4.w;
+                }
+            }
             if (LOAD == LOAD_HALF) {
                 if (s == sb) {
 #pragma unroll
@@ -252,13 +259,6 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                     for (int a = 0; a < 8; ++a) nxt[a] = load_once(xn + T * a);
                 }
             } else {
-                if (WIN_LDS) {
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        const float4 w4 = wl[qd * T];
-                        win[4 * qd] = w4.x, win[4 * qd + 1] = w4.y, win[4 * qd + 2] = w4.z, win[4 * qd + 3] = w4.w;
-                    }
-                }
 #pragma unroll
                 for (int a = 0; a < 16; ++a) {
                     const float2 r = nxt[a];
