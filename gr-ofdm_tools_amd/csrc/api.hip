@@ -1384,6 +1384,11 @@ static int chain_launch(oth_chain *h, const float2 *x, long long first_vec, long
     const int N = h->nfft;
     if (!rows_last) give = 0;
     if (chain_fused_ok(h, give)) return chain_launch_fused(h, x, first_vec, nrows, rows_last, give);
+    if (!h->do_iir && !h->do_peak) {      // no state: rows nobody asked for are not computed at all (latest wins)
+        if (!give) return OTH_OK;
+        first_vec += (nrows - give) * h->keep_n;
+        nrows = give;
+    }
     int rc = ensure(c, &h->d_rows, &h->rows_cap, sizeof(float) * (size_t)nrows * N);
     if (rc) return rc;
     PgramArgs a;

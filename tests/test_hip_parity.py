@@ -432,6 +432,31 @@ def test_chain_keep_one_in_n_matches_gnuradio_rule(ctx, hip):
     check_single_rows(rows[0], ref[3])
 
 
+def test_chain_latest_wins_on_the_coverage_kernel(ctx, hip):
+    """Sizes the fused launch does not cover (8192, 16384, 128): a stateless chain computes only the rows it hands
+    back, a stateful one (peak hold) all of them."""
+    for N in (128, 8192):
+        x = R.synth_iq(N * 40 + 11, 70 + N)
+        ref = R.chain_sensor_v2(x, N, decim=2)
+        ch = ctx.chain(N, None, True, hip.EPI_MAG2_OVER_N2, 2)
+        rows, n = ch.push(x, max_rows=3)
+        assert n == len(ref) == 20 and rows.shape == (3, N)
+        check_single_rows(rows, ref[-3:])
+        ch.reset()
+        rows, n = ch.push(x[:N * 7 + 5], max_rows=1)          # kept vectors 1, 3, 5 -> rows 0..2
+        rows2, n2 = ch.push(x[N * 7 + 5:], max_rows=1)
+        assert n + n2 == 20
+        check_single_rows(rows[0], ref[n - 1])
+        check_single_rows(rows2[0], ref[-1])
+        from ofdm_tools import windows
+        mag, peak = R.chain_psd_logger(x, N, decim=2)
+        ch = ctx.chain(N, windows.blackmanharris(N), False, hip.EPI_MAG, 2)
+        ch.set_peak_hold(True)
+        rows, n = ch.push(x, max_rows=1)
+        assert n == 20 and relerr(ch.peak(), peak[-1]) < RTOL
+        check_single_rows(rows[0], mag[-1], power=False)
+
+
 # ------------------------------------------------------- channel power ----
 
 def test_channel_power_cases(ctx, golden):

@@ -26,6 +26,7 @@ CONFIGS = {
     'w512': ('seg_kernel', 8 * 2 ** 27, 'Welch 512-pt Hann 50 % overlap, 2^27 samples (two 32-thread teams per wave)'),
     'w1024': ('segws_kernel', 8 * 2 ** 27, 'Welch 1024-pt Hann 50 % overlap, 2^27 samples'),
     'w2048': ('segws_kernel', 8 * 2 ** 27, 'Welch 2048-pt Hann 50 % overlap, 2^27 samples'),
+    'w8192': ('welch16k', 8 * 2 ** 27, 'Welch 8192-pt Hann 50 % overlap, 2^27 samples (welch16k_kernel<., 2>: segments loaded whole, two transforms per sample)'),
     'chain256': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 256, 2^26 samples'),
     'chain512': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 512, 2^26 samples'),
     'chain1024': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 1024 (BH window, shift, |X|^2, IIR 0.8 + log), 2^26 samples'),
