@@ -455,7 +455,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         // the role-split 1024 kernel: eight two-wave workgroups per CU even out by themselves (+4 % over the tickets)
         if (seg_ws && p->nfft == 1024 && nstreams == 1 && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC)
             a.sched = OTH_SCHED_CONTIGUOUS;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? 2 : (tuned ? var->chunk : (tuned_seg ? (p->nfft == 1024 && !seg_ws ? 32 : 16) : 8)));
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 8 : 2) : (tuned ? var->chunk : (tuned_seg ? (p->nfft == 1024 && !seg_ws ? 32 : 16) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;

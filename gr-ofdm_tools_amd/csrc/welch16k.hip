@@ -28,7 +28,7 @@ namespace oth {
 namespace {
 
 constexpr int REGION = 16 * RS;                     // float2 per sub-FFT image
-constexpr int LDS16_RED = 32;                       // up to 16 wave sums + ticket
+constexpr int LDS16_RED = 48;                       // up to 16 wave sums of the new half, 16 of a chunk's first half, ticket
 template <int F> constexpr size_t lds16_bytes() { return (F * REGION + LDS16_RED) * sizeof(float2); }
 
 // multiply by exp(-2 pi i q / 16), q a compile-time constant (the products j * k' that occur: 0..7 and 9)
@@ -64,7 +64,9 @@ template <int J, int F> __device__ __forceinline__ void pass0_scatter(float2 (&v
     }
 }
 
-template <bool DETREND, int F>
+// HALF: step = N / 2 - the second half of a segment is the first half of the next one at the same (j, tid), so it
+// is kept (raw) in registers and every sample is read once; otherwise segments are loaded whole (any step).
+template <bool DETREND, int F, bool HALF>
 __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
     constexpr int T16 = 256 * F, N = 4096 * F, NJ = 16 / F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -101,8 +103,10 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
 
     const int sched = p.sched;
     const long long nchunks = sched ? chunk_count(p) : 1;
-    int *lnext = reinterpret_cast<int *>(red + 16);
+    int *lnext = reinterpret_cast<int *>(red + 32);
     unsigned ticket = 0;
+    float2 keep[HALF ? 8 : 1];
+    float2 prev_tot = make_float2(0.f, 0.f);
     for (long long cur = sched ? wg : 0; cur < nchunks;) {
         long long sb = s0, se = s1;
         if (sched) chunk_range(p, cur, sb, se);
@@ -110,18 +114,49 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
             float2 v[16];
             prio_latency();
             const float2 *xs = xb + s * p.step + tid;
+            float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
+            if constexpr (HALF) {
+                constexpr int H = F / 2;
+                if (s == sb) {      // the chunk's first segment brings its own first half
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+                    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int a = 0; a < F; ++a) v[F * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
+                        for (int a = 0; a < H; ++a) {
+                            keep[H * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
+                            sumf = cadd(sumf, keep[H * j + a]);
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int a = 0; a < H; ++a) {
+                        const float2 r = OTH_16K_LOAD(xs + 4096 * (H + a) + T16 * j);
+                        v[F * j + a] = keep[H * j + a];
+                        v[F * j + H + a] = r;
+                        keep[H * j + a] = r;
+                        sum = cadd(sum, r);
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int a = 0; a < F; ++a) {
+                        v[F * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
+                        sum = cadd(sum, v[F * j + a]);
+                    }
+            }
             float2 mean = make_float2(0.f, 0.f);
             if (DETREND) {
-                float2 sum = v[0];
-#pragma unroll
-                for (int a = 1; a < 16; ++a) sum = cadd(sum, v[a]);
                 sum.x = wave_total(sum.x);
                 sum.y = wave_total(sum.y);
-                if ((tid & 63) == 0) red[tid >> 6] = sum;
+                if (HALF && s == sb) {
+                    sumf.x = wave_total(sumf.x);
+                    sumf.y = wave_total(sumf.y);
+                }
+                if ((tid & 63) == 0) {
+                    red[tid >> 6] = sum;
+                    if (HALF && s == sb) red[16 + (tid >> 6)] = sumf;
+                }
             }
             lds_barrier();   // A0: previous segment's reads are done; red[] visible
             prio_compute();
@@ -133,6 +168,17 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
                 float2 tot = red[0];
 #pragma unroll
                 for (int w = 1; w < T16 / 64; ++w) tot = cadd(tot, red[w]);
+                if (HALF) {
+                    if (s == sb) {
+                        float2 ft = red[16];
+#pragma unroll
+                        for (int w = 1; w < T16 / 64; ++w) ft = cadd(ft, red[16 + w]);
+                        prev_tot = ft;
+                    }
+                    const float2 both = cadd(prev_tot, tot);
+                    prev_tot = tot;
+                    tot = both;
+                }
                 mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
             }
 #pragma unroll
@@ -183,19 +229,27 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
 
 }  // namespace
 
-template <bool DETREND, int F> hipError_t launch16k(const WelchArgs &a, hipStream_t s) {
+template <bool DETREND, int F, bool HALF> hipError_t launch16k(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
     constexpr size_t lds = lds16_bytes<F>();
-    const void *fn = reinterpret_cast<const void *>(welch16k_kernel<DETREND, F>);
+    const void *fn = reinterpret_cast<const void *>(welch16k_kernel<DETREND, F, HALF>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((welch16k_kernel<DETREND, F>), grid, dim3(256 * F), lds, s, a);
+    hipLaunchKernelGGL((welch16k_kernel<DETREND, F, HALF>), grid, dim3(256 * F), lds, s, a);
     return hipGetLastError();
 }
 
+template <int F> hipError_t launch16k_f(const WelchArgs &a, hipStream_t s) {
+    // (16384 points with detrend: the kept half does not fit 128 VGPRs next to the sums - 18 spills - and the LDS is
+    // full, so that build loads whole segments at every step)
+    if (a.step == 2048 * F && (F == 2 || !a.detrend))
+        return a.detrend ? launch16k<true, F, (F == 2)>(a, s) : launch16k<false, F, true>(a, s);
+    return a.detrend ? launch16k<true, F, false>(a, s) : launch16k<false, F, false>(a, s);
+}
+
 hipError_t launch_welch_tuned16k(int nfft, const WelchArgs &a, hipStream_t s) {
-    if (nfft == 16384) return a.detrend ? launch16k<true, 4>(a, s) : launch16k<false, 4>(a, s);
-    if (nfft == 8192) return a.detrend ? launch16k<true, 2>(a, s) : launch16k<false, 2>(a, s);
+    if (nfft == 16384) return launch16k_f<4>(a, s);
+    if (nfft == 8192) return launch16k_f<2>(a, s);
     return hipErrorInvalidValue;
 }
 

@@ -36,7 +36,7 @@ CONFIGS = {
 
 
 def one(src, pattern):
-    hits = sorted(glob.glob(os.path.join(src, pattern)))
+    hits = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)      # newest: a re-collected pass wins
     return hits[-1] if hits else None
 
 
