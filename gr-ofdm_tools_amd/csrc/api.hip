@@ -455,7 +455,12 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         // the role-split 1024 kernel: eight two-wave workgroups per CU even out by themselves (+4 % over the tickets)
         if (seg_ws && p->nfft == 1024 && nstreams == 1 && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC)
             a.sched = OTH_SCHED_CONTIGUOUS;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 8 : 2) : (tuned ? var->chunk : (tuned_seg ? (p->nfft == 1024 && !seg_ws ? 32 : 16) : 8)));
+        // 256 / 512 points: a ticket per sixteen 2-4 KiB segments costs more than it evens out; interleaved chunks of
+        // 32 segments when every team gets several of them (256 points: 68 % of the roofline against 43 %)
+        const bool small_static = tuned_seg && p->nfft <= 512 && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC &&
+                                  nseg >= (long long)W * 32 * 2;
+        if (small_static) a.sched = OTH_SCHED_INTERLEAVED;
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 8 : 2) : (tuned ? var->chunk : (tuned_seg ? ((p->nfft == 1024 && !seg_ws) || small_static ? 32 : 16) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;
@@ -1351,7 +1356,10 @@ static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec
         a.rows = rows_last;
     }
     const int tpc = seg_teams_per_cu(N, 2, false);
-    a.chunk = 4;
+    // segments per chunk of the interleaved schedule: 8 once every team gets two chunks (+2-4 % over 4), fewer for
+    // short pushes so that more teams take part
+    const long long teams_max = (long long)c->cu_count * tpc;
+    a.chunk = a.nseg >= 16 * teams_max ? 8 : (a.nseg >= 4 * teams_max ? 4 : 2);
     long long nchunks = (a.nseg + a.chunk - 1) / a.chunk;
     long long W = (long long)c->cu_count * tpc;
     if (W > nchunks) W = nchunks;
