@@ -457,10 +457,15 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
             a.sched = OTH_SCHED_CONTIGUOUS;
         // 256 / 512 points: a ticket per sixteen 2-4 KiB segments costs more than it evens out; interleaved chunks of
         // 32 segments when every team gets several of them (256 points: 68 % of the roofline against 43 %)
-        const bool small_static = tuned_seg && p->nfft <= 512 && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC &&
-                                  nseg >= (long long)W * 32 * 2;
-        if (small_static) a.sched = OTH_SCHED_INTERLEAVED;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 8 : 2) : (tuned ? var->chunk : (tuned_seg ? ((p->nfft == 1024 && !seg_ws) || small_static ? 32 : 16) : 8)));
+        const bool small_static = tuned_seg && seg_kind == 0 && p->nfft <= 512 && p->tune_sched < 0 &&
+                                  p->sched == OTH_SCHED_DYNAMIC && nseg >= (long long)W * 32 * 2;
+        // whole-segment loads (steps other than nfft / 2): the next chunk's first segment is prefetched across the
+        // chunk boundary only under the interleaved schedule - 8-segment chunks: 1024 points, no overlap, 70 % of the
+        // roofline against 49 % with tickets
+        const bool full_static = tuned_seg && seg_kind == 1 && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC &&
+                                 nseg >= (long long)W * 8 * 2;
+        if (small_static || full_static) a.sched = OTH_SCHED_INTERLEAVED;
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 8 : 2) : (tuned ? var->chunk : (tuned_seg ? (full_static ? 8 : ((p->nfft == 1024 && !seg_ws) || small_static ? 32 : 16)) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;

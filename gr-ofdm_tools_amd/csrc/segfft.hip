@@ -159,11 +159,30 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
     // spill reload waits on vmcnt and with it on the prefetch in flight)
     constexpr bool WIN_LDS = CHAIN && (OTH_CHAIN_WIN_LDS != 0);
     float4 *wl = reinterpret_cast<float4 *>(red + 16) + t;      // [4][T] float4, one table per workgroup
+    // the six stored twiddle powers of pass 1 (sub-wave teams) / pass 2 (4096 points) go the same way where the
+    // build would otherwise still spill: [3][T] and [3][R] float4 behind the window table
+    constexpr bool TW1_LDS = WIN_LDS && R <= 2, TW2_LDS = WIN_LDS && R == 16;
+    float4 *tl1 = reinterpret_cast<float4 *>(red + 16) + 4 * T + t;
+    float4 *tl2 = reinterpret_cast<float4 *>(red + 16) + 4 * T + (TW1_LDS ? 3 * T : 0) + lo;
     if (WIN_LDS) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd)
             wl[qd * T] = make_float4(p.win[T * (4 * qd) + t], p.win[T * (4 * qd + 1) + t], p.win[T * (4 * qd + 2) + t],
                                      p.win[T * (4 * qd + 3) + t]);
+        auto pair = [&](int i, int j) {
+            const float2 u = p.tw[i & (N - 1)], w = p.tw[j & (N - 1)];
+            return make_float4(u.x, u.y, w.x, w.y);
+        };
+        if (TW1_LDS) {
+            tl1[0] = pair(t, 2 * t);
+            tl1[T] = pair(3 * t, 4 * t);
+            tl1[2 * T] = pair(8 * t, 12 * t);
+        }
+        if (TW2_LDS && hi == 0) {
+            tl2[0] = pair(16 * lo, 32 * lo);
+            tl2[R] = pair(48 * lo, 64 * lo);
+            tl2[2 * R] = pair(128 * lo, 192 * lo);
+        }
         __syncthreads();      // (teams of one workgroup write identical tables)
     }
     if (TPB > 1 && wg >= W) return;      // the odd team of the last workgroup (no workgroup barrier below when TPB > 1)
@@ -222,10 +241,10 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
         primed = sb_next >= 0;
         for (long long s = sb; s < se; ++s) {
             float2 v[16];
-            // R <= 2: the swizzle constants take 8 / 16 values per access shape; hoisted out of this loop the forty
+            // R <= 2 (and the 4096-point chain build, which is short of registers): the swizzle constants take 8 / 16 values per access shape; hoisted out of this loop the forty
             // (base ^ constant) addresses would live in registers - keep the bases opaque and pay the v_xor instead
             unsigned a_w1 = b_w1, a_rw = b_rw, a_r2 = b_r2;
-            if (R <= 2) asm volatile("" : "+v"(a_w1), "+v"(a_rw), "+v"(a_r2));
+            if (R <= 2 || (CHAIN && R == 16)) asm volatile("" : "+v"(a_w1), "+v"(a_rw), "+v"(a_r2));
             prio_latency();
             // ---- samples, window, raw sums ------------------------------------------------------------
             float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
@@ -316,15 +335,24 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                 for (int a = 0; a < 16; ++a) v[a] = make_float2(fmaf(nm.x, win[a], v[a].x), fmaf(nm.y, win[a], v[a].y));
             }
             // ---- pass 1 -----------------------------------------------------------------------------------
+            auto pow6_from = [](const float4 *tb, int stride) {
+                const float4 q0 = tb[0], q1 = tb[stride], q2 = tb[2 * stride];
+                return Pow6{make_float2(q0.x, q0.y), make_float2(q0.z, q0.w), make_float2(q1.x, q1.y),
+                            make_float2(q1.z, q1.w), make_float2(q2.x, q2.y), make_float2(q2.z, q2.w)};
+            };
+            Pow6 w1 = tw1;
+            if (TW1_LDS) w1 = pow6_from(tl1, T);      // issued before the butterflies that hide them
             prio_compute();
             dft16(v);
             prio_latency();
-            twiddle_pow16(v, tw1, [&](auto kc, float2 val) {
+            twiddle_pow16(v, w1, [&](auto kc, float2 val) {
                 constexpr int k0 = decltype(kc)::value;
                 lds_write_imm<8 * (512 * (k0 >> P) + R * (k0 & KP & ~KM))>(a_w1 ^ (8u * R * (k0 & KM)), val);
             });
             if (G::WAVES > 1) lds_barrier();     // B
             // ---- pass 2: thread (k0, c) gathers b -----------------------------------------------------------
+            Pow6 w2 = tw2;
+            if (TW2_LDS) w2 = pow6_from(tl2, R);      // older than the sixteen reads below: their counted waits still hold
             {
                 double r[16];
                 // rows b with equal (b & KM, b & (R-1)) share one swizzled base
@@ -351,7 +379,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
             if constexpr (R > 1) {
                 prio_latency();
                 // in place: the R lanes that share k0 sit in one wave and have issued their reads of region k0 above
-                twiddle_pow16(v, tw2, [&](auto kc, float2 val) {
+                twiddle_pow16(v, w2, [&](auto kc, float2 val) {
                     constexpr int k1 = decltype(kc)::value;
                     lds_write_imm<256 * k1>(a_rw ^ (8u * (R * (k1 & KM) + (k1 & (R - 1)))), val);
                 });
@@ -411,27 +439,50 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                         acc[m * R + k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[m * R + k2]));
                     }
             } else {
+                // every choice below is uniform over the launch or the segment: one scalar branch per segment each, no
+                // per-bin selects
                 const bool st = s >= p.store_from, ac = s < p.acc_end;
-                float *row = p.rows + ((size_t)stream * (p.nseg - p.store_from) + (size_t)(s - p.store_from)) * N;
-                const int sh = p.fftshift ? N / 2 : 0;
-                float w = 1.0f;
-                if (ac && p.acc_mode == ACC_WSUM) {
-                    const long long kk = p.acc_end - 1 - s;
-                    w = kk == 0 ? 1.0f : exp2f(p.l2 * (float)kk);
-                }
+                float val[16];
+                if (p.epilogue == 0) {
 #pragma unroll
-                for (int m = 0; m < Q; ++m)
+                    for (int m = 0; m < Q; ++m)
 #pragma unroll
-                    for (int k2 = 0; k2 < R; ++k2) {
-                        const float2 X = at(m, k2);
-                        const float pw = fmaf(X.x, X.x, X.y * X.y);
-                        const float val = p.epilogue == 0 ? sqrtf(pw) : pw * p.scale;
-                        if (st) row[(hi + 16 * (lo + R * m) + 256 * k2 + sh) & (N - 1)] = val;
-                        if (ac) {
-                            float &a_ = acc[m * R + k2];
-                            a_ = p.acc_mode == ACC_WSUM ? fmaf(w, val, a_) : (p.acc_mode == ACC_MAX ? fmaxf(a_, val) : a_);
+                        for (int k2 = 0; k2 < R; ++k2) {
+                            const float2 X = at(m, k2);
+                            // v_sqrt_f32 (1 ulp) without sqrtf's denormal rescaling: |X|^2 of a transform is either 0 or far
+                            // above 2^-96
+                            val[m * R + k2] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));
                         }
+                } else {
+                    const float sc = p.scale;
+#pragma unroll
+                    for (int m = 0; m < Q; ++m)
+#pragma unroll
+                        for (int k2 = 0; k2 < R; ++k2) {
+                            const float2 X = at(m, k2);
+                            val[m * R + k2] = fmaf(X.x, X.x, X.y * X.y) * sc;
+                        }
+                }
+                if (st) {
+                    float *row = p.rows + ((size_t)stream * (p.nseg - p.store_from) + (size_t)(s - p.store_from)) * N;
+                    const int sh = p.fftshift ? N / 2 : 0;
+#pragma unroll
+                    for (int m = 0; m < Q; ++m)
+#pragma unroll
+                        for (int k2 = 0; k2 < R; ++k2) row[(hi + 16 * (lo + R * m) + 256 * k2 + sh) & (N - 1)] = val[m * R + k2];
+                }
+                if (ac) {
+                    if (p.acc_mode == ACC_WSUM) {
+                        const long long kk = p.acc_end - 1 - s;
+                        const float w = kk == 0 ? 1.0f : exp2f(p.l2 * (float)kk);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) acc[k] = fmaf(w, val[k], acc[k]);
+                    } else if (p.acc_mode == ACC_MAX) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)      // plain v_max_f32: no NaN canonicalisation (finite by construction)
+                            asm("v_max_f32 %0, %1, %2" : "=v"(acc[k]) : "v"(acc[k]), "v"(val[k]));
                     }
+                }
             }
         }
         if (sched == 0) break;
@@ -747,9 +798,10 @@ template <int R> int occupancy_ws() {
     return n;
 }
 
-// image(s) + sums + tickets, and for the chain build the window table (4 x T float4)
+// image(s) + sums + tickets, and for the chain build the window table (4 x T float4) and twiddle tables
 template <int R, bool CHAIN> constexpr size_t seg_lds_bytes() {
-    return Geo<R>::LDS_BYTES + ((CHAIN && OTH_CHAIN_WIN_LDS) ? 4 * Geo<R>::T * sizeof(float4) : 0);
+    return Geo<R>::LDS_BYTES +
+           ((CHAIN && OTH_CHAIN_WIN_LDS) ? (4 * Geo<R>::T + (R <= 2 ? 3 * Geo<R>::T : 0) + (R == 16 ? 3 * R : 0)) * sizeof(float4) : 0);
 }
 
 template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS> hipError_t launch_one(const SegArgs &a, hipStream_t s) {
