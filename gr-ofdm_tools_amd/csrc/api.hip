@@ -455,17 +455,28 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         // the role-split 1024 kernel: eight two-wave workgroups per CU even out by themselves (+4 % over the tickets)
         if (seg_ws && p->nfft == 1024 && nstreams == 1 && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC)
             a.sched = OTH_SCHED_CONTIGUOUS;
-        // 256 / 512 points: a ticket per sixteen 2-4 KiB segments costs more than it evens out; interleaved chunks of
-        // 32 segments when every team gets several of them (256 points: 68 % of the roofline against 43 %)
-        const bool small_static = tuned_seg && seg_kind == 0 && p->nfft <= 512 && p->tune_sched < 0 &&
-                                  p->sched == OTH_SCHED_DYNAMIC && nseg >= (long long)W * 32 * 2;
+        // 256 / 512 points at 50 % overlap: a ticket per sixteen 2-4 KiB segments costs more than it evens out (17-35 %
+        // of the roofline at every launch size).  Static instead: interleaved chunks of 32 / 16 segments while every
+        // team gets two of them (256 points, 2^27 samples: 66 % against 43 %), one contiguous run per team below that.
+        const bool seg_static = tuned_seg && !seg_ws && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC;
+        const long long per_team = nseg / (W > 0 ? W : 1);
+        int static_chunk = 0;
+        if (seg_static && seg_kind == 0 && p->nfft <= 512) {
+            static_chunk = per_team >= 64 ? 32 : (per_team >= 32 ? 16 : 0);
+            a.sched = static_chunk ? OTH_SCHED_INTERLEAVED : OTH_SCHED_CONTIGUOUS;
+        }
         // whole-segment loads (steps other than nfft / 2): the next chunk's first segment is prefetched across the
         // chunk boundary only under the interleaved schedule - 8-segment chunks: 1024 points, no overlap, 70 % of the
         // roofline against 49 % with tickets
-        const bool full_static = tuned_seg && seg_kind == 1 && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC &&
-                                 nseg >= (long long)W * 8 * 2;
-        if (small_static || full_static) a.sched = OTH_SCHED_INTERLEAVED;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 8 : 2) : (tuned ? var->chunk : (tuned_seg ? (full_static ? 8 : ((p->nfft == 1024 && !seg_ws) || small_static ? 32 : 16)) : 8)));
+        if (seg_static && seg_kind == 1) {
+            static_chunk = per_team >= 16 ? 8 : 0;
+            a.sched = static_chunk ? OTH_SCHED_INTERLEAVED : OTH_SCHED_CONTIGUOUS;
+        }
+        // short launches (fewer than 32 segments per resident workgroup): one contiguous run each - the tickets' guided
+        // tail has nothing to even out and costs 5-20 % (2048 points, 2^22 samples: 17.3 % against 14.0 %)
+        if ((tuned || seg_ws) && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC && per_team < 32)
+            a.sched = OTH_SCHED_CONTIGUOUS;
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 8 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : (p->nfft == 1024 && !seg_ws ? 32 : 16)) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;

@@ -488,6 +488,33 @@ def test_xcorr_fac_golden(ctx, golden):
     assert np.max(np.abs(fc - g['expected_fac'])) / np.max(g['expected_fac']) < 1e-5
 
 
+# ------------------------------ launches large enough for the static default schedules ----
+
+@pytest.mark.parametrize('nfft', [256, 512, 1024])
+def test_large_launch_default_schedules(ctx, hip, nfft):
+    """2^26 samples on the device: at this size the library's own defaults pick the interleaved static schedules
+    (256 / 512 points at 50 % overlap; whole-segment loads at other steps) - tuned against the coverage kernel,
+    and the first 2^18 samples against the float64 oracle."""
+    n = 1 << 26
+    d_in = ctx.alloc(n * 8)
+    try:
+        ctx.synth_iq(d_in, n, 1002, R.TONES, R.DC)
+        for nov in (nfft // 2, 0, nfft // 4):
+            tuned = ctx.welch_plan(nfft, noverlap=nov, window=hann(nfft), fs=1.0, kernel=hip.KERNEL_TUNED)
+            gen = ctx.welch_plan(nfft, noverlap=nov, window=hann(nfft), fs=1.0, kernel=hip.KERNEL_GENERIC)
+            a, b = tuned.exec_device_src(d_in, n), gen.exec_device_src(d_in, n)
+            assert tuned.last_nseg == gen.last_nseg == (n - nov) // (nfft - nov)
+            assert relerr(a, b) < 2e-5, (nfft, nov)
+            again = tuned.exec_device_src(d_in, n)
+            assert np.array_equal(a, again), 'a static schedule is bit-reproducible'
+            m = 1 << 18
+            x = ctx.d2h(d_in, (m,), np.complex64)
+            _, ref = R.welch_np(x, fs=1.0, nperseg=nfft, noverlap=nov, nfft=nfft)
+            assert relerr(tuned.exec_device_src(d_in, m), ref) < RTOL
+    finally:
+        ctx.free(d_in)
+
+
 # -------------------------------------------- full size (BASELINE config 2) ----
 
 def test_full_size_256M_properties(ctx, hip):

@@ -13,7 +13,7 @@ nfft = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 variants = sys.argv[3:] or ['segws:2:16', 'segws:2:32', 'seg3:2:32', 'segws:0:16', 'segws:2:8']
 ctx = _hip.Context(0)
-n = 1 << 27
+n = 1 << int(os.environ.get('AB_LOG2N', '27'))
 d, o = ctx.alloc(n * 8), ctx.alloc(nfft * 4)
 ctx.synth_iq(d, n, 1002, ((0.5, 0.1234), (0.05, -0.31), (2.0, 0.4071)), 0.1 + 0.05j)
 plan = ctx.welch_plan(nfft, window=windows.get_window('hann', nfft), fs=1.0)
