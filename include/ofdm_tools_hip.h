@@ -70,11 +70,13 @@ extern "C" {
 #define OTH_KERNEL_GENERIC   1   /* radix-4 Stockham, any power of two 16..16384 */
 #define OTH_KERNEL_TUNED     2   /* register/LDS radix-16 kernels (nfft 256 ... 16384) */
 
-/* how the welch4096 kernel hands segments to workgroups */
+/* how the tuned kernels hand segments to workgroups */
 #define OTH_SCHED_CONTIGUOUS  0   /* fixed contiguous runs: bit-reproducible sums */
 #define OTH_SCHED_INTERLEAVED 1   /* fixed round-robin chunks: bit-reproducible sums */
-#define OTH_SCHED_DYNAMIC     2   /* chunks drawn from an atomic ticket (default): load-balanced,
-                                     fp32 summation order - hence the last bits - may vary run to run */
+#define OTH_SCHED_DYNAMIC     2   /* the plan's initial value = the library's choice: chunks drawn from an atomic
+                                     ticket for long 2048 / 4096-point launches (load-balanced; the fp32 summation
+                                     order - hence the last bits - may vary run to run), a static schedule where that
+                                     measures faster (256 / 512 / 1024 points, whole-segment loads, short launches) */
 
 typedef struct oth_ctx oth_ctx;
 typedef struct oth_plan oth_plan;
