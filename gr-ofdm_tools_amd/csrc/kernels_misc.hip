@@ -437,43 +437,45 @@ hipError_t launch_synth(float2 *iq, size_t n, uint64_t seed, int ntones, const f
 }
 
 // ---- probes -----------------------------------------------------------------
-__global__ void read_probe_kernel(const float4 *p, size_t n4, float *sink) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const float4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-        acc.x += a.x + b.x + c.x + d.x;
-        acc.y += a.y + b.y + c.y + d.y;
-        acc.z += a.z + b.z + c.z + d.z;
-        acc.w += a.w + b.w + c.w + d.w;
+// Streaming-read probe (the second roofline denominator): every workgroup walks contiguous 32 KiB tiles, eight
+// non-temporal 16-byte loads in flight per thread - the shape that reads fastest on this part
+// (tools/ubench/read_peak.hip: 7.1 TB/s; grid-stride loads 5.5-6.2, the same tiles without the non-temporal hint 6.3).
+__global__ __launch_bounds__(256) void read_probe_kernel(const float4 *p, size_t n4, float *sink) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    const size_t tile = 256 * U, ntiles = n4 / tile;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const f4 *q = reinterpret_cast<const f4 *>(p) + t * tile + threadIdx.x;
+        f4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) v[j] = __builtin_nontemporal_load(q + 256 * j);
+#pragma unroll
+        for (int j = 0; j < U; ++j) acc += v[j];
     }
-    for (; i < n4; i += stride) {
+    for (size_t i = ntiles * tile + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 a = p[i];
-        acc.x += a.x;
-        acc.y += a.y;
-        acc.z += a.z;
-        acc.w += a.w;
+        acc += f4{a.x, a.y, a.z, a.w};
     }
     const float v = acc.x + acc.y + acc.z + acc.w;
     if (v == 1.2345e-30f) sink[0] = v;   // keeps the loads alive, practically never stores
 }
 
 // the same stream read 8 bytes per lane (global_load_dwordx2, the access width of the FFT kernels' sample loads)
-__global__ void read_probe8_kernel(const float2 *p, size_t n2, float *sink) {
-    float2 acc = make_float2(0.f, 0.f);
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 7 * stride < n2; i += 8 * stride) {
+__global__ __launch_bounds__(256) void read_probe8_kernel(const float2 *p, size_t n2, float *sink) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc = {0.f, 0.f};
+    constexpr int U = 16;
+    const size_t tile = 256 * U, ntiles = n2 / tile;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const f2 *q = reinterpret_cast<const f2 *>(p) + t * tile + threadIdx.x;
+        f2 v[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            const f2 a = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p + i + j * stride));
-            acc.x += a.x;
-            acc.y += a.y;
-        }
+        for (int j = 0; j < U; ++j) v[j] = __builtin_nontemporal_load(q + 256 * j);
+#pragma unroll
+        for (int j = 0; j < U; ++j) acc += v[j];
     }
-    for (; i < n2; i += stride) {
+    for (size_t i = ntiles * tile + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
         acc.x += p[i].x;
         acc.y += p[i].y;
     }
@@ -482,7 +484,7 @@ __global__ void read_probe8_kernel(const float2 *p, size_t n2, float *sink) {
 }
 
 hipError_t launch_read_probe8(const void *p, size_t bytes, float *sink, hipStream_t s) {
-    hipLaunchKernelGGL(read_probe8_kernel, dim3(256 * 8), dim3(256), 0, s, (const float2 *)p, bytes / 8, sink);
+    hipLaunchKernelGGL(read_probe8_kernel, dim3(256 * 16), dim3(256), 0, s, (const float2 *)p, bytes / 8, sink);
     return hipGetLastError();
 }
 
