@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Interleaved A/B timing of the 1024 / 2048-point Welch builds and launch parameters in one process.
+"""Interleaved A/B timing of the 256 ... 2048-point Welch builds and launch parameters in one process (AB_LOG2N: samples).
 usage: ab_seg.py nfft rounds build:sched:chunk ...   (build = seg3 | seg4)"""
 import os
 import sys

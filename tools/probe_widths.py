@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The library's two streaming-read probes (16-byte and 8-byte loads per lane, oth_stream_read_probe) on a 2 GiB
+buffer.  usage: probe_widths.py"""
 import sys, os
 sys.path.insert(0, os.path.join(os.getcwd(), 'gr-ofdm_tools_amd'))
 from ofdm_tools import _hip
