@@ -49,6 +49,9 @@ template <int R> struct Geo {
 };
 
 enum { LOAD_HALF = 0, LOAD_FULL = 1 };
+#ifndef OTH_SEG_R2_DPP
+#define OTH_SEG_R2_DPP 1      // 512 points: last radix-2 stage through DPP instead of an LDS exchange
+#endif
 #ifndef OTH_CHAIN_WIN_LDS
 #define OTH_CHAIN_WIN_LDS 1
 #endif
@@ -154,6 +157,11 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
     const int t = TPB > 1 ? (int)threadIdx.x % T : (int)threadIdx.x;
     const int hi = t >> LR, lo = t & (R - 1);
     const int wg = blockIdx.x * TPB + team, W = p.wg_per_stream, stream = blockIdx.y;
+    // (the fused chain keeps the LDS exchange: measured 71 % of the roofline with it against 54 % through DPP - the
+    // exchange's wait is where its three waves per SIMD take turns at the memory pipe)
+    constexpr bool R2DPP = R == 2 && !CHAIN && (OTH_SEG_R2_DPP != 0);
+    // bin held in slot m R + k2 of the per-thread results
+    auto bin_of = [&](int m, int k2) { return R2DPP ? hi + 16 * (m * R + k2) + 256 * lo : hi + 16 * (lo + R * m) + 256 * k2; };
     // WIN_LDS (the chain build): the sixteen window values of a thread live in LDS as four float4 and are read
     // per segment - sixteen registers less, which is what keeps the build's spills out of the segment loop (a
     // spill reload waits on vmcnt and with it on the prefetch in flight)
@@ -376,7 +384,24 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                 }
                 dft16_layer2(v);
             }
-            if constexpr (R > 1) {
+            if constexpr (R2DPP) {
+                // R = 2 without exchange 2: the two lanes that share k0 are neighbours, so the last radix-2 stage
+                // takes the partner's value through DPP inside the multiply-add: lane c keeps y_c[k1] + s y_(1-c)[k1],
+                // s = +1 / -1 for c = 0 / 1, i.e. X[k0 + 16 k1] and -X[k0 + 16 k1 + 256] (only |X|^2 is used).  No LDS
+                // traffic, no extra instruction; lane c ends up with k2 = c for all sixteen k1.
+                prio_compute();
+                float2 y[16];
+                twiddle_pow16(v, w2, [&](auto kc, float2 val) { y[decltype(kc)::value] = val; });
+                const float sgn = lo ? -1.0f : 1.0f;
+                asm volatile("s_nop 1");      // VALU write -> DPP read of the same register needs two wait states
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) {
+                    asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(y[k1].x) : "v"(sgn));
+                    asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(y[k1].y) : "v"(sgn));
+                }
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) v[k1] = y[k1];
+            } else if constexpr (R > 1) {
                 prio_latency();
                 // in place: the R lanes that share k0 sit in one wave and have issued their reads of region k0 above
                 twiddle_pow16(v, w2, [&](auto kc, float2 val) {
@@ -401,7 +426,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                 }
             }
             // X[k0 + 16 (lo + R m) + 256 k2] lands in v[m R + k2] (R = 16: v[r16(k2)]; R = 1: X[k0 + 16 m] in v[r16(m)])
-            if (R == 1) {
+            if (R == 1 || R2DPP) {
             } else if (R == 2) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
@@ -469,7 +494,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
 #pragma unroll
                     for (int m = 0; m < Q; ++m)
 #pragma unroll
-                        for (int k2 = 0; k2 < R; ++k2) row[(hi + 16 * (lo + R * m) + 256 * k2 + sh) & (N - 1)] = val[m * R + k2];
+                        for (int k2 = 0; k2 < R; ++k2) row[(bin_of(m, k2) + sh) & (N - 1)] = val[m * R + k2];
                 }
                 if (ac) {
                     if (p.acc_mode == ACC_WSUM) {
@@ -499,7 +524,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
 #pragma unroll
         for (int m = 0; m < Q; ++m)
 #pragma unroll
-            for (int k2 = 0; k2 < R; ++k2) dst[hi + 16 * (lo + R * m) + 256 * k2] = acc[m * R + k2];
+            for (int k2 = 0; k2 < R; ++k2) dst[bin_of(m, k2)] = acc[m * R + k2];
     }
 }
 
