@@ -93,6 +93,9 @@ struct oth_chain {
     size_t stage_cap = 0;
     float *d_partial = nullptr;        // per-team accumulator rows of the fused kernel
     size_t partial_cap = 0;
+    float *d_tail = nullptr;           // group rows of the two-launch cross-team reduction
+    size_t tail_cap = 0;
+    bool peak_flag_set = false;        // d_peak_init is 1 on the stream's timeline
     int kernel = OTH_KERNEL_AUTO;      // OTH_KERNEL_GENERIC forces the coverage kernels (parity tests)
     float *d_out = nullptr;            // rows handed back by the host-output forms
     size_t out_cap = 0;
@@ -1262,6 +1265,7 @@ int oth_chain_destroy(oth_chain *h) {
     if (h->d_peak_init) hipFree(h->d_peak_init);
     if (h->d_stage) hipFree(h->d_stage);
     if (h->d_partial) hipFree(h->d_partial);
+    if (h->d_tail) hipFree(h->d_tail);
     if (h->d_out) hipFree(h->d_out);
     for (int i = 0; i < oth_chain::kRing; ++i) {
         if (h->h_in[i]) hipHostFree(h->h_in[i]);
@@ -1312,6 +1316,7 @@ int oth_chain_reset(oth_chain *h) {
     HIPCHK(c, hipMemsetAsync(h->d_iir, 0, sizeof(float) * h->nfft, c->stream));
     HIPCHK(c, hipMemsetAsync(h->d_peak, 0, sizeof(float) * h->nfft, c->stream));
     HIPCHK(c, hipMemsetAsync(h->d_peak_init, 0, sizeof(int), c->stream));
+    h->peak_flag_set = false;
     h->leftover = 0;
     h->count = h->keep_n;
     return OTH_OK;
@@ -1385,18 +1390,25 @@ static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec
     a.tail_chunk = a.chunk;
     a.nbig = a.nseg / a.chunk;
     a.queue = nullptr;
+    int groups = 0;
     if (a.acc_mode != 3) {
         if ((rc = ensure(c, &h->d_partial, &h->partial_cap, sizeof(float) * (size_t)W * N))) return rc;
         a.partial = h->d_partial;
+        groups = chain_tail_groups((int)W, N);
+        if (groups && (rc = ensure(c, &h->d_tail, &h->tail_cap, sizeof(float) * (size_t)groups * N))) return rc;
     }
     {
-        Timed tm(c);
+        Timed tm(c);      // the whole push: transform kernel + cross-team reduction + state / rows
         HIPCHK(c, launch_seg(N, a, 2, false, c->stream));
+        if (a.acc_mode != 3)
+            HIPCHK(c, launch_chain_tail(h->d_partial, groups ? h->d_tail : nullptr, (int)W, N, h->fftshift, a.acc_mode, a.acc_end,
+                                        h->alpha, h->kdb, h->d_iir, h->d_peak, h->d_rows, h->do_iir ? give : 0, rows_last,
+                                        c->stream));
     }
-    if (a.acc_mode != 3)
-        HIPCHK(c, launch_chain_tail(h->d_partial, (int)W, N, h->fftshift, a.acc_mode, a.acc_end, h->alpha, h->kdb,
-                                    h->d_iir, h->d_peak, h->d_peak_init, h->d_rows, h->do_iir ? give : 0, rows_last,
-                                    c->stream));
+    if (a.acc_mode == 2 && !h->peak_flag_set) {      // the coverage path (rows_epilogue_kernel) reads the flag
+        HIPCHK(c, launch_set_flag(h->d_peak_init, 1, c->stream));
+        h->peak_flag_set = true;
+    }
     return OTH_OK;
 }
 
@@ -1433,6 +1445,7 @@ static int chain_launch(oth_chain *h, const float2 *x, long long first_vec, long
     if (h->do_iir || h->do_peak)
         HIPCHK(c, launch_rows_epilogue(h->d_rows, nrows, N, h->alpha, h->kdb, h->d_iir, h->d_peak, h->d_peak_init,
                                        h->do_iir, h->do_peak, c->stream));
+    if (h->do_peak && nrows > 0) h->peak_flag_set = true;
     if (rows_last && give > 0)
         HIPCHK(c, hipMemcpyAsync(rows_last, h->d_rows + (size_t)(nrows - give) * N, sizeof(float) * (size_t)give * N,
                                  hipMemcpyDeviceToDevice, c->stream));

@@ -44,8 +44,17 @@ __device__ __forceinline__ void dft4_tail(float2 t0, float2 t1, float2 p1, float
     a1 = make_float2(fmaf(S, r.y, t1.x), fmaf(-S, r.x, t1.y));       // t1 + (-i) S r
     a3 = make_float2(fmaf(-S, r.y, t1.x), fmaf(S, r.x, t1.y));
 }
-__device__ __forceinline__ void dft16_layer2(float2 (&v)[16]) {
 #ifdef OTH_DFT16_PLAIN
+constexpr bool kDft16Plain = true;
+#else
+constexpr bool kDft16Plain = false;
+#endif
+// PLAIN: multiply-then-add (160 operations; every inner twiddle product rounded on its own) - the periodogram-chain
+// builds take it, their single rows are compared bin by bin and the chain is HBM-bound; the Welch averages take the
+// folded form
+template <bool PLAIN = kDft16Plain>
+__device__ __forceinline__ void dft16_layer2(float2 (&v)[16]) {
+  if constexpr (PLAIN) {
     v[5] = mul_w1(v[5]);
     v[9] = mul_w2(v[9]);
     v[13] = mul_w3(v[13]);
@@ -57,7 +66,7 @@ __device__ __forceinline__ void dft16_layer2(float2 (&v)[16]) {
     v[15] = mul_w9(v[15]);
 #pragma unroll
     for (int kl = 0; kl < 4; ++kl) dft4<false>(v[4 * kl], v[4 * kl + 1], v[4 * kl + 2], v[4 * kl + 3]);
-#else
+  } else {
     dft4<false>(v[0], v[1], v[2], v[3]);
     {   // kl = 1: W^1, W^2, W^3 on v[5], v[6], v[7]
         const float2 u1 = v[5], u2 = v[6], u3 = v[7];
@@ -85,14 +94,15 @@ __device__ __forceinline__ void dft16_layer2(float2 (&v)[16]) {
         const float2 t1 = make_float2(fmaf(-RH, p2.x, v[12].x), fmaf(-RH, p2.y, v[12].y));
         dft4_tail(t0, t1, p1, p3, C1, v[12], v[13], v[14], v[15]);
     }
-#endif
+  }
 }
 
 // Forward 16-point DFT in place: in v[a], a = 0..15; out y[k] at v[r16(k)].
+template <bool PLAIN = kDft16Plain>
 __device__ __forceinline__ void dft16(float2 (&v)[16]) {
 #pragma unroll
     for (int a0 = 0; a0 < 4; ++a0) dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
-    dft16_layer2(v);
+    dft16_layer2<PLAIN>(v);
 }
 
 // dft16() of sixteen float2 read from LDS at base[STRIDE * i]: the reads are issued as plain ds_read_b64 in the

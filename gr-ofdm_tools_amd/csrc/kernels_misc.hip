@@ -226,42 +226,169 @@ __global__ void rows_epilogue_kernel(float *rows, long long nrows, int nfft, flo
 
 __global__ void set_flag_kernel(int *flag, int v) { *flag = v; }
 
-// Closes a fused chain launch (segfft.hip): the per-team accumulator rows (natural bin order) become the new IIR /
-// peak state (kept in ROW order, i.e. after the optional fftshift), and the raw rows the launch stored for the
-// caller go through the last steps of the recursion in time order.
+// ---- closing a fused chain launch (segfft.hip) ------------------------------------------------------------
+// The launch leaves W per-team accumulator rows (natural bin order): weighted sums for the IIR form, maxima for
+// peak hold - about 12.6 MB at every transform size (48 / 24 / 12 / 6 / 3 teams per CU x 256 CUs rows of nfft floats).
+// They become the new IIR / peak state (kept in ROW order, i.e. after the optional fftshift), and the raw rows the
+// launch stored for the caller go through the last steps of the recursion in time order.
 //   acc_mode 1  y = (1-alpha)^nbase y0 + alpha sum_w partial[w][k];  per raw row: y = alpha x + (1-alpha) y,
 //               rows_out = 10 log10(y) + kdb      (single_pole_iir_filter_ff + nlog10_ff, local_worker.py:66-69)
 //   acc_mode 2  peak = max(state, max_w partial[w][k])                (psd_logger.py:85); rows were written raw
-__global__ void chain_tail_kernel(const float *partial, int W, int nfft, int fftshift, int acc_mode, long long nbase,
-                                  float alpha, float kdb, float *iir_state, float *peak_state, const int *peak_init,
-                                  const float *raw_rows, long long nraw, float *rows_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // row position
-    if (i >= nfft) return;
-    const int k = fftshift ? ((i + nfft / 2) & (nfft - 1)) : i;
-    if (acc_mode == 1) {
-        double s = 0.0;
-        for (int w = 0; w < W; ++w) s += (double)partial[(size_t)w * nfft + k];
-        float y = iir_state[i];
-        if (nbase > 0) y = (float)((double)y * pow(1.0 - (double)alpha, (double)nbase) + (double)alpha * s);
-        for (long long r = 0; r < nraw; ++r) {
-            y = fmaf(alpha, raw_rows[(size_t)r * nfft + i], (1.0f - alpha) * y);
-            rows_out[(size_t)r * nfft + i] = 10.0f * log10f(y) + kdb;
+// Two launches, both wide (the one-launch form of round 2 walked all W rows in nfft / 256 workgroups: 174-3313 us):
+//   chain_reduce_kernel   grid (nfft / 256, G): group g of the rows -> scratch[g][nfft]; 256 threads = 64 float4
+//                         columns x 4 row lanes; sums in double, fixed order
+//   chain_state_kernel    grid nfft / 16: the G group rows (or the W rows themselves when there are few) -> state,
+//                         16 positions x 64 row slices per block like finalize_wide_kernel, then the raw rows
+// 5 + 5 us, each at the floor of a small kernel.  Tried and dropped: ONE launch in which the last block of a column
+// block to finish reduces the group rows - with __threadfence() it took 60 us (an agent-scope release / acquire
+// writes back / invalidates the XCD's whole L2 from each of ~1000 workgroups), with agent-scope atomic stores / loads
+// for the group rows instead of fences 10-20 us.
+template <bool MAX>
+__global__ __launch_bounds__(256) void chain_reduce_kernel(const float *partial, float *scratch, int W, int nfft, int rows_per_group) {
+    __shared__ double red[3][64][4];
+    const int q = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + q) * 4;
+    const int g = blockIdx.y;
+    const int w0 = g * rows_per_group, w1 = min(W, w0 + rows_per_group);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    const float *base = partial + col;
+    for (int w = w0 + j; w < w1; w += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)w * nfft);
+        if (MAX) {
+            s0 = fmax(s0, (double)v.x), s1 = fmax(s1, (double)v.y), s2 = fmax(s2, (double)v.z), s3 = fmax(s3, (double)v.w);
+        } else {
+            s0 += v.x, s1 += v.y, s2 += v.z, s3 += v.w;
         }
-        iir_state[i] = y;
-    } else if (acc_mode == 2) {
-        float pk = 0.f;
-        for (int w = 0; w < W; ++w) pk = fmaxf(pk, partial[(size_t)w * nfft + k]);
-        if (*peak_init) pk = fmaxf(pk, peak_state[i]);
-        peak_state[i] = pk;
     }
+    if (j) {
+        red[j - 1][q][0] = s0;
+        red[j - 1][q][1] = s1;
+        red[j - 1][q][2] = s2;
+        red[j - 1][q][3] = s3;
+    }
+    __syncthreads();
+    if (j) return;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (MAX) {
+            s0 = fmax(s0, red[r][q][0]), s1 = fmax(s1, red[r][q][1]), s2 = fmax(s2, red[r][q][2]), s3 = fmax(s3, red[r][q][3]);
+        } else {
+            s0 += red[r][q][0], s1 += red[r][q][1], s2 += red[r][q][2], s3 += red[r][q][3];
+        }
+    }
+    *reinterpret_cast<float4 *>(scratch + (size_t)g * nfft + col) = make_float4((float)s0, (float)s1, (float)s2, (float)s3);
 }
 
-hipError_t launch_chain_tail(const float *partial, int W, int nfft, int fftshift, int acc_mode, long long nbase,
-                             float alpha, float kdb, float *iir_state, float *peak_state, int *peak_init,
-                             const float *raw_rows, long long nraw, float *rows_out, hipStream_t s) {
-    hipLaunchKernelGGL(chain_tail_kernel, dim3((nfft + 255) / 256), dim3(256), 0, s, partial, W, nfft, fftshift, acc_mode,
-                       nbase, alpha, kdb, iir_state, peak_state, peak_init, raw_rows, nraw, rows_out);
-    if (acc_mode == 2) hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, s, peak_init, 1);
+struct ChainStateArgs {
+    const float *rows;      // [nrows][nfft] group rows (or the team rows), natural bin order
+    int nrows, nfft, fftshift, acc_mode;
+    long long nbase;
+    float alpha, kdb;
+    float *iir_state, *peak_state;
+    const float *raw_rows;  // [nraw][nfft] row order
+    long long nraw;         // rows taken through the recursion here (0 when chain_rows_kernel follows)
+    float *rows_out;
+};
+
+__global__ __launch_bounds__(256) void chain_state_kernel(ChainStateArgs a) {
+    constexpr int POS = 16, COLS = POS / 4, SLICES = 256 / COLS;
+    __shared__ double red[SLICES][POS + 1];
+    const int col = threadIdx.x % COLS, slice = threadIdx.x / COLS;
+    const float *base = a.rows + blockIdx.x * POS + col * 4;
+    const bool mx = a.acc_mode == 2;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int w = slice; w < a.nrows; w += SLICES) {
+        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)w * a.nfft);
+        if (mx) {
+            s0 = fmax(s0, (double)v.x), s1 = fmax(s1, (double)v.y), s2 = fmax(s2, (double)v.z), s3 = fmax(s3, (double)v.w);
+        } else {
+            s0 += v.x, s1 += v.y, s2 += v.z, s3 += v.w;
+        }
+    }
+    red[slice][col * 4] = s0;
+    red[slice][col * 4 + 1] = s1;
+    red[slice][col * 4 + 2] = s2;
+    red[slice][col * 4 + 3] = s3;
+    __syncthreads();
+    if (threadIdx.x >= POS) return;
+    const int k = blockIdx.x * POS + threadIdx.x;                                   // bin
+    const int i = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;               // row position
+    double t = 0.0;
+    for (int q = 0; q < SLICES; ++q) t = mx ? fmax(t, red[q][threadIdx.x]) : t + red[q][threadIdx.x];
+    if (mx) {
+        // |X| and |X|^2 are >= 0 and the state starts at 0: no "initialised" flag needed
+        a.peak_state[i] = fmaxf((float)t, a.peak_state[i]);
+        return;
+    }
+    float y = a.iir_state[i];
+    if (a.nbase > 0) y = (float)((double)y * pow(1.0 - (double)a.alpha, (double)a.nbase) + (double)a.alpha * t);
+    for (long long r = 0; r < a.nraw; ++r) {
+        y = fmaf(a.alpha, a.raw_rows[(size_t)r * a.nfft + i], (1.0f - a.alpha) * y);
+        a.rows_out[(size_t)r * a.nfft + i] = 10.0f * log10f(y) + a.kdb;
+    }
+    a.iir_state[i] = y;
+}
+
+// many raw rows (a caller that wants more than the latest few): one thread per row position walks them in time order
+__global__ __launch_bounds__(64) void chain_rows_kernel(int nfft, float alpha, float kdb, float *iir_state, const float *raw_rows,
+                                                        long long nraw, float *rows_out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nfft) return;
+    float y = iir_state[i];
+    for (long long r = 0; r < nraw; ++r) {
+        y = fmaf(alpha, raw_rows[(size_t)r * nfft + i], (1.0f - alpha) * y);
+        rows_out[(size_t)r * nfft + i] = 10.0f * log10f(y) + kdb;
+    }
+    iir_state[i] = y;
+}
+
+// rows of scratch the two-launch form needs for W team rows (0: the state kernel reads the team rows directly)
+int chain_tail_groups(int W, int nfft) {
+    if (W <= 128) return 0;
+    // ~12 rows per group gives nfft / 256 x G ~ 1024 workgroups at every size; at most 256 groups, so that the state
+    // kernel (nfft / 16 workgroups) never walks more than four rows per thread
+    int g = (W + 11) / 12;
+    const int gmax = nfft >= 1024 ? 1024 * 256 / nfft : 256;
+    if (g > gmax) g = gmax;
+    return g < 1 ? 1 : g;
+}
+
+hipError_t launch_chain_tail(const float *partial, float *scratch, int W, int nfft, int fftshift, int acc_mode, long long nbase,
+                             float alpha, float kdb, float *iir_state, float *peak_state, const float *raw_rows,
+                             long long nraw, float *rows_out, hipStream_t s) {
+    ChainStateArgs a;
+    a.rows = partial;
+    a.nrows = W;
+    const int G = scratch ? chain_tail_groups(W, nfft) : 0;
+    if (G) {
+        const int rpg = (W + G - 1) / G;
+        const dim3 grid(nfft / 256, G);
+        if (acc_mode == 2) hipLaunchKernelGGL(chain_reduce_kernel<true>, grid, dim3(256), 0, s, partial, scratch, W, nfft, rpg);
+        else hipLaunchKernelGGL(chain_reduce_kernel<false>, grid, dim3(256), 0, s, partial, scratch, W, nfft, rpg);
+        a.rows = scratch;
+        a.nrows = G;
+    }
+    const bool rows_apart = acc_mode == 1 && nraw > 8;
+    a.nfft = nfft;
+    a.fftshift = fftshift;
+    a.acc_mode = acc_mode;
+    a.nbase = nbase;
+    a.alpha = alpha;
+    a.kdb = kdb;
+    a.iir_state = iir_state;
+    a.peak_state = peak_state;
+    a.raw_rows = raw_rows;
+    a.nraw = (acc_mode == 1 && !rows_apart) ? nraw : 0;
+    a.rows_out = rows_out;
+    hipLaunchKernelGGL(chain_state_kernel, dim3(nfft / 16), dim3(256), 0, s, a);
+    if (rows_apart)
+        hipLaunchKernelGGL(chain_rows_kernel, dim3((nfft + 63) / 64), dim3(64), 0, s, nfft, alpha, kdb, iir_state, raw_rows, nraw,
+                           rows_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_flag(int *flag, int v, hipStream_t s) {
+    hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, s, flag, v);
     return hipGetLastError();
 }
 

@@ -140,10 +140,13 @@ int seg_teams_per_cu(int nfft, int kind, bool wps4);
 hipError_t launch_seg(int nfft, const SegArgs &a, int kind, bool wps4, hipStream_t s);
 int segws_teams_per_cu(int nfft);
 hipError_t launch_segws(int nfft, const SegArgs &a, int det, hipStream_t s);
-// partial rows of a chain launch + the stored raw rows -> IIR / peak state and the rows handed back
-hipError_t launch_chain_tail(const float *partial, int W, int nfft, int fftshift, int acc_mode, long long nbase,
-                             float alpha, float kdb, float *iir_state, float *peak_state, int *peak_init,
-                             const float *raw_rows, long long nraw, float *rows_out, hipStream_t s);
+// partial rows of a chain launch + the stored raw rows -> IIR / peak state and the rows handed back; `scratch` holds
+// chain_tail_groups(W, nfft) rows of nfft floats (0 rows: not needed)
+int chain_tail_groups(int W, int nfft);
+hipError_t launch_chain_tail(const float *partial, float *scratch, int W, int nfft, int fftshift, int acc_mode, long long nbase,
+                             float alpha, float kdb, float *iir_state, float *peak_state, const float *raw_rows,
+                             long long nraw, float *rows_out, hipStream_t s);
+hipError_t launch_set_flag(int *flag, int v, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int nstreams, hipStream_t s);
 hipError_t launch_scale(const float *sum, float *out, int nfft, double scale, int fftshift, int trim, int db,
                         hipStream_t s);

@@ -55,6 +55,9 @@ enum { LOAD_HALF = 0, LOAD_FULL = 1 };
 #ifndef OTH_CHAIN_WIN_LDS
 #define OTH_CHAIN_WIN_LDS 1
 #endif
+#ifndef OTH_CHAIN_PLAIN_MASK
+#define OTH_CHAIN_PLAIN_MASK 7       // chain builds: passes (bit 0: pass 1, bit 1: pass 2, bit 2: pass 3) that take the
+#endif                               // multiply-then-add butterflies - their single rows are compared bin by bin
 #ifndef OTH_CHAIN_WPS
 #define OTH_CHAIN_WPS 3      // waves per SIMD of the chain build (2: no spills at all, but half the speed)
 #endif
@@ -79,11 +82,25 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F f)
 }
 
 // 8-point DFT, natural order in and out; the sqrt(1/2) of W8^1 and W8^3 rides on the last layer's additions
+// (PLAIN: multiplied out first, as dft16_layer2<true>)
+template <bool PLAIN = kDft16Plain>
 __device__ __forceinline__ void dft8(float2 (&v)[8]) {
     dft4<false>(v[0], v[2], v[4], v[6]);
     dft4<false>(v[1], v[3], v[5], v[7]);
     const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
     const float2 o0 = v[1], o2 = mul_w4(v[5]);                                   // W8^k = W16^(2k)
+    if constexpr (PLAIN) {
+        const float2 o1 = mul_w2(v[3]), o3 = mul_w6(v[7]);
+        v[0] = cadd(e0, o0);
+        v[4] = csub(e0, o0);
+        v[1] = cadd(e1, o1);
+        v[5] = csub(e1, o1);
+        v[2] = cadd(e2, o2);
+        v[6] = csub(e2, o2);
+        v[3] = cadd(e3, o3);
+        v[7] = csub(e3, o3);
+        return;
+    }
     const float2 p1 = make_float2(v[3].x + v[3].y, v[3].y - v[3].x);             // W8^1 o = RH p1
     const float2 p3 = make_float2(v[7].y - v[7].x, -v[7].x - v[7].y);            // W8^3 o = RH p3
     v[0] = cadd(e0, o0);
@@ -160,6 +177,11 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
     // (the fused chain keeps the LDS exchange: measured 71 % of the roofline with it against 54 % through DPP - the
     // exchange's wait is where its three waves per SIMD take turns at the memory pipe)
     constexpr bool R2DPP = R == 2 && !CHAIN && (OTH_SEG_R2_DPP != 0);
+    // butterfly form per pass.  256 points (two passes): the multiply-then-add form in pass 2 costs 19 % of the launch
+    // (four teams per wave: that build is issue-bound) and measures the same accuracy (tools/acc_rows.py), so only
+    // pass 1 takes it there
+    constexpr int PLM = kDft16Plain ? 7 : (CHAIN ? ((OTH_CHAIN_PLAIN_MASK) & (R == 1 ? 1 : 7)) : 0);
+    constexpr bool PL1 = (PLM & 1) != 0, PL2 = (PLM & 2) != 0, PL3 = (PLM & 4) != 0;
     // bin held in slot m R + k2 of the per-thread results
     auto bin_of = [&](int m, int k2) { return R2DPP ? hi + 16 * (m * R + k2) + 256 * lo : hi + 16 * (lo + R * m) + 256 * k2; };
     // WIN_LDS (the chain build): the sixteen window values of a thread live in LDS as four float4 and are read
@@ -351,7 +373,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
             Pow6 w1 = tw1;
             if (TW1_LDS) w1 = pow6_from(tl1, T);      // issued before the butterflies that hide them
             prio_compute();
-            dft16(v);
+            dft16<PL1>(v);
             prio_latency();
             twiddle_pow16(v, w1, [&](auto kc, float2 val) {
                 constexpr int k0 = decltype(kc)::value;
@@ -382,7 +404,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                     for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = __builtin_bit_cast(float2, r[a0 + 4 * j]);
                     dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
                 }
-                dft16_layer2(v);
+                dft16_layer2<PL2>(v);
             }
             if constexpr (R2DPP) {
                 // R = 2 without exchange 2: the two lanes that share k0 are neighbours, so the last radix-2 stage
@@ -444,15 +466,15 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                     h0[i] = v[i];
                     h1[i] = v[8 + i];
                 }
-                dft8(h0);
-                dft8(h1);
+                dft8<PL3>(h0);
+                dft8<PL3>(h1);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     v[i] = h0[i];
                     v[8 + i] = h1[i];
                 }
             } else {
-                dft16(v);
+                dft16<PL3>(v);
             }
             auto at = [&](int m, int k2) -> float2 & { return v[R == 16 ? r16(k2) : (R == 1 ? r16(m) : m * R + k2)]; };
             if (!CHAIN) {

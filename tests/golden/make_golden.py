@@ -35,6 +35,7 @@ import sys
 
 import numpy as np
 import scipy
+import scipy.fft as sfft
 import scipy.signal as sg
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -235,16 +236,27 @@ def main():
     N = 1024
     X = np.fft.fftshift(np.fft.fft(x.astype(np.complex128).reshape(-1, N), axis=1), axes=1)
     rows = np.abs(X) ** 2 / N ** 2
+    # comparator, not expectation: the same chain on a single-precision CPU FFT (scipy.fft keeps complex64 in fp32 -
+    # FFTW3f-class arithmetic, which is what fft_vcc runs), |X|^2 and the 1/N^2 product in float32 as the GR blocks do.
+    # The GPU tests hold the HIP rows to at most 1.5 x this path's own error against the float64 expectation.
+    Xc = sfft.fft(x.reshape(-1, N), axis=1)
+    assert Xc.dtype == np.complex64
+    Xc = np.fft.fftshift(Xc, axes=1)
+    c64_rows = (Xc.real * Xc.real + Xc.imag * Xc.imag) * np.float32(1.0 / (N * N))
     save('gr_chain_rect_1024.npz', source=np.array('numpy'), seed=1001, x=x, nfft=N,
-         expected_rows=rows, expected_mean8=rows.reshape(-1, 8, N).mean(axis=1))
+         expected_rows=rows, expected_mean8=rows.reshape(-1, 8, N).mean(axis=1), c64_rows=c64_rows)
 
     # a2 - psd_logger chain: BH window, natural order, |.|, running peak (numpy + restated window)
     x = R.synth_iq(65536, 5)
     N = 4096
     w = sg.windows.blackmanharris(N, sym=True)
     mag = np.abs(np.fft.fft(x.astype(np.complex128).reshape(-1, N) * w, axis=1))
+    Xc = sfft.fft(x.reshape(-1, N) * w.astype(np.float32), axis=1)      # single-precision comparator (see a1)
+    assert Xc.dtype == np.complex64
+    c64_mag = np.abs(Xc)
+    assert c64_mag.dtype == np.float32
     save('gr_chain_bh_mag_peak_4096.npz', source=np.array('numpy'), seed=5, x=x, nfft=N, window=w,
-         expected_mag=mag, expected_peak=np.maximum.accumulate(mag, axis=0))
+         expected_mag=mag, expected_peak=np.maximum.accumulate(mag, axis=0), c64_mag=c64_mag)
 
     # a3 - local_worker chain: BH, shifted, |.|^2, IIR(0.8), 10log10 + k (numpy)
     x = R.synth_iq(65536, 6)
@@ -258,8 +270,16 @@ def main():
         lin.append(yv)
     lin = np.array(lin)
     k = -10 * np.log10(N) - 10 * np.log10(Sf)
+    Xc = np.fft.fftshift(sfft.fft(x.reshape(-1, N) * w.astype(np.float32), axis=1), axes=1)      # comparator (see a1)
+    pc = Xc.real * Xc.real + Xc.imag * Xc.imag
+    yc, c64_lin = np.zeros(N, np.float32), []
+    for r in pc:
+        yc = np.float32(alpha) * r + np.float32(1 - alpha) * yc
+        c64_lin.append(yc)
+    c64_lin = np.array(c64_lin)
+    assert c64_lin.dtype == np.float32
     save('gr_chain_bh_iir_log_2048.npz', source=np.array('numpy'), seed=6, x=x, nfft=N, sample_rate=Sf,
-         average=alpha, window=w, expected_lin=lin, expected_db=10 * np.log10(lin) + k)
+         average=alpha, window=w, expected_lin=lin, expected_db=10 * np.log10(lin) + k, c64_lin=c64_lin)
 
     # a7 - src_power: np.convolve('same') moving average + channel sums (restated on numpy calls)
     rng = np.random.default_rng(21)

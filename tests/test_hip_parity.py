@@ -21,16 +21,26 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b) / np.abs(b)))
 
 
-def check_single_rows(rows, ref, power=True, ulps=4):
+def check_single_rows(rows, ref, power=True, ulps=4, c64=None, plain=None, floor_rel=None):
     """SINGLE periodogram rows (the per-vector outputs of the GNU Radio chains: |X|^2 rows when `power`, |X| rows
     otherwise).  A single transform of noise + a strong tone has bins down to 1e-6 of the row's peak (Rayleigh
     nulls, leakage skirts); there the amplitude rounding of ANY fp32 FFT (FFTW3f, which fft_vcc runs, included) -
     about one ulp of the row's LARGEST amplitude, because the tone's energy passes through every butterfly - is
-    1e-4 or more of the bin's own value.  tools/acc_probe.py measures 1.0-1.5 ulp of the peak as the worst
-    amplitude error over sizes and seeds, the same for both butterfly forms.  So single rows are held to
-      * amplitude error <= 4 ulp (2^-21) of the row's peak amplitude on EVERY bin,
-      * the plain 1e-4 on every bin at or above the row's median level (measured < 2e-5),
-      * mean relative error < 2e-6 (measured 3-4e-7).
+    1e-4 or more of the bin's own value.  Every call holds the rows to
+      * amplitude error <= `ulps` (4: 2^-21) ulp of the row's peak amplitude on EVERY bin,
+      * the plain 1e-4 on every bin at or above the row's median level,
+      * mean relative error < 2e-6.
+    Where the committed fixture carries them, the round-1 criteria are asserted again and the HIP rows are measured
+    against a single-precision CPU FFT of the same samples:
+      * `plain`: max relative error over ALL bins < plain (1e-4 where a CPU fp32 FFT meets it too),
+      * `floor_rel`: |d| <= 1e-4 max(ref, floor_rel * median(ref)) on all bins (the a1 criterion of round 1),
+      * `c64` (scipy.fft on complex64 = FFTW3f-class arithmetic, stored in the fixture): no HIP row's worst amplitude
+        error exceeds 1.5 x the worst error of the CPU fp32 rows of the fixture (measured 1.05 x on a1, 1.00 x on a2),
+        and the mean over rows of the per-row worst error stays within 2 x the CPU's (measured 1.5 x at 1024 points,
+        where pocketfft is pure radix 4; 1.0 x at 256 / 512 / 2048 / 4096).  The ratio row by row is NOT asserted: a
+        row's worst bin is an extreme value over 1024-4096 roundings, and two CPU fp32 FFTs of the same samples
+        (pocketfft against a textbook radix-2 in complex64, tools/acc_rows.py) differ by up to 4.7 x per row while
+        their fixture-level worst agree within 12 %.
     Averaged quantities (the 8-row mean, peak hold over many rows, every Welch PSD) keep the plain 1e-4 on every bin."""
     rows = np.atleast_2d(np.asarray(rows, np.float64))
     ref = np.atleast_2d(np.asarray(ref, np.float64))
@@ -41,6 +51,18 @@ def check_single_rows(rows, ref, power=True, ulps=4):
     upper = ref >= np.median(ref, axis=1, keepdims=True)
     assert np.max(np.abs(rows - ref)[upper] / ref[upper]) < RTOL
     assert np.mean(np.abs(rows - ref) / ref) < 2e-6
+    if plain is not None:
+        assert np.max(np.abs(rows - ref) / ref) < plain, np.max(np.abs(rows - ref) / ref)
+    if floor_rel is not None:
+        v = np.max(np.abs(rows - ref) / np.maximum(ref, floor_rel * np.median(ref)))
+        assert v < RTOL, v
+    if c64 is not None:
+        c64 = np.atleast_2d(np.asarray(c64, np.float64))
+        camp = np.sqrt(c64) if power else c64
+        cpu_err = np.abs(camp - amp_ref) / amp_ref.max(axis=1, keepdims=True)
+        eh, ec = amp_err.max(axis=1), cpu_err.max(axis=1)
+        assert np.all(eh <= 1.5 * ec.max()), (eh.max() * 2.0 ** 23, ec.max() * 2.0 ** 23)
+        assert eh.mean() <= 2.0 * ec.mean(), (eh.mean() * 2.0 ** 23, ec.mean() * 2.0 ** 23)
 
 
 @pytest.fixture(scope='module')
@@ -377,7 +399,9 @@ def test_chain_sensor_v2_rows_and_mean8(ctx, hip, golden):
     ch = ctx.chain(1024, None, True, hip.EPI_MAG2_OVER_N2, 1)
     rows, n = ch.push(g['x'])
     assert n == 64 and rows.shape == (64, 1024)
-    check_single_rows(rows, g['expected_rows'])
+    # round-1 criteria again (plain 1e-4 over all bins happens to hold on this fixture for a CPU fp32 FFT too: 5.2e-5)
+    # + the CPU fp32 comparator; measured on MI355X: plain 4.6e-5, floor form 4.1e-5, 0.96 ulp of the peak
+    check_single_rows(rows, g['expected_rows'], c64=g['c64_rows'], plain=RTOL, floor_rel=1e-3)
     assert relerr(ctx.rows_group_mean(rows, 8), g['expected_mean8']) < RTOL
 
 
@@ -387,12 +411,14 @@ def test_chain_psd_logger_mag_and_peak(ctx, hip, golden):
     ch.set_peak_hold(True)
     rows, n = ch.push(g['x'][:5 * 4096])
     assert n == 5
-    check_single_rows(rows, g['expected_mag'][:5], power=False)
-    check_single_rows(ch.peak(), g['expected_peak'][4], power=False)          # the max of five rows still has nulls
+    # the round-1 criterion of this fixture was the plain 1e-4 on every |X| bin (a CPU fp32 FFT reaches 2.3e-4 here;
+    # the HIP rows measure 2.9e-5 with the multiply-then-add butterflies of the chain build)
+    check_single_rows(rows, g['expected_mag'][:5], power=False, c64=g['c64_mag'][:5], plain=RTOL)
+    check_single_rows(ch.peak(), g['expected_peak'][4], power=False, plain=RTOL)      # the max of five rows still has nulls
     rows, n = ch.push(g['x'][5 * 4096:])
     assert n == 11
-    check_single_rows(rows, g['expected_mag'][5:], power=False)
-    check_single_rows(ch.peak(), g['expected_peak'][-1], power=False)
+    check_single_rows(rows, g['expected_mag'][5:], power=False, c64=g['c64_mag'][5:], plain=RTOL)
+    check_single_rows(ch.peak(), g['expected_peak'][-1], power=False, plain=RTOL)
 
 
 def test_chain_local_worker_iir_log(ctx, hip, golden):
@@ -1009,6 +1035,49 @@ def test_fused_chain_many_rows_iir_peak_and_plain(ctx, hip, nfft):
     rows, n = ch.push(x[:nfft * 64], max_rows=1)
     assert n == 64
     check_single_rows(rows[0], ref[-1])
+
+
+@pytest.mark.parametrize('nfft', [256, 4096])
+def test_fused_chain_full_size_push_iir_and_peak(ctx, hip, nfft):
+    """One push of 2^26 device-resident samples (the size profiles/r03_chain*.txt are quoted on; the cross-team
+    reduction runs in its two-launch form over ~12 000 / 768 team rows) in IIR and in peak mode.
+    IIR (alpha = 0.8): the state after the push depends on the last rows only ((1-alpha)^48 = 3e-34), so the oracle
+    runs on the last 48 vectors; a second chain that takes the same samples in two pushes must agree.
+    Peak: the oracle on a 2^20-sample prefix pushed first, then the whole stream against the coverage kernels
+    (transform + sequential row epilogue), which share nothing with the fused launch but the input."""
+    from ofdm_tools import windows
+    n = 1 << 26
+    w = windows.blackmanharris(nfft)
+    d = ctx.alloc(n * 8)
+    try:
+        ctx.synth_iq(d, n, 77, R.TONES, R.DC)
+        tail = ctx.d2h(d + (n - 48 * nfft) * 8, (48 * nfft,), np.complex64)
+        lin, _ = R.chain_local_worker(tail, nfft, 2000000, 0.8)
+        ch = ctx.chain(nfft, w, True, hip.EPI_MAG2, 1)
+        ch.set_iir_log(0.8, 0.0)
+        assert ch.push_dev(d, n) == n // nfft
+        assert relerr(ch.iir(), lin[-1]) < RTOL
+        ch2 = ctx.chain(nfft, w, True, hip.EPI_MAG2, 1)
+        ch2.set_iir_log(0.8, 0.0)
+        cut = (n // 3) + 5
+        assert ch2.push_dev(d, cut) + ch2.push_dev(d + cut * 8, n - cut) == n // nfft
+        assert relerr(ch2.iir(), ch.iir()) < 1e-5
+        # peak hold on |X|
+        npre = 1 << 20
+        mag, peak = R.chain_psd_logger(ctx.d2h(d, (npre,), np.complex64), nfft)
+        pk = ctx.chain(nfft, w, False, hip.EPI_MAG, 1)
+        pk.set_peak_hold(True)
+        assert pk.push_dev(d, npre) == npre // nfft
+        assert relerr(pk.peak(), peak[-1]) < RTOL
+        assert pk.push_dev(d + npre * 8, n - npre) == (n - npre) // nfft
+        gen = ctx.chain(nfft, w, False, hip.EPI_MAG, 1)
+        gen.set_kernel(hip.KERNEL_GENERIC)
+        gen.set_peak_hold(True)
+        assert gen.push_dev(d, n) == n // nfft
+        a, b = pk.peak().astype(np.float64), gen.peak().astype(np.float64)
+        assert np.all(a >= peak[-1] * (1 - 1e-6)) and relerr(a, b) < 2e-5
+    finally:
+        ctx.free(d)
 
 
 @pytest.mark.parametrize('build', ['', 'csd1'])

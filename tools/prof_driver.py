@@ -10,7 +10,8 @@ usage: prof_driver.py <config> [reps] [log2_samples]
   C5        64 channels x 2^22, 16384-pt rect |X|^2/N^2 mean             (welch16k_kernel)
   w1024 / w2048      Hann Welch 50 % at nfft 1024 / 2048, 2^27 samples
   chain1024 / chain2048 / chain4096   periodogram chain (BH window, shift, |X|^2, IIR + log), 2^26 samples
-Prints the HIP-event average of the FFT kernel and the algorithmic GB/s.
+Prints the HIP-event average of the timed kernels (the averaging kernel; for the chains the whole push: transform
+kernel + cross-team reduction + state kernel) and the algorithmic GB/s.
 """
 import os
 import sys
@@ -110,7 +111,7 @@ for _ in range(reps):
 ms, k = ctx.get_timing()
 ctx.set_timing(False)
 per_call = ms / reps
-print('%s: FFT kernel %.4f ms per call (%d launches / %d calls) -> %.1f GB/s algorithmic = %.1f %% of 8 TB/s'
+print('%s: timed kernels %.4f ms per call (%d timed scopes / %d calls; chain*: transform + cross-team reduction + state) -> %.1f GB/s algorithmic = %.1f %% of 8 TB/s'
       % (cfg, per_call, k, reps, nbytes / per_call / 1e6, nbytes / per_call / 1e6 / 80.0))
 if cfg == 'C2':
     probe = ctx.stream_read_probe(bufs[0], nbytes, 2)

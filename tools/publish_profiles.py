@@ -67,10 +67,14 @@ for cfg, (pat, alg, desc) in CONFIGS.items():
     lines = ['%s  (tools/prof_driver.py %s under rocprofv3, separate passes: --kernel-trace --stats | --pmc SQ.. | --pmc '
              'FETCH_SIZE | --pmc WRITE_SIZE..)' % (desc, cfg), '']
     avg_ns = None
+    tail_ns = 0.0      # chains: the cross-team reduction + state kernels that close every push
     for r in csv.DictReader(open(stats)):
         lines.append('%-92s calls %5s  avg %10.1f us' % (r['Name'][:92], r['Calls'], float(r['AverageNs']) / 1e3))
         if pat in r['Name'] and avg_ns is None:
             avg_ns = float(r['AverageNs'])
+        if cfg.startswith('chain') and ('chain_reduce_kernel' in r['Name'] or 'chain_state_kernel' in r['Name']
+                                        or 'chain_tail_kernel' in r['Name']):
+            tail_ns += float(r['AverageNs'])
     v = counters(src, pat)
     lines.append('')
     for k in sorted(v):
@@ -86,6 +90,11 @@ for cfg, (pat, alg, desc) in CONFIGS.items():
         gbps = alg / avg_ns
         lines.append('roofline: algorithmic bytes per launch %d / kernel avg %.1f us = %.1f GB/s = %.1f %% of 8000 GB/s'
                      % (alg, avg_ns / 1e3, gbps, gbps / 80.0))
+        if tail_ns:
+            whole = avg_ns + tail_ns
+            lines.append('whole push (transform kernel %.1f us + cross-team reduction and state kernels %.1f us = %.1f us): '
+                         '%.1f GB/s = %.1f %% of 8000 GB/s' % (avg_ns / 1e3, tail_ns / 1e3, whole / 1e3, alg / whole,
+                                                                 alg / whole / 80.0))
     if 'FETCH_SIZE' in v:
         rd = v['FETCH_SIZE'] * 2048.0
         wr = v.get('WRITE_SIZE', 0.0) * 1024.0
