@@ -9,21 +9,29 @@
 //         256..511  Py  producer of stream y
 //         512..1023 C   eight consumer waves; in each, lanes 0..31 consume x and lanes 32..63 consume y FOR THE SAME
 //                       BINS (consumer index t = 32 wave + lane % 32 on the lane half's own pair of LDS images):
-//                       pass 2, exchange 2, pass 3; x lanes accumulate |X|^2 and Re conj(X) Y, y lanes |Y|^2 and Im.
+//                       pass 2, exchange 2, pass 3; then the lane halves trade spectra and each accumulates all four
+//                       sums of eight of the sixteen bins.
 // Each stream's pair of images works exactly as in the headline kernel (one LDS-only barrier per step, the consumers
 // one segment behind the producers).  What is new is the exchange of spectra: X[k] and Y[k] of one bin sit in
-// lanes l and l + 32 of one wave, so thirty-two ds_bpermute_b32 (the LDS crossbar, no memory, no barrier) hand
-// each lane its partner's sixteen bins.  Every thread carries 32 accumulators (the one-role csd4096 kernel: 64,
-// which held it at three waves per SIMD with no room to keep the overlapped halves or to prefetch): both streams
-// are read once, the halves stay in registers, the next halves are prefetched, four waves per SIMD.
+// lanes l and l + 32 of one wave.  For bins k2 = j and j + 8 one v_permlane32_swap_b32 per component (gfx950: swaps
+// the upper lane half of one register with the lower half of another - VALU, no LDS) leaves X[j], Y[j] in lane l and
+// X[j + 8], Y[j + 8] in lane l + 32: sixteen swaps per step.  (Round 2 handed each lane its partner's sixteen bins
+// through 32 ds_bpermute_b32 and chose Re / Im per lane half with 32 v_cndmask.)  Every thread carries 32
+// accumulators (the one-role csd4096 kernel: 64, which held it at three waves per SIMD with no room to keep the
+// overlapped halves or to prefetch): both streams are read once, the halves stay in registers, the next halves are
+// prefetched, four waves per SIMD.  The fifteen pass-2 twiddles come from a 2 KiB LDS table, read as eight
+// ds_read_b128 between the two butterfly layers of pass 2 (round 2 multiplied them out of two seeds: 52 VALU per step).
 //
 // The two pairs run the same chunk schedule (Px draws the tickets, Py reads them), so x_s and y_s are always in
 // the same step.  Frequency-domain detrend as in welch4096ws.hip (needs WelchArgs.fd).
 #include <type_traits>
 #include "fft4096.hip.h"
 
-#ifndef OTH_CSDWS_STORED_TW
-#define OTH_CSDWS_STORED_TW 0      // 1: the consumer keeps its fifteen pass-2 twiddles in registers (A/B switch)
+#ifndef OTH_CSDWS_TW
+#define OTH_CSDWS_TW 0      // pass-2 twiddles: 0 multiplied out of two seeds per step, 1 kept in registers, 2 LDS table (A/B: no gain)
+#endif
+#ifndef OTH_CSDWS_SWAP
+#define OTH_CSDWS_SWAP 1    // 1: spectra traded with v_permlane32_swap_b32, 0: ds_bpermute_b32 (round 2)
 #endif
 
 namespace oth {
@@ -34,7 +42,8 @@ constexpr int CS_RED = 32;                 // float2 per pair: per image the fou
 constexpr int CS_CTRL = 16;                // ints per pair: item kind per image [0..1], next-chunk ticket [4] (pair 0)
 constexpr size_t CS_PAIR_BYTES = (2 * LDS_X + CS_RED) * sizeof(float2) + CS_CTRL * sizeof(int);
 constexpr size_t CS_FW_BYTES = 256 * sizeof(float4);      // window-spectrum entries of the detrend, one per t
-constexpr size_t CS_LDS_BYTES = 2 * CS_PAIR_BYTES + CS_FW_BYTES;
+constexpr size_t CS_TW_BYTES = 8 * 16 * sizeof(float4);   // pass-2 twiddles [k1 / 2][c]: (W256^(k1 c), W256^((k1 + 1) c))
+constexpr size_t CS_LDS_BYTES = 2 * CS_PAIR_BYTES + CS_FW_BYTES + CS_TW_BYTES;
 static_assert((2 * CS_PAIR_BYTES) % 16 == 0, "the detrend table is read as float4");
 
 enum { CS_STOP = 0, CS_DATA = 1, CS_BUBBLE = 2 };
@@ -240,21 +249,39 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
         // ------------------------------------------------------------------ consumer
         // W256^c, W256^(4c): the fifteen pass-2 twiddles are multiplied out per item (32 accumulators leave no room
         // for the thirty registers the headline kernel's consumer spends on them)
-#if OTH_CSDWS_STORED_TW
+#if OTH_CSDWS_TW == 1
         float2 tw2[16];
 #pragma unroll
         for (int k = 1; k < 16; ++k) tw2[k] = p.tw[16 * lo * k];
-#else
+#elif OTH_CSDWS_TW == 0
         const float2 c1 = p.tw[16 * lo], c4 = p.tw[64 * lo];
+#else
+        // table of the fifteen W256^(k1 c): entry [k1 / 2][c] holds k1 even and odd side by side, so that the sixteen
+        // lanes that differ in c read 256 contiguous bytes per ds_read_b128 (no bank conflict)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        float4 *twl = reinterpret_cast<float4 *>(smem + 2 * CS_PAIR_BYTES + CS_FW_BYTES);
+        if (cidx < 128) {
+            const int j = cidx >> 4, c = cidx & 15;
+            const float2 e = p.tw[16 * c * (2 * j)], o = p.tw[16 * c * (2 * j + 1)];
+            twl[j * 16 + c] = make_float4(e.x, e.y, o.x, o.y);      // visible to all behind the first step's barrier
+        }
+        const unsigned tw_addr = (unsigned)(unsigned long long)(twl + lo);
+        f4 tq[4];      // k1 = 0..7, read between the butterfly layers of pass 2; k1 = 8..15 follow when these are used up
 #endif
         // The detrend's window-spectrum entries and the segment mean are fetched from LDS where they are used: held in
         // registers across the step they pushed the allocation past 128 VGPRs, and the one spilled register came
         // back through scratch memory behind an s_waitcnt vmcnt(0) in every step (42 % of the consumers' time).
         float4 *fwl = reinterpret_cast<float4 *>(smem + 2 * CS_PAIR_BYTES);
         if (DETREND && pair == 0) fwl[t] = p.fd[t];      // lanes l and l + 32 (same t) are in one wave: ordered
+#if OTH_CSDWS_SWAP
+        float axx[8], ayy[8], are[8], aim[8];      // lanes 0..31: bins k2 = j, lanes 32..63: bins k2 = j + 8
+#pragma unroll
+        for (int k = 0; k < 8; ++k) axx[k] = ayy[k] = are[k] = aim[k] = 0.f;
+#else
         float acs[16], acx[16];       // own power |X|^2 (or |Y|^2); cross term Re (pair 0) or Im (pair 1) of conj(X) Y
 #pragma unroll
         for (int k = 0; k < 16; ++k) acs[k] = acx[k] = 0.f;
+#endif
         float2 v[16];
         int it = 0;
 
@@ -267,12 +294,22 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
             const int q = it & 1;
             const float2 *lq = img + q * LDS_X;
             const int kind = __builtin_amdgcn_readfirstlane(ctrl0[q]);      // both streams run the same schedule
+#if OTH_CSDWS_TW == 2
+            dft16_from_lds<17>(v, lq + r1, [] { __builtin_amdgcn_s_setprio(1); }, [&] {
+#define CS_TW_READ(j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tq[j]) : "v"(tw_addr), "n"(256 * (j)))
+                CS_TW_READ(0); CS_TW_READ(1); CS_TW_READ(2); CS_TW_READ(3);
+#undef CS_TW_READ
+            });
+#else
             dft16_from_lds<17>(v, lq + r1, [] { __builtin_amdgcn_s_setprio(1); });
+#endif
             CS_STAMP(1);      // exchange-1 reads + pass 2
             ++it;
             return kind;
         };
+#if !OTH_CSDWS_SWAP
         const int partner = ((tid & 63) ^ 32) << 2;      // ds_bpermute address of the lane that holds the other stream's bin
+#endif
         int item = next_item();
         for (;;) {
             while (item == CS_BUBBLE) item = next_item();
@@ -280,12 +317,32 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
             const int q = (it & 1) ^ 1;   // the image whose pass 2 sits in v
             float2 *lx = img + q * LDS_X;
             __builtin_amdgcn_s_setprio(2);
-#if OTH_CSDWS_STORED_TW
+#if OTH_CSDWS_TW == 1
             lx[w2] = v[r16(0)];
 #pragma unroll
             for (int k1 = 1; k1 < 16; ++k1) lx[w2 + k1 * 17] = cmul(v[r16(k1)], tw2[k1]);
-#else
+#elif OTH_CSDWS_TW == 0
             scatter_pow16<17>(v, lx + w2, c1, c4);
+#else
+            // the first half of the table went out between the butterfly layers of pass 2: long since back.  The second
+            // half reuses its registers (all sixteen at once cost 15-26 spilled registers at the 128-VGPR cap).
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]));
+            lx[w2] = v[r16(0)];
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) {
+                const f4 e = tq[k1 >> 1];
+                lx[w2 + k1 * 17] = cmul(v[r16(k1)], (k1 & 1) ? make_float2(e.z, e.w) : make_float2(e.x, e.y));
+            }
+            f4 tr[4];
+#define CS_TW_READ(j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tr[j]) : "v"(tw_addr), "n"(256 * (4 + (j))))
+            CS_TW_READ(0); CS_TW_READ(1); CS_TW_READ(2); CS_TW_READ(3);
+#undef CS_TW_READ
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tr[0]), "+v"(tr[1]), "+v"(tr[2]), "+v"(tr[3]));
+#pragma unroll
+            for (int k1 = 8; k1 < 16; ++k1) {
+                const f4 e = tr[(k1 - 8) >> 1];
+                lx[w2 + k1 * 17] = cmul(v[r16(k1)], (k1 & 1) ? make_float2(e.z, e.w) : make_float2(e.x, e.y));
+            }
 #endif
             CS_STAMP(2);      // pass-2 twiddles + exchange-2 writes issued
             wave_lds_sync();
@@ -306,6 +363,24 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
                                          v[r16(15)].y - (mean.x * fw.w + mean.y * fw.z));
             }
             __builtin_amdgcn_s_setprio(2);
+#if OTH_CSDWS_SWAP
+            // v_permlane32_swap_b32 a, b swaps a's lanes 32..63 with b's lanes 0..31.  With a = bin j and b = bin j + 8
+            // (x-stream values in lanes 0..31, y-stream values in lanes 32..63 of both): a' = X[j] | X[j + 8],
+            // b' = Y[j] | Y[j + 8] - lane l holds bin j of both streams, lane l + 32 bin j + 8.
+            //   Pxx += |X|^2,  Pyy += |Y|^2,  Pxy += conj(X) Y = (Xr Yr + Xi Yi) + i (Xr Yi - Xi Yr)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float2 a = v[r16(j)], b = v[r16(j + 8)];
+                const auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+                const auto si = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+                const float2 X = make_float2(__uint_as_float(sr[0]), __uint_as_float(si[0]));
+                const float2 Y = make_float2(__uint_as_float(sr[1]), __uint_as_float(si[1]));
+                axx[j] = fmaf(X.x, X.x, fmaf(X.y, X.y, axx[j]));
+                ayy[j] = fmaf(Y.x, Y.x, fmaf(Y.y, Y.y, ayy[j]));
+                are[j] = fmaf(X.x, Y.x, fmaf(X.y, Y.y, are[j]));
+                aim[j] = fmaf(X.x, Y.y, fmaf(-X.y, Y.x, aim[j]));
+            }
+#else
             // conj(X) Y with own = this lane's bin, o = the partner lane's:  x lanes  Re = Xr Yr + Xi Yi = own.x o.x + own.y o.y
             //                                                                y lanes  Im = Xr Yi - Xi Yr = own.y o.x - own.x o.y
 #pragma unroll
@@ -326,15 +401,27 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
                     acs[k2] = fmaf(m.x, m.x, fmaf(m.y, m.y, acs[k2]));
                 }
             }
+#endif
             item = next_item();
         }
         // channels xx, yy, re, im; bin k0 + 16 k1 + 256 k2 at t + 256 k2 (finalize_kernel layout 1)
         float *dst = p.partial + ((size_t)stream * W + wg) * 4 * 4096;
+#if OTH_CSDWS_SWAP
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = 256 * (pair ? j + 8 : j) + t;
+            dst[o] = axx[j];
+            dst[4096 + o] = ayy[j];
+            dst[8192 + o] = are[j];
+            dst[12288 + o] = aim[j];
+        }
+#else
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             dst[(pair ? 4096 : 0) + 256 * k2 + t] = acs[k2];
             dst[(pair ? 12288 : 8192) + 256 * k2 + t] = acx[k2];
         }
+#endif
     }
 #if OTH_CSDWS_DIAG
     if ((tid & 63) == 0) {

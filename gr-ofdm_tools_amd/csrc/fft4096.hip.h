@@ -110,12 +110,15 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
 // and waits for all sixteen), each butterfly waits only for its own four.  The reads must be the wave's most
 // recent LDS operations when this is called; older LDS/scalar-memory operations only make the waits longer.
 // `issued()` runs once the reads are out (e.g. to drop the wave's priority for the butterflies).
-template <int STRIDE, class F>
-__device__ __forceinline__ void dft16_from_lds(float2 (&v)[16], const float2 *base, F issued) {
+// `mid()` runs between the two butterfly layers, when every read of this call has returned: LDS reads issued there
+// (a twiddle table, say) have the second layer to hide behind and do not disturb the counted waits above them.
+template <int STRIDE, class F, class M>
+__device__ __forceinline__ void dft16_from_lds(float2 (&v)[16], const float2 *base, F issued, M mid) {
 #ifdef OTH_PLAIN_LDS_READS      // A/B switch: compiler-scheduled reads
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = base[STRIDE * i];
     issued();
+    mid();
     dft16(v);
     return;
 #endif
@@ -143,7 +146,12 @@ __device__ __forceinline__ void dft16_from_lds(float2 (&v)[16], const float2 *ba
         dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
     }
 #undef OTH_LDS_WAIT
+    mid();
     dft16_layer2(v);
+}
+template <int STRIDE, class F>
+__device__ __forceinline__ void dft16_from_lds(float2 (&v)[16], const float2 *base, F issued) {
+    dft16_from_lds<STRIDE>(v, base, issued, [] {});
 }
 
 // Non-temporal load of a sample that is read once: it does not displace the tables and partial sums in L2.
