@@ -250,10 +250,17 @@ def main():
             err = float(np.max(np.abs(10 ** (chk.exec(pre).astype(np.float64) / 10) - ref) / ref))
         med = statistics.median(per)
         total = SWEEP_SEGMENTS * S
+        kavg = kern_ms / max(launches, 1)
+        ach = 8.0 * S / (kavg * 1e-3) / 1e9 if kavg else 0.0
         out = {'value': total / (med * 1e-3) / 1e6, 'unit': 'Msamples/s', 'ms_per_sweep': med,
                'wall_ms_per_sweep': 1e3 * wall / steps, 'segments': SWEEP_SEGMENTS, 'samples_per_segment': S,
                'segments_on_rank0': len(mine), 'steps': steps,
-               'kernel_avg_ms': kern_ms / max(launches, 1), 'launches': int(launches),
+               'kernel_avg_ms': kavg, 'launches': int(launches),
+               'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                            'frac': ach / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'welch4096ws_kernel (one launch per '
+                            'RF segment)', 'kernel_avg_ms': kavg, 'launches': int(launches),
+                            'algorithmic_bytes_per_launch': 8 * S,
+                            'whole_sweep_frac': 8.0 * total / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                'parity_prefix_max_rel_err': err}
         del seg
         return out, S
@@ -309,13 +316,17 @@ def main():
         med = statistics.median(per)
         kavg_ms = kern_ms / max(launches, 1)
         achieved = 8.0 * n / (kavg_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch: NOT measured by this run (PMC counters need rocprofv3 around the process) - the
+        # figure of the builder's last profile of the same kernel and size, labelled as such
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get('log2_samples') == args.log2_samples:
                     traffic = tj.get('hbm_bytes_per_launch')
+                    traffic_source = 'profiles/traffic.json (builder box, %s; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE ' \
+                                     'passes, not measured by this run)' % tj.get('source', 'profiles/')
             except (OSError, ValueError):
                 pass
         # sanity / parity on a prefix, outside the timed region
@@ -336,7 +347,7 @@ def main():
                        'nfft': NFFT, 'noverlap': NFFT // 2, 'window': 'hann', 'samples_per_gpu': n,
                        'segments_per_gpu': nseg, 'parallelism': 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': 'welch4096ws_kernel', 'kernel_avg_ms': kavg_ms, 'launches': int(launches),
                          'algorithmic_bytes_per_launch': 8 * n,
                          'read_probe_GBps': 8.0 * n / (probe_ms * 1e-3) / 1e9},
@@ -346,21 +357,28 @@ def main():
         if not args.no_extras:
             # host buffer -> PSD on the host through the streaming entry point (pinned staging ring, asynchronous
             # H2D + kernels): the PCIe-inclusive rate; never `value`
+            # sixteen DISTINCT 32 MiB chunks (512 MiB of host memory: well past the CPU's last-level cache, so the
+            # source of every copy comes from DRAM as a recorded stream's would)
             m, chunk = 1 << 26, 1 << 22
-            host = np.empty(chunk, np.complex64)
-            host.real = np.random.default_rng(5).standard_normal(chunk).astype(np.float32)
-            host.imag = 0.25
+            rng = np.random.default_rng(5)
+            hosts = []
+            for i in range(m // chunk):
+                h = np.empty(chunk, np.complex64)
+                h.real = rng.standard_normal(chunk, dtype=np.float32)
+                h.imag = 0.25 + i
+                hosts.append(h)
             sp = ctx.welch_plan(NFFT, window=hann, fs=1.0)
-            for _ in range(4):
-                sp.accumulate(host)
+            for h in hosts[:4]:
+                sp.accumulate(h)
             sp.finalize()
             t0 = time.perf_counter()
-            for _ in range(m // chunk):
-                sp.accumulate(host)
+            for h in hosts:
+                sp.accumulate(h)
             sp.finalize()
             dt = time.perf_counter() - t0
+            del hosts
             result['h2d_inclusive'] = {'value': m / dt / 1e6, 'unit': 'Msamples/s', 'GBps': 8.0 * m / dt / 1e9,
-                                       'sample': '2^26 samples from a pageable host buffer in 2^22-sample chunks '
+                                       'sample': '2^26 samples from sixteen distinct pageable host buffers of 2^22 samples '
                                                  'through oth_welch_accumulate (asynchronous: chunks above 1 MiB use the '
                                                  'runtime\'s staged copy from pageable memory, smaller ones a pinned '
                                                  'ring) + oth_welch_finalize'}

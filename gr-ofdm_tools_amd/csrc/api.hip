@@ -119,6 +119,20 @@ constexpr size_t kPinnedStageMax = 1u << 20;
 
 thread_local std::string g_err = "no error";
 
+// A host buffer the runtime can DMA from directly (hipHostMalloc / hipHostRegister'd, e.g. a torch pinned tensor or a
+// registered scheduler buffer): hipMemcpyAsync from it returns before the bytes are read, so the "input valid only
+// during the call" contract of work() needs a copy that has finished when the call returns.  Pageable memory is
+// staged by the runtime before hipMemcpyAsync returns.
+bool host_ptr_is_pinned(const void *p) {
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();      // unregistered pageable memory: an error on older runtimes, not sticky
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
 int fail(oth_ctx *c, int code, const std::string &msg) {
     if (c)
         c->err = msg;
@@ -1035,9 +1049,10 @@ int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
     const size_t total = p->carry + nsamples;
     int rc = ensure_keep(c, &p->d_stream, &p->stream_cap, total * sizeof(float2), p->carry * sizeof(float2));
     if (rc) return rc;
-    if (nsamples * sizeof(float2) > kPinnedStageMax) {
+    if (nsamples * sizeof(float2) > kPinnedStageMax && !host_ptr_is_pinned(iq_host)) {
         // large chunks: the runtime's own staged copy from pageable memory is faster than a host memcpy into a pinned
-        // slot (55 against 33 GB/s at 32 MiB); it returns once the caller's buffer has been read
+        // slot (55 against 33 GB/s at 32 MiB); it returns once the caller's buffer has been read.  (A pinned /
+        // registered source would be read asynchronously: it takes the ring below whatever its size.)
         HIPCHK(c, hipMemcpyAsync(p->d_stream + p->carry, iq_host, nsamples * sizeof(float2), hipMemcpyHostToDevice,
                                  c->stream));
     } else {
@@ -1569,7 +1584,8 @@ int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uin
         HIPCHK(c, hipEventSynchronize(h->ev[slot]));      // only when the GPU is kRing pushes behind
     }
     const size_t bytes = nsamples * sizeof(float2);
-    if (bytes <= kPinnedStageMax && h->h_in_cap[slot] < bytes) {
+    const bool direct = bytes > kPinnedStageMax && !host_ptr_is_pinned(iq_host);      // the runtime stages pageable memory itself
+    if (!direct && h->h_in_cap[slot] < bytes) {
         if (h->h_in[slot]) HIPCHK(c, hipHostFree(h->h_in[slot]));
         h->h_in[slot] = nullptr;
         h->h_in_cap[slot] = 0;
@@ -1582,7 +1598,7 @@ int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uin
     if (nsamples) {
         if ((rc = ensure(c, &h->d_stage, &h->stage_cap, bytes))) return rc;
         if ((rc = ensure(c, &h->d_out, &h->out_cap, sizeof(float) * N))) return rc;
-        if (bytes > kPinnedStageMax) {      // the runtime's staged copy returns once the caller's buffer has been read
+        if (direct) {      // the runtime's staged copy returns once the caller's buffer has been read
             HIPCHK(c, hipMemcpyAsync(h->d_stage, iq_host, bytes, hipMemcpyHostToDevice, c->stream));
         } else {
             memcpy(h->h_in[slot], iq_host, bytes);      // the scheduler's buffer dies when work() returns
@@ -1640,6 +1656,16 @@ int oth_chain_wait(oth_chain *h, uint64_t ticket, float *row_out, uint64_t *nrow
     CtxGuard guard_(h->ctx);
     int ready = 0;
     return chain_collect(h, ticket, row_out, nrows_out, &ready, false);
+}
+
+int oth_chain_ticket_rows(oth_chain *h, uint64_t ticket, uint64_t *nrows_out) {
+    CtxGuard guard_(h ? h->ctx : nullptr);
+    if (!h || !nrows_out) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
+    const int slot = (int)(ticket % oth_chain::kRing);
+    if (!ticket || h->ticket_of[slot] != ticket)
+        return fail(h->ctx, OTH_ERR_STATE, "ticket unknown or overwritten (the ring keeps the last 4 pushes: latest wins)");
+    *nrows_out = h->nrows_of[slot];
+    return OTH_OK;
 }
 
 int oth_chain_get_peak(oth_chain *h, float *peak_out) {
@@ -1759,6 +1785,32 @@ int oth_scan_decide_dev(oth_ctx *c, const float *psd_rows_dev, int nrows, int nf
     if (nch)
         HIPCHK(c, hipMemcpyAsync(power_out, d + o_pw, sizeof(float) * nrows * nch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OTH_OK;
+}
+
+int oth_scan_decide_dev_out(oth_ctx *c, const float *psd_rows_dev, int nrows, int nfft, double srch_bins, float thr_leveler,
+                            int nch, const int *lo, const int *hi, unsigned char *mask_dev, float *noise_dev,
+                            float *power_dev) {
+    CtxGuard guard_(c);
+    if (!c || !psd_rows_dev || !noise_dev || nrows < 1 || nfft < 1 || nch < 0 || !(srch_bins >= 1.0) ||
+        (nch && (!lo || !hi || !power_dev)))
+        return fail(c, OTH_ERR_INVALID, "bad argument (srch_bins must be >= 1)");
+    for (int i = 0; i < nch; ++i)
+        if (lo[i] < 0 || hi[i] > nfft) return fail(c, OTH_ERR_INVALID, "channel slice outside [0, nfft]");
+    if (use_device(c)) return OTH_ERR_HIP;
+    const size_t nb = (size_t)nrows * nfft;
+    const size_t o_ma = 0, o_lo = up16(o_ma + sizeof(double) * nb), o_hi = up16(o_lo + sizeof(int) * (nch + 1)),
+                 bytes = up16(o_hi + sizeof(int) * (nch + 1));
+    int rc = ensure(c, &c->scratch, &c->scratch_cap, bytes);
+    if (rc) return rc;
+    unsigned char *d = c->scratch;
+    if (nch) {      // pageable host words: staged by the runtime before the call returns
+        HIPCHK(c, hipMemcpyAsync(d + o_lo, lo, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d + o_hi, hi, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, launch_scan_decide(psd_rows_dev, nrows, nfft, srch_bins, thr_leveler, nch, (const int *)(d + o_lo),
+                                 (const int *)(d + o_hi), (double *)(d + o_ma), mask_dev, noise_dev, nch ? power_dev : nullptr,
+                                 c->stream));
     return OTH_OK;
 }
 

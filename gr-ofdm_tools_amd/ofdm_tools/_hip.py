@@ -89,6 +89,7 @@ SIGNATURES = {
     'oth_chain_push_async': (C.c_int, [_p, _p, C.c_size_t, _u64p]),
     'oth_chain_poll': (C.c_int, [_p, C.c_uint64, _f, _u64p, C.POINTER(C.c_int)]),
     'oth_chain_wait': (C.c_int, [_p, C.c_uint64, _f, _u64p]),
+    'oth_chain_ticket_rows': (C.c_int, [_p, C.c_uint64, _u64p]),
     'oth_chain_get_peak': (C.c_int, [_p, _f]),
     'oth_chain_get_iir': (C.c_int, [_p, _f]),
     'oth_rows_group_mean': (C.c_int, [_p, _f, C.c_size_t, C.c_int, C.c_int, _f]),
@@ -97,6 +98,8 @@ SIGNATURES = {
     'oth_bin_threshold': (C.c_int, [_p, _f, C.c_int, C.c_int, C.c_double, C.c_float, C.POINTER(C.c_ubyte), _f]),
     'oth_scan_decide_dev': (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_double, C.c_float, C.c_int, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int), C.POINTER(C.c_ubyte), _f, _f]),
+    'oth_scan_decide_dev_out': (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_double, C.c_float, C.c_int, C.POINTER(C.c_int),
+                                          C.POINTER(C.c_int), _p, _p, _p]),
     'oth_xcorr': (C.c_int, [_p, _p, C.c_size_t, _p, C.c_size_t, C.c_int, _f]),
     'oth_fac': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f]),
 }
@@ -299,6 +302,19 @@ class Context(object):
                                                 mask.ctypes.data_as(C.POINTER(C.c_ubyte)) if want_mask else None,
                                                 _fptr(noise), _fptr(power) if nch else None), 'oth_scan_decide_dev')
         return mask, noise, power
+
+    def scan_decide_dev_out(self, rows_dptr, nrows, nfft, srch_bins, thr_leveler, lo, hi, noise_dptr, power_dptr,
+                            mask_dptr=0):
+        """The same stage with device outputs (asynchronous): noise[nrows], power[nrows][len(lo)], optional mask."""
+        lo = np.ascontiguousarray(lo, np.int32)
+        hi = np.ascontiguousarray(hi, np.int32)
+        nch = len(lo)
+        ip = C.POINTER(C.c_int)
+        self.check(self.lib.oth_scan_decide_dev_out(self.h, C.c_void_p(rows_dptr), int(nrows), int(nfft), float(srch_bins),
+                                                    float(thr_leveler), nch, lo.ctypes.data_as(ip) if nch else None,
+                                                    hi.ctypes.data_as(ip) if nch else None,
+                                                    C.c_void_p(mask_dptr) if mask_dptr else None, C.c_void_p(noise_dptr),
+                                                    C.c_void_p(power_dptr) if nch else None), 'oth_scan_decide_dev_out')
 
     def xcorr(self, a, b, length):
         a, b = _c64(a)[:length], _c64(b)[:length]
@@ -547,6 +563,12 @@ class Chain(object):
         self.ctx.check(self.ctx.lib.oth_chain_push_async(self.h, x.ctypes.data_as(_p), len(x), C.byref(t)),
                        'oth_chain_push_async')
         return int(t.value)
+
+    def ticket_rows(self, ticket):
+        """Rows the push behind `ticket` produces (known at enqueue time; never waits)."""
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_chain_ticket_rows(self.h, int(ticket), C.byref(n)), 'oth_chain_ticket_rows')
+        return int(n.value)
 
     def poll(self, ticket):
         """-> None while the GPU is still working, else (row or None, rows produced by that push)."""

@@ -6,8 +6,8 @@ single_pole_iir_filter_ff(average) -> nlog10_ff(10, N, -10 log10 N - 10 log10 Sf
 latest dB row with ``ascii_plotter.make_plot`` (:169-228) and posts the text on ``pkt_out``.  The chain runs
 as one fused HIP launch (oth_chain_*); the rendering is host text work on ``width`` columns.
 
-Python-2 arithmetic of the reference kept on purpose: ``widthDens = len(axis) / int(width)`` and
-``matrix[width / 2]`` are integer divisions.
+Python-2 arithmetic of the reference kept on purpose: the bins per column and the centre column are integer
+divisions.
 """
 import math
 import os
@@ -21,6 +21,16 @@ from .ofdm_cr_tools import _py2div
 
 
 class ascii_plotter(object):
+    """Text rendering of one dB row (behaviour of ascii_plot.py:154-228, pinned byte for byte by
+    tests/golden/ref_ascii_plot.npz, which the reference's own ``make_plot`` produced).
+
+    The row is cut into ``width`` columns of ``bins_per_col = len(axis) // width`` bins (Python-2 integer division in
+    the reference; trailing bins are not drawn).  A column's level is the mean of its bins scaled to
+    ``0 .. height - 1`` over ``floor(max - min)`` dB; the column shows ``|`` below its level, ``^`` at it, the centre
+    column is a line of ``*``.  Every fifth text row carries its dB value, every tenth column its frequency.
+    One deviation: a level above the top row (possible because the scale uses floor(max - min)) is drawn in the top
+    row; the reference indexes past its matrix there and its watcher thread dies with an IndexError."""
+
     def __init__(self, width, height, tune_freq, sample_rate, fft_len):
         self.width = width
         self.height = height
@@ -30,55 +40,47 @@ class ascii_plotter(object):
         self.updateWindow()
 
     def set_axis(self, axis):
-        self.axis = axis
-        self.widthDens = len(self.axis) // int(self.width)
-        self.matrix = [[' ' for x in range(self.height)] for y in range(self.width)]
+        self.axis = np.asarray(axis)
+        self.widthDens = len(self.axis) // int(self.width)      # bins per column
 
     def updateWindow(self):
-        self.set_axis(_py2div(self.sample_rate, 2) * np.linspace(-1, 1, self.fft_len) + self.tune_freq)   # :157,166
+        self.set_axis(_py2div(self.sample_rate, 2) * np.linspace(-1, 1, self.fft_len) + self.tune_freq)
+
+    def column_levels(self, row):
+        """-> (levels[width] as ints, min, floor(max - min)) of a dB row."""
+        d = np.asarray(row, np.float64)
+        lo, hi = float(d.min()), float(d.max())
+        span = math.floor(hi - lo)
+        if span == 0:
+            raise ZeroDivisionError('the row spans less than 1 dB')          # as the reference
+        w, n = int(self.width), self.widthDens
+        # left-to-right sums in double, the order Python's sum() takes (np.sum adds pairwise: last-bit differences
+        # could move a level across a floor boundary)
+        means = np.cumsum(d[:w * n].reshape(w, n), axis=1)[:, -1] / n
+        levels = np.floor((means - lo) * (self.height - 1) / span).astype(int)
+        return np.minimum(levels, self.height - 1), lo, span
 
     def make_plot(self, fft_data):
-        """ascii_plot.py:169-228."""
-        minValue = min(fft_data)
-        maxValue = max(fft_data)
-        toClient = ''
-        auxWidth = 0
-        span = math.floor((maxValue - minValue))
-        for i in range(self.width):
-            htValue = sum(fft_data[auxWidth:auxWidth + self.widthDens]) / self.widthDens
-            htValueNormed = int(math.floor(((htValue - minValue) * (self.height - 1)) / span))
-            for k in range(htValueNormed + 1, self.height):
-                self.matrix[i][k] = ' '
-            self.matrix[i][htValueNormed] = '^'
-            for k in range(htValueNormed):
-                self.matrix[i][k] = '|'
-            auxWidth += self.widthDens
-        for i in reversed(range(self.height)):
-            self.matrix[self.width // 2][i] = '*'
-            if i % 5 == 0:
-                NewValue = (((i - 0) * span) / self.height) + minValue
-                toClient += ('%.3f' % NewValue)[:6] + ' '
-            else:
-                toClient += '------ '
-            for j in range(self.width):
-                toClient += self.matrix[j][i] + ' '
-            toClient += '\n'
-        toClient += '------ '
-        for a in range(self.width):
-            if a % 10 == 0:
-                NewValue = (((a - 0) * (self.axis[-1] - self.axis[0])) / self.width) + self.axis[0]
-                toClient += '| ' + ('%.3f' % NewValue)[:5] + ' ' * (2 * 10 - 5 - 2)
-        toClient += '\n'
-        toClient += 'Tune freq: %s MHz, Sample rate: %s MS/s, FFT: %s W:%d L:%d\n' % (
-            self.tune_freq / 1e6, self.sample_rate / 1e6, self.fft_len, self.width, self.height)
-        for a in range(self.width):
-            toClient += '_ '
-        toClient += '_ _ _ _'
-        return toClient
+        w, h = int(self.width), int(self.height)
+        levels, lo, span = self.column_levels(fft_data)
+        rows = np.arange(h)[:, None]                                           # text row index, 0 = bottom
+        grid = np.where(rows < levels, '|', np.where(rows == levels, '^', ' '))
+        grid[:, w // 2] = '*'
+        out = []
+        for i in range(h - 1, -1, -1):
+            label = ('%.3f' % (i * span / h + lo))[:6] if i % 5 == 0 else '------'
+            out.append(label + ' ' + ' '.join(grid[i]) + ' \n')
+        f0, f1 = self.axis[0], self.axis[-1]
+        ticks = ''.join('| ' + ('%.3f' % (a * (f1 - f0) / w + f0))[:5] + ' ' * 13 for a in range(0, w, 10))
+        out.append('------ ' + ticks + '\n')
+        out.append('Tune freq: %s MHz, Sample rate: %s MS/s, FFT: %s W:%d L:%d\n'
+                   % (self.tune_freq / 1e6, self.sample_rate / 1e6, self.fft_len, w, h))
+        out.append('_ ' * w + '_ _ _ _')
+        return ''.join(out)
 
 
 class ascii_plot(ChainBlockMixin, sync_block):
-    def __init__(self, fft_len, sample_rate, tune_freq, average, rate, width, height, ctx=None, threaded=False,
+    def __init__(self, fft_len, sample_rate, tune_freq, average, rate, width, height, ctx=None, threaded=True,
                  echo=False):
         sync_block.__init__(self, 'ascii plot', [np.complex64], None)
         self.fft_len = fft_len

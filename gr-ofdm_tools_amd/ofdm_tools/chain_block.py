@@ -9,10 +9,12 @@ full the new message is dropped.
 Here ``work()`` (the gr.sync_block contract of python/spectrum_sensor.py:71-75: input valid only during the
 call, must not block) hands the samples to ``oth_chain_push_async`` - pinned copy, H2D + kernels + D2H of the
 latest row enqueued on the context's stream, event recorded - and gets a ticket back.  With
-``threaded=True`` the ticket goes into a lossy depth-2 queue (dropped when the watcher lags, the stream side
-carries on) and the watcher thread waits for the ticket's event outside the context lock, then runs
-``_on_vector(row)``.  With ``threaded=False`` (deterministic hosts and tests) the ticket is collected
-right away on the caller's thread - same code path, no second thread.
+``threaded=True`` - the default of every block, as the reference always runs its watcher threads
+(spectrum_sensor_v2.py:138-155) - the ticket goes into a lossy depth-2 queue (dropped when the watcher lags, the
+stream side carries on) and the watcher thread waits for the ticket's event outside the context lock, then runs
+``_on_vector(row)``: ``work()`` never waits for the GPU.  ``threaded=False`` (deterministic hosts and the
+tests, which pass it explicitly) collects the ticket right away on the caller's thread - same code path, no
+second thread.  ``drain()`` lets a host that stops feeding wait until the watcher has caught up.
 """
 import threading
 
@@ -21,12 +23,15 @@ from .gr_compat import LossyQueue
 
 
 class ChainBlockMixin(object):
-    def _chain_init(self, chain, threaded=False):
+    def _chain_init(self, chain, threaded=True):
         self._chain = chain
         self.msgq0 = LossyQueue(2)
         self._threaded = bool(threaded)
         self.keep_running = True
         self.vectors_lost = 0            # tickets the ring had already recycled when the watcher got to them
+        self._queued = self._done = 0    # tickets handed to / finished by the watcher thread (drain())
+        self.rows_total = 0              # PSD vectors the chain has produced so far (all work() calls)
+        self.vector_rows_end = self.vector_nrows = 0
         self._watch_thread = None
         if self._threaded:
             self._watch_thread = threading.Thread(target=self._watch, daemon=True)
@@ -37,13 +42,18 @@ class ChainBlockMixin(object):
         in0 = input_items[0]
         ticket = self._chain.push_async(in0)          # returns after enqueue; the GPU works behind it
         self.last_ticket = ticket
+        nrows = self._chain.ticket_rows(ticket)       # known at enqueue time: the stream's vector count goes on even
+        self.rows_total += nrows                      # when the watcher drops this ticket
+        item = (ticket, self.rows_total, nrows)
         if self._threaded:
-            self.msgq0.insert_tail(ticket)            # dont_block: dropped when two are already waiting
+            if self.msgq0.insert_tail(item):          # dont_block: dropped when two are already waiting
+                self._queued += 1
         else:
-            self._collect(ticket)
+            self._collect(item)
         return len(in0)
 
-    def _collect(self, ticket):
+    def _collect(self, item):
+        ticket, self.vector_rows_end, self.vector_nrows = item      # the vector handed to _on_vector is row rows_end - 1
         try:
             row, n = self._chain.wait(ticket)
         except _hip.HipError as e:
@@ -56,9 +66,23 @@ class ChainBlockMixin(object):
 
     def _watch(self):
         while self.keep_running:
-            ticket = self.msgq0.delete_head(timeout=0.05)
-            if ticket is not None:
-                self._collect(ticket)
+            item = self.msgq0.delete_head(timeout=0.05)
+            if item is not None:
+                try:
+                    self._collect(item)
+                finally:
+                    self._done += 1
+
+    def drain(self, timeout=5.0):
+        """Wait until the watcher thread has consumed what work() queued (hosts that stop feeding and want the last
+        vector's effects; never called from work()).  -> True when idle."""
+        import time
+        end = time.monotonic() + timeout
+        while self._threaded and time.monotonic() < end:
+            if self._done >= self._queued:
+                return True
+            time.sleep(0.001)
+        return not self._threaded or self._done >= self._queued
 
     def stop(self):
         self.keep_running = False

@@ -5,16 +5,17 @@ powers through ``src_power`` on the device, then the reference's edge logic
 import numpy as np
 
 from . import _hip
+from .chain_block import ChainBlockMixin
 from .gr_compat import sync_block
 from .ofdm_cr_tools import _py2div
 from .scanner import ChannelScanner
 from .sensing_log import logger
 
 
-class flanck_detector(sync_block):
+class flanck_detector(ChainBlockMixin, sync_block):
     def __init__(self, fft_len, sens_per_sec, sample_rate, channel_space=1, search_bw=1, thr_leveler=10,
                  tune_freq=0, alpha_avg=1, test_duration=1, period=3600, trunc_band=1, verbose=False,
-                 peak_alpha=0, subject_channels=[], ctx=None, log_directory=None):
+                 peak_alpha=0, subject_channels=[], ctx=None, log_directory=None, threaded=True):
         sync_block.__init__(self, 'flank detector', [np.complex64], None)
         self.fft_len = fft_len
         self.sens_per_sec = sens_per_sec
@@ -30,7 +31,7 @@ class flanck_detector(sync_block):
         self.verbose = verbose
         self.ctx = ctx or _hip.default_context()
         self.decimation = max(1, int(_py2div(_py2div(sample_rate, fft_len), sens_per_sec)))      # :238-239
-        self._chain = self.ctx.chain(fft_len, None, True, _hip.EPI_MAG2_OVER_N2, self.decimation)
+        chain = self.ctx.chain(fft_len, None, True, _hip.EPI_MAG2_OVER_N2, self.decimation)
         self._logger = logger(fft_len, period, test_duration, directory=log_directory)
         self._scanner = ChannelScanner(fft_len, sample_rate, channel_space, search_bw, tune_freq, trunc_band,
                                        thr_leveler, alpha_avg, self.ctx)
@@ -43,17 +44,15 @@ class flanck_detector(sync_block):
         self.flag = [True] * n                                  # starts in pseudo-detection (:300)
         self.peak_alpha = np.array([0.0] * n)
         self.events = []
+        self._chain_init(chain, threaded)      # work() / watcher plumbing: chain_block.ChainBlockMixin
 
-    def work(self, input_items, output_items):
-        in0 = input_items[0]
-        rows, n = self._chain.push(in0, max_rows=1)
-        if n:
-            self.flank_detector(rows[-1])
-            lg = self._logger
-            lg.settings['n_measurements'] = lg.settings.get('n_measurements', 0) + 1
-            lg.n_measurements_period += 1
-            lg.settings['noise_estimate'] = self.noise_estimate
-        return len(in0)
+    def _on_vector(self, row):
+        """_queue0_watcher.run body (flanck_detector.py:320-343): the latest vector of a message."""
+        self.flank_detector(row)
+        lg = self._logger
+        lg.settings['n_measurements'] = lg.settings.get('n_measurements', 0) + 1
+        lg.n_measurements_period += 1
+        lg.settings['noise_estimate'] = self.noise_estimate
 
     def flank_detector(self, samples):
         """flanck_detector.py:345-399."""

@@ -12,7 +12,7 @@ from .ofdm_cr_tools import _py2div
 
 
 class local_worker(ChainBlockMixin, sync_block):
-    def __init__(self, fft_len, sample_rate, average, rate, max_tu, data_precision, ctx=None, threaded=False):
+    def __init__(self, fft_len, sample_rate, average, rate, max_tu, data_precision, ctx=None, threaded=True):
         sync_block.__init__(self, 'local_worker', [np.complex64], None)
         self.fft_len = fft_len
         self.sample_rate = sample_rate

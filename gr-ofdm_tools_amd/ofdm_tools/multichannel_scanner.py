@@ -13,7 +13,7 @@ from .scanner import ChannelScanner, top4
 
 class multichannel_scanner(ChainBlockMixin, sync_block):
     def __init__(self, fft_len, sens_per_sec, sample_rate, channel_space=1, search_bw=1, tune_freq=0,
-                 trunc_band=1, verbose=False, output=False, subject_channels=[], ctx=None, threaded=False):
+                 trunc_band=1, verbose=False, output=False, subject_channels=[], ctx=None, threaded=True):
         sync_block.__init__(self, 'multichannel_scanner', [np.complex64], None)
         self.fft_len = fft_len
         self.sens_per_sec = sens_per_sec

@@ -14,7 +14,7 @@ from .ofdm_cr_tools import _py2div
 
 
 class psd_logger(ChainBlockMixin, sync_block):
-    def __init__(self, fft_len, rate, sample_rate, ctx=None, mat_file=None, threaded=False):
+    def __init__(self, fft_len, rate, sample_rate, ctx=None, mat_file=None, threaded=True):
         sync_block.__init__(self, 'psd_logger', [np.complex64], None)
         self.fft_len = fft_len
         self.rate = rate

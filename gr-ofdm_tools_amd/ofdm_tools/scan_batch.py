@@ -66,12 +66,20 @@ class BatchScanPlan(object):
         width = self.fft_len + 1 + nchan
         local = torch.zeros((spr, width), dtype=torch.float32, device=device)
         if mine:
+            # rows, noise floors and channel powers stay on the device from the averaging kernel to the all-gather
             rows = torch.empty((len(mine), self.fft_len), dtype=torch.float32, device=device)
+            noise = torch.empty(len(mine), dtype=torch.float32, device=device)
+            power = torch.empty((len(mine), max(nchan, 1)), dtype=torch.float32, device=device)
+            lo, hi = self._slices()
+            sweep.torch_then_ctx(self.ctx, device)
             self.psd_rows_dev(iq_dptr, nsamples, len(mine), stream_stride, rows.data_ptr())
-            _, noise, power = self.decide_dev(rows.data_ptr(), len(mine), want_mask=False)
+            self.ctx.scan_decide_dev_out(rows.data_ptr(), len(mine), self.fft_len, self.scanner.srch_bins,
+                                         self.thr_leveler, lo, hi, noise.data_ptr(), power.data_ptr())
+            sweep.ctx_then_torch(self.ctx)
             local[:len(mine), :self.fft_len] = rows
-            local[:len(mine), self.fft_len] = torch.from_numpy(noise).to(device)
-            local[:len(mine), self.fft_len + 1:] = torch.from_numpy(power).to(device)
+            local[:len(mine), self.fft_len] = noise
+            if nchan:
+                local[:len(mine), self.fft_len + 1:] = power
         allr = sweep.gather_rows(local, nch_total, rank, world, group)
         return allr[:, :self.fft_len], allr[:, self.fft_len], allr[:, self.fft_len + 1:]
 

@@ -17,7 +17,7 @@ class spectrum_sensor_v1(spectrum_sensor_v2):
 
     def __init__(self, fft_len, sens_per_sec, sample_rate, channel_space=1, search_bw=1, thr_leveler=10,
                  tune_freq=0, alpha_avg=1, test_duration=1, period=3600, trunc_band=1, verbose=False,
-                 psd=False, waterfall=False, subject_channels=[], ctx=None, threaded=False, log_directory=None):
+                 psd=False, waterfall=False, subject_channels=[], ctx=None, threaded=True, log_directory=None):
         spectrum_sensor_v2.__init__(self, fft_len, sens_per_sec, sample_rate, channel_space, search_bw,
                                     thr_leveler, tune_freq, alpha_avg, test_duration, period, trunc_band, verbose,
                                     stats=True, psd=psd, waterfall=waterfall, output=False,

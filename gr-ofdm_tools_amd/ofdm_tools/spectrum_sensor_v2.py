@@ -28,7 +28,7 @@ class spectrum_sensor_v2(ChainBlockMixin, sync_block):
     def __init__(self, fft_len, sens_per_sec, sample_rate, channel_space=1, search_bw=1, thr_leveler=10,
                  tune_freq=0, alpha_avg=1, test_duration=1, period=3600, trunc_band=1, verbose=False,
                  stats=False, psd=False, waterfall=False, output=False, subject_channels=[],
-                 ctx=None, threaded=False, log_directory=None, strobe_period_ms=1000):
+                 ctx=None, threaded=True, log_directory=None, strobe_period_ms=1000):
         sync_block.__init__(self, self._block_name, [np.complex64], None)
         self.fft_len = fft_len
         self.sens_per_sec = sens_per_sec
@@ -65,7 +65,7 @@ class spectrum_sensor_v2(ChainBlockMixin, sync_block):
                                        thr_leveler, alpha_avg, self.ctx)
         self._idx_subject = self._scanner.subject_index(self.subject_channels) if output else []
         self.subject_channels_pwr = np.array([1.0] * len(self.subject_channels))
-        self._waterfall_count = 0
+        self._waterfall_group = 0
         self._lock = threading.Lock()
         self._chain_init(chain, threaded)      # work() / watcher plumbing: chain_block.ChainBlockMixin
 
@@ -98,11 +98,16 @@ class spectrum_sensor_v2(ChainBlockMixin, sync_block):
                                       else np.maximum(float_data, lg.cumulative_psd))
                 lg.set_periodic_psd_peaks(float_data.copy() if lg.periodic_psd_peaks is None
                                           else np.maximum(float_data, lg.periodic_psd_peaks))
-            if self.waterfall:                                                 # keep 1 in sens_per_sec, :102
-                self._waterfall_count += 1
-                if self._waterfall_count >= max(1, int(self.sens_per_sec)):
-                    self._waterfall_count = 0
+            if self.waterfall:
+                # keep_one_in_n(sens_per_sec) on the PSD vector stream (:102,121-122) -> waterfall_watcher.run
+                # (:304-322): one row per group of sens_per_sec vectors, counted over ALL vectors the chain produced
+                # (the ones a lagging watcher dropped included).  The kept vector is the group's last; when that is
+                # not the last vector of its work() call, the call's last vector (at most nrows - 1 later) stands in.
+                group = self.vector_rows_end // max(1, int(self.sens_per_sec))
+                if group > self._waterfall_group:
+                    self._waterfall_group = group
                     self._logger.cumulative_waterfall.append(float_data.copy())
+                    self._logger.set_cumulative_waterfall(self._logger.cumulative_waterfall)
             if self.output:
                 self.publish()
 

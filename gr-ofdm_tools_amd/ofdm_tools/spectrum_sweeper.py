@@ -168,11 +168,13 @@ class spectrum_sweeper(sync_block):
         def compute(iq, out_row):
             if not torch.is_tensor(iq):
                 iq = torch.from_numpy(np.ascontiguousarray(iq, np.complex64).view(np.float32)).to(device)
-                torch.cuda.current_stream(device).synchronize()      # the copy ran on torch's stream
             nsamples = iq.numel() // 2 if iq.dtype == torch.float32 else iq.numel()
+            # a context on its own stream: torch's copy / the caller's producer kernels / the zero fill of the row
+            # buffer must have landed before the plan reads and writes them, and the plan must be done before the
+            # all-gather (torch's stream) reads the row
+            sweep.torch_then_ctx(self.ctx, device)
             self._plan.exec_dev(iq.data_ptr(), nsamples, out_row.data_ptr())
-            if not self.ctx.on_torch_stream():
-                self.ctx.sync()      # the all-gather runs on torch's stream, the plan on the context's own
+            sweep.ctx_then_torch(self.ctx)
 
         wide = sweep.sweep_psd(lambda i: capture(i, self.tune_frequencies[i]), compute,
                                len(self.tune_frequencies), nbins, device, rank, world, group)

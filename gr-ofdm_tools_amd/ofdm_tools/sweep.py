@@ -71,27 +71,36 @@ def time_shard(nsamples, nperseg, step, rank, world):
     return s0 * step, (s1 - s0 - 1) * step + nperseg, s0, s1 - s0
 
 
-def reduce_partials(local_sums, nseg_local, rank=None, world=None, group=None):
+def reduce_partials(local_sums, nseg_local, rank=None, world=None, group=None, nseg_total=None):
     """local_sums: 1-D float32 tensor of raw sums (zeros when this rank has no segment).  Returns
-    (sums float32 tensor, nseg_total) - the same bits on every rank (fixed summation order)."""
+    (sums float32 tensor, nseg_total) - the same bits on every rank (fixed summation order).
+    When the caller knows the total segment count (time_shard() makes it a function of the stream length alone)
+    it passes nseg_total: nothing but the sums travels and nothing comes back to the host.  Otherwise the counts
+    ride along in two floats each and are read on the host AFTER the sums have been formed on the device."""
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        return local_sums, int(nseg_local)
+        return local_sums, int(nseg_local if nseg_total is None else nseg_total)
     n = local_sums.numel()
-    packed = torch.empty(n + 2, dtype=torch.float32, device=local_sums.device)
-    packed[:n] = local_sums
-    packed[n] = float(int(nseg_local) >> 16)          # the count travels exactly in two floats
-    packed[n + 1] = float(int(nseg_local) & 0xFFFF)
-    out = torch.empty(world * (n + 2), dtype=torch.float32, device=local_sums.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
-    out = out.view(world, n + 2)
+    extra = 0 if nseg_total is not None else 2
+    packed = local_sums
+    if extra:
+        packed = torch.empty(n + 2, dtype=torch.float32, device=local_sums.device)
+        packed[:n] = local_sums
+        packed[n] = float(int(nseg_local) >> 16)          # the count travels exactly in two floats
+        packed[n + 1] = float(int(nseg_local) & 0xFFFF)
+    out = torch.empty(world * (n + extra), dtype=torch.float32, device=local_sums.device)
+    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
+    out = out.view(world, n + extra)
     total = torch.zeros(n, dtype=torch.float64, device=local_sums.device)
     for r in range(world):                            # rank order: deterministic, identical everywhere
         total += out[r, :n].to(torch.float64)
+    sums = total.to(torch.float32)                    # enqueued before any host read below
+    if nseg_total is not None:
+        return sums, int(nseg_total)
     counts = out[:, n:].to(torch.float64).cpu()
     nseg = int(sum(int(counts[r, 0]) * 65536 + int(counts[r, 1]) for r in range(world)))
-    return total.to(torch.float32), nseg
+    return sums, nseg
 
 
 def welch_time_sharded(partial, scale, nsamples, nperseg, step, nsums, device, rank, world, group=None):
@@ -99,10 +108,11 @@ def welch_time_sharded(partial, scale, nsamples, nperseg, step, nsums, device, r
     [first_sample, first_sample + n) to raw sums in the float32 tensor `out` (nsums floats) and returns
     its segment count; scale(sums, nseg_total) turns the summed partials into the result."""
     first, n, _, nseg_local = time_shard(nsamples, nperseg, step, rank, world)
+    nseg_total = (nsamples - (nperseg - step)) // step if nsamples >= nperseg else 0      # every rank can count them
     local = torch.zeros(nsums, dtype=torch.float32, device=device)
     got = partial(first, n, local) if nseg_local else 0
     assert got == nseg_local, (got, nseg_local)
-    sums, nseg = reduce_partials(local, nseg_local, rank, world, group)
+    sums, nseg = reduce_partials(local, nseg_local, rank, world, group, nseg_total=nseg_total)
     return scale(sums, nseg), nseg
 
 
@@ -113,22 +123,40 @@ def gather_rows(local_rows, nrows_total, rank=None, world=None, group=None):
 
 
 # ---- the same two paths on HIP plans (device pointers; ofdm_tools._hip.WelchPlan) ---------------------------
+# Stream ordering.  The library launches on its context's stream, torch (fills, casts, collectives) on torch's current
+# stream.  A context created on torch's stream (Context(dev, stream=...), what bench.py does) needs nothing.  With a
+# context on its own stream every hand-over is synchronised in BOTH directions: before a library call that reads or
+# writes memory torch has produced (torch.zeros, the summed partials, a caller's tensor) torch's stream is drained,
+# and after it the context's stream is, before torch touches the result.
+
+def torch_then_ctx(ctx, device):
+    """Call before a library call whose operands torch's current stream may still be writing."""
+    if not ctx.on_torch_stream() and torch.device(device).type == 'cuda':
+        torch.cuda.current_stream(device).synchronize()
+
+
+def ctx_then_torch(ctx):
+    """Call after a library call whose results torch's current stream will read."""
+    if not ctx.on_torch_stream():
+        ctx.sync()
+
 
 def welch_long_stream(plan, local_dptr, local_first_sample, nsamples_total, device, rank, world, group=None):
     """Welch PSD of one stream of nsamples_total samples spread over the ranks in time order.  This rank's HBM
     buffer at local_dptr starts at stream sample local_first_sample and must cover its run + halo
     (time_shard()).  -> (psd float32 tensor [plan.out_len] on `device`, nseg_total), identical on every rank."""
     def partial(first, n, out):
+        torch_then_ctx(plan.ctx, device)     # torch.zeros(out) has landed
         nseg = plan.partial_dev(local_dptr + 8 * (first - local_first_sample), n, out.data_ptr())
-        if not plan.ctx.on_torch_stream():
-            plan.ctx.sync()                  # the collective runs on torch's stream
+        ctx_then_torch(plan.ctx)             # the collective runs on torch's stream
         return nseg
 
     def scale(sums, nseg):
         out = torch.empty(plan.out_len, dtype=torch.float32, device=device)
-        plan.scale_dev(sums.contiguous().data_ptr(), nseg, out.data_ptr())
-        if not plan.ctx.on_torch_stream():
-            plan.ctx.sync()
+        sums = sums.contiguous()
+        torch_then_ctx(plan.ctx, device)     # the rank-order sum and its cast have landed
+        plan.scale_dev(sums.data_ptr(), nseg, out.data_ptr())
+        ctx_then_torch(plan.ctx)
         return out
     return welch_time_sharded(partial, scale, nsamples_total, plan.nperseg, plan.step, plan.nfft, device, rank, world,
                               group)
@@ -139,19 +167,19 @@ def csd_long_stream(plan, x_dptr, y_dptr, local_first_sample, nsamples_total, de
     sum |Y|^2, sum conj(X) Y = 4 * nfft floats per rank).  -> ((pxx, pyy, pxy [out_len][2], cxy), nseg_total)."""
     def partial(first, n, out):
         off = 8 * (first - local_first_sample)
+        torch_then_ctx(plan.ctx, device)
         nseg = plan.csd_partial_dev(x_dptr + off, y_dptr + off, n, out.data_ptr())
-        if not plan.ctx.on_torch_stream():
-            plan.ctx.sync()
+        ctx_then_torch(plan.ctx)
         return nseg
 
     def scale(sums, nseg):
         m = plan.out_len
         pxx, pyy, cxy = (torch.empty(m, dtype=torch.float32, device=device) for _ in range(3))
         pxy = torch.empty((m, 2), dtype=torch.float32, device=device)
-        plan.csd_scale_dev(sums.contiguous().data_ptr(), nseg, pxx.data_ptr(), pyy.data_ptr(), pxy.data_ptr(),
-                           cxy.data_ptr())
-        if not plan.ctx.on_torch_stream():
-            plan.ctx.sync()
+        sums = sums.contiguous()
+        torch_then_ctx(plan.ctx, device)
+        plan.csd_scale_dev(sums.data_ptr(), nseg, pxx.data_ptr(), pyy.data_ptr(), pxy.data_ptr(), cxy.data_ptr())
+        ctx_then_torch(plan.ctx)
         return pxx, pyy, pxy, cxy
     return welch_time_sharded(partial, scale, nsamples_total, plan.nperseg, plan.step, 4 * plan.nfft, device, rank,
                               world, group)

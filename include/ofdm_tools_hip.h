@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OTH_ABI_VERSION 2
+#define OTH_ABI_VERSION 3
 
 #define OTH_OK               0
 #define OTH_ERR_INVALID     -1   /* bad argument */
@@ -224,6 +224,9 @@ int oth_chain_push_dev(oth_chain *chain, const void *iq_dev, size_t nsamples, fl
 int oth_chain_push_async(oth_chain *chain, const void *iq_host, size_t nsamples, uint64_t *ticket_out);
 int oth_chain_poll(oth_chain *chain, uint64_t ticket, float *row_out, uint64_t *nrows_out, int *ready);
 int oth_chain_wait(oth_chain *chain, uint64_t ticket, float *row_out, uint64_t *nrows_out);
+/* rows the push behind `ticket` produces (known when it is enqueued; never waits): lets a consumer that counts
+ * vectors - the waterfall's keep_one_in_n(sens_per_sec), spectrum_sensor_v2.py:102 - count the ones it drops too */
+int oth_chain_ticket_rows(oth_chain *chain, uint64_t ticket, uint64_t *nrows_out);
 int oth_chain_get_peak(oth_chain *chain, float *peak_out);    /* float[nfft] */
 int oth_chain_get_iir(oth_chain *chain, float *lin_out);      /* float[nfft], linear IIR state */
 /* mean of each `group` consecutive rows (BASELINE config 1 "8-seg avg") */
@@ -252,6 +255,13 @@ int oth_bin_threshold(oth_ctx *ctx, const float *psd_host, int nrows, int nfft, 
 int oth_scan_decide_dev(oth_ctx *ctx, const float *psd_rows_dev, int nrows, int nfft, double srch_bins,
                         float thr_leveler, int nch, const int *lo, const int *hi, unsigned char *mask_out,
                         float *noise_out, float *power_out);
+/* the same stage with DEVICE outputs (asynchronous on the context's stream, no host copy of anything but the
+ * channel slice bounds): mask_dev [nrows][nfft] bytes (nullable), noise_dev [nrows], power_dev [nrows][nch]
+ * (nullable when nch == 0).  The sharded scanner (multichannel_scanner over ranks) feeds these
+ * straight into its all-gather. */
+int oth_scan_decide_dev_out(oth_ctx *ctx, const float *psd_rows_dev, int nrows, int nfft, double srch_bins,
+                            float thr_leveler, int nch, const int *lo, const int *hi, unsigned char *mask_dev,
+                            float *noise_dev, float *power_dev);
 
 /* ---- xcorr (ofdm_cr_tools.py:155-161) ------------------------------------
  * |fftshift(ifft(fft(b,L) * conj(fft(a,L))))[L/2:]|, L a power of two <= 16384;

@@ -181,6 +181,33 @@ def reference_fixtures():
          plc_seq=np.array(sent), subject_pwr=od.subject_channels_pwr, top4=np.array(freqs[0]))
 
 
+    # f4 - ascii_plotter.make_plot (ascii_plot.py:169-228), the reference's own method body on a stand-in object.
+    # It was written for Python 2: ``self.matrix[self.width/2]`` needs an integer quotient.  The method text is NOT
+    # touched; the stand-in's ``width`` is an int whose ``/`` by an int floors, which is what Python 2 did (its only
+    # other ``/ self.width`` has a float on the left).  ``height`` stays a plain int: every ``/ self.height`` has a
+    # float numerator in Python 2 (math.floor returned a float), i.e. true division then as now.  The row goes in as
+    # Python floats: the NumPy of the reference's day summed float32 scalars in double through Python's sum().
+    class Py2Int(int):
+        def __truediv__(self, other):
+            return Py2Int(int(self) // other) if isinstance(other, int) else int(self) / other
+
+    make_plot = E.load_method('ascii_plot.py', 'ascii_plotter', 'make_plot')
+    rng = np.random.default_rng(3)
+    out = {}
+    cases = ((64, 20, 2048, 2000000, 100.0e6), (50, 15, 1024, 1000000, 433.0e6), (33, 12, 256, 250000, 2.4e9),
+             (80, 25, 4096, 2000000, 0.0))
+    for i, (W, H, N, Sf, tf) in enumerate(cases):
+        row = (rng.standard_normal(N) * 6 - 80 + 20 * np.exp(-((np.arange(N) - N * 0.7) / 15.0) ** 2)).astype(np.float32)
+        axis = Sf // 2 * np.linspace(-1, 1, N) + tf                                          # :157 (even-int Sf)
+        me = NS(width=Py2Int(W), height=H, tune_freq=tf, sample_rate=Sf, fft_len=N, axis=axis,
+                widthDens=len(axis) // W, matrix=[[' ' for x in range(H)] for y in range(W)])
+        text = make_plot(me, [float(v) for v in row])
+        out['row_%d' % i] = row
+        out['text_%d' % i] = np.frombuffer(text.encode('ascii'), np.uint8)
+        out['case_%d' % i] = np.array([W, H, N, Sf, tf], np.float64)
+    save('ref_ascii_plot.npz', source=np.array('reference'), n=len(cases), **out)
+
+
 def T_db(v):
     return np.asarray(v, np.float64)
 

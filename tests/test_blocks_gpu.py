@@ -31,7 +31,7 @@ def test_spectrum_sensor_v2_state_sequence(ctx, golden, tmp_path):
     subj = list(g['subject_channels'])
     blk = ofdm_tools.spectrum_sensor_v2(1024, 1000, 1000000, channel_space=25e3, search_bw=12.5e3, thr_leveler=4,
                                         tune_freq=100000000, alpha_avg=0.5, trunc_band=800000, stats=True, psd=True,
-                                        output='o', subject_channels=subj, ctx=ctx, log_directory=str(tmp_path))
+                                        output='o', subject_channels=subj, ctx=ctx, threaded=False, log_directory=str(tmp_path))
     assert blk.decimation == 1 and np.allclose(blk.ax_ch, g['ax_ch'])
     msgs = []
     for i in range(4):
@@ -57,7 +57,7 @@ def test_spectrum_sensor_v1_is_the_stats_path(ctx, golden, tmp_path):
     import ofdm_tools
     g = golden('scanner_state_seq.npz')
     blk = ofdm_tools.spectrum_sensor_v1(1024, 1000, 1000000, channel_space=25e3, search_bw=12.5e3, thr_leveler=4,
-                                        tune_freq=100000000, alpha_avg=0.5, trunc_band=800000, psd=True, ctx=ctx,
+                                        tune_freq=100000000, alpha_avg=0.5, trunc_band=800000, psd=True, ctx=ctx, threaded=False,
                                         log_directory=str(tmp_path))
     blk.feed(g['x'], max_items=1024)
     assert np.isclose(blk.noise_estimate, g['noise_seq'][-1], rtol=1e-4)
@@ -75,7 +75,7 @@ def test_spectrum_sensor_v2_decimation_and_scheduler_chunks(ctx):
     import ofdm_tools
     fft_len, Sf = 256, 256 * 100
     blk = ofdm_tools.spectrum_sensor_v2(fft_len, 20, Sf, channel_space=1600, search_bw=800, trunc_band=Sf - 3200,
-                                        stats=True, ctx=ctx)
+                                        stats=True, ctx=ctx, threaded=False)
     assert blk.decimation == 5                             # int(25600/256/20), keep_one_in_n(5)
     x = R.synth_iq(fft_len * 40 + 13, 17)
     assert blk.feed(x, max_items=1000) == len(x)           # ragged scheduler chunks
@@ -95,7 +95,7 @@ def test_multichannel_scanner_top4(ctx):
     st = R.ScannerState(fft_len, Sf, 15625.0, 10e3, tune_freq=0, trunc_band=Sf)     # trunc = 0: all 64 channels
     subj = [st.ax_ch[i] for i in (5, 12, 20, 33, 40, 51)]
     blk = ofdm_tools.multichannel_scanner(fft_len, 1000, Sf, channel_space=15625.0, search_bw=10e3, tune_freq=0,
-                                          trunc_band=Sf, subject_channels=subj, ctx=ctx)
+                                          trunc_band=Sf, subject_channels=subj, ctx=ctx, threaded=False)
     x = R.synth_iq(fft_len * 3, 3000)
     dec = blk.decimation
     assert dec == 1
@@ -112,7 +112,7 @@ def test_psd_logger_peak_file(ctx, golden, tmp_path):
     import ofdm_tools
     g = golden('gr_chain_bh_mag_peak_4096.npz')
     path = str(tmp_path / 'psd_log.npy')
-    blk = ofdm_tools.psd_logger(4096, 1000, 4096 * 1000, ctx=ctx, mat_file=path)
+    blk = ofdm_tools.psd_logger(4096, 1000, 4096 * 1000, ctx=ctx, threaded=False, mat_file=path)
     assert blk.decimation == 1
     blk.feed(g['x'], max_items=4096)
     assert relerr(blk.peak_vals, g['expected_peak'][-1]) < RTOL
@@ -124,7 +124,7 @@ def test_local_worker_pdus(ctx, golden):
     from ofdm_tools import packets
     g = golden('gr_chain_bh_iir_log_2048.npz')
     N, Sf, alpha = 2048, int(g['sample_rate']), float(g['average'])
-    blk = ofdm_tools.local_worker(N, Sf, alpha, Sf / N, 1472, True, ctx=ctx)   # rate = one PSD per vector
+    blk = ofdm_tools.local_worker(N, Sf, alpha, Sf / N, 1472, True, ctx=ctx, threaded=False)   # rate = one PSD per vector
     frames = []
     blk.msg_connect('pdus', lambda m: frames.append(m[1]))
     x = g['x']
@@ -326,7 +326,7 @@ def test_flanck_detector_edges(ctx, tmp_path):
     gate = ((t // N >= 8) & (t // N < 18)).astype(np.float64)        # on for vectors 8..17
     x = (x + 3.0 * gate * np.exp(2j * np.pi * f_on * t)).astype(np.complex64)
     kw = dict(channel_space=cs, search_bw=16e3, thr_leveler=4, alpha_avg=0.2, trunc_band=Sf, peak_alpha=0.5)
-    blk = ofdm_tools.flanck_detector(N, Sf / N, Sf, subject_channels=subj, ctx=ctx, log_directory=str(tmp_path), **kw)
+    blk = ofdm_tools.flanck_detector(N, Sf / N, Sf, subject_channels=subj, ctx=ctx, threaded=False, log_directory=str(tmp_path), **kw)
     ref = R.FlankState(N, Sf, cs, 16e3, subj, trunc_band=Sf, thr_leveler=4, alpha_avg=0.2, peak_alpha=0.5)
     rows = R.chain_sensor_v2(x, N)
     want = []
@@ -414,7 +414,7 @@ def test_threaded_watcher_drops_when_stalled_and_never_back_pressures(ctx, golde
     kw = dict(channel_space=25e3, search_bw=12.5e3, thr_leveler=4, tune_freq=100000000, alpha_avg=0.5,
               trunc_band=800000, stats=True, ctx=ctx)
     x = g['x']
-    inline = ofdm_tools.spectrum_sensor_v2(1024, 1000, 1000000, **kw)
+    inline = ofdm_tools.spectrum_sensor_v2(1024, 1000, 1000000, threaded=False, **kw)
     inline.work([x[:1024]], [])
     blk = ofdm_tools.spectrum_sensor_v2(1024, 1000, 1000000, threaded=True, **kw)
     gate = threading.Event()
@@ -454,7 +454,7 @@ def test_strobes_reemit_and_file_logger_thread(ctx, golden, tmp_path):
     subj = list(g['subject_channels'])
     blk = ofdm_tools.spectrum_sensor_v2(1024, 1000, 1000000, channel_space=25e3, search_bw=12.5e3, thr_leveler=4,
                                         tune_freq=100000000, alpha_avg=0.5, trunc_band=800000, stats=True, psd=True,
-                                        output='o', subject_channels=subj, ctx=ctx, log_directory=str(tmp_path),
+                                        output='o', subject_channels=subj, ctx=ctx, threaded=False, log_directory=str(tmp_path),
                                         period=0.05, test_duration=0.2, strobe_period_ms=20)
     msgs = []
     blk.msg_connect('freq_out_0', msgs.append)
@@ -468,6 +468,102 @@ def test_strobes_reemit_and_file_logger_thread(ctx, golden, tmp_path):
     import glob
     assert glob.glob(str(tmp_path / 'sdr_psd_cumulative_log-*.matz')) and \
         len(glob.glob(str(tmp_path / 'sdr_ss_periodic_log-*.log'))) >= 1
+
+
+def test_waterfall_block_end_to_end(ctx, tmp_path):
+    """waterfall=True (spectrum_sensor_v2.py:98-107,121-122,304-322): the PSD vector stream goes through
+    keep_one_in_n(sens_per_sec) into the waterfall watcher, which appends the vector to the logger's
+    cumulative_waterfall; file_logger appends the rows as '%1.2e' CSV (ofdm_cr_tools.py:2039-2046).  Rows must be the
+    LAST vector of every group of sens_per_sec PSD vectors, whatever the work() chunking."""
+    import glob
+    import ofdm_tools
+    N, S = 256, 5
+    x = R.synth_iq(N * 23 + 40, 71)
+    ref = R.chain_sensor_v2(x, N)                      # decimation 1: every vector is a PSD row
+    want = ref[S - 1::S][:len(ref) // S]
+    for chunk in (N, 3 * N + 17):                      # one vector per work() call; calls that straddle vectors
+        blk = ofdm_tools.spectrum_sensor_v2(N, S, N * S, waterfall=True, ctx=ctx, threaded=False,
+                                            log_directory=str(tmp_path / ('c%d' % chunk)))
+        assert blk.decimation == 1
+        blk.feed(x, max_items=chunk)
+        rows = np.array(blk._logger.cumulative_waterfall)
+        if chunk == N:                                 # exact: the group's last vector is the call's last vector
+            from test_hip_parity import check_single_rows
+            assert rows.shape == want.shape
+            check_single_rows(rows, want)
+        else:                                          # one row per completed group, each a PSD row at or after the group's last
+            assert len(rows) == len(want)
+            for i, r in enumerate(rows):
+                j = next(j for j in range((i + 1) * S - 1, len(ref)) if relerr(r, ref[j]) < 1e-3)
+                assert j - ((i + 1) * S - 1) < 4
+        out = blk._logger.flush()
+        txt = open(out['waterfall']).read().strip().split('\n')
+        assert len(txt) == len(rows) and txt[0].split(',')[0] == '%1.2e' % rows[0][0]
+        assert len(txt[0].split(',')) == N
+        assert blk._logger.cumulative_waterfall == []          # a new period starts empty, the file keeps appending
+        assert glob.glob(str(tmp_path / ('c%d' % chunk) / 'sdr_waterfall_cumulative_log-*.matz'))
+
+
+def test_default_work_never_waits_for_the_gpu(ctx):
+    """Every chain block runs its watcher thread by default, as the reference does (spectrum_sensor_v2.py:138-155):
+    work() enqueues and returns; the vector's effects appear once the watcher has collected the ticket."""
+    import inspect
+    import time
+    import ofdm_tools
+    from ofdm_tools import chain_block
+    for cls in (ofdm_tools.spectrum_sensor_v2, ofdm_tools.spectrum_sensor_v1, ofdm_tools.psd_logger,
+                ofdm_tools.local_worker, ofdm_tools.multichannel_scanner, ofdm_tools.flanck_detector,
+                ofdm_tools.ascii_plot):
+        assert inspect.signature(cls.__init__).parameters['threaded'].default is True, cls
+    seen = []
+    blk = ofdm_tools.spectrum_sensor_v2(4096, 1000, 4096 * 1000, channel_space=25e3, search_bw=12.5e3, ctx=ctx)
+    assert blk._threaded and blk._watch_thread.is_alive()
+    inner = blk._on_vector
+    blk._on_vector = lambda row: (seen.append(row.copy()), inner(row))
+    x = R.synth_iq(4096 * 64, 5)
+    done = ctx.chain(4096, None, True, 2, 1)           # an unrelated long launch queued first on the same stream
+    d = ctx.alloc(8 << 26)
+    try:
+        ctx.synth_iq(d, 1 << 26, 3, R.TONES, R.DC)
+        done.push_dev(d, 1 << 26)
+        t0 = time.perf_counter()
+        assert blk.work([x], []) == len(x)
+        dt = time.perf_counter() - t0
+        assert blk.drain(10.0)
+    finally:
+        ctx.free(d)
+    blk.stop()
+    assert len(seen) == 1 and relerr(seen[0], R.chain_sensor_v2(x, 4096)[-1]) < 1e-3
+    assert dt < 0.05, dt                               # (the enqueue; the GPU work behind it is not waited for)
+    assert chain_block.ChainBlockMixin._chain_init.__defaults__ == (True,)
+
+
+def test_pinned_source_buffers_are_copied_before_the_call_returns(ctx):
+    """A caller's buffer is only valid during work() (python/spectrum_sensor.py:71-75).  Pageable memory is staged by
+    the runtime before hipMemcpyAsync returns; a PINNED / registered buffer (a torch pinned tensor, a registered
+    scheduler buffer) would be read asynchronously - the library must have copied it when the call returns.  Scribble
+    over the buffer right after push_async / accumulate and compare with the untouched run."""
+    import torch
+    n = 1 << 18                                        # 2 MiB: above the pinned-ring threshold of the large-copy path
+    x = R.synth_iq(n, 91)
+    pinned = torch.empty(n * 2, dtype=torch.float32).pin_memory()
+    view = pinned.numpy().view(np.complex64)
+    for _ in range(3):
+        view[:] = x
+        ch = ctx.chain(1024, None, True, 2, 1)
+        t = ch.push_async(view)
+        view[:] = 0                                    # the scheduler reuses its buffer
+        row, k = ch.wait(t)
+        assert k == n // 1024 and relerr(row, R.chain_sensor_v2(x[-1024:], 1024)[0]) < 1e-3
+        ch.close()
+        view[:] = x
+        plan = ctx.welch_plan(1024, window=None)
+        plan.accumulate(view)
+        view[:] = 0
+        psd = plan.finalize()
+        want = ctx.welch_plan(1024, window=None).exec(x)
+        assert relerr(psd, want) < 1e-5
+        plan.close()
 
 
 # ---- multi-GPU host paths on one GPU (world 1 and ranks simulated one after another) -------------------------
@@ -537,7 +633,7 @@ def test_ascii_plot_block(ctx):
     row rendered by make_plot and posted on pkt_out; against the oracle's chain + renderer."""
     import ofdm_tools
     N, Sf = 1024, 1024 * 30
-    blk = ofdm_tools.ascii_plot(N, Sf, 433.0e6, 0.3, 10, 64, 20, ctx=ctx)
+    blk = ofdm_tools.ascii_plot(N, Sf, 433.0e6, 0.3, 10, 64, 20, ctx=ctx, threaded=False)
     assert blk._decimation() == 3
     msgs = []
     blk.msg_connect('pkt_out', msgs.append)

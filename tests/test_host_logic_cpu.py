@@ -326,6 +326,22 @@ def test_time_shard_covers_every_segment_once():
         assert seen == list(range(nseg))
 
 
+def test_ascii_plotter_matches_the_reference_byte_for_byte(golden):
+    """tests/golden/ref_ascii_plot.npz holds the text the reference's OWN ascii_plotter.make_plot
+    (ascii_plot.py:169-228) produced for four rows (make_golden.py --reference runs its unmodified method body under
+    Python-2 integer division): the product renderer and the oracle's restatement must both reproduce every byte."""
+    from ofdm_tools.ascii_plot import ascii_plotter
+    g = golden('ref_ascii_plot.npz')
+    assert str(g['source']) == 'reference'
+    for i in range(int(g['n'])):
+        W, H, N, Sf = (int(v) for v in g['case_%d' % i][:4])
+        tf = float(g['case_%d' % i][4])
+        want = g['text_%d' % i].tobytes().decode('ascii')
+        row = g['row_%d' % i]
+        assert ascii_plotter(W, H, tf, Sf, N).make_plot(row) == want, i
+        assert R.ascii_make_plot(row, W, H, tf, Sf, N) == want, i
+
+
 def test_ascii_plotter_layout_and_oracle():
     """ascii_plot.py:154-228: the text plot of a dB row (host work; the block's chain is a GPU test)."""
     from ofdm_tools.ascii_plot import ascii_plotter
@@ -343,4 +359,9 @@ def test_ascii_plotter_layout_and_oracle():
     assert peak_row == min(i for i, ln in enumerate(top) for c in ln if c == '^')
     assert all(ln[W // 2] == '*' for ln in top)                  # centre marker
     assert lines[H + 1].startswith('Tune freq: 100.0 MHz, Sample rate: 2.0 MS/s, FFT: 1024 W:64 L:20')
-    assert pl.make_plot(row) == txt                              # the reused matrix gives the same picture again
+    assert pl.make_plot(row) == txt                              # a second call gives the same picture again
+    # a level above the top text row (the scale divides by floor(max - min)) is clipped, not an IndexError
+    tall = np.full(N, -80.0, np.float32)
+    tall[:N // W] = -69.05                                       # column 0 at 10.95 dB over floor(10.95) = 10
+    lv, lo, span = ascii_plotter(W, H, 0.0, 2000000, N).column_levels(tall)
+    assert span == 10 and lv[0] == H - 1 and lv[1] == 0
