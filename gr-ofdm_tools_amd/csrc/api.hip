@@ -96,6 +96,7 @@ struct oth_chain {
     float *d_tail = nullptr;           // group rows of the two-launch cross-team reduction
     size_t tail_cap = 0;
     bool peak_flag_set = false;        // d_peak_init is 1 on the stream's timeline
+    bool rect = false;                 // the window is all ones (fft_vcc's `()`): the 8192 / 16384 chain skips the multiply
     int kernel = OTH_KERNEL_AUTO;      // OTH_KERNEL_GENERIC forces the coverage kernels (parity tests)
     float *d_out = nullptr;            // rows handed back by the host-output forms
     size_t out_cap = 0;
@@ -411,14 +412,16 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     const bool tuned_16k = !csd && (p->nfft == 16384 || p->nfft == 8192) && p->nperseg == p->nfft &&
                            p->kernel != OTH_KERNEL_GENERIC;
     // segfft.hip: nperseg = nfft = 256 / 512 / 1024 / 2048, any step (team of nfft / 16 threads per segment)
-    const bool tuned_seg = !csd && (p->nfft == 256 || p->nfft == 512 || p->nfft == 1024 || p->nfft == 2048) && p->nperseg == p->nfft &&
-                           p->kernel != OTH_KERNEL_GENERIC;
-    const int seg_kind = p->step == p->nfft / 2 ? 0 : 1;
+    // ... and zero-padded segments nperseg = nfft / 4 (the sweeper's call, spectrum_sweeper.py:263) or nfft / 2 at 1024 / 2048
+    const bool seg_pad = !csd && seg_padded_supported(p->nfft, p->nperseg) && p->kernel != OTH_KERNEL_GENERIC;
+    const bool tuned_seg = (!csd && (p->nfft == 256 || p->nfft == 512 || p->nfft == 1024 || p->nfft == 2048) && p->nperseg == p->nfft &&
+                            p->kernel != OTH_KERNEL_GENERIC) || seg_pad;
+    const int seg_kind = p->step * 2 == p->nperseg ? 0 : 1;
     const bool seg_wps4 = p->tune_variant == "seg4";
     // role-split build (segws_kernel): 50 % overlap; detrend in the time domain at 1024 (one producer wave), in the
     // frequency domain at 2048 (needs the window-spectrum table); "seg3" / "seg4" force the one-role builds
     const int seg_det = p->detrend == OTH_DETREND_NONE ? 0 : (p->nfft == 1024 ? 1 : 2);
-    const bool seg_ws = tuned_seg && p->nfft >= 1024 && seg_kind == 0 && p->tune_variant != "seg3" && !seg_wps4 &&
+    const bool seg_ws = tuned_seg && !seg_pad && p->nfft >= 1024 && seg_kind == 0 && p->tune_variant != "seg3" && !seg_wps4 &&
                         (seg_det != 2 || p->d_fd != nullptr);
     if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
     if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd && !tuned_16k && !tuned_seg)
@@ -433,7 +436,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         // exactly the resident workgroups: one wave of workgroups, no tail round
         const int bpc = tuned ? var->blocks_per_cu()
                               : (tuned_csd ? (csd_ws ? csd4096ws_blocks_per_cu() : csd4096_blocks_per_cu())
-                                           : (tuned_seg ? (seg_ws ? segws_teams_per_cu(p->nfft) : seg_teams_per_cu(p->nfft, seg_kind, seg_wps4))
+                                           : (tuned_seg ? (seg_pad ? seg_padded_teams_per_cu(p->nfft, p->nperseg, seg_kind)
+                                                                   : (seg_ws ? segws_teams_per_cu(p->nfft) : seg_teams_per_cu(p->nfft, seg_kind, seg_wps4)))
                                                         : (p->nfft == 8192 ? 2 : 1)));      // welch16k: 139 / 70 KiB of LDS
         long long w = ((long long)c->cu_count * bpc + nstreams - 1) / nstreams;
         W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
@@ -478,7 +482,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         const bool seg_static = tuned_seg && !seg_ws && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC;
         const long long per_team = nseg / (W > 0 ? W : 1);
         int static_chunk = 0;
-        if (seg_static && seg_kind == 0 && p->nfft <= 512) {
+        if (seg_static && seg_kind == 0 && (p->nfft <= 512 || seg_pad)) {      // (zero-padded: nfft / 8 new samples per segment)
             static_chunk = per_team >= 64 ? 32 : (per_team >= 32 ? 16 : 0);
             a.sched = static_chunk ? OTH_SCHED_INTERLEAVED : OTH_SCHED_CONTIGUOUS;
         }
@@ -534,7 +538,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         g.queue = a.queue;
         g.fd = p->d_fd;
         Timed tm(c);
-        HIPCHK(c, seg_ws ? launch_segws(p->nfft, g, seg_det, c->stream) : launch_seg(p->nfft, g, seg_kind, seg_wps4, c->stream));
+        HIPCHK(c, seg_pad ? launch_seg_padded(p->nfft, p->nperseg, g, seg_kind, c->stream)
+                          : (seg_ws ? launch_segws(p->nfft, g, seg_det, c->stream) : launch_seg(p->nfft, g, seg_kind, seg_wps4, c->stream)));
     } else {
         Timed tm(c);
         HIPCHK(c, tuned ? var->launch(a, c->stream)
@@ -1248,7 +1253,11 @@ int oth_chain_create(oth_ctx *c, int nfft, const float *window, int fftshift, in
         return rc;
     }
     std::vector<float> w(nfft);
-    for (int i = 0; i < nfft; ++i) w[i] = window ? window[i] : 1.0f;
+    h->rect = true;
+    for (int i = 0; i < nfft; ++i) {
+        w[i] = window ? window[i] : 1.0f;
+        if (w[i] != 1.0f) h->rect = false;
+    }
     hipError_t e = hipMalloc(&h->d_win, sizeof(float) * nfft);
     if (e == hipSuccess) e = hipMalloc(&h->d_iir, sizeof(float) * nfft);
     if (e == hipSuccess) e = hipMalloc(&h->d_peak, sizeof(float) * nfft);
@@ -1343,7 +1352,8 @@ int oth_chain_reset(oth_chain *h) {
 constexpr long long kTailRows = 256;
 
 static bool chain_fused_ok(const oth_chain *h, long long give) {
-    if (h->kernel == OTH_KERNEL_GENERIC || !seg_supported(h->nfft)) return false;
+    const bool big = h->nfft == 8192 || h->nfft == 16384;      // welch16k.hip's chain build
+    if (h->kernel == OTH_KERNEL_GENERIC || !(seg_supported(h->nfft) || big)) return false;
     if (h->do_iir && h->do_peak) return false;
     if (h->do_iir && !(h->alpha > 0.f && h->alpha <= 1.f)) return false;
     return give <= kTailRows;
@@ -1391,7 +1401,8 @@ static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec
         a.store_from = 0;
         a.rows = rows_last;
     }
-    const int tpc = seg_teams_per_cu(N, 2, false);
+    const bool big = N >= 8192;      // one workgroup per segment: 2 (8192) / 1 (16384) per CU
+    const int tpc = big ? (N == 8192 ? 2 : 1) : seg_teams_per_cu(N, 2, false);
     // segments per chunk of the interleaved schedule: 8 once every team gets two chunks (+2-4 % over 4), fewer for
     // short pushes so that more teams take part
     const long long teams_max = (long long)c->cu_count * tpc;
@@ -1414,7 +1425,7 @@ static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec
     }
     {
         Timed tm(c);      // the whole push: transform kernel + cross-team reduction + state / rows
-        HIPCHK(c, launch_seg(N, a, 2, false, c->stream));
+        HIPCHK(c, big ? launch_chain16k(N, a, h->rect, c->stream) : launch_seg(N, a, 2, false, c->stream));
         if (a.acc_mode != 3)
             HIPCHK(c, launch_chain_tail(h->d_partial, groups ? h->d_tail : nullptr, (int)W, N, h->fftshift, a.acc_mode, a.acc_end,
                                         h->alpha, h->kdb, h->d_iir, h->d_peak, h->d_rows, h->do_iir ? give : 0, rows_last,

@@ -132,12 +132,18 @@ hipError_t launch_csd_tuned4096ws(const WelchArgs &a, hipStream_t s);
 int csd4096ws_blocks_per_cu();
 // welch16k.hip: nfft = nperseg = 16384 (one 1024-thread workgroup per CU) or 8192 (two 512-thread workgroups)
 hipError_t launch_welch_tuned16k(int nfft, const WelchArgs &a, hipStream_t s);
+// the fused periodogram chain at 8192 / 16384 points (one workgroup per segment; workgroups per CU: 2 / 1)
+hipError_t launch_chain16k(int nfft, const SegArgs &a, bool rect, hipStream_t s);
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
 // segfft.hip
 bool seg_supported(int nfft);
 // kind: 0 Welch with step = nfft / 2 (the overlapped half stays in registers), 1 Welch with any step, 2 chain
 int seg_teams_per_cu(int nfft, int kind, bool wps4);
 hipError_t launch_seg(int nfft, const SegArgs &a, int kind, bool wps4, hipStream_t s);
+// zero-padded segments (nperseg = nfft / 4 or nfft / 2 at nfft = 1024 / 2048: the sweeper's call at those sizes)
+bool seg_padded_supported(int nfft, int nperseg);
+int seg_padded_teams_per_cu(int nfft, int nperseg, int kind);
+hipError_t launch_seg_padded(int nfft, int nperseg, const SegArgs &a, int kind, hipStream_t s);
 int segws_teams_per_cu(int nfft);
 hipError_t launch_segws(int nfft, const SegArgs &a, int det, hipStream_t s);
 // partial rows of a chain launch + the stored raw rows -> IIR / peak state and the rows handed back; `scratch` holds

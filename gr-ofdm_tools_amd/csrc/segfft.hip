@@ -157,8 +157,14 @@ template <int T> __device__ __forceinline__ float team_total(float v) {
 }
 
 // WPS = waves per SIMD the register allocation is held to (4 -> 128 VGPRs, 3 -> 168)
-template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS>
+// NA: rows of the 16 x T sample matrix that hold samples, nperseg = NA T = NA N / 16; the rest of the segment is the
+// zero padding of scipy.signal.welch(nperseg < nfft) - the sweeper's call is nperseg = nfft / 4 for whatever fft_len
+// the flowgraph passes (spectrum_sweeper.py:263): NA = 4.  Rows a >= NA are compile-time zeros, so loads, window
+// products and the first butterfly layer of pass 1 shrink with NA; LOAD_HALF keeps NA / 2 rows (step = nperseg / 2).
+template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS, int NA = 16>
 __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
+    static_assert(NA == 16 || (!CHAIN && R >= 4 && (NA == 4 || NA == 8)), "zero-padded builds: Welch at 1024 / 2048 points");
+    constexpr int NHALF = NA / 2;
     using G = Geo<R>;
     constexpr int T = G::T, N = G::N, Q = G::Q, LR = G::LR, P = G::P, KP = G::KP, KM = G::KM, TPB = G::TPB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
     float win[16];
     if (!WIN_LDS) {
 #pragma unroll
-        for (int a = 0; a < 16; ++a) win[a] = p.win[T * a + t];
+        for (int a = 0; a < NA; ++a) win[a] = p.win[T * a + t];
     }
     // W_N^(k t) for pass 1 and W_N^(16 k c) for pass 2, k = 1, 2, 3, 4, 8, 12 (table index mod N)
     const Pow6 tw1 = {p.tw[t], p.tw[(2 * t) & (N - 1)], p.tw[(3 * t) & (N - 1)], p.tw[(4 * t) & (N - 1)],
@@ -237,8 +243,8 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.f;
 
-    constexpr int NH = (LOAD == LOAD_HALF) ? 8 : 16;
-    float2 kw[LOAD == LOAD_HALF ? 8 : 1], nxt[NH];
+    constexpr int NH = (LOAD == LOAD_HALF) ? NHALF : NA;
+    float2 kw[LOAD == LOAD_HALF ? NHALF : 1], nxt[NH];
     float2 prev_tot = make_float2(0.f, 0.f);
 
     const int sched = p.sched;
@@ -260,12 +266,12 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
             const float2 *xs = xb + sb * p.step + t;
             if (LOAD == LOAD_HALF) {
 #pragma unroll
-                for (int a = 0; a < 8; ++a) kw[a] = xs[T * a];
+                for (int a = 0; a < NHALF; ++a) kw[a] = xs[T * a];
 #pragma unroll
-                for (int a = 0; a < 8; ++a) nxt[a] = xs[8 * T + T * a];
+                for (int a = 0; a < NHALF; ++a) nxt[a] = xs[NHALF * T + T * a];
             } else {
 #pragma unroll
-                for (int a = 0; a < 16; ++a) nxt[a] = load_once(xs + T * a);
+                for (int a = 0; a < NA; ++a) nxt[a] = load_once(xs + T * a);
             }
         }
         primed = sb_next >= 0;
@@ -288,28 +294,28 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
             if (LOAD == LOAD_HALF) {
                 if (s == sb) {
 #pragma unroll
-                    for (int a = 0; a < 8; ++a) {      // kw holds the raw first half of the chunk's first segment
+                    for (int a = 0; a < NHALF; ++a) {      // kw holds the raw first half of the chunk's first segment
                         sumf = cadd(sumf, kw[a]);
                         kw[a] = make_float2(kw[a].x * win[a], kw[a].y * win[a]);
                     }
                 }
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
+                for (int a = 0; a < NHALF; ++a) {
                     const float2 r = nxt[a];
                     v[a] = kw[a];
-                    v[8 + a] = make_float2(r.x * win[8 + a], r.y * win[8 + a]);
+                    v[NHALF + a] = make_float2(r.x * win[NHALF + a], r.y * win[NHALF + a]);
                     kw[a] = make_float2(r.x * win[a], r.y * win[a]);
                     sum = cadd(sum, r);
                 }
                 {   // unconditional: a prefetch under `if (s + 1 < se)` makes nxt a phi and costs 32 register copies per
                     // segment; the chunk's last segment re-reads the half it has just consumed (valid, L2-resident)
-                    const float2 *xn = xb + (s + (s + 1 < se ? 2 : 1)) * (long long)(N / 2) + t;
+                    const float2 *xn = xb + (s + (s + 1 < se ? 2 : 1)) * (long long)(NHALF * T) + t;
 #pragma unroll
-                    for (int a = 0; a < 8; ++a) nxt[a] = load_once(xn + T * a);
+                    for (int a = 0; a < NHALF; ++a) nxt[a] = load_once(xn + T * a);
                 }
             } else {
 #pragma unroll
-                for (int a = 0; a < 16; ++a) {
+                for (int a = 0; a < NA; ++a) {
                     const float2 r = nxt[a];
                     v[a] = make_float2(r.x * win[a], r.y * win[a]);
                     sum = cadd(sum, r);
@@ -317,9 +323,11 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                 {   // unconditional (see above): the chunk's last segment fetches the next chunk's first one, or itself
                     const float2 *xn = xb + (s + 1 < se ? s + 1 : (sb_next >= 0 ? sb_next : s)) * p.step + t;
 #pragma unroll
-                    for (int a = 0; a < 16; ++a) nxt[a] = load_once(xn + T * a);
+                    for (int a = 0; a < NA; ++a) nxt[a] = load_once(xn + T * a);
                 }
             }
+#pragma unroll
+            for (int a = NA; a < 16; ++a) v[a] = make_float2(0.f, 0.f);      // the zero padding
             float2 tot = make_float2(0.f, 0.f);
             if (DETREND) {
                 sum.x = team_total<T>(sum.x);
@@ -360,9 +368,9 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                 } else {
                     tot = sum;
                 }
-                const float2 nm = make_float2(tot.x * (-1.0f / N), tot.y * (-1.0f / N));
+                const float2 nm = make_float2(tot.x * (-1.0f / (NA * T)), tot.y * (-1.0f / (NA * T)));      // mean over nperseg
 #pragma unroll
-                for (int a = 0; a < 16; ++a) v[a] = make_float2(fmaf(nm.x, win[a], v[a].x), fmaf(nm.y, win[a], v[a].y));
+                for (int a = 0; a < NA; ++a) v[a] = make_float2(fmaf(nm.x, win[a], v[a].x), fmaf(nm.y, win[a], v[a].y));
             }
             // ---- pass 1 -----------------------------------------------------------------------------------
             auto pow6_from = [](const float4 *tb, int stride) {
@@ -851,20 +859,31 @@ template <int R, bool CHAIN> constexpr size_t seg_lds_bytes() {
            ((CHAIN && OTH_CHAIN_WIN_LDS) ? (4 * Geo<R>::T + (R <= 2 ? 3 * Geo<R>::T : 0) + (R == 16 ? 3 * R : 0)) * sizeof(float4) : 0);
 }
 
-template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS> hipError_t launch_one(const SegArgs &a, hipStream_t s) {
+template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS, int NA = 16> hipError_t launch_one(const SegArgs &a, hipStream_t s) {
     const dim3 grid((a.wg_per_stream + Geo<R>::TPB - 1) / Geo<R>::TPB, a.nstreams);
     constexpr size_t lds = seg_lds_bytes<R, CHAIN>();
-    hipLaunchKernelGGL((seg_kernel<R, LOAD, DETREND, CHAIN, WPS>), grid, dim3(Geo<R>::BLOCK), lds, s, a);
+    hipLaunchKernelGGL((seg_kernel<R, LOAD, DETREND, CHAIN, WPS, NA>), grid, dim3(Geo<R>::BLOCK), lds, s, a);
     return hipGetLastError();
 }
 
-template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS> int occupancy_one() {
+template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS, int NA = 16> int occupancy_one() {
     int n = 0;
     constexpr size_t lds = seg_lds_bytes<R, CHAIN>();
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_kernel<R, LOAD, DETREND, CHAIN, WPS>, Geo<R>::BLOCK, lds) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_kernel<R, LOAD, DETREND, CHAIN, WPS, NA>, Geo<R>::BLOCK, lds) != hipSuccess ||
         n < 1)
         n = 1;
     return n * Geo<R>::TPB;
+}
+
+// zero-padded Welch builds (nperseg = nfft / 4 or nfft / 2): kind 0 step = nperseg / 2, kind 1 any step
+template <int R, int NA> hipError_t launch_pad(const SegArgs &a, int kind, hipStream_t s) {
+    constexpr int WPS = NA == 4 ? 4 : 3;      // (nperseg = nfft / 2 spills a few registers at 128)
+    if (kind == 0) return a.detrend ? launch_one<R, LOAD_HALF, true, false, WPS, NA>(a, s) : launch_one<R, LOAD_HALF, false, false, WPS, NA>(a, s);
+    return a.detrend ? launch_one<R, LOAD_FULL, true, false, WPS, NA>(a, s) : launch_one<R, LOAD_FULL, false, false, WPS, NA>(a, s);
+}
+template <int R, int NA> int occupancy_pad(int kind) {
+    constexpr int WPS = NA == 4 ? 4 : 3;
+    return kind == 0 ? occupancy_one<R, LOAD_HALF, true, false, WPS, NA>() : occupancy_one<R, LOAD_FULL, true, false, WPS, NA>();
 }
 
 // kind: 0 Welch step = N/2 (half kept in registers), 1 Welch any step, 2 chain.  wps4: the 128-VGPR build of kind 0.
@@ -918,6 +937,24 @@ hipError_t launch_segws(int nfft, const SegArgs &a, int det, hipStream_t s) {
     if (nfft == 1024) return det == 0 ? launch_ws_one<4, 0>(a, s) : (det == 1 ? launch_ws_one<4, 1>(a, s) : launch_ws_one<4, 2>(a, s));
     if (nfft == 2048) return det == 0 ? launch_ws_one<8, 0>(a, s) : (det == 2 ? launch_ws_one<8, 2>(a, s) : hipErrorInvalidValue);
     return hipErrorInvalidValue;
+}
+
+bool seg_padded_supported(int nfft, int nperseg) {
+    return (nfft == 1024 || nfft == 2048) && (nperseg * 4 == nfft || nperseg * 2 == nfft);
+}
+
+int seg_padded_teams_per_cu(int nfft, int nperseg, int kind) {
+    static int cache[2][2][2] = {};
+    int &c = cache[nfft == 1024 ? 0 : 1][nperseg * 4 == nfft ? 0 : 1][kind ? 1 : 0];
+    if (c) return c;
+    if (nfft == 1024) return c = nperseg * 4 == nfft ? occupancy_pad<4, 4>(kind) : occupancy_pad<4, 8>(kind);
+    return c = nperseg * 4 == nfft ? occupancy_pad<8, 4>(kind) : occupancy_pad<8, 8>(kind);
+}
+
+hipError_t launch_seg_padded(int nfft, int nperseg, const SegArgs &a, int kind, hipStream_t s) {
+    if (!seg_padded_supported(nfft, nperseg)) return hipErrorInvalidValue;
+    if (nfft == 1024) return nperseg * 4 == nfft ? launch_pad<4, 4>(a, kind, s) : launch_pad<4, 8>(a, kind, s);
+    return nperseg * 4 == nfft ? launch_pad<8, 4>(a, kind, s) : launch_pad<8, 8>(a, kind, s);
 }
 
 hipError_t launch_seg(int nfft, const SegArgs &a, int kind, bool wps4, hipStream_t s) {

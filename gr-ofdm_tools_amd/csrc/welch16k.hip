@@ -64,6 +64,43 @@ template <int J, int F> __device__ __forceinline__ void pass0_scatter(float2 (&v
     }
 }
 
+// Transform of one segment whose windowed points sit in v[F j + a'] (n = 4096 a' + T j + tid): pass 0 (radix F, scatter to
+// the F sub-FFT images), then the 4096-point scheme of welch4096.hip on this thread's sub-FFT k'.  On return
+// v[r16(k2)] = X[k' + F (k0 + 16 k1 + 256 k2)] with (k0, k1) = (hi, lo) of t = tid & 255.  The caller has passed
+// barrier A0 (the previous segment's exchange reads are done everywhere).
+template <int F>
+__device__ __forceinline__ void transform16k(float2 (&v)[16], const float2 (&wt)[4], float2 b1, float2 b4, float2 c1, float2 c4,
+                                             float2 *l0, float2 *lx, int t, int w1, int r1, int w2, int r2) {
+    prio_latency();
+    pass0_scatter<0, F>(v, wt, l0);
+    pass0_scatter<1, F>(v, wt, l0);
+    pass0_scatter<2, F>(v, wt, l0);
+    pass0_scatter<3, F>(v, wt, l0);
+    if constexpr (F == 2) {
+        pass0_scatter<4, F>(v, wt, l0);
+        pass0_scatter<5, F>(v, wt, l0);
+        pass0_scatter<6, F>(v, wt, l0);
+        pass0_scatter<7, F>(v, wt, l0);
+    }
+    lds_barrier();   // B0
+#pragma unroll
+    for (int a = 0; a < 16; ++a) v[a] = lx[256 * a + t];
+    lds_barrier();   // A: every thread holds its 16 points, the image may be overwritten
+    prio_compute();
+
+    // 4096-point transform of sub-FFT k' (welch4096.hip passes 1..3)
+    dft16(v);
+    prio_latency();
+    scatter_pow16<RS>(v, lx + w1, b1, b4);
+    lds_barrier();   // B
+    dft16_from_lds<17>(v, lx + r1, [] { prio_compute(); });      // ordered reads, counted waits
+    prio_latency();
+    wave_lds_sync();
+    scatter_pow16<17>(v, lx + w2, c1, c4);
+    wave_lds_sync();
+    dft16_from_lds<1>(v, lx + r2, [] { prio_compute(); });
+}
+
 // HALF: step = N / 2 - the second half of a segment is the first half of the next one at the same (j, tid), so it
 // is kept (raw) in registers and every sample is read once; otherwise segments are loaded whole (any step).
 template <bool DETREND, int F, bool HALF>
@@ -183,34 +220,7 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
             }
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
-            prio_latency();
-            pass0_scatter<0, F>(v, wt, l0);
-            pass0_scatter<1, F>(v, wt, l0);
-            pass0_scatter<2, F>(v, wt, l0);
-            pass0_scatter<3, F>(v, wt, l0);
-            if constexpr (F == 2) {
-                pass0_scatter<4, F>(v, wt, l0);
-                pass0_scatter<5, F>(v, wt, l0);
-                pass0_scatter<6, F>(v, wt, l0);
-                pass0_scatter<7, F>(v, wt, l0);
-            }
-            lds_barrier();   // B0
-#pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = lx[256 * a + t];
-            lds_barrier();   // A: every thread holds its 16 points, the image may be overwritten
-            prio_compute();
-
-            // 4096-point transform of sub-FFT k' (welch4096.hip passes 1..3)
-            dft16(v);
-            prio_latency();
-            scatter_pow16<RS>(v, lx + w1, b1, b4);
-            lds_barrier();   // B
-            dft16_from_lds<17>(v, lx + r1, [] { prio_compute(); });      // ordered reads, counted waits
-            prio_latency();
-            wave_lds_sync();
-            scatter_pow16<17>(v, lx + w2, c1, c4);
-            wave_lds_sync();
-            dft16_from_lds<1>(v, lx + r2, [] { prio_compute(); });
+            transform16k<F>(v, wt, b1, b4, c1, c4, l0, lx, t, w1, r1, w2, r2);
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 const float2 X = v[r16(k2)];
@@ -227,7 +237,164 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
     for (int k2 = 0; k2 < 16; ++k2) dst[256 * k2 + t] = acc[k2];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// chain16k: the fused periodogram chain (segfft.hip's CHAIN build) at 8192 / 16384 points - multichannel_scanner /
+// spectrum_sensor_v2 as a streaming block at BASELINE config 5's size (python/multichannel_scanner.py:78-86 takes any
+// fft_len).  Kept vectors are segments with step = keep_n N; window, shift, |X| or |X|^2 [x 1/N^2], IIR weighted sum /
+// peak max accumulated per workgroup (closed by chain_reduce / chain_state, kernels_misc.hip), rows stored only for
+// s >= store_from.  The next segment is prefetched while this one is transformed (one workgroup per CU at 16384
+// points: without it all sixteen waves wait for their loads at the same barrier).
+// WINDOW = false: rectangular (the v2 / scanner chain passes `()` as its window, spectrum_sensor_v2.py:90) - no window
+// registers, which is what lets the prefetch fit under 128 VGPRs at 16384 points.  PREFETCH = false: the windowed
+// 16384-point build (psd_logger / local_worker at that size) loads at the top of the step instead.
+enum { C16_WSUM = 1, C16_MAX = 2 };
+template <int F> constexpr size_t chain16k_lds_bytes() { return lds16_bytes<F>() + (256 + 16) * sizeof(float4); }
+template <int F, bool WINDOW, bool PREFETCH>
+__global__ __launch_bounds__(256 * F, 4) void chain16k_kernel(SegArgs p) {
+    constexpr int T16 = 256 * F, N = 4096 * F, NJ = 16 / F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    const int kp = tid >> 8, t = tid & 255;
+    const int hi = t >> 4, lo = t & 15;
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const float2 *xb = p.x + (size_t)stream * p.stream_stride + p.first + tid;
+
+    float win[WINDOW ? 16 : 1];
+    if (WINDOW) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int a = 0; a < F; ++a) win[F * j + a] = p.win[4096 * a + T16 * j + tid];
+    }
+    float2 wt[4] = {};
+#pragma unroll
+    for (int k = 1; k < F; ++k) wt[k] = p.tw[k * tid];
+    // the twiddle seeds of the 4096-point passes live in a small LDS table, read per segment: eight registers less,
+    // which is what keeps the prefetching build out of scratch memory
+    float4 *tb = reinterpret_cast<float4 *>(lds + F * REGION + LDS16_RED);      // [256]: W^(F t), W^(4 F t); [16]: W256^c, W256^(4c)
+    if (tid < 256) {
+        const float2 u = p.tw[F * tid], w = p.tw[4 * F * tid];
+        tb[tid] = make_float4(u.x, u.y, w.x, w.y);
+    }
+    if (tid < 16) {
+        const float2 u = p.tw[16 * F * tid], w = p.tw[64 * F * tid];
+        tb[256 + tid] = make_float4(u.x, u.y, w.x, w.y);
+    }
+    __syncthreads();
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    float2 *l0 = lds + tid, *lx = lds + kp * REGION;
+    const int w1 = hi * 17 + lo, r1 = hi * RS + lo, w2 = hi * RS + lo, r2 = hi * RS + lo * 17;
+    const int kbase = kp + F * (hi + 16 * lo);      // bin of v[r16(k2)]: kbase + 256 F k2
+
+    const int sched = p.sched;
+    const long long nchunks = sched ? chunk_count_of(p.nseg, p.nbig, p.chunk, p.tail_chunk) : 1;
+    const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
+    auto load_segment = [&](float2(&d)[16], long long s) {
+        const float2 *xs = xb + s * p.step;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int a = 0; a < F; ++a) d[F * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
+    };
+    float2 nxt[PREFETCH ? 16 : 1];
+    bool primed = false;
+    for (long long cur = sched ? wg : 0; cur < nchunks;) {
+        long long sb = s0, se = s1;
+        if (sched) chunk_range_of(p.nseg, p.nbig, p.chunk, p.tail_chunk, cur, sb, se);
+        long long sb_next = -1;
+        if (PREFETCH && sched && cur + W < nchunks) {
+            long long se_next;
+            chunk_range_of(p.nseg, p.nbig, p.chunk, p.tail_chunk, cur + W, sb_next, se_next);
+        }
+        if constexpr (PREFETCH) {
+            if (sb < se && !primed) load_segment(nxt, sb);
+        }
+        primed = sb_next >= 0;
+        for (long long s = sb; s < se; ++s) {
+            float2 v[16];
+            prio_latency();
+            if constexpr (PREFETCH) {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) v[a] = nxt[a];
+                // unconditional prefetch (a conditional one turns nxt into a phi: 32 copies per segment): the chunk's
+                // last segment fetches the next chunk's first one, or itself again (valid, L2-resident)
+                load_segment(nxt, s + 1 < se ? s + 1 : (sb_next >= 0 ? sb_next : s));
+            } else {
+                load_segment(v, s);
+            }
+            if (WINDOW) {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) v[a] = make_float2(v[a].x * win[a], v[a].y * win[a]);
+            }
+            lds_barrier();   // A0: the previous segment's exchange reads are done everywhere
+            const float4 bb = tb[t], cc = tb[256 + lo];
+            transform16k<F>(v, wt, make_float2(bb.x, bb.y), make_float2(bb.z, bb.w), make_float2(cc.x, cc.y),
+                            make_float2(cc.z, cc.w), l0, lx, t, w1, r1, w2, r2);
+            const bool st = s >= p.store_from, ac = s < p.acc_end;
+            float val[16];
+            if (p.epilogue == 0) {
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    const float2 X = v[r16(k2)];
+                    val[k2] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));
+                }
+            } else {
+                const float sc = p.scale;
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    const float2 X = v[r16(k2)];
+                    val[k2] = fmaf(X.x, X.x, X.y * X.y) * sc;
+                }
+            }
+            if (st) {
+                float *row = p.rows + ((size_t)stream * (p.nseg - p.store_from) + (size_t)(s - p.store_from)) * N;
+                const int sh = p.fftshift ? N / 2 : 0;
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) row[(kbase + 256 * F * k2 + sh) & (N - 1)] = val[k2];
+            }
+            if (ac) {
+                if (p.acc_mode == C16_WSUM) {
+                    const long long kk = p.acc_end - 1 - s;
+                    const float w = kk == 0 ? 1.0f : exp2f(p.l2 * (float)kk);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[k] = fmaf(w, val[k], acc[k]);
+                } else if (p.acc_mode == C16_MAX) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) asm("v_max_f32 %0, %1, %2" : "=v"(acc[k]) : "v"(acc[k]), "v"(val[k]));
+                }
+            }
+        }
+        if (sched == 0) break;
+        cur += W;
+    }
+    if (p.partial) {      // natural bin order, as chain_reduce_kernel / chain_state_kernel read it
+        float *dst = p.partial + ((size_t)stream * W + wg) * N;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) dst[kbase + 256 * F * k2] = acc[k2];
+    }
+}
+
 }  // namespace
+
+template <int F, bool WINDOW, bool PREFETCH> hipError_t launch_chain16k_f(const SegArgs &a, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    constexpr size_t lds = chain16k_lds_bytes<F>();
+    const void *fn = reinterpret_cast<const void *>(chain16k_kernel<F, WINDOW, PREFETCH>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((chain16k_kernel<F, WINDOW, PREFETCH>), grid, dim3(256 * F), lds, s, a);
+    return hipGetLastError();
+}
+
+// rect: the chain's window is all ones (a.win is still valid)
+hipError_t launch_chain16k(int nfft, const SegArgs &a, bool rect, hipStream_t s) {
+    if (nfft == 16384) return rect ? launch_chain16k_f<4, false, true>(a, s) : launch_chain16k_f<4, true, false>(a, s);
+    if (nfft == 8192) return rect ? launch_chain16k_f<2, false, true>(a, s) : launch_chain16k_f<2, true, false>(a, s);
+    return hipErrorInvalidValue;
+}
 
 template <bool DETREND, int F, bool HALF> hipError_t launch16k(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);

@@ -459,12 +459,13 @@ def test_chain_keep_one_in_n_matches_gnuradio_rule(ctx, hip):
 
 
 def test_chain_latest_wins_on_the_coverage_kernel(ctx, hip):
-    """Sizes the fused launch does not cover (8192, 16384, 128): a stateless chain computes only the rows it hands
-    back, a stateful one (peak hold) all of them."""
+    """Sizes the fused launch does not cover (64, 128) and the same calls forced onto the coverage kernels at 8192: a
+    stateless chain computes only the rows it hands back, a stateful one (peak hold) all of them."""
     for N in (128, 8192):
         x = R.synth_iq(N * 40 + 11, 70 + N)
         ref = R.chain_sensor_v2(x, N, decim=2)
         ch = ctx.chain(N, None, True, hip.EPI_MAG2_OVER_N2, 2)
+        ch.set_kernel(hip.KERNEL_GENERIC)
         rows, n = ch.push(x, max_rows=3)
         assert n == len(ref) == 20 and rows.shape == (3, N)
         check_single_rows(rows, ref[-3:])
@@ -477,6 +478,7 @@ def test_chain_latest_wins_on_the_coverage_kernel(ctx, hip):
         from ofdm_tools import windows
         mag, peak = R.chain_psd_logger(x, N, decim=2)
         ch = ctx.chain(N, windows.blackmanharris(N), False, hip.EPI_MAG, 2)
+        ch.set_kernel(hip.KERNEL_GENERIC)
         ch.set_peak_hold(True)
         rows, n = ch.push(x, max_rows=1)
         assert n == 20 and relerr(ch.peak(), peak[-1]) < RTOL
@@ -985,13 +987,68 @@ def test_seg_welch_vs_oracle_and_generic(ctx, hip, nfft, build):
             ctx.free(ptr)
 
 
-@pytest.mark.parametrize('nfft', [256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize('nfft', [1024, 2048])
+@pytest.mark.parametrize('frac', [4, 2])
+def test_seg_zero_padded_segments_vs_oracle_and_generic(ctx, hip, nfft, frac):
+    """nperseg = nfft / 4 zero-padded to nfft - the sweeper's `_src_power` call for the fft_len a flowgraph passes
+    (spectrum_sweeper.py:263: welch(flattop, nperseg=nFFT/4.0, nfft=nFFT)) - and nperseg = nfft / 2, on the
+    team-per-segment kernel with compile-time zero rows: against the float64 oracle (flattop, detrend, 50 % overlap of
+    nperseg, fftshift + dB as the sweeper does; other steps; a DC offset 30 x the noise), then device-resident against
+    the coverage kernel over segment counts around chunk and grid multiples."""
+    nps = nfft // frac
+    rng = np.random.default_rng(nfft + frac)
+    x = R.synth_iq(nps * 40 + 77, 600 + nfft)
+    for nov, det in ((nps // 2, True), (nps // 2, False), (0, True), (nps - 1, True), (nps // 4, False)):
+        _, ref = R.welch_np(x[:nps * 12 + 5], fs=2.0e6, window='flattop', nperseg=nps, noverlap=nov, nfft=nfft,
+                            detrend='constant' if det else False)
+        plan = ctx.welch_plan(nfft, nperseg=nps, noverlap=nov, window=flattop(nps), fs=2.0e6,
+                              detrend=hip.DETREND_CONSTANT if det else hip.DETREND_NONE, kernel=hip.KERNEL_TUNED)
+        assert relerr(plan.exec(x[:nps * 12 + 5]), ref) < RTOL, (nov, det)
+        plan.close()
+    # the sweeper's own form: shift, trim, dB
+    ex = nfft // 16
+    want = R.sweeper_src_power(x, nfft, 2.0e6, ex) if frac == 4 else None
+    if want is not None:
+        plan = ctx.welch_plan(nfft, nperseg=nps, window=flattop(nps), fs=2.0e6, fftshift=True, trim_bins=ex, db=True,
+                              kernel=hip.KERNEL_TUNED)
+        got = plan.exec(x)
+        assert relerr(10 ** (got.astype(np.float64) / 10), 10 ** (np.asarray(want) / 10)) < RTOL
+    xdc = (rng.standard_normal(nps * 30) + 1j * rng.standard_normal(nps * 30) + (30.0 - 18.0j)).astype(np.complex64)
+    _, ref = R.welch_np(xdc, window='flattop', nperseg=nps, nfft=nfft)
+    plan = ctx.welch_plan(nfft, nperseg=nps, window=flattop(nps), kernel=hip.KERNEL_TUNED)
+    assert relerr(plan.exec(xdc), ref) < RTOL
+    step = nps // 2
+    nmax = nps + step * 20000
+    d_in = ctx.alloc(3 * nmax * 8)
+    d_a, d_b = ctx.alloc(3 * nfft * 4), ctx.alloc(3 * nfft * 4)
+    try:
+        ctx.synth_iq(d_in, 3 * nmax, 31, R.TONES, R.DC)
+        gen = ctx.welch_plan(nfft, nperseg=nps, window=flattop(nps), kernel=hip.KERNEL_GENERIC)
+        for nseg in [1, 2, 3, 31, 32, 33, 255, 4095, 4097, 16383, 20000] + [int(v) for v in rng.integers(1, 20000, 5)]:
+            n = nps + step * (nseg - 1) + int(rng.integers(0, step))
+            ns = int(rng.integers(1, 4))
+            plan.set_schedule(int(rng.integers(0, 3)))
+            plan.set_tuning(None, chunk=int(rng.integers(0, 6)))
+            assert plan.exec_dev(d_in, n, d_a, nstreams=ns, stream_stride=nmax) == nseg
+            assert gen.exec_dev(d_in, n, d_b, nstreams=ns, stream_stride=nmax) == nseg
+            a = ctx.d2h(d_a, (ns, nfft), np.float32)
+            b = ctx.d2h(d_b, (ns, nfft), np.float32)
+            err = np.max(np.abs(a.astype(np.float64) - b) / np.maximum(b, 0.1 * np.median(b)))
+            assert err < 5e-5, (nseg, ns, err)
+    finally:
+        for ptr in (d_in, d_a, d_b):
+            ctx.free(ptr)
+
+
+@pytest.mark.parametrize('nfft', [256, 512, 1024, 2048, 4096, 8192, 16384])
 def test_fused_chain_many_rows_iir_peak_and_plain(ctx, hip, nfft):
     """The fused periodogram chain over thousands of kept vectors in one launch (IIR as a weighted sum over the
     launch, peak hold as a max) against the sequential oracle, against the coverage kernels, across pushes that
-    split vectors, with keep_one_in_n = 3."""
+    split vectors, with keep_one_in_n = 3.  256 ... 4096: segfft.hip's team-per-segment build; 8192 / 16384 (the
+    scanner's size in BASELINE config 5): welch16k.hip's workgroup-per-segment build, rectangular (no window
+    registers, prefetching) and windowed."""
     from ofdm_tools import windows
-    rows_n, keep = 700, 3
+    rows_n, keep = (700, 3) if nfft <= 4096 else (400, 3)
     x = R.synth_iq(nfft * rows_n * keep + 123, 900 + nfft)
     w = windows.blackmanharris(nfft)
     k = -10 * np.log10(nfft) - 10 * np.log10(2.0e6)

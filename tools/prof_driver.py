@@ -80,12 +80,21 @@ elif cfg in ('w1024', 'w2048', 'w512', 'w256', 'w8192', 'w16384'):
     plan = ctx.welch_plan(N, window=hann(N), fs=1.0)
     run = lambda: plan.exec_dev(d, n, o)      # noqa: E731
     nbytes = 8 * n
+elif cfg in ('p1024', 'p2048'):      # the sweeper's call at these sizes: flattop, nperseg = nfft / 4 zero-padded, 50 % overlap
+    N = int(cfg[1:])
+    n = 1 << (log2n or 27)
+    d, o = dev(n * 8), dev(N * 4)
+    ctx.synth_iq(d, n, 1002, TONES, DC)
+    plan = ctx.welch_plan(N, nperseg=N // 4, window=windows.get_window('flattop', N // 4), fs=2.0e6, fftshift=True, db=True)
+    run = lambda: plan.exec_dev(d, n, o)      # noqa: E731
+    nbytes = 8 * n
 elif cfg.startswith('chain'):
-    N = int(cfg[5:])
+    rect = cfg.startswith('chainr')          # chainrN: rectangular window (ascii_plot's chain), chainN: Blackman-Harris
+    N = int(cfg[6:] if rect else cfg[5:])
     n = 1 << (log2n or 26)
     d = dev(n * 8)
     ctx.synth_iq(d, n, 1001, TONES, DC)
-    ch = ctx.chain(N, windows.blackmanharris(N), True, _hip.EPI_MAG2, 1)
+    ch = ctx.chain(N, None if rect else windows.blackmanharris(N), True, _hip.EPI_MAG2, 1)
     ch.set_iir_log(0.8, -10.0)
     run = lambda: ch.push_dev(d, n)      # noqa: E731
     nbytes = 8 * n
