@@ -376,6 +376,48 @@ bool window_spectrum_table_seg(const std::vector<float> &w, int n, std::vector<f
     return true;
 }
 
+// The same table for welch16k.hip (N = 4096 F, F = 2 or 4): thread tid = 256 k' + 16 k0 + k1 holds, after pass 3, the bins
+// k' + F (k0 + 16 k1 + 256 k2); it corrects k2 = 0 and k2 = 15, i.e. the table exists when the window's spectrum is
+// confined to [0, 256 F) U [N - 256 F, N).
+bool window_spectrum_table_16k(const std::vector<float> &w, int n, std::vector<float> &fd) {
+    const int F = n / 4096;
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    std::vector<double> re(n), im(n, 0.0);
+    double s2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        int r = 0;
+        for (int b = 0; b < lg; ++b) r |= ((i >> b) & 1) << (lg - 1 - b);
+        re[r] = (double)w[i];
+        s2 += (double)w[i] * (double)w[i];
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / len;
+        for (int i = 0; i < n; i += len)
+            for (int j = 0; j < len / 2; ++j) {
+                const double c = cos(ang * j), s = sin(ang * j);
+                const int a = i + j, b = a + len / 2;
+                const double tr = re[b] * c - im[b] * s, ti = re[b] * s + im[b] * c;
+                re[b] = re[a] - tr;
+                im[b] = im[a] - ti;
+                re[a] += tr;
+                im[a] += ti;
+            }
+    }
+    for (int k = 256 * F; k < n - 256 * F; ++k)
+        if (re[k] * re[k] + im[k] * im[k] > 1e-10 * s2) return false;
+    fd.assign((size_t)4 * 256 * F, 0.f);
+    for (int tid = 0; tid < 256 * F; ++tid) {
+        const int kp = tid >> 8, k0 = (tid >> 4) & 15, k1 = tid & 15;
+        const int lo = kp + F * (k0 + 16 * k1), hi = kp + F * (k0 + 16 * k1 + 3840);
+        fd[4 * tid] = (float)re[lo];
+        fd[4 * tid + 1] = (float)im[lo];
+        fd[4 * tid + 2] = (float)re[hi];
+        fd[4 * tid + 3] = (float)im[hi];
+    }
+    return true;
+}
+
 int segments(const oth_plan *p, size_t nsamples, long long *nseg) {
     if (nsamples < (size_t)p->nperseg) return OTH_ERR_INVALID;
     *nseg = (long long)((nsamples - (size_t)p->noverlap) / (size_t)p->step);
@@ -497,7 +539,11 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         // tail has nothing to even out and costs 5-20 % (2048 points, 2^22 samples: 17.3 % against 14.0 %)
         if ((tuned || seg_ws) && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC && per_team < 32)
             a.sched = OTH_SCHED_CONTIGUOUS;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 8 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : (p->nfft == 1024 && !seg_ws ? 32 : 16)) : 8)));
+        // 16384 points at 50 % overlap: one workgroup per CU and equal work per segment - contiguous runs (no chunk head
+        // is read twice): 30.8 % against 29.3 % with tickets; 8192: tickets over chunks of 16 (33.4 % against 32.5 % at 8)
+        if (tuned_16k && p->nfft == 16384 && p->step * 2 == p->nfft && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC)
+            a.sched = OTH_SCHED_CONTIGUOUS;
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 16 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : (p->nfft == 1024 && !seg_ws ? 32 : 16)) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;
@@ -850,7 +896,8 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     std::vector<float> fd;
     if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT &&
         ((nfft == 4096 && nperseg == 4096 && window_spectrum_table(w, fd)) ||
-         (nfft == 2048 && nperseg == 2048 && window_spectrum_table_seg(w, nfft, fd)))) {
+         (nfft == 2048 && nperseg == 2048 && window_spectrum_table_seg(w, nfft, fd)) ||
+         ((nfft == 8192 || nfft == 16384) && nperseg == nfft && window_spectrum_table_16k(w, nfft, fd)))) {
         e = hipMalloc(&p->d_fd, sizeof(float) * fd.size());
         if (e == hipSuccess)
             e = hipMemcpyAsync(p->d_fd, fd.data(), sizeof(float) * fd.size(), hipMemcpyHostToDevice, c->stream);

@@ -28,7 +28,8 @@ namespace oth {
 namespace {
 
 constexpr int REGION = 16 * RS;                     // float2 per sub-FFT image
-constexpr int LDS16_RED = 48;                       // up to 16 wave sums of the new half, 16 of a chunk's first half, ticket
+constexpr int LDS16_RED = 48;                       // up to 16 wave sums of the new half, 16 of a chunk's first half, ticket [32],
+                                                    // segment totals by step parity [40..41] (frequency-domain detrend)
 template <int F> constexpr size_t lds16_bytes() { return (F * REGION + LDS16_RED) * sizeof(float2); }
 
 // multiply by exp(-2 pi i q / 16), q a compile-time constant (the products j * k' that occur: 0..7 and 9)
@@ -103,8 +104,13 @@ __device__ __forceinline__ void transform16k(float2 (&v)[16], const float2 (&wt)
 
 // HALF: step = N / 2 - the second half of a segment is the first half of the next one at the same (j, tid), so it
 // is kept (raw) in registers and every sample is read once; otherwise segments are loaded whole (any step).
-template <bool DETREND, int F, bool HALF>
+// DET: 0 none, 1 in the time domain (the mean is subtracted before the window), 2 in the frequency domain
+// (X -= mean FFT(w) on the two bins of each thread the window's spectrum reaches, WelchArgs.fd - as welch4096ws.hip;
+// the mean is then needed only at the end of the step, which is what lets the 16384-point build keep the
+// overlapped half in registers: with DET = 1 it spilled 18 registers and loaded every sample twice).
+template <int DET, int F, bool HALF>
 __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
+    constexpr bool DETREND = DET != 0;
     constexpr int T16 = 256 * F, N = 4096 * F, NJ = 16 / F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
@@ -183,7 +189,27 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
                     }
             }
             float2 mean = make_float2(0.f, 0.f);
-            if (DETREND) {
+            if (DET == 2) {      // windowed before the barrier: the mean comes off in the frequency domain
+#pragma unroll
+                for (int a = 0; a < 16; ++a) v[a] = make_float2(v[a].x * win[a], v[a].y * win[a]);
+            }
+            // DET = 2 (HALF builds): the per-wave sums of the new half go to the slot of this step's parity, the other
+            // slot still holds the half before it (a chunk's first step fills both); after the barrier wave 0 adds the
+            // 32 values up and leaves the segment total in LDS, where every thread picks it up at the END of the step.
+            // Nothing of the detrend stays in registers across the transform.
+            const int par = (int)(s & 1);
+            if (DET == 2) {
+                sum.x = wave_total_lane63(sum.x);
+                sum.y = wave_total_lane63(sum.y);
+                if (s == sb) {
+                    sumf.x = wave_total_lane63(sumf.x);
+                    sumf.y = wave_total_lane63(sumf.y);
+                }
+                if ((tid & 63) == 63) {
+                    red[16 * par + (tid >> 6)] = sum;
+                    if (s == sb) red[16 * (par ^ 1) + (tid >> 6)] = sumf;
+                }
+            } else if (DETREND) {
                 sum.x = wave_total(sum.x);
                 sum.y = wave_total(sum.y);
                 if (HALF && s == sb) {
@@ -201,7 +227,14 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
                 if (s == sb) ticket = atomicAdd(p.queue + stream, 1u);
                 if (s == se - 1) *lnext = (int)ticket;
             }
-            if (DETREND) {
+            if (DET == 2 && tid < 64) {      // wave 0: slots 0 .. T16/64-1 and 16 .. 16+T16/64-1 hold this segment's halves
+                float2 part = make_float2(0.f, 0.f);
+                if ((tid & 15) < T16 / 64 && tid < 32) part = red[tid];
+                part.x = wave_total_lane63(part.x);
+                part.y = wave_total_lane63(part.y);
+                if (tid == 63) red[40 + par] = part;      // read behind the barriers of the transform
+            }
+            if (DET == 1) {
                 float2 tot = red[0];
 #pragma unroll
                 for (int w = 1; w < T16 / 64; ++w) tot = cadd(tot, red[w]);
@@ -218,9 +251,19 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
                 }
                 mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
             }
+            if (DET != 2) {
 #pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
+                for (int a = 0; a < 16; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
+            }
             transform16k<F>(v, wt, b1, b4, c1, c4, l0, lx, t, w1, r1, w2, r2);
+            if (DET == 2) {
+                const float4 fw = p.fd[tid];      // FFT(w) at this thread's k2 = 0 and k2 = 15 bins (zero where out of reach)
+                const float2 tot = red[40 + par];
+                mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
+                v[r16(0)] = make_float2(v[r16(0)].x - (mean.x * fw.x - mean.y * fw.y), v[r16(0)].y - (mean.x * fw.y + mean.y * fw.x));
+                v[r16(15)] = make_float2(v[r16(15)].x - (mean.x * fw.z - mean.y * fw.w),
+                                         v[r16(15)].y - (mean.x * fw.w + mean.y * fw.z));
+            }
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 const float2 X = v[r16(k2)];
@@ -396,22 +439,25 @@ hipError_t launch_chain16k(int nfft, const SegArgs &a, bool rect, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
-template <bool DETREND, int F, bool HALF> hipError_t launch16k(const WelchArgs &a, hipStream_t s) {
+template <int DET, int F, bool HALF> hipError_t launch16k(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
     constexpr size_t lds = lds16_bytes<F>();
-    const void *fn = reinterpret_cast<const void *>(welch16k_kernel<DETREND, F, HALF>);
+    const void *fn = reinterpret_cast<const void *>(welch16k_kernel<DET, F, HALF>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((welch16k_kernel<DETREND, F, HALF>), grid, dim3(256 * F), lds, s, a);
+    hipLaunchKernelGGL((welch16k_kernel<DET, F, HALF>), grid, dim3(256 * F), lds, s, a);
     return hipGetLastError();
 }
 
 template <int F> hipError_t launch16k_f(const WelchArgs &a, hipStream_t s) {
-    // (16384 points with detrend: the kept half does not fit 128 VGPRs next to the sums - 18 spills - and the LDS is
-    // full, so that build loads whole segments at every step)
-    if (a.step == 2048 * F && (F == 2 || !a.detrend))
-        return a.detrend ? launch16k<true, F, (F == 2)>(a, s) : launch16k<false, F, true>(a, s);
-    return a.detrend ? launch16k<true, F, false>(a, s) : launch16k<false, F, false>(a, s);
+    // 50 % overlap: the overlapped half stays in registers.  With a detrend that needs the frequency-domain form at
+    // 16384 points (a.fd: the window's spectrum is confined); a window without the table loads whole segments there.
+    if (a.step == 2048 * F) {
+        if (!a.detrend) return launch16k<0, F, true>(a, s);
+        if (a.fd) return launch16k<2, F, true>(a, s);
+        if (F == 2) return launch16k<1, F, true>(a, s);
+    }
+    return a.detrend ? launch16k<1, F, false>(a, s) : launch16k<0, F, false>(a, s);
 }
 
 hipError_t launch_welch_tuned16k(int nfft, const WelchArgs &a, hipStream_t s) {

@@ -217,6 +217,43 @@ def test_welch16k_hann_overlap_detrend_many_segments(ctx, hip, N):
         plan = ctx.welch_plan(N, window=hann(N), detrend=hip.DETREND_CONSTANT if det else hip.DETREND_NONE,
                               kernel=hip.KERNEL_TUNED)
         assert relerr(plan.exec(xdc), ref) < RTOL
+    # the detrend at 50 % overlap runs in the frequency domain when the window's spectrum is confined (periodic
+    # cosine-sum windows: Hann above, flattop here), in the time domain otherwise (a symmetric Hamming); both keep the
+    # overlapped half in registers at 8192, the 16384-point build only with the frequency-domain form
+    import scipy.signal as sg
+    for wname, w in (('flattop', flattop(N)), ('hamming_sym', sg.windows.hamming(N, sym=True).astype(np.float32))):
+        _, ref = R.welch_np(xdc, window=w.astype(np.float64), nperseg=N, nfft=N)
+        plan = ctx.welch_plan(N, window=w, kernel=hip.KERNEL_TUNED)
+        assert relerr(plan.exec(xdc), ref) < RTOL, wname
+    # many segments, device-resident, against the coverage kernel: counts around chunk and grid multiples, 1-3 streams
+    step = N // 2
+    nmax = N + step * 2100
+    d_in, d_a, d_b = ctx.alloc(3 * nmax * 8), ctx.alloc(3 * N * 4), ctx.alloc(3 * N * 4)
+    try:
+        ctx.synth_iq(d_in, 3 * nmax, 77, R.TONES, 3.0 - 2.0j)
+        tuned = ctx.welch_plan(N, window=hann(N), kernel=hip.KERNEL_TUNED)
+        gen = ctx.welch_plan(N, window=hann(N), kernel=hip.KERNEL_GENERIC)
+        for nseg in [1, 2, 3, 7, 8, 9, 255, 256, 257, 511, 513, 2047, 2100] + [int(v) for v in rng.integers(1, 2100, 4)]:
+            n = N + step * (nseg - 1) + int(rng.integers(0, step))
+            ns = int(rng.integers(1, 4))
+            tuned.set_schedule(int(rng.integers(0, 3)))
+            tuned.set_tuning(None, chunk=int(rng.integers(0, 6)))
+            assert tuned.exec_dev(d_in, n, d_a, nstreams=ns, stream_stride=nmax) == nseg
+            assert gen.exec_dev(d_in, n, d_b, nstreams=ns, stream_stride=nmax) == nseg
+            a = ctx.d2h(d_a, (ns, N), np.float32).astype(np.float64)
+            b = ctx.d2h(d_b, (ns, N), np.float32)
+            err = np.max(np.abs(a - b) / np.maximum(b, 0.1 * np.median(b)))
+            if nseg >= 8:
+                assert err < 5e-5, (nseg, ns, err)
+            else:
+                # a handful of segments of a stream whose DC is 3.6 x the noise: the bins the window's spectrum reaches
+                # carry the single-row rounding of both kernels' detrend (one subtracts m in time, the other m FFT(w)
+                # in frequency) - held to 8 ulp of the row's peak amplitude, as single periodogram rows are
+                amp = np.abs(np.sqrt(a) - np.sqrt(b)) / np.sqrt(b.max(axis=1, keepdims=True))
+                assert amp.max() <= 8 * 2.0 ** -23 and err < 1e-3, (nseg, ns, err, amp.max() * 2.0 ** 23)
+    finally:
+        for ptr in (d_in, d_a, d_b):
+            ctx.free(ptr)
 
 
 def test_welch_no_detrend_rect_raw_scaling(ctx, hip):
