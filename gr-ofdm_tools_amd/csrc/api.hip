@@ -543,7 +543,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         // is read twice): 30.8 % against 29.3 % with tickets; 8192: tickets over chunks of 16 (33.4 % against 32.5 % at 8)
         if (tuned_16k && p->nfft == 16384 && p->step * 2 == p->nfft && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC)
             a.sched = OTH_SCHED_CONTIGUOUS;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 16 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : (p->nfft == 1024 && !seg_ws ? 32 : 16)) : 8)));
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 16 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : ((p->nfft == 1024 && !seg_ws) || (p->nfft == 2048 && seg_ws) ? 32 : 16)) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
         a.nbig = nseg / a.chunk;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Copy what tools/collect_all_profiles.sh (and tools/collect_profiles.sh for the bench command) left under
+"""usage: publish_profiles.py <tag> <round-prefix> [<dst-dir>]
+Copy what tools/collect_all_profiles.sh (and tools/collect_profiles.sh for the bench command) left under
 gpurun_out/ into profiles/ (tracked) as one text summary per configuration, with the roofline recomputation
 written next to the counters, and refresh profiles/traffic.json (HBM bytes per launch of the headline kernel, read
 by bench.py).   usage: publish_profiles.py <tag> <round-prefix, e.g. r02>"""
@@ -12,7 +13,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
-dst = os.path.join(ROOT, 'profiles')
+# optional third argument: write there instead of profiles/ (collect_all_profiles.sh runs this on the GPU box, so that
+# only the summaries - not the per-dispatch CSVs, which exceed gpurun's 64 MiB return limit - come back)
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
 
 # config -> (kernel-name pattern, algorithmic bytes per launch, description)
 CONFIGS = {
@@ -26,12 +30,17 @@ CONFIGS = {
     'w512': ('seg_kernel', 8 * 2 ** 27, 'Welch 512-pt Hann 50 % overlap, 2^27 samples (two 32-thread teams per wave)'),
     'w1024': ('segws_kernel', 8 * 2 ** 27, 'Welch 1024-pt Hann 50 % overlap, 2^27 samples'),
     'w2048': ('segws_kernel', 8 * 2 ** 27, 'Welch 2048-pt Hann 50 % overlap, 2^27 samples'),
-    'w8192': ('welch16k', 8 * 2 ** 27, 'Welch 8192-pt Hann 50 % overlap, 2^27 samples (welch16k_kernel<., 2>: segments loaded whole, two transforms per sample)'),
+    'w8192': ('welch16k', 8 * 2 ** 27, 'Welch 8192-pt Hann 50 % overlap, 2^27 samples (welch16k_kernel<2, 2, HALF>: frequency-domain detrend, overlapped half kept in registers; two transforms per sample)'),
+    'w16384': ('welch16k', 8 * 2 ** 27, 'Welch 16384-pt Hann 50 % overlap + detrend, 2^27 samples (welch16k_kernel<2, 4, HALF>: frequency-domain detrend, overlapped half kept in registers; two transforms per sample)'),
+    'p1024': ('seg_kernel', 8 * 2 ** 27, 'the sweeper call at fft_len 1024 (spectrum_sweeper.py:263): flattop, nperseg 256 zero-padded to 1024, step 128: 8 transforms per 1024 new samples (seg_kernel<4, HALF, ., NA=4>)'),
+    'p2048': ('seg_kernel', 8 * 2 ** 27, 'the sweeper call at fft_len 2048: flattop, nperseg 512 zero-padded to 2048, step 256 (seg_kernel<8, HALF, ., NA=4>)'),
     'chain256': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 256, 2^26 samples'),
     'chain512': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 512, 2^26 samples'),
     'chain1024': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 1024 (BH window, shift, |X|^2, IIR 0.8 + log), 2^26 samples'),
     'chain2048': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 2048, 2^26 samples'),
     'chain4096': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 4096, 2^26 samples'),
+    'chain8192': ('chain16k', 8 * 2 ** 26, 'periodogram chain 8192 (BH window, shift, |X|^2, IIR 0.8 + log), 2^26 samples (chain16k_kernel<2, windowed>)'),
+    'chain16384': ('chain16k', 8 * 2 ** 26, 'periodogram chain 16384 (BH window, shift, |X|^2, IIR 0.8 + log), 2^26 samples (chain16k_kernel<4, windowed>)'),
 }
 
 
@@ -109,13 +118,19 @@ for cfg, (pat, alg, desc) in CONFIGS.items():
                                  'MI355X_MICROARCH.md HBM section); WRITE_SIZE [KB] x 1024; per-launch mean',
                        'algorithmic_bytes_per_launch': alg,
                        'source': 'profiles/%s_%s.txt' % (rnd, cfg)}, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+    valu_pct = None
     if 'SQ_INSTS_VALU' in v and avg_ns:
         # issue slots: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles; the clock from GRBM_GUI_ACTIVE / 8 XCDs
         clk = v.get('GRBM_GUI_ACTIVE', 0.0) / 8.0 / (avg_ns * 1e-9) if v.get('GRBM_GUI_ACTIVE') else 2.0e9
         slots = 1024 * clk * avg_ns * 1e-9 / 2.0
+        valu_pct = 100 * v['SQ_INSTS_VALU'] / slots
         lines.append('VALU issue: %.4g wave-instructions per launch / %.4g issue slots (1024 SIMDs, 2 cycles each, '
-                     '%.2f GHz from GRBM_GUI_ACTIVE) = %.0f %%' % (v['SQ_INSTS_VALU'], slots, clk / 1e9,
-                                                                   100 * v['SQ_INSTS_VALU'] / slots))
+                     '%.2f GHz from GRBM_GUI_ACTIVE) = %.0f %%' % (v['SQ_INSTS_VALU'], slots, clk / 1e9, valu_pct))
+        hbm_pct = alg / avg_ns / 80.0
+        if valu_pct > 1.5 * hbm_pct:
+            lines.append('binding ceiling: VALU issue (%.0f %% of the issue slots against %.1f %% of the byte roofline): at 100 %% '
+                         'issue this launch would take %.1f us = %.1f %% of 8000 GB/s'
+                         % (valu_pct, hbm_pct, avg_ns / 1e3 * valu_pct / 100, hbm_pct * 100 / valu_pct))
     out = os.path.join(dst, '%s_%s.txt' % (rnd, cfg))
     open(out, 'w').write('\n'.join(lines) + '\n')
     st = one(src, 'trace/*/*_kernel_stats.csv')
