@@ -30,6 +30,22 @@
 #ifndef OTH_CSDWS_TW
 #define OTH_CSDWS_TW 0      // pass-2 twiddles: 0 multiplied out of two seeds per step, 1 kept in registers, 2 LDS table (A/B: no gain)
 #endif
+// wave priorities: producer latency sections / butterflies, consumer latency sections / butterflies / swap + accumulate
+#ifndef OTH_CSDWS_PAL
+#define OTH_CSDWS_PAL 2
+#endif
+#ifndef OTH_CSDWS_PAC
+#define OTH_CSDWS_PAC 0
+#endif
+#ifndef OTH_CSDWS_PBL
+#define OTH_CSDWS_PBL 2
+#endif
+#ifndef OTH_CSDWS_PBC
+#define OTH_CSDWS_PBC 1
+#endif
+#ifndef OTH_CSDWS_PBA
+#define OTH_CSDWS_PBA 2
+#endif
 #ifndef OTH_CSDWS_SWAP
 #define OTH_CSDWS_SWAP 1    // 1: spectra traded with v_permlane32_swap_b32, 0: ds_bpermute_b32 (round 2)
 #endif
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
             constexpr int MODE = decltype(mode_)::value;
             const int q = it & 1;
             float2 *lx = img + q * LDS_X;
-            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(OTH_CSDWS_PAL);
             float2 v[16];
 #if OTH_CSDWS_DIAG
             CS_STAMP(0);      // loop / chunk bookkeeping
@@ -180,9 +196,9 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
                 if ((t & 63) == 63) red[q * 8 + wave] = cadd(sum, other);
                 prev_new = sum;
             }
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(OTH_CSDWS_PAC);
             dft16(v);
-            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(OTH_CSDWS_PAL);
             scatter_pow16<RS>(v, lx + w1, b1, b4);
             step_end(CS_DATA);
         };
@@ -287,7 +303,7 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
 
         // barrier A of step `it`, then what the producer left in image it & 1: item word, sums, pass 2
         auto next_item = [&]() -> int {
-            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(OTH_CSDWS_PBL);
             CS_STAMP(4);      // exchange + accumulation (loop tail)
             lds_barrier();
             CS_STAMP(0);      // barrier
@@ -295,13 +311,13 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
             const float2 *lq = img + q * LDS_X;
             const int kind = __builtin_amdgcn_readfirstlane(ctrl0[q]);      // both streams run the same schedule
 #if OTH_CSDWS_TW == 2
-            dft16_from_lds<17>(v, lq + r1, [] { __builtin_amdgcn_s_setprio(1); }, [&] {
+            dft16_from_lds<17>(v, lq + r1, [] { __builtin_amdgcn_s_setprio(OTH_CSDWS_PBC); }, [&] {
 #define CS_TW_READ(j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tq[j]) : "v"(tw_addr), "n"(256 * (j)))
                 CS_TW_READ(0); CS_TW_READ(1); CS_TW_READ(2); CS_TW_READ(3);
 #undef CS_TW_READ
             });
 #else
-            dft16_from_lds<17>(v, lq + r1, [] { __builtin_amdgcn_s_setprio(1); });
+            dft16_from_lds<17>(v, lq + r1, [] { __builtin_amdgcn_s_setprio(OTH_CSDWS_PBC); });
 #endif
             CS_STAMP(1);      // exchange-1 reads + pass 2
             ++it;
@@ -316,7 +332,7 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
             if (item == CS_STOP) break;
             const int q = (it & 1) ^ 1;   // the image whose pass 2 sits in v
             float2 *lx = img + q * LDS_X;
-            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(OTH_CSDWS_PBL);
 #if OTH_CSDWS_TW == 1
             lx[w2] = v[r16(0)];
 #pragma unroll
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
                 fw = fwl[t];
                 h0 = red[q * 8], h1 = red[q * 8 + 1], h2 = red[q * 8 + 2], h3 = red[q * 8 + 3];
             }
-            dft16_from_lds<1>(v, lx + r2, [] { __builtin_amdgcn_s_setprio(1); });
+            dft16_from_lds<1>(v, lx + r2, [] { __builtin_amdgcn_s_setprio(OTH_CSDWS_PBC); });
             CS_STAMP(3);      // exchange-2 reads + pass 3
             if (DETREND) {
                 const float2 tot = cadd(cadd(h0, h1), cadd(h2, h3));
@@ -362,7 +378,7 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
                 v[r16(15)] = make_float2(v[r16(15)].x - (mean.x * fw.z - mean.y * fw.w),
                                          v[r16(15)].y - (mean.x * fw.w + mean.y * fw.z));
             }
-            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(OTH_CSDWS_PBA);
 #if OTH_CSDWS_SWAP
             // v_permlane32_swap_b32 a, b swaps a's lanes 32..63 with b's lanes 0..31.  With a = bin j and b = bin j + 8
             // (x-stream values in lanes 0..31, y-stream values in lanes 32..63 of both): a' = X[j] | X[j + 8],

@@ -17,9 +17,25 @@ tests, which pass it explicitly) collects the ticket right away on the caller's 
 second thread.  ``drain()`` lets a host that stops feeding wait until the watcher has caught up.
 """
 import threading
+import weakref
 
 from . import _hip
 from .gr_compat import LossyQueue
+
+
+def _watch_loop(ref, queue):
+    """Watcher thread body (the reference's _queue_watcher.run loops, e.g. spectrum_sensor_v2.py:395-414)."""
+    while True:
+        item = queue.delete_head(timeout=0.05)
+        blk = ref()
+        if blk is None or not blk.keep_running:
+            return
+        if item is not None:
+            try:
+                blk._collect(item)
+            finally:
+                blk._done += 1
+        del blk
 
 
 class ChainBlockMixin(object):
@@ -34,7 +50,8 @@ class ChainBlockMixin(object):
         self.vector_rows_end = self.vector_nrows = 0
         self._watch_thread = None
         if self._threaded:
-            self._watch_thread = threading.Thread(target=self._watch, daemon=True)
+            # the thread holds the block only weakly: a block that is dropped without stop() takes its watcher with it
+            self._watch_thread = threading.Thread(target=_watch_loop, args=(weakref.ref(self), self.msgq0), daemon=True)
             self._watch_thread.start()
 
     # -- gr.sync_block ----------------------------------------------------------------------------
@@ -63,15 +80,6 @@ class ChainBlockMixin(object):
             return
         if n:
             self._on_vector(row)
-
-    def _watch(self):
-        while self.keep_running:
-            item = self.msgq0.delete_head(timeout=0.05)
-            if item is not None:
-                try:
-                    self._collect(item)
-                finally:
-                    self._done += 1
 
     def drain(self, timeout=5.0):
         """Wait until the watcher thread has consumed what work() queued (hosts that stop feeding and want the last
