@@ -268,6 +268,7 @@ const W4096Variant kVariants[] = {
     {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp, 8, 1, false},            // any step
     {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe, 16, 1, false},        // step 2048 (50 % overlap)
     {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 20, 1, true},     // step 2048, confined window spectrum
+    {"ws2", launch_welch_tuned4096_ws2, tuned4096_blocks_per_cu_ws2, 20, 2, true},  // the same in one 1024-thread workgroup per CU (A/B)
 #ifdef OTH_EXPERIMENTS
     {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16, 1, false},      // stamped build (tools/diag_stamps.py)
     {"exp1", launch_welch_tuned4096_exp1, tuned4096_blocks_per_cu_exp1, 16, 1, false},
@@ -473,6 +474,11 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
                               (p->detrend == OTH_DETREND_NONE || p->d_fd) && nseg < (1LL << 30),   // ws: 32-bit segment indices
                               p->tune_variant)
               : nullptr;
+    // "ws2" cuts the stream into two equal runs of segments: an odd count (or a single segment) stays on "ws"
+    const bool two_runs = var && !strcmp(var->tag, "ws2");
+    if (two_runs && (nseg < 2 || (nseg & 1))) var = &kVariants[2];
+    const bool ws2 = var && !strcmp(var->tag, "ws2");
+    const long long nseg_run = ws2 ? nseg / 2 : nseg;      // segments the schedule of one run covers
     int W = generic_wg(c, p->nfft, nseg, nstreams);
     if (tuned || tuned_csd || tuned_16k || tuned_seg) {
         // exactly the resident workgroups: one wave of workgroups, no tail round
@@ -482,7 +488,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
                                                                    : (seg_ws ? segws_teams_per_cu(p->nfft) : seg_teams_per_cu(p->nfft, seg_kind, seg_wps4)))
                                                         : (p->nfft == 8192 ? 2 : 1)));      // welch16k: 139 / 70 KiB of LDS
         long long w = ((long long)c->cu_count * bpc + nstreams - 1) / nstreams;
-        W = (int)(w > nseg ? nseg : (w < 1 ? 1 : w));
+        W = (int)(w > nseg_run ? nseg_run : (w < 1 ? 1 : w));
     }
     const int nch = csd ? 4 : 1;
     const int rows = tuned ? var->rows : 1;      // rows of partial sums per workgroup
@@ -498,7 +504,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.win = p->d_win;
     a.tw = p->d_tw;
     a.partial = p->d_partial;
-    a.nseg = nseg;
+    a.nseg = nseg_run;
+    if (ws2) a.y = x + (size_t)nseg_run * 2048;      // run B starts nseg / 2 segments in (its first half-block is run A's last)
     a.stream_stride = stride;
     a.nperseg = p->nperseg;
     a.step = p->step;
@@ -522,7 +529,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         // of the roofline at every launch size).  Static instead: interleaved chunks of 32 / 16 segments while every
         // team gets two of them (256 points, 2^27 samples: 66 % against 43 %), one contiguous run per team below that.
         const bool seg_static = tuned_seg && !seg_ws && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC;
-        const long long per_team = nseg / (W > 0 ? W : 1);
+        const long long per_team = nseg_run / (W > 0 ? W : 1);
         int static_chunk = 0;
         if (seg_static && seg_kind == 0 && (p->nfft <= 512 || seg_pad)) {      // (zero-padded: nfft / 8 new samples per segment)
             static_chunk = per_team >= 64 ? 32 : (per_team >= 32 ? 16 : 0);
@@ -546,7 +553,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 16 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : ((p->nfft == 1024 && !seg_ws) || (p->nfft == 2048 && seg_ws) ? 32 : 16)) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         a.tail_chunk = a.chunk;
-        a.nbig = nseg / a.chunk;
+        a.nbig = nseg_run / a.chunk;
         if (a.sched < 0 || a.sched > 2) a.sched = 0;
         if (a.sched == 2) {
             if (nstreams > 64) a.sched = 1;
@@ -556,7 +563,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
                 a.tail_chunk = p->tune_tail > 0 ? p->tune_tail : (a.chunk >= 4 ? a.chunk / 4 : 1);
                 if (a.tail_chunk < 1) a.tail_chunk = 1;
                 const long long tail_segs = (long long)W * a.chunk / 2;
-                a.nbig = nseg > tail_segs ? (nseg - tail_segs) / a.chunk : 0;
+                a.nbig = nseg_run > tail_segs ? (nseg_run - tail_segs) / a.chunk : 0;
                 if (!c->queue_clean) HIPCHK(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned) * 64, c->stream));
                 c->queue_clean = false;      // until the finalize launch that follows has re-zeroed them
                 c->queue_used = nstreams;

@@ -118,6 +118,9 @@ OTH_DECL_W4096(pipe)
 // welch4096ws.hip: wave-specialised producer/consumer form; step 2048, detrend needs WelchArgs.fd
 // (built once per tag like welch4096.hip)
 OTH_DECL_W4096(ws)
+// welch4096ws2.hip: the same arithmetic in one 1024-thread workgroup per CU, two runs of segments (A/B variant "ws2");
+// WelchArgs.y = first sample of the second run, WelchArgs.nseg = segments per run, two partial rows per workgroup
+OTH_DECL_W4096(ws2)
 #ifdef OTH_EXPERIMENTS
 OTH_DECL_W4096(wsx1)
 OTH_DECL_W4096(wsx2)

@@ -678,7 +678,7 @@ def test_randomized_welch_plans_vs_oracle(ctx, hip):
         plan.close()
 
 
-@pytest.mark.parametrize('variant', ['', 'ws', 'pipe', 'dpp'])
+@pytest.mark.parametrize('variant', ['', 'ws', 'ws2', 'pipe', 'dpp'])
 def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip, variant):
     """Chunked schedules at the edges: segment counts around multiples of the chunk size and of the
     resident workgroup count, one to three streams, all three schedules, default and tiny chunks
@@ -692,8 +692,8 @@ def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip, variant):
         ctx.synth_iq(d_in, 3 * nmax, 31, R.TONES, R.DC)
         tuned = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_TUNED)
         gen = ctx.welch_plan(4096, window=hann(4096), kernel=hip.KERNEL_GENERIC)
-        counts = [1, 2, 3, 7, 8, 9, 15, 16, 17, 1023, 1024, 1025, 4095, 4097, 8191, 8192, 8193, 9000] + \
-            [int(v) for v in rng.integers(1, 9000, 6)]
+        counts = [1, 2, 3, 4, 6, 7, 8, 9, 15, 16, 17, 1023, 1024, 1025, 1026, 4095, 4096, 4097, 8191, 8192, 8193, 9000] + \
+            [int(v) for v in rng.integers(1, 9000, 6)]      # ('ws2' takes the even counts, 'ws' stands in on the odd ones)
         for nseg in counts:
             n = 4096 + 2048 * (nseg - 1) + int(rng.integers(0, 2048))
             ns = int(rng.integers(1, 4))
@@ -714,7 +714,7 @@ def test_tuned_vs_generic_on_awkward_segment_counts(ctx, hip, variant):
             ctx.free(ptr)
 
 
-@pytest.mark.parametrize('variant', ['', 'pipe'])
+@pytest.mark.parametrize('variant', ['', 'pipe', 'ws2'])
 def test_welch4096_large_dc_offset(ctx, hip, variant):
     """A DC offset 30x the noise level (uncalibrated SDR front end): the default build removes the mean in
     the frequency domain (X - mean * FFT(w)), the fallback in the time domain; both must hold 1e-4 on every
@@ -761,7 +761,7 @@ def test_tuned_kernels_repeat_without_drift(ctx, hip):
         want = ctx.d2h(d_b, (2, 4096), np.float32).astype(np.float64)
         worst = 0.0
         for it in range(300):
-            tuned.set_tuning(('ws', 'pipe', 'dpp')[it % 3], chunk=int(rng.choice([1, 2, 3, 5, 8, 16, 32, 64])))
+            tuned.set_tuning(('ws', 'pipe', 'dpp', 'ws2')[it % 4], chunk=int(rng.choice([1, 2, 3, 5, 8, 16, 32, 64])))
             tuned.set_schedule(int(rng.integers(0, 3)))
             assert tuned.exec_dev(d_in, n, d_a, nstreams=2, stream_stride=n) == 2047
             got = ctx.d2h(d_a, (2, 4096), np.float32)

@@ -40,7 +40,7 @@ if cfg in ('28', '26'):          # old calling convention: prof_driver.py <log2n
 log2n = int(sys.argv[3]) if len(sys.argv) > 3 else None
 nbytes = 0
 if cfg == 'C2':
-    n = 1 << (log2n or 28)
+    n = (1 << (log2n or 28)) - (2048 if os.environ.get('PROF_EVEN') else 0)      # PROF_EVEN: an even segment count (variant ws2)
     d, o = dev(n * 8), dev(4096 * 4)
     ctx.synth_iq(d, n, 1002, TONES, DC)
     plan = ctx.welch_plan(4096, window=hann(4096), fs=1.0)
