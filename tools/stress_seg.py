@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised stress of the 256 ... 2048-point Welch builds (role-split, one-role), the two-channel kernels and the
-fused chain against the coverage kernels on device-resident data.  usage: stress_seg.py [seconds] [seed]"""
+"""Randomised stress of the 256 ... 2048-point Welch builds (role-split, one-role, zero-padded), the 8192 / 16384 builds,
+the two-channel kernels and the fused chain (256 ... 16384) against the coverage kernels on device-resident data.  usage: stress_seg.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -15,32 +15,37 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = _hip.Context(0)
 nmax = 1 << 24
 d_x, d_y = ctx.alloc(4 * nmax * 8), ctx.alloc(nmax * 8)
-d_a, d_b = ctx.alloc(5 * 4096 * 4 * 4), ctx.alloc(5 * 4096 * 4 * 4)
+d_a, d_b = ctx.alloc(16 * 16384 * 4), ctx.alloc(16 * 16384 * 4)      # up to 16 rows of 16384 floats / 5 x 4096 CSD outputs
 ctx.synth_iq(d_x, 4 * nmax, 3, ((0.5, 0.1234), (2.0, 0.4071)), 0.3 - 0.2j)
 ctx.synth_iq(d_y, nmax, 4, ((0.7, 0.1234), (1.0, -0.2)), -0.1 + 0.4j)
 t0, cases, worst = time.time(), 0, 0.0
 while time.time() - t0 < secs:
     kind = rng.choice(['welch', 'welch', 'csd', 'chain'])
     if kind == 'welch':
-        nfft = int(rng.choice([256, 512, 1024, 2048]))
-        nov = int(rng.choice([nfft // 2, nfft // 2, nfft // 2, 0, nfft // 4, nfft - 1]))
+        nfft = int(rng.choice([256, 512, 1024, 2048, 8192, 16384]))
+        # zero-padded segments (the sweeper's nperseg = nfft / 4, and nfft / 2) at 1024 / 2048
+        nps = nfft // int(rng.choice([1, 1, 2, 4])) if nfft in (1024, 2048) else nfft
+        nov = int(rng.choice([nps // 2, nps // 2, nps // 2, 0, nps // 4, nps - 1]))
         det = _hip.DETREND_CONSTANT if rng.random() < 0.7 else _hip.DETREND_NONE
-        step = nfft - nov
+        step = nps - nov
         nseg = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(1, 3000)), int(rng.integers(3000, 30000))]))
         ns = int(rng.integers(1, 5))
-        n = min(nfft + step * (nseg - 1) + int(rng.integers(0, step)), nmax)
+        n = min(nps + step * (nseg - 1) + int(rng.integers(0, step)), nmax)
         nseg = (n - nov) // step
-        w = windows.get_window(str(rng.choice(['hann', 'flattop', 'blackmanharris'])), nfft)
-        tuned = ctx.welch_plan(nfft, noverlap=nov, window=w, detrend=det, kernel=_hip.KERNEL_TUNED)
-        gen = ctx.welch_plan(nfft, noverlap=nov, window=w, detrend=det, kernel=_hip.KERNEL_GENERIC)
-        build = str(rng.choice(['segws', 'segws', 'seg3']))
-        tuned.set_tuning(build, sched=int(rng.integers(-1, 3)), chunk=int(rng.choice([0, 1, 2, 3, 7, 16, 33])))
+        w = windows.get_window(str(rng.choice(['hann', 'flattop', 'blackmanharris'])), nps)
+        tuned = ctx.welch_plan(nfft, nperseg=nps, noverlap=nov, window=w, detrend=det, kernel=_hip.KERNEL_TUNED)
+        gen = ctx.welch_plan(nfft, nperseg=nps, noverlap=nov, window=w, detrend=det, kernel=_hip.KERNEL_GENERIC)
+        build = str(rng.choice(['segws', 'segws', 'seg3'])) if nfft <= 2048 and nps == nfft else ''
+        tuned.set_tuning(build or None, sched=int(rng.integers(-1, 3)), chunk=int(rng.choice([0, 1, 2, 3, 7, 16, 33])))
         assert tuned.exec_dev(d_x, n, d_a, nstreams=ns, stream_stride=nmax) == nseg
         assert gen.exec_dev(d_x, n, d_b, nstreams=ns, stream_stride=nmax) == nseg
         a = ctx.d2h(d_a, (ns, nfft), np.float32).astype(np.float64)
         b = ctx.d2h(d_b, (ns, nfft), np.float32).astype(np.float64)
         err = float(np.max(np.abs(a - b) / np.maximum(b, 0.1 * np.median(b))))
-        info = (kind, nfft, nov, det, nseg, ns, build)
+        if nseg < 8:      # a handful of segments: single-row rounding of two fp32 transforms (8 ulp of the row's peak amplitude)
+            amp = float(np.max(np.abs(np.sqrt(a) - np.sqrt(b)) / np.sqrt(b.max(axis=1, keepdims=True)))) * 2.0 ** 23
+            err = min(err, amp * 1e-4 / 8.0)
+        info = (kind, nfft, nps, nov, det, nseg, ns, build)
         tuned.close()
         gen.close()
     elif kind == 'csd':
@@ -65,17 +70,19 @@ while time.time() - t0 < secs:
         tuned.close()
         gen.close()
     else:
-        nfft = int(rng.choice([256, 512, 1024, 2048, 4096]))
+        nfft = int(rng.choice([256, 512, 1024, 2048, 4096, 8192, 16384]))
         keep = int(rng.integers(1, 5))
         mode = str(rng.choice(['iir', 'peak', 'plain']))
         nrows = int(rng.choice([int(rng.integers(1, 12)), int(rng.integers(1, 600))]))
         n = min(nfft * keep * nrows + int(rng.integers(0, nfft)), nmax)
         give = int(rng.choice([1, 1, 3, 16]))
         shift = bool(rng.integers(2))
+        win_bh = bool(rng.integers(2))      # Blackman-Harris, or rectangular (8192 / 16384: the prefetching build)
         cut = int(rng.integers(0, n + 1))
         outs = []
         for kern, o in ((_hip.KERNEL_AUTO, d_a), (_hip.KERNEL_GENERIC, d_b)):
-            ch = ctx.chain(nfft, windows.blackmanharris(nfft), shift, _hip.EPI_MAG if mode == 'peak' else _hip.EPI_MAG2, keep)
+            ch = ctx.chain(nfft, windows.blackmanharris(nfft) if win_bh else None, shift,
+                           _hip.EPI_MAG if mode == 'peak' else _hip.EPI_MAG2, keep)
             ch.set_kernel(kern)
             if mode == 'iir':
                 ch.set_iir_log(0.2, -3.0)

@@ -28,7 +28,7 @@ while time.time() - t0 < secs:
     n = 4096 + 2048 * (nseg - 1) + int(rng.integers(0, 2048))
     ns = int(rng.integers(1, 5))
     det = _hip.DETREND_CONSTANT if rng.random() < 0.7 else _hip.DETREND_NONE
-    variant = str(rng.choice(['ws', 'ws', 'pipe', 'dpp']))
+    variant = str(rng.choice(['ws', 'ws', 'ws2', 'pipe', 'dpp']))
     chunk = int(rng.choice([0, 1, 2, 3, 4, 7, 20, 33]))
     tuned, gen = plans[det]
     tuned.set_tuning(variant, chunk=chunk)
