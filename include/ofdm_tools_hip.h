@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OTH_ABI_VERSION 3
+#define OTH_ABI_VERSION 3      /* 3 = 2 + oth_chain_ticket_rows, oth_scan_decide_dev_out (additions only) */
 
 #define OTH_OK               0
 #define OTH_ERR_INVALID     -1   /* bad argument */
