@@ -365,3 +365,74 @@ def test_ascii_plotter_layout_and_oracle():
     tall[:N // W] = -69.05                                       # column 0 at 10.95 dB over floor(10.95) = 10
     lv, lo, span = ascii_plotter(W, H, 0.0, 2000000, N).column_levels(tall)
     assert span == 10 and lv[0] == H - 1 and lv[1] == 0
+
+
+def test_chain_block_plumbing_with_a_fake_chain():
+    """ofdm_tools.chain_block without a GPU: a fake chain stands in for oth_chain_*.  Default = watcher thread
+    (spectrum_sensor_v2.py:138-155): work() only enqueues, the vector arrives through the lossy depth-2 queue, drain()
+    waits for it, rows_total counts every vector the pushes produced (dropped tickets included), a stalled watcher
+    drops instead of back-pressuring, stop() joins, and a block that is dropped without stop() takes its thread along."""
+    import gc
+    import threading
+    import time
+    import weakref
+    from ofdm_tools.chain_block import ChainBlockMixin
+    from ofdm_tools import _hip
+
+    class FakeChain(object):
+        def __init__(self):
+            self.t, self.rows = 0, {}
+
+        def push_async(self, x):
+            self.t += 1
+            self.rows[self.t] = (np.full(4, float(self.t), np.float32), len(x) // 4)
+            return self.t
+
+        def ticket_rows(self, t):
+            return self.rows[t][1]
+
+        def wait(self, t):
+            if t <= self.t - 4:
+                raise _hip.HipError(-5, 'oth_chain_wait', 'overwritten')
+            row, n = self.rows[t]
+            return (row if n else None), n
+
+    class Blk(ChainBlockMixin):
+        def __init__(self, threaded=True):
+            self.seen, self.gate = [], threading.Event()
+            self.gate.set()
+            self._chain_init(FakeChain(), threaded)
+
+        def _on_vector(self, row):
+            self.gate.wait(5.0)
+            self.seen.append((float(row[0]), self.vector_rows_end, self.vector_nrows))
+
+    x = np.zeros(8, np.complex64)
+    blk = Blk()
+    assert blk._threaded and blk._watch_thread.is_alive()
+    assert blk.work([x], []) == 8 and blk.drain(2.0)
+    assert blk.seen == [(1.0, 2, 2)] and blk.rows_total == 2
+    blk.work([x[:3]], [])                       # a push that completes no vector: nothing to hand on
+    assert blk.drain(2.0) and len(blk.seen) == 1 and blk.rows_total == 2
+    blk.gate.clear()                            # stall the watcher: depth 2 + the one in progress survive
+    t0 = time.perf_counter()
+    for _ in range(12):
+        blk.work([x], [])
+    assert time.perf_counter() - t0 < 0.5 and blk.msgq0.dropped >= 9 and blk.rows_total == 26
+    blk.gate.set()
+    assert blk.drain(5.0)
+    assert len(blk.seen) + blk.vectors_lost + blk.msgq0.dropped == 13
+    assert blk.seen[-1][1] <= 26 and all(n == 2 for _, _, n in blk.seen)
+    th = blk._watch_thread
+    assert blk.stop() and not th.is_alive()
+    # inline form: same bookkeeping, no thread
+    inline = Blk(threaded=False)
+    inline.work([x], [])
+    assert inline.seen == [(1.0, 2, 2)] and inline._watch_thread is None and inline.drain(0.1)
+    # a dropped block does not keep its watcher (or itself) alive
+    orphan = Blk()
+    th, ref = orphan._watch_thread, weakref.ref(orphan)
+    del orphan
+    gc.collect()
+    th.join(2.0)
+    assert ref() is None and not th.is_alive()
