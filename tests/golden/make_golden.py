@@ -181,16 +181,40 @@ def reference_fixtures():
          plc_seq=np.array(sent), subject_pwr=od.subject_channels_pwr, top4=np.array(freqs[0]))
 
 
+    # a12 - xcorr / fac (ofdm_cr_tools.py:155-166) and a14 - src_power_fft (:173-192), fast_spectrum_scan('fft')
+    # (:471-537): function text untouched, run in the namespace of the reference's day (ref_extract.py: Python-2 `/` on
+    # len(), scipy.signal's old window re-exports)
+    P = E.load('ofdm_cr_tools.py', ['xcorr', 'fac', 'src_power_fft'], E.py2_namespace())
+    g = np.load(os.path.join(HERE, 'xcorr_fac.npz'))
+    L = int(g['L'])
+    save('ref_xcorr_fac.npz', source=np.array('reference'), input_from=np.array('xcorr_fac.npz'), L=L,
+         expected_xcorr=P['xcorr'](c128(g['a']), c128(g['b']), L), expected_fac=P['fac'](c128(g['a']), L),
+         expected_xcorr_short=P['xcorr'](c128(g['a'][:700]), c128(g['b'][:900]), 1024))
+    x = np.load(os.path.join(HERE, 'welch_flattop_2048.npz'))['x']
+    Sf, N, cs, sbw = 1000000, 2048, 50e3, 25e3
+    Fr = float(Sf) / N
+    bb = T['frange'](-Sf / 2, Sf / 2, cs)
+    psd, ax, plc = P['src_power_fft'](c128(x[:N]), N, N, Fr, Sf, bb, sbw / Fr)
+    psd2, ax2, plc2 = P['src_power_fft'](c128(x[3000:4500]), 1500, N, Fr, Sf, bb, sbw / Fr)      # npts < nFFT: zero-padded
+    scan = E.load('ofdm_cr_tools.py', ['fast_spectrum_scan'],
+                  dict(E.py2_namespace(), frange=T['frange'], src_power_fft=P['src_power_fft'],
+                       src_power_welch=T['src_power_welch']))['fast_spectrum_scan']
+    thr, plc_s, ne, occ = scan(c128(x[:N]), 100.0e6, cs, sbw, N, Sf, 'fft', 4, 1e-11, 0.5, False)
+    ax_ch = T['frange'](100.0e6 - Sf / 2, 100.0e6 + Sf / 2, cs)
+    save('ref_src_power_fft.npz', source=np.array('reference'), input_from=np.array('welch_flattop_2048.npz'),
+         Sf=Sf, nfft=N, channel_rate=cs, srch_bw=sbw, bb_freqs=np.array(bb), expected_psd=np.array(psd),
+         expected_axis=np.array(ax), expected_plc=np.array(plc), short_range=np.array([3000, 4500]),
+         expected_psd_short=np.array(psd2), expected_plc_short=np.array(plc2), scan_fc=100.0e6, scan_thr_leveler=4,
+         scan_alpha=0.5, scan_noise0=1e-11, scan_thr=thr, scan_plc=np.array(plc_s), scan_noise=ne,
+         scan_occupied=np.array([1.0 if a in occ else 0.0 for a in ax_ch]))
+
     # f4 - ascii_plotter.make_plot (ascii_plot.py:169-228), the reference's own method body on a stand-in object.
     # It was written for Python 2: ``self.matrix[self.width/2]`` needs an integer quotient.  The method text is NOT
     # touched; the stand-in's ``width`` is an int whose ``/`` by an int floors, which is what Python 2 did (its only
     # other ``/ self.width`` has a float on the left).  ``height`` stays a plain int: every ``/ self.height`` has a
     # float numerator in Python 2 (math.floor returned a float), i.e. true division then as now.  The row goes in as
     # Python floats: the NumPy of the reference's day summed float32 scalars in double through Python's sum().
-    class Py2Int(int):
-        def __truediv__(self, other):
-            return Py2Int(int(self) // other) if isinstance(other, int) else int(self) / other
-
+    Py2Int = E.Py2Int
     make_plot = E.load_method('ascii_plot.py', 'ascii_plotter', 'make_plot')
     rng = np.random.default_rng(3)
     out = {}

@@ -9,9 +9,13 @@ reference's text is written anywhere: only the numbers the functions return go i
 (``make_golden.py``), and nothing here is importable on the GPU box (``/root/reference`` is absent
 there; callers skip).
 
-Functions that do NOT run unmodified under Python 3 / SciPy 1.15 are deliberately left out (a shim would
-pin the shim, not the reference): ``xcorr`` / ``fac`` (``h[len(h)/2:]`` needs Python-2 integer ``/``),
-``src_power_fft`` (``sg.flattop`` moved to ``scipy.signal.windows``).
+Three helpers need the ENVIRONMENT of the reference's day, not different text.  Their function bodies are exec'd
+unmodified as well; only the namespace they run in is the older one (``py2_namespace()``):
+  * ``src_power_fft`` calls ``sg.flattop``: SciPy up to 1.12 re-exported the window functions from ``scipy.signal``
+    (removed in 1.13).  The ``sg`` handed to it resolves names in ``scipy.signal`` first and in
+    ``scipy.signal.windows`` second - the same function object either way.
+  * ``xcorr`` / ``fac`` slice with ``h[len(h)/2:]``: under Python 2 ``int / int`` floors.  The ``len`` handed to them
+    returns an ``int`` subclass whose ``/`` by an int floors (``Py2Int``, also used for ``ascii_plotter.make_plot``).
 """
 import ast
 import math
@@ -21,6 +25,27 @@ import numpy as np
 import scipy.signal as sg
 
 REF_PY = '/root/reference/python'
+
+
+class Py2Int(int):
+    """An int whose true division by an int floors, as Python 2's ``/`` did."""
+
+    def __truediv__(self, other):
+        return Py2Int(int(self) // other) if isinstance(other, int) else int(self) / other
+
+
+class _SignalOfItsDay(object):
+    """scipy.signal as the reference imported it: window functions reachable as ``sg.<name>`` (SciPy <= 1.12)."""
+
+    def __getattr__(self, name):
+        if hasattr(sg, name):
+            return getattr(sg, name)
+        return getattr(sg.windows, name)
+
+
+def py2_namespace():
+    """Globals for the helpers that rely on Python-2 ``/`` on ``len()`` or on the old ``scipy.signal`` re-exports."""
+    return {'sg': _SignalOfItsDay(), 'len': lambda v: Py2Int(len(v))}
 
 
 def available():

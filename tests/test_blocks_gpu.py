@@ -248,6 +248,31 @@ def test_helper_functions_match_oracle(ctx):
         assert relerr(psd, psd2) < RTOL and np.allclose(plc, plc2, rtol=1e-4) and np.allclose(axis, axis2)
 
 
+def test_ref_src_power_fft_and_fft_scan_on_the_gpu(ctx, golden):
+    """a14 through the product helpers (HIP periodogram + device channel sums) against the reference's own
+    `src_power_fft` / `fast_spectrum_scan(method='fft')` output (ref_src_power_fft.npz)."""
+    from ofdm_tools import ofdm_cr_tools as T
+    g = golden('ref_src_power_fft.npz')
+    x = golden(str(g['input_from']))['x']
+    Sf, N = int(g['Sf']), int(g['nfft'])
+    cs, sbw = float(g['channel_rate']), float(g['srch_bw'])
+    Fr = float(Sf) / N
+    bb = T.frange(-Sf // 2, Sf // 2, cs)
+    psd, ax, plc = T.src_power_fft(x[:N], N, N, Fr, Sf, bb, sbw / Fr, ctx)
+    assert relerr(psd, g['expected_psd']) < 1e-3 and np.allclose(ax, g['expected_axis'])      # single periodogram row ...
+    amp = np.abs(np.sqrt(np.asarray(psd, np.float64)) - np.sqrt(g['expected_psd'])) / np.sqrt(g['expected_psd'].max())
+    assert amp.max() <= 4 * 2.0 ** -23                                                         # ... held to 4 ulp of its peak
+    assert np.allclose(plc, g['expected_plc'], rtol=1e-4)
+    lo, hi = (int(v) for v in g['short_range'])
+    psd, _, plc = T.src_power_fft(x[lo:hi], hi - lo, N, Fr, Sf, bb, sbw / Fr, ctx)
+    assert np.allclose(plc, g['expected_plc_short'], rtol=1e-4)
+    thr, plc, ne, occ = T.fast_spectrum_scan(x[:N], float(g['scan_fc']), cs, sbw, N, Sf, 'fft', int(g['scan_thr_leveler']),
+                                             float(g['scan_noise0']), float(g['scan_alpha']), ctx=ctx)
+    assert np.isclose(thr, float(g['scan_thr']), rtol=1e-4) and np.allclose(plc, g['scan_plc'], rtol=1e-4)
+    ax_ch = T.frange(float(g['scan_fc']) - Sf // 2, float(g['scan_fc']) + Sf // 2, cs)
+    assert [1.0 if a in occ else 0.0 for a in ax_ch] == list(g['scan_occupied'])
+
+
 def test_batched_scan_config5(ctx):
     """64-channel-style batch (here 5 streams x 4 vectors of 16384): PSD rows, per-bin mask, channel powers."""
     from ofdm_tools.scan_batch import BatchScanPlan

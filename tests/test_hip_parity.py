@@ -551,6 +551,12 @@ def test_xcorr_fac_golden(ctx, golden):
     assert int(np.argmax(xc)) == 37
     fc = ctx.fac(g['a'], L)
     assert np.max(np.abs(fc - g['expected_fac'])) / np.max(g['expected_fac']) < 1e-5
+    # the same against the reference's OWN xcorr / fac output (ref_xcorr_fac.npz)
+    r = golden('ref_xcorr_fac.npz')
+    assert np.max(np.abs(xc - r['expected_xcorr'])) / np.max(r['expected_xcorr']) < 1e-5
+    assert np.max(np.abs(fc - r['expected_fac'])) / np.max(r['expected_fac']) < 1e-5
+    xs = ctx.xcorr(g['a'][:700], g['b'][:900], 1024)
+    assert np.max(np.abs(xs - r['expected_xcorr_short'])) / np.max(r['expected_xcorr_short']) < 1e-5
 
 
 # ------------------------------ launches large enough for the static default schedules ----

@@ -192,7 +192,8 @@ def test_reference_fixtures_are_tagged(golden):
     import glob
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'ref_*.npz')))
     assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_scanner_seq.npz', 'ref_src_power_cases.npz',
-                     'ref_src_power_welch_2048.npz', 'ref_sweeper_src_power.npz', 'ref_welch_hann_4096.npz']
+                     'ref_src_power_fft.npz', 'ref_src_power_welch_2048.npz', 'ref_sweeper_src_power.npz',
+                     'ref_welch_hann_4096.npz', 'ref_xcorr_fac.npz']
     for n in names:
         g = golden(n)
         assert str(g['source']) == 'reference'
@@ -296,3 +297,42 @@ def test_ref_scanner_ema_and_top4(golden):
         assert np.allclose(st.plc, g['plc_seq'][i], rtol=1e-12, atol=0)
     pwr, top4 = R.publish_top4(st.plc, st.ax_ch, list(c['subject_channels']))
     assert np.allclose(pwr, g['subject_pwr'], rtol=1e-12) and top4 == list(g['top4'])
+
+
+def test_ref_xcorr_fac(golden):
+    """a12: ofdm_cr_tools.py:155-166 - the reference's own `xcorr` / `fac` bodies, run in the namespace of their day
+    (Python-2 `/` on `len()`, tests/golden/ref_extract.py)."""
+    g = golden('ref_xcorr_fac.npz')
+    x = golden(str(g['input_from']))
+    L = int(g['L'])
+    a, b = x['a'].astype(np.complex128), x['b'].astype(np.complex128)      # (NumPy 2 keeps complex64 input in single precision)
+    assert relerr(R.xcorr(a, b, L), g['expected_xcorr']) < RTOL
+    assert relerr(R.fac(a, L), g['expected_fac']) < RTOL
+    assert relerr(R.xcorr(a[:700], b[:900], 1024), g['expected_xcorr_short']) < RTOL
+    # the NumPy-made golden of round 1 (computed from the complex64 arrays, i.e. in single precision under NumPy 2)
+    # agrees with the reference's float64 output to single precision
+    assert relerr(x['expected_xcorr'], g['expected_xcorr']) < 1e-5 and relerr(x['expected_fac'], g['expected_fac']) < 1e-5
+
+
+def test_ref_src_power_fft_and_fft_scan(golden):
+    """a14: `src_power_fft` (ofdm_cr_tools.py:173-192, with `sg.flattop` as SciPy <= 1.12 exported it) and
+    `fast_spectrum_scan(method='fft')` (:471-537) - the reference's own bodies."""
+    g = golden('ref_src_power_fft.npz')
+    x = golden(str(g['input_from']))['x']
+    Sf, N = int(g['Sf']), int(g['nfft'])
+    cs, sbw = float(g['channel_rate']), float(g['srch_bw'])
+    Fr = float(Sf) / N
+    bb = R.frange(-Sf / 2, Sf / 2, cs)
+    assert np.allclose(bb, g['bb_freqs'])
+    psd, ax, plc = R.src_power_fft(x[:N].astype(np.complex128), N, N, Fr, Sf, bb, sbw / Fr)
+    assert relerr(psd, g['expected_psd']) < RTOL and np.allclose(ax, g['expected_axis'], rtol=0, atol=1e-6)
+    assert np.allclose(plc, g['expected_plc'], rtol=1e-12)
+    lo, hi = (int(v) for v in g['short_range'])
+    psd, _, plc = R.src_power_fft(x[lo:hi].astype(np.complex128), hi - lo, N, Fr, Sf, bb, sbw / Fr)
+    assert relerr(psd, g['expected_psd_short']) < RTOL and np.allclose(plc, g['expected_plc_short'], rtol=1e-12)
+    thr, plc, ne, occ = R.fast_spectrum_scan(x[:N].astype(np.complex128), float(g['scan_fc']), cs, sbw, N, Sf, 'fft',
+                                             int(g['scan_thr_leveler']), float(g['scan_noise0']), float(g['scan_alpha']))
+    assert np.isclose(thr, float(g['scan_thr']), rtol=1e-12) and np.isclose(ne, float(g['scan_noise']), rtol=1e-12)
+    assert np.allclose(plc, g['scan_plc'], rtol=1e-12)
+    ax_ch = R.frange(float(g['scan_fc']) - Sf / 2, float(g['scan_fc']) + Sf / 2, cs)
+    assert [1.0 if a in occ else 0.0 for a in ax_ch] == list(g['scan_occupied'])
