@@ -1481,7 +1481,8 @@ static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec
         Timed tm(c);      // the whole push: transform kernel + cross-team reduction + state / rows
         HIPCHK(c, big ? launch_chain16k(N, a, h->rect, c->stream) : launch_seg(N, a, 2, false, c->stream));
         if (a.acc_mode != 3)
-            HIPCHK(c, launch_chain_tail(h->d_partial, groups ? h->d_tail : nullptr, (int)W, N, h->fftshift, a.acc_mode, a.acc_end,
+            HIPCHK(c, launch_chain_tail(h->d_partial, groups ? h->d_tail : nullptr, (int)W, N, big ? (N == 16384 ? 2 : 3) : 0,
+                                        h->fftshift, a.acc_mode, a.acc_end,
                                         h->alpha, h->kdb, h->d_iir, h->d_peak, h->d_rows, h->do_iir ? give : 0, rows_last,
                                         c->stream));
     }

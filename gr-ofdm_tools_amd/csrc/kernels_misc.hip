@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256) void chain_reduce_kernel(const float *partial,
 }
 
 struct ChainStateArgs {
-    const float *rows;      // [nrows][nfft] group rows (or the team rows), natural bin order
-    int nrows, nfft, fftshift, acc_mode;
+    const float *rows;      // [nrows][nfft] group rows (or the team rows); bin order by `layout` (bin_pos)
+    int nrows, nfft, fftshift, acc_mode, layout;
     long long nbase;
     float alpha, kdb;
     float *iir_state, *peak_state;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void chain_state_kernel(ChainStateArgs a) {
     red[slice][col * 4 + 3] = s3;
     __syncthreads();
     if (threadIdx.x >= POS) return;
-    const int k = blockIdx.x * POS + threadIdx.x;                                   // bin
+    const int k = bin_pos(blockIdx.x * POS + threadIdx.x, a.layout);                // bin held at this position of a row
     const int i = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;               // row position
     double t = 0.0;
     for (int q = 0; q < SLICES; ++q) t = mx ? fmax(t, red[q][threadIdx.x]) : t + red[q][threadIdx.x];
@@ -353,7 +353,7 @@ int chain_tail_groups(int W, int nfft) {
     return g < 1 ? 1 : g;
 }
 
-hipError_t launch_chain_tail(const float *partial, float *scratch, int W, int nfft, int fftshift, int acc_mode, long long nbase,
+hipError_t launch_chain_tail(const float *partial, float *scratch, int W, int nfft, int layout, int fftshift, int acc_mode, long long nbase,
                              float alpha, float kdb, float *iir_state, float *peak_state, const float *raw_rows,
                              long long nraw, float *rows_out, hipStream_t s) {
     ChainStateArgs a;
@@ -370,6 +370,7 @@ hipError_t launch_chain_tail(const float *partial, float *scratch, int W, int nf
     }
     const bool rows_apart = acc_mode == 1 && nraw > 8;
     a.nfft = nfft;
+    a.layout = layout;
     a.fftshift = fftshift;
     a.acc_mode = acc_mode;
     a.nbase = nbase;

@@ -152,7 +152,8 @@ hipError_t launch_segws(int nfft, const SegArgs &a, int det, hipStream_t s);
 // partial rows of a chain launch + the stored raw rows -> IIR / peak state and the rows handed back; `scratch` holds
 // chain_tail_groups(W, nfft) rows of nfft floats (0 rows: not needed)
 int chain_tail_groups(int W, int nfft);
-hipError_t launch_chain_tail(const float *partial, float *scratch, int W, int nfft, int fftshift, int acc_mode, long long nbase,
+// layout: bin order of the partial rows (kernels_misc.hip bin_pos: 0 natural, 2 / 3 welch16k order at 16384 / 8192)
+hipError_t launch_chain_tail(const float *partial, float *scratch, int W, int nfft, int layout, int fftshift, int acc_mode, long long nbase,
                              float alpha, float kdb, float *iir_state, float *peak_state, const float *raw_rows,
                              long long nraw, float *rows_out, hipStream_t s);
 hipError_t launch_set_flag(int *flag, int v, hipStream_t s);

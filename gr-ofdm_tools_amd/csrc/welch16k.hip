@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
 // chain16k: the fused periodogram chain (segfft.hip's CHAIN build) at 8192 / 16384 points - multichannel_scanner /
 // spectrum_sensor_v2 as a streaming block at BASELINE config 5's size (python/multichannel_scanner.py:78-86 takes any
 // fft_len).  Kept vectors are segments with step = keep_n N; window, shift, |X| or |X|^2 [x 1/N^2], IIR weighted sum /
-// peak max accumulated per workgroup (closed by chain_reduce / chain_state, kernels_misc.hip), rows stored only for
+// peak max accumulated per workgroup (closed by chain_reduce / chain_state, kernels_misc.hip; partial rows in this
+// kernel's own bin order, finalize layout 2 / 3), rows stored only for
 // s >= store_from.  The next segment is prefetched while this one is transformed (one workgroup per CU at 16384
 // points: without it all sixteen waves wait for their loads at the same barrier).
 // WINDOW = false: rectangular (the v2 / scanner chain passes `()` as its window, spectrum_sensor_v2.py:90) - no window
@@ -413,10 +414,13 @@ __global__ __launch_bounds__(256 * F, 4) void chain16k_kernel(SegArgs p) {
         if (sched == 0) break;
         cur += W;
     }
-    if (p.partial) {      // natural bin order, as chain_reduce_kernel / chain_state_kernel read it
-        float *dst = p.partial + ((size_t)stream * W + wg) * N;
+    if (p.partial) {
+        // the kernel's own order, contiguous per wave (bin k' + F (k0 + 16 k1 + 256 k2) at 4096 k' + 16 k0 + k1 + 256 k2:
+        // layout 2 / 3 of bin_pos, un-permuted by chain_state_kernel).  Natural-order 4-byte stores at a stride of 64
+        // floats cost 4 x their bytes in HBM writes at 16384 points (profiles: 70 MB against 16.8).
+        float *dst = p.partial + ((size_t)stream * W + wg) * N + 4096 * kp;
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) dst[kbase + 256 * F * k2] = acc[k2];
+        for (int k2 = 0; k2 < 16; ++k2) dst[256 * k2 + t] = acc[k2];
     }
 }
 
