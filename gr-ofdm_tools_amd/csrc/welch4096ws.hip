@@ -39,6 +39,12 @@
 #else
 #define OTH_WS_LOAD_HEAD(p) (*(p))
 #endif
+// 1: the producer keeps six pass-1 twiddle powers (W^1,2,3,4,8,12: nine products per segment instead of thirteen) and
+// pays for their eight registers by reading the second half of its window values from an 8 KiB LDS table per step
+// (same-box A/B, five interleaved runs each: 0.5855 against 0.5906 ms = -0.9 %, profiles/r03_ab_headline_pow6.txt)
+#ifndef OTH_WS_POW6
+#define OTH_WS_POW6 1
+#endif
 #ifndef OTH_WS_DIAG
 #define OTH_WS_DIAG 0        // 1: per-wave phase cycle counters behind the partial sums (tools/diag_ws.py)
 #endif
@@ -84,7 +90,8 @@ namespace {
 constexpr int TWS = 512;
 constexpr int WS_RED = 32;                 // float2: per image the four producer waves' segment sums (8 slots each)
 constexpr int WS_CTRL = 16;                // ints: item kind per image [0..1], next-chunk ticket [4]
-constexpr size_t WS_LDS_BYTES = (2 * LDS_X + WS_RED) * sizeof(float2) + WS_CTRL * sizeof(int);
+constexpr size_t WS_WIN_BYTES = OTH_WS_POW6 ? 256 * 2 * sizeof(float4) : 0;      // window values 8..15 of every producer thread
+constexpr size_t WS_LDS_BYTES = (2 * LDS_X + WS_RED) * sizeof(float2) + WS_CTRL * sizeof(int) + WS_WIN_BYTES;
 
 enum { ITEM_STOP = 0, ITEM_DATA = 1, ITEM_BUBBLE = 2 };
 
@@ -116,11 +123,21 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
     if (producer) {
         // ------------------------------------------------------------------ producer
         float win[16];
+#if OTH_WS_POW6
+        float4 *wl = reinterpret_cast<float4 *>(ctrl + WS_CTRL) + t;      // [2][256] float4: win[8..11], win[12..15]
+#pragma unroll
+        for (int a = 0; a < 8; ++a) win[a] = p.win[256 * a + t];
+        wl[0] = make_float4(p.win[256 * 8 + t], p.win[256 * 9 + t], p.win[256 * 10 + t], p.win[256 * 11 + t]);
+        wl[256] = make_float4(p.win[256 * 12 + t], p.win[256 * 13 + t], p.win[256 * 14 + t], p.win[256 * 15 + t]);
+        const float2 b1 = p.tw[t], b2 = p.tw[2 * t], b3 = p.tw[3 * t], b4 = p.tw[4 * t], b8 = p.tw[8 * t],
+                     b12 = p.tw[(12 * t) & 4095];
+#else
 #pragma unroll
         for (int a = 0; a < 16; ++a) win[a] = p.win[256 * a + t];
         // pass-1 twiddle seeds W4096^t, W4096^(4t): the fifteen twiddles are multiplied out per segment (keeping
         // even W^2, W^3, W^8, W^12 in registers as well spills at the 128-VGPR cap)
         const float2 b1 = p.tw[t], b4 = p.tw[4 * t];
+#endif
         float2 kw[8], nxt[8];
         float2 prev_new = make_float2(0.f, 0.f);     // this wave's sum of the previous segment's new half
         int it = 0;
@@ -171,6 +188,13 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             WS_STAMP(0);
 #endif
             float2 sumf = make_float2(0.f, 0.f), sum = make_float2(0.f, 0.f);
+#if OTH_WS_POW6
+            {
+                const float4 wa = wl[0], wb = wl[256];      // own slots: no barrier needed
+                win[8] = wa.x, win[9] = wa.y, win[10] = wa.z, win[11] = wa.w;
+                win[12] = wb.x, win[13] = wb.y, win[14] = wb.z, win[15] = wb.w;
+            }
+#endif
             if (FIRST) {
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {      // kw still holds the raw first half of the chunk's first segment
@@ -216,7 +240,11 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             dft16(v);
             WS_STAMP(2);
             __builtin_amdgcn_s_setprio(OTH_WS_PAS);
+#if OTH_WS_POW6
+            scatter_pow16_six<RS>(v, lx + w1, b1, b2, b3, b4, b8, b12);
+#else
             scatter_pow16<RS>(v, lx + w1, b1, b4);
+#endif
 #if OTH_WS_DIAG
             __builtin_amdgcn_s_waitcnt(0xC07F);
             WS_STAMP(3);
