@@ -122,7 +122,7 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
 
     if (producer) {
         // ------------------------------------------------------------------ producer
-        float win[16];
+        float win[OTH_WS_POW6 ? 8 : 16];
 #if OTH_WS_POW6
         float4 *wl = reinterpret_cast<float4 *>(ctrl + WS_CTRL) + t;      // [2][256] float4: win[8..11], win[12..15]
 #pragma unroll
@@ -189,11 +189,10 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
 #endif
             float2 sumf = make_float2(0.f, 0.f), sum = make_float2(0.f, 0.f);
 #if OTH_WS_POW6
-            {
-                const float4 wa = wl[0], wb = wl[256];      // own slots: no barrier needed
-                win[8] = wa.x, win[9] = wa.y, win[10] = wa.z, win[11] = wa.w;
-                win[12] = wb.x, win[13] = wb.y, win[14] = wb.z, win[15] = wb.w;
-            }
+            const float4 wa = wl[0], wb = wl[256];      // own slots: no barrier needed
+            const float wh[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};      // window values 8..15, this step only
+#else
+            const float *wh = win + 8;
 #endif
             if (FIRST) {
 #pragma unroll
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             for (int a = 0; a < 8; ++a) {      // the new half is windowed for both of its roles as it arrives
                 const float2 r = nxt[a];
                 v[a] = kw[a];
-                v[8 + a] = make_float2(r.x * win[8 + a], r.y * win[8 + a]);
+                v[8 + a] = make_float2(r.x * wh[a], r.y * wh[a]);
                 if (MODE == 0) kw[a] = make_float2(r.x * win[a], r.y * win[a]);      // (else kw is reloaded below)
                 sum = cadd(sum, r);
             }
