@@ -243,6 +243,9 @@ __global__ void set_flag_kernel(int *flag, int v) { *flag = v; }
 // block to finish reduces the group rows - with __threadfence() it took 60 us (an agent-scope release / acquire
 // writes back / invalidates the XCD's whole L2 from each of ~1000 workgroups), with agent-scope atomic stores / loads
 // for the group rows instead of fences 10-20 us.
+#ifndef OTH_CHAIN_TAIL_DIRECT
+#define OTH_CHAIN_TAIL_DIRECT 1
+#endif
 template <bool MAX>
 __global__ __launch_bounds__(256) void chain_reduce_kernel(const float *partial, float *scratch, int W, int nfft, int rows_per_group) {
     __shared__ double red[3][64][4];
@@ -345,6 +348,9 @@ __global__ __launch_bounds__(64) void chain_rows_kernel(int nfft, float alpha, f
 // rows of scratch the two-launch form needs for W team rows (0: the state kernel reads the team rows directly)
 int chain_tail_groups(int W, int nfft) {
     if (W <= 128) return 0;
+    // 8192 / 16384 points: the state kernel alone has 512 / 1024 workgroups and 8 / 4 team rows per thread - one launch
+    // instead of two (same-box A/B: -0.5 ... -1 % of the push; at 2048 / 4096 points the direct form is 1.4-4 % SLOWER)
+    if (OTH_CHAIN_TAIL_DIRECT && nfft >= 8192 && W <= 1536) return 0;
     // ~12 rows per group gives nfft / 256 x G ~ 1024 workgroups at every size; at most 256 groups, so that the state
     // kernel (nfft / 16 workgroups) never walks more than four rows per thread
     int g = (W + 11) / 12;
