@@ -277,8 +277,17 @@ __device__ __forceinline__ float wave_total_lane63(float v) {
     v = dpp_add<0x4E>(v);
     v = dpp_add<0x141>(v);
     v = dpp_add<0x140>(v);
+    // row_bcast:15 into rows 1, 3 and row_bcast:31 into rows 2, 3 as ONE masked add each: rows the mask leaves out
+    // keep their value.  Through __builtin_amdgcn_update_dpp(0, ...) + add the compiler emits v_mov 0, v_mov_dpp, v_add
+    // per step (the builtin's semantics give the other rows 0 first): 8 VALU instructions more per complex sum.  The
+    // s_nop covers the VALU-write -> DPP-read hazard, which the compiler does not see inside the asm.
+#ifdef OTH_WAVE_TOTAL_BUILTIN      // A/B switch: the form of rounds 1-2
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));   // row_bcast:31
+#else
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+#endif
     return v;
 }
 
