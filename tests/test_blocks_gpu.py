@@ -620,13 +620,16 @@ def test_long_stream_welch_and_coherence_through_the_hip_plans(ctx, golden):
         first, cnt, s0, k = sweep.time_shard(n, 4096, 2048, r, world)
         local = x[first:first + cnt].contiguous()
         part = torch.zeros(4096, dtype=torch.float32, device=dev)
+        sweep.torch_then_ctx(ctx, dev)       # `ctx` runs on its own stream: torch's copy and fill must have landed
         assert plan.partial_dev(local.data_ptr(), cnt, part.data_ptr()) == k
-        ctx.sync()
+        sweep.ctx_then_torch(ctx)
         total += part.to(torch.float64)
         count += k
     out = torch.empty(4096, dtype=torch.float32, device=dev)
-    plan.scale_dev(total.to(torch.float32).data_ptr(), count, out.data_ptr())
-    ctx.sync()
+    sums = total.to(torch.float32)
+    sweep.torch_then_ctx(ctx, dev)
+    plan.scale_dev(sums.data_ptr(), count, out.data_ptr())
+    sweep.ctx_then_torch(ctx)
     assert count == 31 and relerr(out.cpu().numpy(), want) < 2e-6
 
 
