@@ -117,6 +117,9 @@ namespace {
 // host chunks up to this size go through the pinned staging rings (work()-sized buffers: the copy is trivial and the
 // call returns at once); larger ones use the runtime's staged copy from pageable memory directly
 constexpr size_t kPinnedStageMax = 1u << 20;
+// a PINNED / registered source above this size is not copied into the ring (that would pin as much again): its DMA is
+// enqueued directly and the call waits for that one copy - the only case in which a push waits for the stream
+constexpr size_t kPinnedRingMax = 64u << 20;
 
 thread_local std::string g_err = "no error";
 
@@ -165,6 +168,18 @@ struct CtxGuard {
 
 int use_device(oth_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
+    return OTH_OK;
+}
+
+// H2D copy of a caller's host buffer that must be consumed before the call returns, without a ring slot
+int copy_in_and_wait(oth_ctx *c, void *dst, const void *src, size_t bytes) {
+    hipEvent_t ev = nullptr;
+    HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ev);
+    hipEventDestroy(ev);
+    if (e != hipSuccess) return fail(c, OTH_ERR_HIP, std::string("host copy: ") + hipGetErrorString(e));
     return OTH_OK;
 }
 
@@ -1108,7 +1123,10 @@ int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
     const size_t total = p->carry + nsamples;
     int rc = ensure_keep(c, &p->d_stream, &p->stream_cap, total * sizeof(float2), p->carry * sizeof(float2));
     if (rc) return rc;
-    if (nsamples * sizeof(float2) > kPinnedStageMax && !host_ptr_is_pinned(iq_host)) {
+    const bool pinned_src = nsamples * sizeof(float2) > kPinnedStageMax && host_ptr_is_pinned(iq_host);
+    if (pinned_src && nsamples * sizeof(float2) > kPinnedRingMax) {
+        if ((rc = copy_in_and_wait(c, p->d_stream + p->carry, iq_host, nsamples * sizeof(float2)))) return rc;
+    } else if (nsamples * sizeof(float2) > kPinnedStageMax && !pinned_src) {
         // large chunks: the runtime's own staged copy from pageable memory is faster than a host memcpy into a pinned
         // slot (55 against 33 GB/s at 32 MiB); it returns once the caller's buffer has been read.  (A pinned /
         // registered source would be read asynchronously: it takes the ring below whatever its size.)
@@ -1650,8 +1668,10 @@ int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uin
         HIPCHK(c, hipEventSynchronize(h->ev[slot]));      // only when the GPU is kRing pushes behind
     }
     const size_t bytes = nsamples * sizeof(float2);
-    const bool direct = bytes > kPinnedStageMax && !host_ptr_is_pinned(iq_host);      // the runtime stages pageable memory itself
-    if (!direct && h->h_in_cap[slot] < bytes) {
+    const bool pinned_src = bytes > kPinnedStageMax && host_ptr_is_pinned(iq_host);
+    const bool direct = bytes > kPinnedStageMax && !pinned_src;      // the runtime stages pageable memory itself
+    const bool wait_copy = pinned_src && bytes > kPinnedRingMax;
+    if (!direct && !wait_copy && h->h_in_cap[slot] < bytes) {
         if (h->h_in[slot]) HIPCHK(c, hipHostFree(h->h_in[slot]));
         h->h_in[slot] = nullptr;
         h->h_in_cap[slot] = 0;
@@ -1664,7 +1684,9 @@ int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uin
     if (nsamples) {
         if ((rc = ensure(c, &h->d_stage, &h->stage_cap, bytes))) return rc;
         if ((rc = ensure(c, &h->d_out, &h->out_cap, sizeof(float) * N))) return rc;
-        if (direct) {      // the runtime's staged copy returns once the caller's buffer has been read
+        if (wait_copy) {
+            if ((rc = copy_in_and_wait(c, h->d_stage, iq_host, bytes))) return rc;
+        } else if (direct) {      // the runtime's staged copy returns once the caller's buffer has been read
             HIPCHK(c, hipMemcpyAsync(h->d_stage, iq_host, bytes, hipMemcpyHostToDevice, c->stream));
         } else {
             memcpy(h->h_in[slot], iq_host, bytes);      // the scheduler's buffer dies when work() returns

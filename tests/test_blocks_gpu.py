@@ -589,6 +589,23 @@ def test_pinned_source_buffers_are_copied_before_the_call_returns(ctx):
         want = ctx.welch_plan(1024, window=None).exec(x)
         assert relerr(psd, want) < 1e-5
         plan.close()
+    # a pinned source past 64 MiB is not copied into the ring (that would pin as much again): its DMA is enqueued
+    # directly and the call waits for that copy alone
+    nbig = (72 << 20) // 8
+    big = torch.empty(nbig * 2, dtype=torch.float32).pin_memory()
+    bv = big.numpy().view(np.complex64)
+    bv[:] = np.resize(x, nbig)
+    plan = ctx.welch_plan(1024, window=None)
+    plan.accumulate(bv)
+    bv[:] = 0
+    psd = plan.finalize()
+    assert relerr(psd, ctx.welch_plan(1024, window=None).exec(np.resize(x, nbig))) < 1e-5
+    ch = ctx.chain(4096, None, True, 2, 1)
+    bv[:] = np.resize(x, nbig)
+    t = ch.push_async(bv)
+    bv[:] = 0
+    row, k = ch.wait(t)
+    assert k == nbig // 4096 and relerr(row, R.chain_sensor_v2(np.resize(x, nbig)[-4096 - nbig % 4096:][:4096], 4096)[0]) < 1e-3
 
 
 # ---- multi-GPU host paths on one GPU (world 1 and ranks simulated one after another) -------------------------
