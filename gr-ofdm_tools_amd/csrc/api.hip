@@ -467,7 +467,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     // wave-specialised pairs (csd4096ws.hip): 50 % overlap, frequency-domain detrend; "csd1" forces the one-role kernel
     const bool csd_ws = tuned_csd && p->step == 2048 && (p->detrend == OTH_DETREND_NONE || p->d_fd) &&
                         nseg < (1LL << 30) && p->tune_variant != "csd1";
-    const bool tuned_16k = !csd && (p->nfft == 16384 || p->nfft == 8192) && p->nperseg == p->nfft &&
+    const bool tuned_16k = !csd && (p->nfft == 16384 || p->nfft == 8192) &&
+                           (p->nperseg == p->nfft || p->nperseg * 4 == p->nfft) &&      // (nfft / 4: the sweeper's zero padding)
                            p->kernel != OTH_KERNEL_GENERIC;
     // segfft.hip: nperseg = nfft = 256 / 512 / 1024 / 2048, any step (team of nfft / 16 threads per segment)
     // ... and zero-padded segments nperseg = nfft / 4 (the sweeper's call, spectrum_sweeper.py:263) or nfft / 2 at 1024 / 2048

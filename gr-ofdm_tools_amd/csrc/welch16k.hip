@@ -108,8 +108,12 @@ __device__ __forceinline__ void transform16k(float2 (&v)[16], const float2 (&wt)
 // (X -= mean FFT(w) on the two bins of each thread the window's spectrum reaches, WelchArgs.fd - as welch4096ws.hip;
 // the mean is then needed only at the end of the step, which is what lets the 16384-point build keep the
 // overlapped half in registers: with DET = 1 it spilled 18 registers and loaded every sample twice).
-template <int DET, int F, bool HALF>
+// PAD: nperseg = N / 4 zero-padded to N (the sweeper's call at these sizes, spectrum_sweeper.py:263): samples only at
+// a' = 0, j < 4 - four loads per thread, the rest compile-time zeros (the window array is zero-extended, so the
+// detrended, windowed padding is exactly 0 as well); the mean is over nperseg.  Whole-segment loads, any step.
+template <int DET, int F, bool HALF, bool PAD = false>
 __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
+    static_assert(!PAD || (!HALF && DET != 2), "zero-padded build: whole-segment loads, time-domain detrend");
     constexpr bool DETREND = DET != 0;
     constexpr int T16 = 256 * F, N = 4096 * F, NJ = 16 / F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -184,8 +188,12 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int a = 0; a < F; ++a) {
-                        v[F * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
-                        sum = cadd(sum, v[F * j + a]);
+                        if (PAD && (a != 0 || j >= 4)) {
+                            v[F * j + a] = make_float2(0.f, 0.f);
+                        } else {
+                            v[F * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
+                            sum = cadd(sum, v[F * j + a]);
+                        }
                     }
             }
             float2 mean = make_float2(0.f, 0.f);
@@ -249,7 +257,8 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
                     prev_tot = tot;
                     tot = both;
                 }
-                mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
+                constexpr float inv = 1.0f / (PAD ? N / 4 : N);      // mean over nperseg
+                mean = make_float2(tot.x * inv, tot.y * inv);
             }
             if (DET != 2) {
 #pragma unroll
@@ -443,17 +452,19 @@ hipError_t launch_chain16k(int nfft, const SegArgs &a, bool rect, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
-template <int DET, int F, bool HALF> hipError_t launch16k(const WelchArgs &a, hipStream_t s) {
+template <int DET, int F, bool HALF, bool PAD = false> hipError_t launch16k(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
     constexpr size_t lds = lds16_bytes<F>();
-    const void *fn = reinterpret_cast<const void *>(welch16k_kernel<DET, F, HALF>);
+    const void *fn = reinterpret_cast<const void *>(welch16k_kernel<DET, F, HALF, PAD>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((welch16k_kernel<DET, F, HALF>), grid, dim3(256 * F), lds, s, a);
+    hipLaunchKernelGGL((welch16k_kernel<DET, F, HALF, PAD>), grid, dim3(256 * F), lds, s, a);
     return hipGetLastError();
 }
 
 template <int F> hipError_t launch16k_f(const WelchArgs &a, hipStream_t s) {
+    if (a.nperseg * 4 == 4096 * F)      // zero-padded segments
+        return a.detrend ? launch16k<1, F, false, true>(a, s) : launch16k<0, F, false, true>(a, s);
     // 50 % overlap: the overlapped half stays in registers.  With a detrend that needs the frequency-domain form at
     // 16384 points (a.fd: the window's spectrum is confined); a window without the table loads whole segments there.
     if (a.step == 2048 * F) {

@@ -1030,12 +1030,12 @@ def test_seg_welch_vs_oracle_and_generic(ctx, hip, nfft, build):
             ctx.free(ptr)
 
 
-@pytest.mark.parametrize('nfft', [1024, 2048])
-@pytest.mark.parametrize('frac', [4, 2])
+@pytest.mark.parametrize('nfft,frac', [(1024, 4), (1024, 2), (2048, 4), (2048, 2), (8192, 4), (16384, 4)])
 def test_seg_zero_padded_segments_vs_oracle_and_generic(ctx, hip, nfft, frac):
     """nperseg = nfft / 4 zero-padded to nfft - the sweeper's `_src_power` call for the fft_len a flowgraph passes
     (spectrum_sweeper.py:263: welch(flattop, nperseg=nFFT/4.0, nfft=nFFT)) - and nperseg = nfft / 2, on the
-    team-per-segment kernel with compile-time zero rows: against the float64 oracle (flattop, detrend, 50 % overlap of
+    team-per-segment kernel (1024 / 2048) and the workgroup-per-segment kernel (8192 / 16384, nfft / 4 only) with
+    compile-time zero rows: against the float64 oracle (flattop, detrend, 50 % overlap of
     nperseg, fftshift + dB as the sweeper does; other steps; a DC offset 30 x the noise), then device-resident against
     the coverage kernel over segment counts around chunk and grid multiples."""
     nps = nfft // frac

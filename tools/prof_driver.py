@@ -80,7 +80,7 @@ elif cfg in ('w1024', 'w2048', 'w512', 'w256', 'w8192', 'w16384'):
     plan = ctx.welch_plan(N, window=hann(N), fs=1.0)
     run = lambda: plan.exec_dev(d, n, o)      # noqa: E731
     nbytes = 8 * n
-elif cfg in ('p1024', 'p2048'):      # the sweeper's call at these sizes: flattop, nperseg = nfft / 4 zero-padded, 50 % overlap
+elif cfg in ('p1024', 'p2048', 'p8192', 'p16384'):      # the sweeper's call at these sizes: flattop, nperseg = nfft / 4 zero-padded, 50 % overlap
     N = int(cfg[1:])
     n = 1 << (log2n or 27)
     d, o = dev(n * 8), dev(N * 4)
