@@ -286,6 +286,7 @@ struct ChainStateArgs {
     const float *rows;      // [nrows][nfft] group rows (or the team rows); bin order by `layout` (bin_pos)
     int nrows, nfft, fftshift, acc_mode, layout;
     long long nbase;
+    double decay;           // (1 - alpha)^nbase, computed on the host (a device pow() in double is a long routine)
     float alpha, kdb;
     float *iir_state, *peak_state;
     const float *raw_rows;  // [nraw][nfft] row order
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void chain_state_kernel(ChainStateArgs a) {
         return;
     }
     float y = a.iir_state[i];
-    if (a.nbase > 0) y = (float)((double)y * pow(1.0 - (double)a.alpha, (double)a.nbase) + (double)a.alpha * t);
+    if (a.nbase > 0) y = (float)((double)y * a.decay + (double)a.alpha * t);
     for (long long r = 0; r < a.nraw; ++r) {
         y = fmaf(a.alpha, a.raw_rows[(size_t)r * a.nfft + i], (1.0f - a.alpha) * y);
         a.rows_out[(size_t)r * a.nfft + i] = 10.0f * log10f(y) + a.kdb;
@@ -380,6 +381,7 @@ hipError_t launch_chain_tail(const float *partial, float *scratch, int W, int nf
     a.fftshift = fftshift;
     a.acc_mode = acc_mode;
     a.nbase = nbase;
+    a.decay = nbase > 0 ? pow(1.0 - (double)alpha, (double)nbase) : 1.0;
     a.alpha = alpha;
     a.kdb = kdb;
     a.iir_state = iir_state;
