@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,7 @@ struct oth_plan {
     float *d_win = nullptr;
     const float2 *d_tw = nullptr;
     float4 *d_fd = nullptr;            // window spectrum for the frequency-domain detrend (welch4096ws), or nullptr
+    bool exact_detrend = false;        // OTH_DETREND_CONSTANT_EXACT: time-domain detrend only (d_fd stays nullptr)
     float *d_partial = nullptr;
     size_t partial_cap = 0;
     int last_W = 0;
@@ -123,6 +125,9 @@ constexpr size_t kPinnedRingMax = 64u << 20;
 
 thread_local std::string g_err = "no error";
 
+// fewest segments per stream for which the frequency-domain detrend builds are chosen (run_average)
+constexpr long long kFdMinSegments = 8;
+
 // A host buffer the runtime can DMA from directly (hipHostMalloc / hipHostRegister'd, e.g. a torch pinned tensor or a
 // registered scheduler buffer): hipMemcpyAsync from it returns before the bytes are read, so the "input valid only
 // during the call" contract of work() needs a copy that has finished when the call returns.  Pageable memory is
@@ -165,6 +170,29 @@ struct CtxGuard {
         if (e_ != hipSuccess)                                                                           \
             return fail((c), OTH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
+
+// The exception barrier of the C ABI (include/ofdm_tools_hip.h: "nothing throws or aborts").  Every extern "C" body
+// sits between OTH_TRY and OTH_CATCH(context): a std::bad_alloc (std::vector / std::string growth), a
+// std::system_error (the context's recursive mutex) or anything else a C++ runtime call may raise becomes an error
+// code + last-error text instead of std::terminate() inside the host's ctypes call.  The handlers themselves must not
+// throw: the text is stored through fail_nothrow().
+int fail_nothrow(oth_ctx *c, int code, const char *what) noexcept {
+    try {
+        if (c)
+            c->err = what;
+        else
+            g_err = what;
+    } catch (...) {
+    }
+    return code;
+}
+
+#define OTH_TRY try {
+#define OTH_CATCH(ctxexpr)                                                                                     \
+    }                                                                                                          \
+    catch (const std::bad_alloc &) { return fail_nothrow((ctxexpr), OTH_ERR_NOMEM, "out of host memory"); }    \
+    catch (const std::exception &e_) { return fail_nothrow((ctxexpr), OTH_ERR_INTERNAL, e_.what()); }          \
+    catch (...) { return fail_nothrow((ctxexpr), OTH_ERR_INTERNAL, "unknown C++ exception"); }
 
 int use_device(oth_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
@@ -283,8 +311,8 @@ const W4096Variant kVariants[] = {
     {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp, 8, 1, false},            // any step
     {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe, 16, 1, false},        // step 2048 (50 % overlap)
     {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 20, 1, true},     // step 2048, confined window spectrum
-    {"ws2", launch_welch_tuned4096_ws2, tuned4096_blocks_per_cu_ws2, 20, 2, true},  // the same in one 1024-thread workgroup per CU (A/B)
 #ifdef OTH_EXPERIMENTS
+    {"ws2", launch_welch_tuned4096_ws2, tuned4096_blocks_per_cu_ws2, 20, 2, true},  // the same in one 1024-thread workgroup per CU (A/B, +7 %)
     {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16, 1, false},      // stamped build (tools/diag_stamps.py)
     {"exp1", launch_welch_tuned4096_exp1, tuned4096_blocks_per_cu_exp1, 16, 1, false},
     {"exp2", launch_welch_tuned4096_exp2, tuned4096_blocks_per_cu_exp2, 16, 1, false},
@@ -296,15 +324,22 @@ const W4096Variant kVariants[] = {
     {"wsx4", launch_welch_tuned4096_wsx4, tuned4096_blocks_per_cu_wsx4, 32, 1, true},
 #endif
 };
+// the three shipped builds are looked up by tag, never by position: the table is edited between rounds
+const W4096Variant *variant_by_tag(const char *tag) {
+    for (const auto &v : kVariants)
+        if (!strcmp(v.tag, tag)) return &v;
+    return &kVariants[0];
+}
 const W4096Variant *w4096_variant(int step, bool fd_ok, const std::string &want) {
-    const W4096Variant *pick = (step == 2048) ? (fd_ok ? &kVariants[2] : &kVariants[1]) : &kVariants[0];
+    const W4096Variant *const dpp = variant_by_tag("dpp"), *const pipe = variant_by_tag("pipe"), *const ws = variant_by_tag("ws");
+    const W4096Variant *pick = (step == 2048) ? (fd_ok ? ws : pipe) : dpp;
     if (!want.empty())
         for (const auto &v : kVariants)
             if (want == v.tag) pick = &v;
     // the wave-specialised build detrends in the frequency domain: only with a confined window spectrum
-    if (pick->fd && !fd_ok) pick = &kVariants[1];
+    if (pick->fd && !fd_ok) pick = pipe;
     // the pipelined builds keep the overlapped half in registers: only for step = nperseg / 2
-    if (pick != &kVariants[0] && step != 2048) pick = &kVariants[0];
+    if (pick != dpp && step != 2048) pick = dpp;
     return pick;
 }
 
@@ -461,11 +496,20 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     if (segments(p, nsamples, &nseg) != OTH_OK)
         return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
     const bool csd = (y != nullptr);
+    // Which detrend form.  The role-split / half-keeping builds remove the segment mean AFTER the transform,
+    // FFT((x - m) w) = FFT(x w) - m FFT(w): the fp32 transform then carries the rounding of a DC line m sum(w) into bins
+    // 0, +-1 that the time-domain form never sees - per segment about 1e-7 * sqrt(nfft) * |m| / sigma relative to the
+    // detrended power (measured: tests/test_hip_parity.py::test_detrend_forms_few_segments_and_large_dc).
+    // Averaging takes it down by sqrt(nseg), so launches with fewer than kFdMinSegments segments per stream - which do
+    // not need those builds' throughput either - take the time-domain builds.  A variant forced through
+    // oth_plan_set_tuning (parity suite, A/B tools) is honoured; "td" forces the time-domain builds at any length.
+    const bool fd_forced = !p->tune_variant.empty() && p->tune_variant != "td";
+    const float4 *fd_tab = (p->d_fd && p->tune_variant != "td" && (fd_forced || nseg >= kFdMinSegments)) ? p->d_fd : nullptr;
     // welch4096 covers nperseg = 256, 512, ..., 4096 (zero-padded to 4096)
     bool tuned = p->nfft == 4096 && p->nperseg >= 256 && (p->nperseg & (p->nperseg - 1)) == 0 && !csd;
     const bool tuned_csd = csd && p->nfft == 4096 && p->nperseg == 4096 && p->kernel != OTH_KERNEL_GENERIC;
     // wave-specialised pairs (csd4096ws.hip): 50 % overlap, frequency-domain detrend; "csd1" forces the one-role kernel
-    const bool csd_ws = tuned_csd && p->step == 2048 && (p->detrend == OTH_DETREND_NONE || p->d_fd) &&
+    const bool csd_ws = tuned_csd && p->step == 2048 && (p->detrend == OTH_DETREND_NONE || fd_tab) &&
                         nseg < (1LL << 30) && p->tune_variant != "csd1";
     const bool tuned_16k = !csd && (p->nfft == 16384 || p->nfft == 8192) &&
                            (p->nperseg == p->nfft || p->nperseg * 4 == p->nfft) &&      // (nfft / 4: the sweeper's zero padding)
@@ -481,18 +525,18 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     // frequency domain at 2048 (needs the window-spectrum table); "seg3" / "seg4" force the one-role builds
     const int seg_det = p->detrend == OTH_DETREND_NONE ? 0 : (p->nfft == 1024 ? 1 : 2);
     const bool seg_ws = tuned_seg && !seg_pad && p->nfft >= 1024 && seg_kind == 0 && p->tune_variant != "seg3" && !seg_wps4 &&
-                        (seg_det != 2 || p->d_fd != nullptr);
+                        (seg_det != 2 || fd_tab != nullptr);
     if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
     if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd && !tuned_16k && !tuned_seg)
         return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
     const W4096Variant *var =
         tuned ? w4096_variant(p->nperseg == 4096 ? p->step : 0,
-                              (p->detrend == OTH_DETREND_NONE || p->d_fd) && nseg < (1LL << 30),   // ws: 32-bit segment indices
+                              (p->detrend == OTH_DETREND_NONE || fd_tab) && nseg < (1LL << 30),   // ws: 32-bit segment indices
                               p->tune_variant)
               : nullptr;
     // "ws2" cuts the stream into two equal runs of segments: an odd count (or a single segment) stays on "ws"
     const bool two_runs = var && !strcmp(var->tag, "ws2");
-    if (two_runs && (nseg < 2 || (nseg & 1))) var = &kVariants[2];
+    if (two_runs && (nseg < 2 || (nseg & 1))) var = variant_by_tag("ws");
     const bool ws2 = var && !strcmp(var->tag, "ws2");
     const long long nseg_run = ws2 ? nseg / 2 : nseg;      // segments the schedule of one run covers
     int W = generic_wg(c, p->nfft, nseg, nstreams);
@@ -533,7 +577,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.tail_chunk = 1;
     a.nbig = 0;
     a.queue = nullptr;
-    a.fd = p->d_fd;
+    a.fd = fd_tab;
     if (tuned || tuned_csd || tuned_16k || tuned_seg) {
         a.sched = p->tune_sched >= 0 ? p->tune_sched : p->sched;
         // one 1024-thread workgroup per CU and equal work per segment: contiguous runs beat the ticket queue (+3 %)
@@ -605,7 +649,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         g.tail_chunk = a.tail_chunk;
         g.nbig = a.nbig;
         g.queue = a.queue;
-        g.fd = p->d_fd;
+        g.fd = fd_tab;
         Timed tm(c);
         HIPCHK(c, seg_pad ? launch_seg_padded(p->nfft, p->nperseg, g, seg_kind, c->stream)
                           : (seg_ws ? launch_segws(p->nfft, g, seg_det, c->stream) : launch_seg(p->nfft, g, seg_kind, seg_wps4, c->stream)));
@@ -650,13 +694,15 @@ const char *oth_strerror(int code) {
         case OTH_ERR_INVALID: return "invalid argument";
         case OTH_ERR_HIP: return "HIP runtime error / no usable GPU";
         case OTH_ERR_UNSUPPORTED: return "unsupported size or mode";
-        case OTH_ERR_NOMEM: return "out of device memory";
+        case OTH_ERR_NOMEM: return "out of memory (device or host)";
         case OTH_ERR_STATE: return "invalid call order";
+        case OTH_ERR_INTERNAL: return "internal error (C++ exception caught at the ABI)";
         default: return "unknown error";
     }
 }
 
 int oth_device_count(int *count) {
+    OTH_TRY
     if (!count) return fail(nullptr, OTH_ERR_INVALID, "count is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -666,6 +712,7 @@ int oth_device_count(int *count) {
     }
     *count = n;
     return OTH_OK;
+    OTH_CATCH(nullptr)
 }
 
 static int ctx_create(int device_id, void *stream, bool adopt, oth_ctx **out) {
@@ -707,12 +754,19 @@ static int ctx_create(int device_id, void *stream, bool adopt, oth_ctx **out) {
     return OTH_OK;
 }
 
-int oth_ctx_create(int device_id, oth_ctx **out) { return ctx_create(device_id, nullptr, false, out); }
+int oth_ctx_create(int device_id, oth_ctx **out) {
+    OTH_TRY
+    return ctx_create(device_id, nullptr, false, out);
+    OTH_CATCH(nullptr)
+}
 int oth_ctx_create_on_stream(int device_id, void *hip_stream, oth_ctx **out) {
+    OTH_TRY
     return ctx_create(device_id, hip_stream, true, out);
+    OTH_CATCH(nullptr)
 }
 
 int oth_ctx_destroy(oth_ctx *c) {
+    OTH_TRY
     if (!c) return OTH_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
@@ -732,32 +786,40 @@ int oth_ctx_destroy(oth_ctx *c) {
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 const char *oth_last_error(oth_ctx *c) { return c ? c->err.c_str() : g_err.c_str(); }
 
 int oth_ctx_sync(oth_ctx *c) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_ctx_device_name(oth_ctx *c, char *buf, size_t buflen) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !buf || !buflen) return fail(c, OTH_ERR_INVALID, "bad argument");
     std::snprintf(buf, buflen, "%s", c->name.c_str());
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_ctx_set_timing(oth_ctx *c, int enable) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
     c->timing = enable != 0;
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_ctx_get_timing(oth_ctx *c, double *total_ms, uint64_t *launches, int reset) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -775,53 +837,65 @@ int oth_ctx_get_timing(oth_ctx *c, double *total_ms, uint64_t *launches, int res
         c->launches = 0;
     }
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_dev_alloc(oth_ctx *c, size_t bytes, void **dptr) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !dptr) return fail(c, OTH_ERR_INVALID, "bad argument");
     if (use_device(c)) return OTH_ERR_HIP;
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
     if (e != hipSuccess) return fail(c, OTH_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_dev_free(oth_ctx *c, void *dptr) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c) return fail(nullptr, OTH_ERR_INVALID, "ctx is NULL");
     if (!dptr) return OTH_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(dptr));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_memcpy_h2d(oth_ctx *c, void *dst, const void *src, size_t bytes) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !dst || !src) return fail(c, OTH_ERR_INVALID, "bad argument");
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_memcpy_d2h(oth_ctx *c, void *dst, const void *src, size_t bytes) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !dst || !src) return fail(c, OTH_ERR_INVALID, "bad argument");
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_synth_iq(oth_ctx *c, void *iq_dev, size_t nsamples, uint64_t seed, int ntones, const float *tone_amp,
                  const float *tone_freq, float dc_re, float dc_im) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !iq_dev || ntones < 0 || ntones > 8 || (ntones && (!tone_amp || !tone_freq)))
         return fail(c, OTH_ERR_INVALID, "bad argument (at most 8 tones)");
     if (use_device(c)) return OTH_ERR_HIP;
     HIPCHK(c, launch_synth((float2 *)iq_dev, nsamples, seed, ntones, tone_amp, tone_freq, dc_re, dc_im, c->stream));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_stream_read_probe(oth_ctx *c, const void *dptr, size_t bytes, int repeats, double *ms_per_pass) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !dptr || bytes < 16 || repeats == 0 || !ms_per_pass) return fail(c, OTH_ERR_INVALID, "bad argument");
     if (use_device(c)) return OTH_ERR_HIP;
@@ -843,9 +917,11 @@ int oth_stream_read_probe(oth_ctx *c, const void *dptr, size_t bytes, int repeat
     hipEventDestroy(b);
     *ms_per_pass = (double)ms / repeats;
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_iq_power(oth_ctx *c, const void *iq_dev, size_t nsamples, double *mean_re, double *mean_im, double *var) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !iq_dev || !nsamples) return fail(c, OTH_ERR_INVALID, "bad argument");
     if (use_device(c)) return OTH_ERR_HIP;
@@ -859,12 +935,14 @@ int oth_iq_power(oth_ctx *c, const void *iq_dev, size_t nsamples, double *mean_r
     if (mean_im) *mean_im = mi;
     if (var) *var = h[2] / nsamples - (mr * mr + mi * mi);
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 /* ---- Welch ---------------------------------------------------------------- */
 
 int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float *window, int detrend, int scaling,
                    double fs, int fftshift, int trim_bins, oth_plan **out) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !out) return fail(c, OTH_ERR_INVALID, "ctx/out is NULL");
     *out = nullptr;
@@ -872,8 +950,10 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
         return fail(c, OTH_ERR_UNSUPPORTED, "nfft must be a power of two in [64, 16384]");
     if (nperseg < 1 || nperseg > nfft) return fail(c, OTH_ERR_INVALID, "need 1 <= nperseg <= nfft");
     if (noverlap < 0 || noverlap >= nperseg) return fail(c, OTH_ERR_INVALID, "need 0 <= noverlap < nperseg");
-    if (detrend != OTH_DETREND_NONE && detrend != OTH_DETREND_CONSTANT)
+    if (detrend != OTH_DETREND_NONE && detrend != OTH_DETREND_CONSTANT && detrend != OTH_DETREND_CONSTANT_EXACT)
         return fail(c, OTH_ERR_INVALID, "unknown detrend");
+    const bool exact_detrend = detrend == OTH_DETREND_CONSTANT_EXACT;
+    if (exact_detrend) detrend = OTH_DETREND_CONSTANT;      // the kernels know two forms of one operation
     if (scaling < OTH_SCALE_RAW || scaling > OTH_SCALE_SPECTRUM) return fail(c, OTH_ERR_INVALID, "unknown scaling");
     if (trim_bins < 0 || 2 * trim_bins >= nfft) return fail(c, OTH_ERR_INVALID, "trim_bins out of range");
     if (!(fs > 0.0)) return fail(c, OTH_ERR_INVALID, "fs must be positive");
@@ -886,6 +966,7 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     p->noverlap = noverlap;
     p->step = nperseg - noverlap;
     p->detrend = detrend;
+    p->exact_detrend = exact_detrend;
     p->scaling = scaling;
     p->fs = fs;
     p->fftshift = fftshift != 0;
@@ -917,7 +998,7 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_win, w.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_sum, 0, sizeof(float) * nfft, c->stream);
     std::vector<float> fd;
-    if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT &&
+    if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT && !exact_detrend &&
         ((nfft == 4096 && nperseg == 4096 && window_spectrum_table(w, fd)) ||
          (nfft == 2048 && nperseg == 2048 && window_spectrum_table_seg(w, nfft, fd)) ||
          ((nfft == 8192 || nfft == 16384) && nperseg == nfft && window_spectrum_table_16k(w, nfft, fd)))) {
@@ -932,9 +1013,11 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     }
     *out = p;
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_plan_destroy(oth_plan *p) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return OTH_OK;
     oth_ctx *c = p->ctx;
@@ -954,32 +1037,40 @@ int oth_plan_destroy(oth_plan *p) {
     }
     delete p;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_plan_set_output_db(oth_plan *p, int enable) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     p->db = enable != 0;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_plan_set_kernel(oth_plan *p, int which) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     if (which < OTH_KERNEL_AUTO || which > OTH_KERNEL_TUNED) return fail(p->ctx, OTH_ERR_INVALID, "unknown kernel id");
     p->kernel = which;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_plan_set_schedule(oth_plan *p, int which) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     if (which < OTH_SCHED_CONTIGUOUS || which > OTH_SCHED_DYNAMIC) return fail(p->ctx, OTH_ERR_INVALID, "unknown schedule");
     p->sched = which;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, int tail_chunk) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     if (sched < -1 || sched > OTH_SCHED_DYNAMIC || chunk < 0 || tail_chunk < 0)
@@ -995,17 +1086,21 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
     p->tune_chunk = chunk;
     p->tune_tail = tail_chunk;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_plan_out_len(oth_plan *p, int *n) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p || !n) return fail(p ? p->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
     *n = p->nfft - 2 * p->trim;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_welch_exec_dev(oth_plan *p, const void *iq_dev, size_t nsamples, int nstreams, size_t stream_stride,
                        float *psd_out_dev, uint64_t *nseg_out) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1032,6 +1127,7 @@ int oth_welch_exec_dev(oth_plan *p, const void *iq_dev, size_t nsamples, int nst
     if (int frc = finalize_and_rearm(c, f, nstreams)) return frc;
     if (nseg_out) *nseg_out = (uint64_t)nseg;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 static int stage_host(oth_plan *p, const void *x, const void *y, size_t nsamples, const float2 **dx, const float2 **dy) {
@@ -1050,6 +1146,7 @@ static int stage_host(oth_plan *p, const void *x, const void *y, size_t nsamples
 
 int oth_welch_exec(oth_plan *p, const void *iq, size_t nsamples, int src_is_device, float *psd_out,
                    uint64_t *nseg_out) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1065,9 +1162,11 @@ int oth_welch_exec(oth_plan *p, const void *iq, size_t nsamples, int src_is_devi
     HIPCHK(c, hipMemcpyAsync(psd_out, p->d_out, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_welch_partial_dev(oth_plan *p, const void *iq_dev, size_t nsamples, float *sum_out_dev, uint64_t *nseg_out) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1090,9 +1189,11 @@ int oth_welch_partial_dev(oth_plan *p, const void *iq_dev, size_t nsamples, floa
     if (int frc = finalize_and_rearm(c, f, 1)) return frc;
     if (nseg_out) *nseg_out = (uint64_t)nseg;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_welch_scale_dev(oth_plan *p, const float *sum_dev, uint64_t nseg_total, float *psd_out_dev) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1101,9 +1202,11 @@ int oth_welch_scale_dev(oth_plan *p, const float *sum_dev, uint64_t nseg_total, 
     HIPCHK(c, launch_scale(sum_dev, psd_out_dev, p->nfft, p->scale / (double)nseg_total, p->fftshift, p->trim, p->db,
                            c->stream));
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_welch_reset(oth_plan *p) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1112,9 +1215,11 @@ int oth_welch_reset(oth_plan *p) {
     p->nseg_total = 0;
     p->carry = 0;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1190,9 +1295,11 @@ int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
     }
     p->carry = keep;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_welch_finalize(oth_plan *p, float *psd_out, uint64_t *nseg_out) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1208,6 +1315,7 @@ int oth_welch_finalize(oth_plan *p, float *psd_out, uint64_t *nseg_out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (nseg_out) *nseg_out = p->nseg_total;
     return oth_welch_reset(p);
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 // Averaging launch + cross-workgroup reduction of the two-channel path.  raw: unscaled sums in natural
@@ -1241,6 +1349,7 @@ static int csd_run(oth_plan *p, const float2 *dx, const float2 *dy, size_t nsamp
 
 int oth_csd_exec_dev(oth_plan *p, const void *x_dev, const void *y_dev, size_t nsamples, float *pxx_dev,
                      float *pyy_dev, float *pxy_dev, float *cxy_dev, uint64_t *nseg_out) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1250,10 +1359,12 @@ int oth_csd_exec_dev(oth_plan *p, const void *x_dev, const void *y_dev, size_t n
     if (use_device(c)) return OTH_ERR_HIP;
     return csd_run(p, (const float2 *)x_dev, (const float2 *)y_dev, nsamples, false, pxx_dev, pyy_dev, pxy_dev,
                    cxy_dev, nseg_out);
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_csd_partial_dev(oth_plan *p, const void *x_dev, const void *y_dev, size_t nsamples, float *sums_out_dev,
                         uint64_t *nseg_out) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1263,10 +1374,12 @@ int oth_csd_partial_dev(oth_plan *p, const void *x_dev, const void *y_dev, size_
     const int N = p->nfft;
     return csd_run(p, (const float2 *)x_dev, (const float2 *)y_dev, nsamples, true, sums_out_dev, sums_out_dev + N,
                    sums_out_dev + 2 * N, nullptr, nseg_out);
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_csd_scale_dev(oth_plan *p, const float *sums_dev, uint64_t nseg_total, float *pxx_dev, float *pyy_dev,
                       float *pxy_dev, float *cxy_dev) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1275,10 +1388,12 @@ int oth_csd_scale_dev(oth_plan *p, const float *sums_dev, uint64_t nseg_total, f
     HIPCHK(c, launch_csd_scale(sums_dev, p->nfft, p->scale / (double)nseg_total, p->fftshift, p->trim, pxx_dev,
                                pyy_dev, pxy_dev, cxy_dev, c->stream));
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 int oth_csd_exec(oth_plan *p, const void *x, const void *y, size_t nsamples, int src_is_device, float *pxx,
                  float *pyy, float *pxy, float *cxy, uint64_t *nseg_out) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     oth_ctx *c = p->ctx;
@@ -1299,12 +1414,14 @@ int oth_csd_exec(oth_plan *p, const void *x, const void *y, size_t nsamples, int
     if (cxy) HIPCHK(c, hipMemcpyAsync(cxy, o3, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 /* ---- periodogram chain ------------------------------------------------------ */
 
 int oth_chain_create(oth_ctx *c, int nfft, const float *window, int fftshift, int epilogue, int keep_one_in_n,
                      oth_chain **out) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !out) return fail(c, OTH_ERR_INVALID, "ctx/out is NULL");
     *out = nullptr;
@@ -1346,9 +1463,11 @@ int oth_chain_create(oth_ctx *c, int nfft, const float *window, int fftshift, in
     }
     *out = h;
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_chain_destroy(oth_chain *h) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return OTH_OK;
     oth_ctx *c = h->ctx;
@@ -1371,41 +1490,51 @@ int oth_chain_destroy(oth_chain *h) {
     }
     delete h;
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_chain_set_keep_one_in_n(oth_chain *h, int n) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     if (n < 1) return fail(h->ctx, OTH_ERR_INVALID, "keep_one_in_n must be >= 1");
     h->keep_n = h->count = n;   // keep_one_in_n::set_n restarts the count
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_chain_set_iir_log(oth_chain *h, float alpha, float k_db) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     h->do_iir = alpha > 0.f;
     h->alpha = alpha;
     h->kdb = k_db;
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_chain_set_peak_hold(oth_chain *h, int enable) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     h->do_peak = enable != 0;
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_chain_set_kernel(oth_chain *h, int which) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     if (which < OTH_KERNEL_AUTO || which > OTH_KERNEL_TUNED) return fail(h->ctx, OTH_ERR_INVALID, "unknown kernel id");
     h->kernel = which;
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_chain_reset(oth_chain *h) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     oth_ctx *c = h->ctx;
@@ -1417,6 +1546,7 @@ int oth_chain_reset(oth_chain *h) {
     h->leftover = 0;
     h->count = h->keep_n;
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 // The fused path (segfft.hip): FFT + epilogue + IIR / peak accumulation in one launch over all kept vectors, a
@@ -1608,6 +1738,7 @@ static int chain_feed(oth_chain *h, const float2 *src, size_t nsamples, float *r
 
 int oth_chain_push_dev(oth_chain *h, const void *iq_dev, size_t nsamples, float *rows_out_dev, size_t rows_capacity,
                        uint64_t *nrows_out) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     oth_ctx *c = h->ctx;
@@ -1616,10 +1747,12 @@ int oth_chain_push_dev(oth_chain *h, const void *iq_dev, size_t nsamples, float 
     if (!nsamples) return OTH_OK;
     if (use_device(c)) return OTH_ERR_HIP;
     return chain_feed(h, (const float2 *)iq_dev, nsamples, rows_out_dev, rows_out_dev ? rows_capacity : 0, nrows_out);
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_chain_push(oth_chain *h, const void *iq, size_t nsamples, int src_is_device, float *rows_out,
                    size_t rows_capacity, uint64_t *nrows_out) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     oth_ctx *c = h->ctx;
@@ -1647,11 +1780,13 @@ int oth_chain_push(oth_chain *h, const void *iq, size_t nsamples, int src_is_dev
     HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller's buffer and rows_out are the caller's again
     if (nrows_out) *nrows_out = nrows;
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 // sync_block.work() form: copy the scheduler's buffer into a pinned slot, enqueue H2D + kernels + the D2H of the
 // latest row, record an event and return.  The watcher collects the row with oth_chain_poll / oth_chain_wait.
 int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uint64_t *ticket_out) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     oth_ctx *c = h->ctx;
@@ -1703,6 +1838,7 @@ int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uin
     h->next_ticket = ticket + 1;
     *ticket_out = ticket;
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 static int chain_collect(oth_chain *h, uint64_t ticket, float *row_out, uint64_t *nrows_out, int *ready, bool wait) {
@@ -1723,13 +1859,16 @@ static int chain_collect(oth_chain *h, uint64_t ticket, float *row_out, uint64_t
 }
 
 int oth_chain_poll(oth_chain *h, uint64_t ticket, float *row_out, uint64_t *nrows_out, int *ready) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h || !ready) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
     *ready = 0;
     return chain_collect(h, ticket, row_out, nrows_out, ready, false);
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_chain_wait(oth_chain *h, uint64_t ticket, float *row_out, uint64_t *nrows_out) {
+    OTH_TRY
     // the wait itself runs WITHOUT the context lock: work() on the scheduler thread must be able to enqueue meanwhile
     hipEvent_t ev = nullptr;
     {
@@ -1745,9 +1884,11 @@ int oth_chain_wait(oth_chain *h, uint64_t ticket, float *row_out, uint64_t *nrow
     CtxGuard guard_(h->ctx);
     int ready = 0;
     return chain_collect(h, ticket, row_out, nrows_out, &ready, false);
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_chain_ticket_rows(oth_chain *h, uint64_t ticket, uint64_t *nrows_out) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h || !nrows_out) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
     const int slot = (int)(ticket % oth_chain::kRing);
@@ -1755,27 +1896,33 @@ int oth_chain_ticket_rows(oth_chain *h, uint64_t ticket, uint64_t *nrows_out) {
         return fail(h->ctx, OTH_ERR_STATE, "ticket unknown or overwritten (the ring keeps the last 4 pushes: latest wins)");
     *nrows_out = h->nrows_of[slot];
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_chain_get_peak(oth_chain *h, float *peak_out) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h || !peak_out) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
     oth_ctx *c = h->ctx;
     HIPCHK(c, hipMemcpyAsync(peak_out, h->d_peak, sizeof(float) * h->nfft, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_chain_get_iir(oth_chain *h, float *lin_out) {
+    OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h || !lin_out) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
     oth_ctx *c = h->ctx;
     HIPCHK(c, hipMemcpyAsync(lin_out, h->d_iir, sizeof(float) * h->nfft, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
 }
 
 int oth_rows_group_mean(oth_ctx *c, const float *rows_host, size_t nrows, int nfft, int group, float *out_host) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !rows_host || !out_host || nfft < 1 || group < 1 || nrows < (size_t)group)
         return fail(c, OTH_ERR_INVALID, "bad argument");
@@ -1790,12 +1937,14 @@ int oth_rows_group_mean(oth_ctx *c, const float *rows_host, size_t nrows, int nf
     HIPCHK(c, hipMemcpyAsync(out_host, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 int oth_channel_power(oth_ctx *c, const float *psd_host, int nfft, double srch_bins, int nch, const int *lo,
                       const int *hi, float *power_out, float *movavg_out) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !psd_host || !lo || !hi || !power_out || nfft < 1 || nch < 1 || !(srch_bins >= 1.0))
         return fail(c, OTH_ERR_INVALID, "bad argument (srch_bins must be >= 1)");
@@ -1819,10 +1968,12 @@ int oth_channel_power(oth_ctx *c, const float *psd_host, int nfft, double srch_b
         HIPCHK(c, hipMemcpyAsync(movavg_out, d + o_maf, sizeof(float) * nfft, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_bin_threshold(oth_ctx *c, const float *psd_host, int nrows, int nfft, double srch_bins, float thr_leveler,
                       unsigned char *mask_out, float *noise_out) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !psd_host || !mask_out || nrows < 1 || nfft < 1 || !(srch_bins >= 1.0))
         return fail(c, OTH_ERR_INVALID, "bad argument (srch_bins must be >= 1)");
@@ -1840,6 +1991,7 @@ int oth_bin_threshold(oth_ctx *c, const float *psd_host, int nrows, int nfft, do
         HIPCHK(c, hipMemcpyAsync(noise_out, d + o_noise, sizeof(float) * nrows, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 // Decision stage of the batched scanner on PSD rows that are already in HBM (BASELINE config 5): one launch
@@ -1848,6 +2000,7 @@ int oth_bin_threshold(oth_ctx *c, const float *psd_host, int nrows, int nfft, do
 int oth_scan_decide_dev(oth_ctx *c, const float *psd_rows_dev, int nrows, int nfft, double srch_bins, float thr_leveler,
                         int nch, const int *lo, const int *hi, unsigned char *mask_out, float *noise_out,
                         float *power_out) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !psd_rows_dev || nrows < 1 || nfft < 1 || nch < 0 || !(srch_bins >= 1.0) || (nch && (!lo || !hi || !power_out)))
         return fail(c, OTH_ERR_INVALID, "bad argument (srch_bins must be >= 1)");
@@ -1875,11 +2028,13 @@ int oth_scan_decide_dev(oth_ctx *c, const float *psd_rows_dev, int nrows, int nf
         HIPCHK(c, hipMemcpyAsync(power_out, d + o_pw, sizeof(float) * nrows * nch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_scan_decide_dev_out(oth_ctx *c, const float *psd_rows_dev, int nrows, int nfft, double srch_bins, float thr_leveler,
                             int nch, const int *lo, const int *hi, unsigned char *mask_dev, float *noise_dev,
                             float *power_dev) {
+    OTH_TRY
     CtxGuard guard_(c);
     if (!c || !psd_rows_dev || !noise_dev || nrows < 1 || nfft < 1 || nch < 0 || !(srch_bins >= 1.0) ||
         (nch && (!lo || !hi || !power_dev)))
@@ -1901,6 +2056,7 @@ int oth_scan_decide_dev_out(oth_ctx *c, const float *psd_rows_dev, int nrows, in
                                  (const int *)(d + o_hi), (double *)(d + o_ma), mask_dev, noise_dev, nch ? power_dev : nullptr,
                                  c->stream));
     return OTH_OK;
+    OTH_CATCH(c)
 }
 
 static int xcorr_impl(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, int L, float *out, int mode) {
@@ -1923,12 +2079,15 @@ static int xcorr_impl(oth_ctx *c, const void *a, size_t na, const void *b, size_
 }
 
 int oth_xcorr(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, int L, float *out) {
+    OTH_TRY
     CtxGuard guard_(c);
     return xcorr_impl(c, a, na, b, nb, L, out, 0);
+    OTH_CATCH(c)
 }
 
 // Not part of the ABI (not in the header): raw bytes behind the partial sums (diagnostic kernel builds).
 int oth__debug_tail(oth_plan *p, void *out, size_t nbytes, int *nwg) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p || !out || !nwg) return OTH_ERR_INVALID;
     oth_ctx *c = p->ctx;
@@ -1937,10 +2096,12 @@ int oth__debug_tail(oth_plan *p, void *out, size_t nbytes, int *nwg) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *nwg = p->last_W;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 // Not part of the ABI (not in the header): reads the per-workgroup stamps of the diagnostic kernel build.
 int oth__debug_stamps(oth_plan *p, unsigned long long *out, int max_wg, int *nwg) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p || !out || !nwg) return OTH_ERR_INVALID;
     oth_ctx *c = p->ctx;
@@ -1951,10 +2112,12 @@ int oth__debug_stamps(oth_plan *p, unsigned long long *out, int max_wg, int *nwg
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *nwg = n;
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
 }
 
 // Not part of the ABI: raw bytes of the plan's partial-sum buffer from a float offset on (diagnostic builds' stamps).
 int oth__debug_partial_raw(oth_plan *p, size_t float_offset, void *out, size_t nbytes) {
+    OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p || !out) return OTH_ERR_INVALID;
     oth_ctx *c = p->ctx;
@@ -1962,11 +2125,31 @@ int oth__debug_partial_raw(oth_plan *p, size_t float_offset, void *out, size_t n
     HIPCHK(c, hipMemcpyAsync(out, p->d_partial + float_offset, nbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
+}
+
+// Not part of the ABI: raises inside the barrier so that a host without a GPU can check it (tests/test_abi_cpu.py).
+// kind 0 = std::bad_alloc, 1 = std::runtime_error, 2 = a non-std exception, 3 = a real over-sized std::vector.
+int oth__debug_throw(oth_ctx *c, int kind) {
+    OTH_TRY
+    CtxGuard guard_(c);
+    if (kind == 0) throw std::bad_alloc();
+    if (kind == 1) throw std::runtime_error("debug: runtime_error");
+    if (kind == 2) throw 42;
+    if (kind == 3) {
+        std::vector<double> v;
+        v.resize(v.max_size());          // std::length_error or std::bad_alloc, whichever the runtime raises first
+        return (int)v.size();
+    }
+    return OTH_OK;
+    OTH_CATCH(c)
 }
 
 int oth_fac(oth_ctx *c, const void *data, size_t n, int L, float *out) {
+    OTH_TRY
     CtxGuard guard_(c);
     return xcorr_impl(c, data, n, nullptr, 0, L, out, 1);
+    OTH_CATCH(c)
 }
 
 }  // extern "C"

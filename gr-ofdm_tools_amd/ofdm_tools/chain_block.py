@@ -24,17 +24,30 @@ from .gr_compat import LossyQueue
 
 
 def _watch_loop(ref, queue):
-    """Watcher thread body (the reference's _queue_watcher.run loops, e.g. spectrum_sensor_v2.py:395-414)."""
+    """Watcher thread body (the reference's _queue_watcher.run loops, e.g. spectrum_sensor_v2.py:395-414).
+    Counters: ``_queued`` is written only by the thread that calls work(), ``_done`` only by this thread - one writer
+    each, so the plain ``+=`` needs no lock; drain() only reads them.  An item taken off the queue always counts as
+    done, whether it was processed, discarded because the block has stopped, or failed: drain() must never wait for a
+    vector nobody will look at.  A failure in ``_collect`` / ``_on_vector`` (a logger's disk, a scanner's state, a HIP
+    error other than "lost against newer vectors") is kept in ``_watch_error`` and raised by the next work() or
+    drain() on the stream side - with threaded=False the same error would have come straight out of work(); the
+    watcher itself carries on with the next vector, as the reference's loops do after their prints."""
     while True:
         item = queue.delete_head(timeout=0.05)
         blk = ref()
-        if blk is None or not blk.keep_running:
+        if blk is None:
             return
         if item is not None:
             try:
-                blk._collect(item)
+                if blk.keep_running:
+                    blk._collect(item)
+            except Exception as e:
+                blk._watch_error = e
+                blk.watch_errors += 1
             finally:
                 blk._done += 1
+        if not blk.keep_running:
+            return
         del blk
 
 
@@ -46,6 +59,8 @@ class ChainBlockMixin(object):
         self.keep_running = True
         self.vectors_lost = 0            # tickets the ring had already recycled when the watcher got to them
         self._queued = self._done = 0    # tickets handed to / finished by the watcher thread (drain())
+        self._watch_error = None         # last exception of the watcher thread, re-raised on the stream side
+        self.watch_errors = 0
         self.rows_total = 0              # PSD vectors the chain has produced so far (all work() calls)
         self.vector_rows_end = self.vector_nrows = 0
         self._watch_thread = None
@@ -55,7 +70,13 @@ class ChainBlockMixin(object):
             self._watch_thread.start()
 
     # -- gr.sync_block ----------------------------------------------------------------------------
+    def _raise_watch_error(self):
+        if self._watch_error is not None:
+            e, self._watch_error = self._watch_error, None
+            raise RuntimeError('%s: the watcher thread failed on a vector: %r' % (type(self).__name__, e)) from e
+
     def work(self, input_items, output_items):
+        self._raise_watch_error()
         in0 = input_items[0]
         ticket = self._chain.push_async(in0)          # returns after enqueue; the GPU works behind it
         self.last_ticket = ticket
@@ -86,11 +107,13 @@ class ChainBlockMixin(object):
         vector's effects; never called from work()).  -> True when idle."""
         import time
         end = time.monotonic() + timeout
-        while self._threaded and time.monotonic() < end:
+        while self._threaded and self.keep_running and self._watch_thread is not None and time.monotonic() < end:
             if self._done >= self._queued:
-                return True
+                break
             time.sleep(0.001)
-        return not self._threaded or self._done >= self._queued
+        self._raise_watch_error()
+        # a stopped block has no watcher: whatever is still queued will never be looked at, nothing is pending
+        return not self._threaded or not self.keep_running or self._done >= self._queued
 
     def stop(self):
         self.keep_running = False

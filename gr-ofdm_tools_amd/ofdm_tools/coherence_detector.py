@@ -47,6 +47,7 @@ class coherence_detector(sync_block):
         self.ax_ch = np.array(range(-(N // 2), N // 2)) * self.Fr + tune_freq             # :188
         self.n_chans = len(self.subject_channels)
         self.idx_subject_channels = [find_nearest_index(self.ax_ch, ch) for ch in self.subject_channels]
+        self._idx = np.array(self.idx_subject_channels, dtype=np.intp)
         self.subject_channels_coherence = [0] * self.n_chans
 
     def set_subject_channels_outcome(self, outcome):
@@ -62,20 +63,24 @@ class coherence_detector(sync_block):
             self.scanner(v[0][n - 1], v[1][n - 1], v[2][n - 1])        # last vector of the call (:236-241)
         return n
 
+    def _pair_sums(self, vector):
+        """Sum of bins [idx - 1, idx] per subject channel (the slice ``[ch-1:ch+1]`` of coherence_detector.py:259-261).
+        Python slice rules at the left edge are kept: idx 0 gives the slice [-1:1], which is empty -> 0."""
+        idx = self._idx
+        v = np.asarray(vector)
+        return np.where(idx > 0, v[idx - 1] + v[idx], v.dtype.type(0))
+
     def scanner(self, data, data1, data2):
-        """coherence_detector.py:254-274."""
-        outcome = [0] * self.n_chans
-        for j, channel in zip(range(self.n_chans), self.idx_subject_channels):
-            coherence = data[(channel - 1):(channel + 1)].sum()
-            mtmL = data1[(channel - 1):(channel + 1)].sum()
-            mtmR = data2[(channel - 1):(channel + 1)].sum()
-            self.subject_channels_coherence[j] = coherence
-            if coherence > self.threshold and mtmL < self.threshold_mtm and mtmR < self.threshold_mtm:
-                outcome[j] = 1
-                self.valve_callback(0)
-            else:
-                outcome[j] = 0.1
-                self.valve_callback(1)
+        """Decision stage of coherence_detector.py:254-274 for all subject channels at once: the detector fires where
+        the coherence pair sum is above ``threshold`` while both MTM pair sums stay below ``threshold_mtm``; outcome
+        1 where it fires, 0.1 elsewhere; the valve is driven once per channel, in channel order, 0 = fired."""
+        coh = self._pair_sums(data)
+        fired = (coh > self.threshold) & (self._pair_sums(data1) < self.threshold_mtm) \
+            & (self._pair_sums(data2) < self.threshold_mtm)
+        self.subject_channels_coherence = list(coh)
+        for hit in fired:
+            self.valve_callback(0 if hit else 1)
+        outcome = [1 if hit else 0.1 for hit in fired]
         self.set_subject_channels_outcome(outcome)
         return outcome
 

@@ -2,7 +2,12 @@
 
 ``work()`` keeps the latest ``block_length`` samples (:71-75); a PDU request on
 ``PDU from_cogeng`` (:77-120) runs ``fast_spectrum_scan`` ('SC' -> 'thre', 'nois', 'cons') or the
-PAPR probe ('PAPR' -> 'papr') and answers on ``PDU spect_msg``.  Constructor as :37."""
+PAPR probe ('PAPR' -> 'papr') and answers on ``PDU spect_msg``.  Constructor as :37.
+``log=True`` keeps the reference's request log (:59-62,:96-120): ``/tmp/ss_log-<yymmdd>-<HHMMSS>``, one
+``Time,<HHMMSS>,<field>,<value>`` line per answered quantity."""
+import os
+import time
+
 import numpy as np
 
 from . import _hip
@@ -10,9 +15,27 @@ from .gr_compat import HAVE_GNURADIO, sync_block, to_msg
 from .ofdm_cr_tools import fast_spectrum_scan
 
 
+class _RequestLog(object):
+    """The CSV the reference writes when ``log`` is set: a header line with the block's geometry (:59-62), then per
+    request ``Time,<HHMMSS>,<field>,<value>`` rows (:96-120).  Every row is flushed: the reference leaves the file to
+    interpreter exit, which loses the tail of a campaign that is killed."""
+
+    def __init__(self, directory, clock=None):
+        self._clock = clock or (lambda fmt: time.strftime(fmt))
+        self.path = os.path.join(directory, 'ss_log' + '-' + self._clock('%y%m%d') + '-' + self._clock('%H%M%S'))
+        self._fh = open(self.path, 'w')
+
+    def row(self, *fields):
+        self._fh.write(','.join(['Time', self._clock('%H%M%S')] + [str(f) for f in fields]) + '\n')
+        self._fh.flush()
+
+    def close(self):
+        self._fh.close()
+
+
 class spectrum_sensor(sync_block):
     def __init__(self, block_length, sample_rate=1, fft_len=1, channel_space=1, search_bw=1, method='fft',
-                 thr_leveler=10, tune_freq=0, alpha_avg=1, source=None, log=False, ctx=None):
+                 thr_leveler=10, tune_freq=0, alpha_avg=1, source=None, log=False, ctx=None, log_dir='/tmp'):
         sync_block.__init__(self, 'spectrum_sensor', [np.complex64], None)
         self.block_length = block_length
         self.sample_rate = sample_rate
@@ -31,6 +54,11 @@ class spectrum_sensor(sync_block):
         self.alpha_avg = alpha_avg
         self.source = source
         self.log = log
+        self.log_file = None
+        if self.log:                                                                    # :59-62
+            self.log_file = _RequestLog(log_dir)
+            self.log_file.row('sample_rate', sample_rate, 'channel_space', channel_space, 'channel_bw', search_bw,
+                              'tune_freq', tune_freq)
         self.ctx = ctx
         self.message_port_register_out('PDU spect_msg')
         self.message_port_register_in('PDU from_cogeng')
@@ -50,13 +78,23 @@ class spectrum_sensor(sync_block):
         if data == 'PAPR':
             self.set_papr(self.get_vector_sample())
             self.send_msg('papr', self.get_papr())
+            if self.log:                                                                # :96-98
+                self.log_file.row('tune_freq', self.get_tune_freq())
+                self.log_file.row('papr', self.get_papr())
         elif data == 'SC':
             self.set_spectrum_constraint_hz(self.get_vector_sample())
             self.send_msg('thre', self.get_threshold())
             self.send_msg('nois', self.get_noise_estimate())
             self.send_msg('cons', self.get_spectrum_constraint_hz())
+            if self.log:                                                                # :113-117
+                self.log_file.row('tune_freq[Hz]', self.get_tune_freq())
+                self.log_file.row('threshold[dB]', 10 * np.log10(self.get_threshold() + 1e-20))
+                self.log_file.row('noise[dB]', 10 * np.log10(self.get_noise_estimate() + 1e-20))
+                self.log_file.row('spectrum_constraint[Hz]', self.get_spectrum_constraint_hz())
         else:
             self.send_msg('unkn', 'received unknown request')
+            if self.log:                                                                # :120
+                self.log_file.row('received unknown request')
 
     def send_msg(self, meta, data):
         self.message_port_pub('PDU spect_msg', to_msg(meta, data))

@@ -103,6 +103,11 @@ class spectrum_sensor_v2(ChainBlockMixin, sync_block):
                 # (:304-322): one row per group of sens_per_sec vectors, counted over ALL vectors the chain produced
                 # (the ones a lagging watcher dropped included).  The kept vector is the group's last; when that is
                 # not the last vector of its work() call, the call's last vector (at most nrows - 1 later) stands in.
+                # One row per work() call at most, also when the call spans two or more groups: the reference's
+                # message_sink packs every kept vector of a scheduler call into ONE message and waterfall_watcher.run
+                # decodes only its last item (:308-313), so there too a burst of kept vectors logs a single row and
+                # the skipped groups are never made up (tests: test_waterfall_block_end_to_end, the chunk that spans
+                # several groups).
                 group = self.vector_rows_end // max(1, int(self.sens_per_sec))
                 if group > self._waterfall_group:
                     self._waterfall_group = group

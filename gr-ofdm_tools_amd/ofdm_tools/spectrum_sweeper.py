@@ -8,10 +8,22 @@ welch(flattop, nperseg=nFFT/4, nfft=nFFT) -> fftshift -> trim excess_bins -> 10 
 one HIP plan; concatenate; blend with psd_old (re-initialised each sweep, :213); pack ``<f``;
 fragment.  ``sweep_once_sharded`` runs the same sweep with one segment per rank and an
 all-gather (ofdm_tools.sweep).
+
+Threads.  The reference starts ``data_colector`` and ``spectrum_stitcher`` from ``__init__``
+(:99-105); the stitcher waits 2 s and then sweeps for as long as the flowgraph lives (:207-231),
+with ``set_tune_delay`` / ``set_average`` forwarded to it (:110-112,:142-144).  Here ``work()`` IS
+the collector (it stores the kept vector directly, no queue to pop) and ``_stitch_loop`` is the
+stitcher: a daemon thread started by the constructor (``threaded=True``, the default) that calls
+``sweep_once()`` until ``stop()``.  It reads ``tune_delay`` / ``average`` from the block on every
+retune, so the setters reach it without forwarding.  ``start_sharded`` runs the rank-local form
+of the same loop (one process per GPU): this rank retunes and captures only its own segments,
+the all-gather of sweep i overlaps the kernels of sweep i + 1 (``sweep.SweepPipeline``).
 """
 import math
 import struct
+import threading
 import time
+import weakref
 
 import numpy as np
 
@@ -29,9 +41,34 @@ def frange(x, y, jump):
     return out
 
 
+def _stitch_loop(ref, wake, start_delay, one_sweep, collective):
+    """spectrum_stitcher.run (:207-231): the start-up wait (:208), then sweep after sweep while keep_running.
+    The thread holds the block only weakly, so a block that is dropped without stop() takes its stitcher along;
+    ``wake`` ends both the start-up wait and a tune-delay sleep early when stop() is called.  A ``collective`` loop
+    (start_sharded) never leaves on its own rank's flag - the other ranks would wait for it in the next gather for
+    ever - but only when one_sweep() reports what the ranks agreed on."""
+    if start_delay > 0 and wake.wait(start_delay) and not collective:
+        return
+    while True:
+        blk = ref()
+        if blk is None or not (blk.keep_running or collective):
+            return
+        try:
+            more = one_sweep(blk)
+            blk.sweeps_done += 1
+            if collective and not more:
+                blk.keep_running = False
+                return
+        except Exception as e:                       # a dead stitcher must not go unnoticed: work() re-raises it
+            blk._stitch_error = e
+            blk.keep_running = False
+            return
+        del blk
+
+
 class spectrum_sweeper(sync_block):
     def __init__(self, rf_receiver, receiver_type, fft_len, sample_rate, trunc_sample_rate, fstart, ffinish,
-                 rate, average, t_obs, tune_delay, max_tu, ctx=None):
+                 rate, average, t_obs, tune_delay, max_tu, ctx=None, threaded=True, start_delay=2.0):
         sync_block.__init__(self, 'spectrum_sweeper', [np.complex64], None)
         self.rf_receiver = rf_receiver
         self.receiver_type = receiver_type
@@ -68,9 +105,95 @@ class spectrum_sweeper(sync_block):
                                          fs=float(self.sample_rate), fftshift=True, trim_bins=self.excess_bins,
                                          db=True)
         self.psd = None
+        self._threads_init()
+        if threaded:
+            self.start(start_delay)
+
+    # -- threads (:99-105) --------------------------------------------------------
+    def _threads_init(self):
+        self.keep_running = True
+        self.sweeps_done = 0
+        self.captures = 0                 # vectors work() has stored (what data_colector would have set)
+        self._stitch_error = None
+        self._stitch_thread = None
+        self._wake = threading.Event()
+
+    def _launch(self, start_delay, one_sweep, collective=False):
+        if self._stitch_thread is not None:
+            raise RuntimeError('spectrum_sweeper: the stitcher is already running')
+        self.keep_running = True
+        self._wake.clear()
+        self._stitch_thread = threading.Thread(target=_stitch_loop, daemon=True,
+                                               args=(weakref.ref(self), self._wake, start_delay, one_sweep, collective))
+        self._stitch_thread.start()
+        return True
+
+    def start(self, start_delay=2.0):
+        """Start the stitcher thread (the constructor does, as spectrum_sweeper.py:103-105; the 2 s are :208)."""
+        return self._launch(start_delay, lambda blk: blk.sweep_once(sleep=blk._sleep))
+
+    def start_sharded(self, capture, rank, world, device, group=None, start_delay=0.0, publish_rank=None,
+                      sweeps=None):
+        """The stitcher loop of one rank of a sharded sweeper (one process per GPU): sweep after
+        sweep through ``sweep.SweepPipeline`` - this rank retunes ITS receiver to its own segments only
+        (``capture(i, f)`` returns what it then observed), the gather of a sweep overlaps the next sweep's kernels,
+        and the stitched PSD of the sweep before is blended and sent while those run.  ``publish_rank`` = the rank
+        whose 'pdus' port carries the frames (None: every rank's, each process has its own flowgraph).
+        Ending: a collective that one rank has left never completes, so the ranks agree once per sweep (a one-word
+        MIN all-reduce of keep_running, world > 1 only) and all leave after the same sweep - ``stop()`` on ANY rank,
+        or ``sweeps`` reached, ends the loop everywhere; the last gathered sweep is still published."""
+        state = {'n': 0}
+
+        def one_sweep(blk):
+            if 'pipe' not in state:
+                state['pipe'] = blk._sharded_pipeline(rank, world, device, group)
+            pipe = state['pipe']
+            slot = blk._sharded_sweep(pipe, capture, device)
+            state['n'] += 1
+            more = blk._agree_to_continue(sweeps is None or state['n'] < sweeps, world, device, group)
+            publish = publish_rank is None or publish_rank == rank
+            prev = state.get('slot')
+            state['slot'] = slot
+            if prev is not None and publish:
+                blk._blend_and_send(pipe.wideband(prev).cpu().numpy().astype(np.float64))
+            if not more:
+                if publish:
+                    blk._blend_and_send(pipe.wideband(slot).cpu().numpy().astype(np.float64))
+                pipe.drain()
+            return more
+        return self._launch(start_delay, one_sweep, collective=True)
+
+    def _agree_to_continue(self, mine, world, device, group=None):
+        mine = bool(mine and self.keep_running)
+        if world == 1:
+            return mine
+        import torch
+        import torch.distributed as dist
+        flag = torch.tensor([1.0 if mine else 0.0], dtype=torch.float32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(flag.item() > 0.5)
+
+    def stop(self):
+        self.keep_running = False
+        self._wake.set()
+        t, self._stitch_thread = self._stitch_thread, None
+        if t is not None and t is not threading.current_thread():
+            t.join(5.0)
+        return True
+
+    def _sleep(self, seconds):
+        # time.sleep(self.tune_delay) of :219, cut short by stop()
+        if seconds > 0:
+            self._wake.wait(seconds)
+
+    def _check_stitcher(self):
+        if getattr(self, '_stitch_error', None) is not None:
+            e, self._stitch_error = self._stitch_error, None
+            raise RuntimeError('spectrum_sweeper: the stitcher thread died: %r' % (e,)) from e
 
     # -- flowgraph side -----------------------------------------------------------
     def work(self, input_items, output_items):
+        self._check_stitcher()
         in0 = input_items[0]
         buf = np.concatenate((self._partial, in0)) if len(self._partial) else np.asarray(in0)
         n = self.vector_probe_pts
@@ -95,6 +218,7 @@ class spectrum_sweeper(sync_block):
 
     def set_samples(self, samples):
         self.samples = samples
+        self.captures = getattr(self, 'captures', 0) + 1
 
     def set_rate(self, rate):
         self.rate = rate
@@ -140,16 +264,21 @@ class spectrum_sweeper(sync_block):
             self.message_port_pub('pdus', pdu(frame))
         return psd
 
+    def _tune(self, f):
+        try:
+            self.rf_receiver.set_center_freq(f, 0)
+        except Exception:
+            print('cant tune receiver')
+
     def sweep_once(self, sleep=time.sleep):
         """One iteration of spectrum_stitcher.run (:211-231)."""
         psd = np.array([])
         for f in self.tune_frequencies:
-            try:
-                self.rf_receiver.set_center_freq(f, 0)
-            except Exception:
-                print('cant tune receiver')
+            self._tune(f)
             sleep(self.tune_delay)
             psd = np.concatenate((psd, self._src_power(self.get_samples())), axis=0)
+            if not getattr(self, 'keep_running', True):      # stop() during a sweep: nothing half-stitched goes out
+                return None
         return self._blend_and_send(psd)
 
     def sweep_once_sharded(self, capture, rank, world, device, group=None):
@@ -160,22 +289,47 @@ class spectrum_sweeper(sync_block):
         comes back to the host, for the PDU fragments."""
         import torch
         from . import sweep
-        device = torch.device(device)
-        if device.type != 'cuda':
-            raise ValueError('sweep_once_sharded computes on the GPU: pass the rank\'s cuda device')
+        device = self._cuda_device(device)
         nbins = self.fft_len - 2 * self.excess_bins
-
-        def compute(iq, out_row):
-            if not torch.is_tensor(iq):
-                iq = torch.from_numpy(np.ascontiguousarray(iq, np.complex64).view(np.float32)).to(device)
-            nsamples = iq.numel() // 2 if iq.dtype == torch.float32 else iq.numel()
-            # a context on its own stream: torch's copy / the caller's producer kernels / the zero fill of the row
-            # buffer must have landed before the plan reads and writes them, and the plan must be done before the
-            # all-gather (torch's stream) reads the row
-            sweep.torch_then_ctx(self.ctx, device)
-            self._plan.exec_dev(iq.data_ptr(), nsamples, out_row.data_ptr())
-            sweep.ctx_then_torch(self.ctx)
-
-        wide = sweep.sweep_psd(lambda i: capture(i, self.tune_frequencies[i]), compute,
+        wide = sweep.sweep_psd(lambda i: capture(i, self.tune_frequencies[i]),
+                               lambda iq, out_row: self._segment_to_row(iq, out_row, device),
                                len(self.tune_frequencies), nbins, device, rank, world, group)
         return self._blend_and_send(wide.cpu().numpy().astype(np.float64))
+
+    @staticmethod
+    def _cuda_device(device):
+        import torch
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise ValueError('the sharded sweep computes on the GPU: pass the rank\'s cuda device')
+        return device
+
+    def _segment_to_row(self, iq, out_row, device):
+        """One captured segment -> its dB row of the gather buffer (device in, device out)."""
+        import torch
+        from . import sweep
+        device = self._cuda_device(device)
+        if not torch.is_tensor(iq):
+            iq = torch.from_numpy(np.ascontiguousarray(iq, np.complex64).view(np.float32)).to(device)
+        nsamples = iq.numel() // 2 if iq.dtype == torch.float32 else iq.numel()
+        # a context on its own stream: torch's copy / the caller's producer kernels / the zero fill of the row
+        # buffer must have landed before the plan reads and writes them, and the plan must be done before the
+        # all-gather (torch's stream) reads the row
+        sweep.torch_then_ctx(self.ctx, device)
+        self._plan.exec_dev(iq.data_ptr(), nsamples, out_row.data_ptr())
+        sweep.ctx_then_torch(self.ctx)
+
+    def _sharded_pipeline(self, rank, world, device, group=None, depth=2):
+        from . import sweep
+        return sweep.SweepPipeline(len(self.tune_frequencies), self.fft_len - 2 * self.excess_bins, device, rank,
+                                   world, group, depth)
+
+    def _sharded_sweep(self, pipe, capture, device):
+        """This rank's share of one sweep: retune to each of its segments, wait tune_delay, take the capture, run
+        the plan into the pipeline's row; then start the gather.  -> the pipeline slot to read the sweep from."""
+        def compute(i, out_row):
+            f = self.tune_frequencies[i]
+            self._tune(f)
+            self._sleep(self.tune_delay)
+            self._segment_to_row(capture(i, f), out_row, device)
+        return pipe.run(compute)

@@ -364,6 +364,53 @@ def worker_fragments(fft_data, max_tu, fft_len, data_precision):
     return frames
 
 
+def consumer_handler(frames, data_type, header=0, clear_on_error=False):
+    """The consumers' reassembly, frame by frame: remote_client_qt.py:100-164 (header=0; on a decode error the
+    pending string is kept, :161-162) and sdr_webserver/sdr_webserver_ws.py:235-287 (header=10 = ``msg_str[10:]``
+    :241; the pending string is cleared on error, :279).  -> (list of decoded vectors in completion order,
+    final max_fft_data)."""
+    pending = b''
+    max_fft_data = np.array([])
+    strt = True
+    out = []
+    for msg in frames:
+        msg = bytes(msg)[header:]
+        n_frags = struct.unpack('!B', msg[0:1])[0]
+        frag_id = struct.unpack('!B', msg[1:2])[0]
+        body = msg[2:]
+        if n_frags == 1:
+            try:
+                fft_data = np.frombuffer(body, data_type)
+            except ValueError:
+                continue
+        else:
+            pending += body
+            if frag_id != n_frags - 1:
+                continue
+            try:
+                fft_data = np.frombuffer(pending, data_type)
+            except ValueError:
+                if clear_on_error:
+                    pending = b''
+                continue
+            pending = b''
+        if len(max_fft_data) != len(fft_data):
+            max_fft_data = fft_data
+        if strt:
+            max_fft_data = fft_data
+            strt = False
+        max_fft_data = np.maximum(max_fft_data, fft_data)
+        out.append(fft_data)
+    return out, max_fft_data
+
+
+def zmq_pdu_header(nbytes):
+    """PMT serialisation of cons(PMT_NIL, u8vector(nbytes)) up to the first data byte (GNU Radio pmt_serialize.cc:
+    PST_PAIR 0x07, PST_NULL 0x06, PST_UNIFORM_VECTOR 0x0a, UVI_U8 0x00, uint32 BE count, npad 1, pad 0) - the ten
+    bytes sdr_webserver_ws.py:241 strips."""
+    return bytes([7, 6, 10, 0]) + struct.pack('>I', nbytes) + bytes([1, 0])
+
+
 # --------------------------------------------------------------------------
 # GNU Radio 3.7 block semantics (parity unpinned, see module docstring)
 # --------------------------------------------------------------------------

@@ -29,6 +29,7 @@ chains a1-a3 stay unpinned.  Only numbers are written; no reference text is stor
 
 Run from the repo root:  python tests/golden/make_golden.py            (everything)
                          python tests/golden/make_golden.py --reference  (only the ref_*.npz files)
+                         python tests/golden/make_golden.py --consumer   (only fragments_consumer.bin)
 """
 import os
 import sys
@@ -232,6 +233,32 @@ def reference_fixtures():
     save('ref_ascii_plot.npz', source=np.array('reference'), n=len(cases), **out)
 
 
+def consumer_fixture():
+    """fragments_consumer.bin (restated): what the two consumers receive and what they must decode.  Three streams of
+    frames - local_worker float32 frames as they leave a ZMQ PUB sink (10-byte PMT header in front of each),
+    local_worker int8 frames bare (the Qt client's msg port), sweeper frames with the header - each followed by the
+    vectors the consumer decodes from it.  Layout: u32 nstreams; per stream u32 header_len, u32 itemsize (4 = '<f4',
+    1 = int8), u32 nframes, frames as u32 length + bytes, u32 nvectors, vectors as u32 nbytes + raw bytes."""
+    rows = [(np.arange(2048, dtype=np.float32) * 0.02 - 95 + 3 * k).astype('<f4') for k in range(3)]
+    f32 = [R.zmq_pdu_header(len(fr)) + fr for row in rows for fr in R.worker_fragments(row, 1470, 2048, True)]
+    i8 = [fr for row in rows for fr in R.worker_fragments(row, 1470, 2048, False)]
+    sw = [R.zmq_pdu_header(len(fr)) + fr for row in rows[:2] for fr in R.sweeper_fragments(row.tobytes(), 1470)]
+    with open(os.path.join(HERE, 'fragments_consumer.bin'), 'wb') as fh:
+        fh.write(np.uint32(3).tobytes())
+        for frames, header, dt in ((f32, 10, '<f4'), (i8, 0, np.int8), (sw, 10, '<f4')):
+            vecs, _ = R.consumer_handler(frames, dt, header)
+            fh.write(np.array([header, np.dtype(dt).itemsize, len(frames)], np.uint32).tobytes())
+            for fr in frames:
+                fh.write(np.uint32(len(fr)).tobytes())
+                fh.write(fr)
+            fh.write(np.uint32(len(vecs)).tobytes())
+            for v in vecs:
+                b = np.ascontiguousarray(v).tobytes()
+                fh.write(np.uint32(len(b)).tobytes())
+                fh.write(b)
+    print('wrote fragments_consumer.bin')
+
+
 def T_db(v):
     return np.asarray(v, np.float64)
 
@@ -239,6 +266,9 @@ def T_db(v):
 def main():
     import warnings
     warnings.simplefilter('ignore')
+    if '--consumer' in sys.argv:
+        consumer_fixture()
+        return
     if '--reference' in sys.argv:
         return reference_fixtures()
 
@@ -406,6 +436,7 @@ def main():
                 fh.write(np.uint32(len(fr)).tobytes())
                 fh.write(fr)
     print('wrote fragments.bin')
+    consumer_fixture()
     sys.path.insert(0, HERE)
     import ref_extract
     if ref_extract.available():

@@ -47,7 +47,7 @@ def test_no_cpu_fallback_without_gpu():
     from ofdm_tools import _hip
     if not os.path.exists(_hip.LIB_PATH):
         pytest.skip('library not built yet')
-    assert _hip.load().oth_abi_version() == 3
+    assert _hip.load().oth_abi_version() == 4
     with pytest.raises(_hip.HipError) as ei:
         _hip.Context(0)
     assert ei.value.code == -2 and 'no CPU fallback' in str(ei.value)
@@ -55,6 +55,34 @@ def test_no_cpu_fallback_without_gpu():
     import numpy as np
     with pytest.raises(_hip.HipError):
         T.welch_power_estimate(np.zeros(8192, np.complex64), 4096, 1.0)
+
+
+def test_exception_barrier_at_the_abi():
+    """include/ofdm_tools_hip.h: "nothing throws or aborts".  A C++ exception below an entry point must come back as
+    an error code (a bad_alloc crossing ctypes would be std::terminate and take the flowgraph down).  The
+    oth__debug_throw hook raises inside the same OTH_TRY / OTH_CATCH pair every entry point has; no GPU needed."""
+    from ofdm_tools import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        pytest.skip('library not built yet')
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    lib.oth__debug_throw.restype = ctypes.c_int
+    lib.oth__debug_throw.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.oth_last_error.restype = ctypes.c_char_p
+    lib.oth_last_error.argtypes = [ctypes.c_void_p]
+    lib.oth_strerror.restype = ctypes.c_char_p
+    assert lib.oth__debug_throw(None, -1) == 0
+    assert lib.oth__debug_throw(None, 0) == -4 and b'memory' in lib.oth_last_error(None)
+    assert lib.oth__debug_throw(None, 1) == -6 and lib.oth_last_error(None) == b'debug: runtime_error'
+    assert lib.oth__debug_throw(None, 2) == -6 and b'unknown C++ exception' in lib.oth_last_error(None)
+    assert lib.oth__debug_throw(None, 3) in (-4, -6)             # a real over-sized std::vector, not a staged throw
+    assert b'internal' in lib.oth_strerror(-6)
+    # and every extern "C" body in the source sits inside the barrier
+    src = open(os.path.join(ROOT, 'gr-ofdm_tools_amd', 'csrc', 'api.hip')).read()
+    ext = src[src.index('extern "C" {'):]
+    bodies = re.findall(r'^int (oth_\w+)\([^)]*\) \{\n(.*?)^\}', ext, flags=re.S | re.M)
+    assert len(bodies) >= 55
+    for name, body in bodies:
+        assert body.lstrip().startswith('OTH_TRY') and 'OTH_CATCH(' in body.rstrip().splitlines()[-1], name
 
 
 def test_missing_library_fails_loudly(monkeypatch):

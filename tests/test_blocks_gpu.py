@@ -1,5 +1,6 @@
 """GPU tests of the block classes (same names / constructor signatures as the reference) against
 the CPU oracle: the whole chain from complex64 stream to decisions, messages and PDUs."""
+import os
 import struct
 
 import numpy as np
@@ -156,7 +157,8 @@ def test_spectrum_sweeper_sweep_and_wire_format(ctx):
     from ofdm_tools import packets
     rx = FakeReceiver()
     fft_len, Sf, tSf = 4096, 2000000, 1750000
-    blk = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 15, 0.0, 8, 0, 1472, ctx=ctx)
+    blk = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 15, 0.0, 8, 0, 1472, ctx=ctx,
+                                      threaded=False)
     pts, tune, excess = R.sweeper_geometry(fft_len, Sf, tSf, 100e6, 107e6, 8)
     assert (blk.vector_probe_pts, blk.tune_frequencies, blk.excess_bins) == (pts, tune, excess) == (16384, tune, 256)
     assert len(tune) == 4
@@ -182,10 +184,87 @@ def test_spectrum_sweeper_sweep_and_wire_format(ctx):
     wide = blk.sweep_once_sharded(lambda i, f: tv[i], 0, 1, dev)
     assert np.allclose(wide, psd, rtol=1e-6)
     # flowgraph side: work() keeps the last complete capture
-    blk2 = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 1e9, 0.0, 8, 0, 1472, ctx=ctx)
+    blk2 = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 1e9, 0.0, 8, 0, 1472, ctx=ctx,
+                                       threaded=False)
     x = R.synth_iq(pts * 2 + 100, 5)
     blk2.feed(x, max_items=5000)
     assert np.array_equal(blk2.get_samples(), x[pts:2 * pts])
+
+
+def test_spectrum_sweeper_stitcher_thread_sweeps_by_itself(ctx):
+    """spectrum_sweeper.py:99-105,207-231: constructing the block starts the stitcher; a flowgraph only feeds work().
+    Nothing here calls sweep_once."""
+    import time
+    import ofdm_tools
+    from ofdm_tools import packets
+    rx = FakeReceiver()
+    fft_len, Sf, tSf = 1024, 2000000, 1750000
+    blk = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 1e9, 0.0, 4, 2, 1472, ctx=ctx,
+                                      start_delay=0.05)
+    pts, tune, excess = R.sweeper_geometry(fft_len, Sf, tSf, 100e6, 107e6, 4)
+    nbins = fft_len - 2 * excess
+    frames = []
+    blk.msg_connect('pdus', lambda m: frames.append(m[1]))
+    x = R.synth_iq(pts, 77)
+    end = time.monotonic() + 20
+    while blk.sweeps_done < 3 and time.monotonic() < end:
+        blk.feed(x, max_items=4096)              # the scheduler thread: the same capture over and over
+        time.sleep(0.002)
+    assert blk.sweeps_done >= 3
+    blk.set_tune_delay(1)                        # reaches the running stitcher (:110-112)
+    assert blk.get_tune_delay() == 1e-3
+    blk.stop()
+    assert blk._stitch_thread is None
+    n_tuned, n_frames = len(rx.tuned), len(frames)
+    time.sleep(0.05)
+    assert (len(rx.tuned), len(frames)) == (n_tuned, n_frames)          # really stopped
+    k = len(tune)
+    assert rx.tuned[:3 * k] == tune * 3
+    per_sweep = packets.sweeper_fragment_count(4 * k * nbins, 1470)
+    assert len(frames) >= 3 * per_sweep
+    payload = packets.reassemble(frames[:per_sweep])
+    got = np.frombuffer(payload, '<f4').astype(np.float64)
+    # every segment of the first sweep saw either the initial 1e-10 vector (:84) or the capture x
+    ref_x = R.sweeper_src_power(x, fft_len, Sf, excess)
+    ref_0 = R.sweeper_src_power(np.array([1e-10] * pts, np.complex64), fft_len, Sf, excess)
+    assert got.shape == (k * nbins,)
+    for j in range(k):
+        seg = got[j * nbins:(j + 1) * nbins]
+        ok_x = relerr(10 ** (seg / 10), 10 ** (ref_x / 10)) < RTOL
+        assert ok_x or np.allclose(seg, ref_0, atol=1e-3) or not np.all(np.isfinite(ref_0))
+    last = np.frombuffer(packets.reassemble(frames[2 * per_sweep:3 * per_sweep]), '<f4').astype(np.float64)
+    for j in range(k):                           # by the third sweep every capture is x
+        assert relerr(10 ** (last[j * nbins:(j + 1) * nbins] / 10), 10 ** (ref_x / 10)) < RTOL
+
+
+def test_spectrum_sweeper_sharded_stitcher_loop_world_1(ctx):
+    """start_sharded: the rank-local stitcher loop over SweepPipeline (one rank here), captures already on the device."""
+    import time
+    import torch
+    import ofdm_tools
+    from ofdm_tools import packets
+    rx = FakeReceiver()
+    fft_len, Sf, tSf = 4096, 2000000, 1750000
+    blk = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 15, 0.0, 8, 0, 1472, ctx=ctx,
+                                      threaded=False)
+    pts, tune, excess = R.sweeper_geometry(fft_len, Sf, tSf, 100e6, 107e6, 8)
+    dev = torch.device('cuda', 0)
+    vectors = [R.synth_iq(pts, 2100 + i) for i in range(len(tune))]
+    tv = [torch.from_numpy(v).to(dev) for v in vectors]
+    frames = []
+    blk.msg_connect('pdus', lambda m: frames.append(m[1]))
+    blk.start_sharded(lambda i, f: tv[i], 0, 1, dev, sweeps=3)
+    end = time.monotonic() + 20
+    while blk.keep_running and time.monotonic() < end:
+        time.sleep(0.005)
+    blk.stop()
+    assert blk.sweeps_done == 3 and rx.tuned == tune * 3
+    ref = R.sweeper_stitch(vectors, fft_len, Sf, excess, 0.0)
+    per_sweep = packets.sweeper_fragment_count(4 * len(ref), 1470)
+    assert len(frames) == 3 * per_sweep                         # every sweep published, the last one at the end
+    for s in range(3):
+        got = np.frombuffer(packets.reassemble(frames[s * per_sweep:(s + 1) * per_sweep]), '<f4').astype(np.float64)
+        assert relerr(10 ** (got / 10), 10 ** (ref / 10)) < RTOL
 
 
 def test_coherence_estimator_feeds_detector(ctx, golden):
@@ -208,12 +287,14 @@ def test_coherence_estimator_feeds_detector(ctx, golden):
     assert np.allclose(det.subject_channels_coherence, coh, atol=2e-4)
 
 
-def test_legacy_spectrum_sensor_request_response(ctx):
+def test_legacy_spectrum_sensor_request_response(ctx, tmp_path):
     import ofdm_tools
     Sf, N = 1000000, 1024
     for method in ('welch', 'fft'):
+        os.makedirs(str(tmp_path / method))
         blk = ofdm_tools.spectrum_sensor(8192, sample_rate=Sf, fft_len=N, channel_space=50e3, search_bw=25e3,
-                                         method=method, thr_leveler=5, tune_freq=0, alpha_avg=1, ctx=ctx)
+                                         method=method, thr_leveler=5, tune_freq=0, alpha_avg=1, ctx=ctx,
+                                         log=True, log_dir=str(tmp_path / method))
         out = []
         blk.msg_connect('PDU spect_msg', out.append)
         x = R.synth_iq(20000, 41)
@@ -227,6 +308,11 @@ def test_legacy_spectrum_sensor_request_response(ctx):
         blk.post('PDU from_cogeng', ({}, 'PAPR'))
         blk.post('PDU from_cogeng', ({}, 'bogus'))
         assert out[-2][0] == 'papr' and out[-1] == ('unkn', 'received unknown request')
+        # the request log of spectrum_sensor.py:59-62,96-120
+        rows = [ln.split(',', 3) for ln in open(blk.log_file.path).read().splitlines()]
+        assert [r[2] for r in rows] == ['sample_rate', 'tune_freq[Hz]', 'threshold[dB]', 'noise[dB]',
+                                        'spectrum_constraint[Hz]', 'tune_freq', 'papr', 'received unknown request']
+        assert np.isclose(float(rows[2][3]), 10 * np.log10(thr + 1e-20), atol=1e-3) and rows[4][3] == str(cons)
 
 
 def test_helper_functions_match_oracle(ctx):
@@ -506,7 +592,8 @@ def test_waterfall_block_end_to_end(ctx, tmp_path):
     x = R.synth_iq(N * 23 + 40, 71)
     ref = R.chain_sensor_v2(x, N)                      # decimation 1: every vector is a PSD row
     want = ref[S - 1::S][:len(ref) // S]
-    for chunk in (N, 3 * N + 17):                      # one vector per work() call; calls that straddle vectors
+    for chunk in (N, 3 * N + 17, 11 * N):              # one vector per work() call; calls that straddle vectors;
+                                                       # calls that span two groups (one message -> ONE row, :308-313)
         blk = ofdm_tools.spectrum_sensor_v2(N, S, N * S, waterfall=True, ctx=ctx, threaded=False,
                                             log_directory=str(tmp_path / ('c%d' % chunk)))
         assert blk.decimation == 1
@@ -516,6 +603,10 @@ def test_waterfall_block_end_to_end(ctx, tmp_path):
             from test_hip_parity import check_single_rows
             assert rows.shape == want.shape
             check_single_rows(rows, want)
+        elif chunk == 11 * N:                          # 23 vectors in calls of 11, 11, 1: rows 10 and 21, nothing else
+            assert len(rows) == 2
+            check = __import__('test_hip_parity').check_single_rows
+            check(rows, ref[[10, 21]])
         else:                                          # one row per completed group, each a PSD row at or after the group's last
             assert len(rows) == len(want)
             for i, r in enumerate(rows):

@@ -41,6 +41,80 @@ def test_packet_framing_matches_golden_and_oracle():
     assert len(fr) == 3 and fr[2][2:] == b'' and fr == R.sweeper_fragments(b'x' * 2940, 1470)
 
 
+def read_consumer_fixture():
+    raw = open(os.path.join(ROOT, 'tests', 'golden', 'fragments_consumer.bin'), 'rb').read()
+    pos = [0]
+
+    def u32():
+        v = struct.unpack_from('<I', raw, pos[0])[0]
+        pos[0] += 4
+        return v
+
+    def blob():
+        n = u32()
+        b = raw[pos[0]:pos[0] + n]
+        pos[0] += n
+        return b
+    streams = []
+    for _ in range(u32()):
+        header, itemsize, nframes = u32(), u32(), u32()
+        frames = [blob() for _ in range(nframes)]
+        dt = '<f4' if itemsize == 4 else np.int8
+        streams.append((header, itemsize == 4, frames, [np.frombuffer(blob(), dt) for _ in range(u32())]))
+    assert pos[0] == len(raw)
+    return streams
+
+
+def test_fragment_consumers_int8_float_and_zmq_header():
+    """remote_client_qt.py:100-164 / sdr_webserver_ws.py:235-287: the stream reassembler against the byte fixture
+    (float32 frames behind the 10-byte ZMQ/PMT header, bare int8 frames, sweeper frames with their floor+1 count)."""
+    from ofdm_tools import packets
+    streams = read_consumer_fixture()
+    assert [(h, p, len(f), len(v)) for h, p, f, v in streams] == [(10, True, 18, 3), (0, False, 6, 3), (10, True, 12, 2)]
+    for header, precision, frames, vectors in streams:
+        ra = packets.FragmentReassembler(precision, header=header)
+        got = [v for v in (ra.push(f) for f in frames) if v is not None]
+        assert len(got) == len(vectors) and all(np.array_equal(a, b) and a.dtype == b.dtype
+                                                for a, b in zip(got, vectors))
+        assert np.array_equal(ra.max_data, np.maximum.reduce(vectors)) and ra.errors == 0
+        if header:
+            assert all(f[:header] == packets.zmq_pdu_header(len(f) - header) for f in frames)
+        # the one-vector form: any arrival order, the same decode
+        n = frames[0][header]
+        assert np.array_equal(packets.reassemble(list(reversed(frames[:n])), precision, header), vectors[0])
+    # int8 frames are what local_worker sends with data_precision False: the float dB vector cast to int8
+    row = (np.arange(2048, dtype=np.float32) * 0.02 - 95).astype('<f4')
+    assert np.array_equal(streams[1][3][0], row.astype(np.int8))
+    assert packets.worker_fragments(row, 1470, 2048, False) == streams[1][2][:2]
+    # arrival-order concatenation is the consumers' behaviour: a lost fragment shortens an int8 vector ...
+    _, _, i8frames, i8vec = streams[1]
+    ra = packets.FragmentReassembler(False)
+    short = ra.push(i8frames[1])                                     # frame 0 of the vector never arrived
+    ref, _ = R.consumer_handler(i8frames[1:2], np.int8, 0)
+    assert len(short) == 2048 - 1470 and np.array_equal(short, ref[0]) and np.array_equal(short, i8vec[0][1470:])
+    # ... and makes a float vector undecodable (1470 is not a multiple of 4): an error, nothing delivered
+    header, precision, frames, vectors = streams[0]
+    lossy = [f for i, f in enumerate(frames) if i != 2]
+    ra = packets.FragmentReassembler(True, header=10, clear_on_error=True)        # the web consumer (:279)
+    out = [v for v in (ra.push(f) for f in lossy) if v is not None]
+    ref, _ = R.consumer_handler(lossy, '<f4', 10, clear_on_error=True)
+    assert ra.errors == 1 and len(out) == len(ref) == 2 and all(np.array_equal(a, b) for a, b in zip(out, ref))
+    ra = packets.FragmentReassembler(True, header=10, clear_on_error=False)       # the Qt client keeps the bytes
+    out = [v for v in (ra.push(f) for f in lossy) if v is not None]
+    ref, _ = R.consumer_handler(lossy, '<f4', 10, clear_on_error=False)
+    assert len(out) == len(ref) and all(np.array_equal(a, b) for a, b in zip(out, ref))
+    # strict=True drops the damaged vector and resynchronises on the next frag_id 0
+    ra = packets.FragmentReassembler(True, header=10, strict=True)
+    out = [v for v in (ra.push(f) for f in lossy) if v is not None]
+    assert len(out) == 2 and np.array_equal(out[0], vectors[1]) and np.array_equal(out[1], vectors[2])
+    # a lost FINAL fragment glues two vectors (frag_id only marks the end)
+    glued = i8frames[:1] + i8frames[2:4]
+    ra = packets.FragmentReassembler(False)
+    out = [v for v in (ra.push(f) for f in glued) if v is not None]
+    ref, _ = R.consumer_handler(glued, np.int8, 0)
+    assert len(out) == 1 and len(out[0]) == 1470 + 2048 and np.array_equal(out[0], ref[0])
+
+
 def test_coherence_detector_decision_stage(golden):
     import ofdm_tools
     g = golden('coherence_scanner.npz')
@@ -137,6 +211,249 @@ def test_keep_one_in_n_capture_of_the_sweeper_without_gpu():
     for lo in range(0, len(x), 50):
         assert blk.work([x[lo:lo + 50]], []) == len(x[lo:lo + 50])
     assert np.array_equal(blk.get_samples(), x[64 * 5:64 * 6])       # vectors 2 and 5 kept; 5 is the latest
+
+
+def test_legacy_spectrum_sensor_request_log(tmp_path, monkeypatch):
+    """spectrum_sensor.py:59-62,96-120: /tmp/ss_log-<date>-<time>, a geometry header and one CSV row per answered
+    quantity (the scan itself is stubbed: no GPU here)."""
+    import importlib
+    import ofdm_tools
+    mod = importlib.import_module('ofdm_tools.spectrum_sensor')
+    monkeypatch.setattr(mod, 'fast_spectrum_scan', lambda *a: (2e-7, [1e-8, 3e-7], 4e-8, [25000.0]))
+    clock = {'%y%m%d': '261004', '%H%M%S': '101112'}
+    monkeypatch.setattr(mod.time, 'strftime', lambda fmt: clock[fmt])
+    blk = ofdm_tools.spectrum_sensor(64, sample_rate=1000000, fft_len=64, channel_space=25e3, search_bw=12.5e3,
+                                     tune_freq=433000000, log=True, log_dir=str(tmp_path))
+    assert blk.log_file.path == str(tmp_path / 'ss_log-261004-101112')
+    out = []
+    blk.msg_connect('PDU spect_msg', out.append)
+    x = (np.arange(64) % 7 - 3 + 1j).astype(np.complex64)
+    assert blk.work([x], []) == 64
+    for req in ('SC', 'PAPR', 'what'):
+        blk.post('PDU from_cogeng', ({}, req))
+    papr = blk.get_papr()
+    assert open(blk.log_file.path).read().splitlines() == [
+        'Time,101112,sample_rate,1000000,channel_space,25000.0,channel_bw,12500.0,tune_freq,433000000',
+        'Time,101112,tune_freq[Hz],433000000',
+        'Time,101112,threshold[dB],' + str(10 * np.log10(2e-7 + 1e-20)),
+        'Time,101112,noise[dB],' + str(10 * np.log10(4e-8 + 1e-20)),
+        'Time,101112,spectrum_constraint[Hz],[25000.0]',
+        'Time,101112,tune_freq,433000000',
+        'Time,101112,papr,' + str(papr),
+        'Time,101112,received unknown request']
+    assert [m[0] for m in out] == ['thre', 'nois', 'cons', 'papr', 'unkn']
+    quiet = ofdm_tools.spectrum_sensor(64, log=False)
+    assert quiet.log_file is None
+
+
+def test_chain_block_watcher_errors_surface_on_the_stream_side():
+    """A watcher thread that fails on a vector must not die silently (the depth-2 queue would fill and every later
+    vector would be dropped): the error is raised by the next work() / drain(), the watcher carries on, and after
+    stop() drain() returns at once."""
+    import time
+    from ofdm_tools.chain_block import ChainBlockMixin
+
+    class Chain(object):
+        def __init__(self):
+            self.t = 0
+
+        def push_async(self, in0):
+            self.t += 1
+            return self.t
+
+        def ticket_rows(self, ticket):
+            return 1
+
+        def wait(self, ticket):
+            return np.full(4, float(ticket), np.float32), 1
+
+    class Blk(ChainBlockMixin):
+        def __init__(self):
+            self.seen, self.fail = [], True
+            self._chain_init(Chain(), threaded=True)
+
+        def _on_vector(self, row):
+            if self.fail:
+                raise IOError('disk full')
+            self.seen.append(float(row[0]))
+
+    blk = Blk()
+    x = np.zeros(8, np.complex64)
+    assert blk.work([x], []) == 8
+    end = time.monotonic() + 5
+    while blk.watch_errors == 0 and time.monotonic() < end:
+        time.sleep(0.001)
+    with pytest.raises(RuntimeError, match='watcher thread failed'):
+        blk.work([x], [])
+    blk.fail = False
+    assert blk.work([x], []) == 8 and blk.drain(5.0)         # the watcher is still alive and drain() is honest
+    assert blk.seen == [2.0] and blk._watch_thread.is_alive()
+    blk.fail = True
+    blk.work([x], [])
+    with pytest.raises(RuntimeError, match='disk full'):
+        end = time.monotonic() + 5
+        while time.monotonic() < end:
+            blk.drain(0.05)
+    blk.stop()
+    blk.msgq0.insert_tail((99, 99, 1))                        # something nobody will ever look at
+    blk._queued += 1
+    t0 = time.monotonic()
+    assert blk.drain(5.0) and time.monotonic() - t0 < 0.5
+
+
+class _FakePlan(object):
+    def __init__(self, nbins):
+        self.nbins, self.calls, self.fail = nbins, 0, False
+
+    def exec(self, vector):
+        self.calls += 1
+        if self.fail:
+            raise RuntimeError('device lost')
+        return np.full(self.nbins, float(np.real(vector[0])))
+
+
+class _FakeCtx(object):
+    def welch_plan(self, nfft, nperseg=None, window=None, fs=1.0, fftshift=False, trim_bins=0, db=False):
+        assert nperseg == nfft // 4 and len(window) == nperseg and fftshift and db      # spectrum_sweeper.py:263-276
+        self.plan = _FakePlan(nfft - 2 * trim_bins)
+        return self.plan
+
+
+class _Rx(object):
+    def __init__(self):
+        self.tuned = []
+
+    def set_center_freq(self, f, chan):
+        self.tuned.append(f)
+
+
+def test_spectrum_sweeper_stitcher_thread_start_stop_without_gpu():
+    """spectrum_sweeper.py:99-105,110-112,207-231: the constructor starts the stitcher; it retunes, sleeps tune_delay,
+    takes get_samples(), stitches and sends, for as long as the block runs; setters reach it; stop() joins it; a
+    failure inside it surfaces in work()."""
+    import time
+    import ofdm_tools
+    from ofdm_tools import packets
+    rx, ctx = _Rx(), _FakeCtx()
+    blk = ofdm_tools.spectrum_sweeper(rx, 'rtl', 1024, 2000000, 1750000, 100e6, 107e6, 1e9, 0.25, 1, 1, 1472,
+                                      ctx=ctx, start_delay=0.05)
+    assert blk._stitch_thread is not None and blk._stitch_thread.daemon
+    k, nbins = len(blk.tune_frequencies), 1024 - 2 * blk.excess_bins
+    frames = []
+    blk.msg_connect('pdus', lambda m: frames.append(m[1]))
+    assert blk.sweeps_done == 0 and rx.tuned == []           # still inside the start-up wait (:208)
+    x = np.full(blk.vector_probe_pts, 3.0 + 0j, np.complex64)
+    end = time.monotonic() + 10
+    while blk.sweeps_done < 2 and time.monotonic() < end:
+        assert blk.work([x], []) == len(x)                  # the flowgraph thread plays data_colector
+        time.sleep(0.001)
+    assert blk.sweeps_done >= 2 and blk.captures > 0
+    per_sweep = packets.sweeper_fragment_count(4 * k * nbins, 1470)
+    assert rx.tuned[:2 * k] == blk.tune_frequencies * 2 and len(frames) >= 2 * per_sweep
+    second = packets.reassemble(frames[per_sweep:2 * per_sweep], True)
+    assert second.shape == (k * nbins,)
+    assert np.allclose(second, (1 - 0.25) * 3.0 + 0.25 * 1e-10)                     # the :227 blend with average
+    blk.set_average(0.5)                                      # :142-144 - the running stitcher uses it from now on
+    blk.set_tune_delay(0)
+    n0 = blk.sweeps_done
+    while blk.sweeps_done < n0 + 2 and time.monotonic() < end:
+        time.sleep(0.001)
+    tail = frames[-per_sweep:] if frames[-1][1] == per_sweep - 1 else None
+    blk.stop()
+    assert blk._stitch_thread is None and not blk.keep_running
+    n = (len(rx.tuned), len(frames))
+    time.sleep(0.03)
+    assert (len(rx.tuned), len(frames)) == n
+    last = packets.reassemble(frames[-per_sweep:], True)
+    assert tail is None or np.allclose(last, 0.5 * 3.0 + 0.5 * 1e-10)
+    # a stitcher that dies is reported by the next work() call instead of silently never sweeping again
+    blk.start(0.0)
+    ctx.plan.fail = True
+    end = time.monotonic() + 5
+    while blk._stitch_error is None and time.monotonic() < end:
+        time.sleep(0.001)
+    with pytest.raises(RuntimeError, match='stitcher thread died'):
+        blk.work([x], [])
+    blk.stop()
+    # threaded=False: nothing runs until the host calls sweep_once itself
+    quiet = ofdm_tools.spectrum_sweeper(_Rx(), 'rtl', 1024, 2000000, 1750000, 100e6, 107e6, 1e9, 0.0, 1, 0, 1472,
+                                        ctx=_FakeCtx(), threaded=False)
+    time.sleep(0.02)
+    assert quiet._stitch_thread is None and quiet.rf_receiver.tuned == [] and quiet.sweeps_done == 0
+
+
+SHARDED_LOOP_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'gr-ofdm_tools_amd'))
+import numpy as np, torch, torch.distributed as dist
+import ofdm_tools
+from ofdm_tools import packets
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+
+class Plan(object):
+    pass
+class Ctx(object):
+    def welch_plan(self, nfft, **kw):
+        return Plan()
+class Rx(object):
+    def __init__(self): self.tuned = []
+    def set_center_freq(self, f, chan): self.tuned.append(f)
+
+class Blk(ofdm_tools.spectrum_sweeper):
+    def _segment_to_row(self, iq, out_row, device):      # CPU ranks: a stand-in for the HIP plan
+        out_row.fill_(float(iq))
+
+rx = Rx()
+blk = Blk(rx, 'rtl', 1024, 2000000, 1750000, 100e6, 100e6 + 1750000 * %(nseg)d - 1, 1e9, 0.0, 1, 0, 1472, ctx=Ctx(),
+          threaded=False)
+k, nbins = len(blk.tune_frequencies), 1024 - 2 * blk.excess_bins
+assert k == %(nseg)d, k
+frames = []
+blk.msg_connect('pdus', lambda m: frames.append(m[1]))
+sweep_no = [0]
+def capture(i, f):
+    assert f == blk.tune_frequencies[i]
+    return 1000.0 * (blk.sweeps_done + 1) + i           # which sweep, which segment
+sweeps = %(sweeps)s
+blk.start_sharded(capture, rank, world, torch.device('cpu'), publish_rank=0, sweeps=sweeps)
+if sweeps is None and rank == 1:                        # stop() on ONE rank ends the loop on all of them
+    while blk.sweeps_done < 3: time.sleep(0.001)
+    blk.stop()
+end = time.monotonic() + 60
+while blk.keep_running and time.monotonic() < end: time.sleep(0.002)
+blk.stop()
+assert blk._stitch_error is None, blk._stitch_error
+n = blk.sweeps_done
+assert n >= 3 and (sweeps is None or n == sweeps), n
+mine = list(range(rank, k, world))
+assert rx.tuned == [blk.tune_frequencies[i] for i in mine] * n, (rx.tuned, n)
+per = packets.sweeper_fragment_count(4 * k * nbins, 1470)
+if rank == 0:
+    assert len(frames) == n * per, (len(frames), n, per)
+    for s in range(n):
+        wide = packets.reassemble(frames[s * per:(s + 1) * per], True).reshape(k, nbins)
+        assert np.array_equal(wide[:, 0], 1000.0 * (s + 1) + np.arange(k)), (s, wide[:, 0])
+else:
+    assert frames == []
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'ok', n)
+'''
+
+
+@pytest.mark.parametrize('nseg,sweeps', [(8, 4), (5, None)])
+def test_sharded_stitcher_loop_world_size_2_gloo(nseg, sweeps, tmp_path):
+    """start_sharded: each rank retunes only to its own segments, the sweeps come out in tune order on the publishing
+    rank, and every rank leaves the loop after the same sweep (sweeps=N, or stop() on one rank)."""
+    script = tmp_path / 'worker.py'
+    script.write_text(SHARDED_LOOP_WORKER % {'root': ROOT, 'nseg': nseg, 'sweeps': sweeps})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29540 + nseg), WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert outs[0].split()[-1] == outs[1].split()[-1]           # the same number of sweeps on both ranks
 
 
 GLOO_WORKER = r'''

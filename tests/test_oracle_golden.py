@@ -142,6 +142,16 @@ def test_xcorr_fac(golden):
     assert relerr(R.fac(g['a'], L), g['expected_fac']) < RTOL
 
 
+def test_fragment_consumer_restatement_against_the_byte_fixture():
+    """oracle.consumer_handler (remote_client_qt.py:100-164, sdr_webserver_ws.py:235-287) vs fragments_consumer.bin."""
+    from test_host_logic_cpu import read_consumer_fixture
+    for header, precision, frames, vectors in read_consumer_fixture():
+        got, mx = R.consumer_handler(frames, '<f4' if precision else np.int8, header)
+        assert len(got) == len(vectors) and all(np.array_equal(a, b) for a, b in zip(got, vectors))
+        assert np.array_equal(mx, np.maximum.reduce(vectors))
+    assert R.zmq_pdu_header(1472) == bytes([7, 6, 10, 0, 0, 0, 5, 0xc0, 1, 0]) and len(R.zmq_pdu_header(5)) == 10
+
+
 def test_fragment_wire_format(golden):
     path = os.path.join(os.path.dirname(__file__), 'golden', 'fragments.bin')
     raw = open(path, 'rb').read()
