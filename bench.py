@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - IQ Msamples/s through the 4096-point Welch PSD on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]                 (N > 1: spawns its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the hot path over one batch of synthetic IQ that is already resident in HBM.
@@ -9,8 +9,13 @@ A step = one pass of the hot path over one batch of synthetic IQ that is already
 N = 1  workload "C2" (the configuration BASELINE.json's metric is quoted on): one 2^28-sample complex64
        stream (2 GiB), Hann, nperseg = nfft = 4096, 50 % overlap, detrend constant, density scaling
        (the welch() call of ofdm_cr_tools.py:342): welch4096ws kernel + the cross-workgroup finalize.
-       Extra keys on the same line: `sweep_c4` (the N > 1 workload run on this one GPU, so that the N-GPU
-       speed-up is a plain division), `h2d_inclusive` (host buffer -> PSD through the streaming entry point).
+       Extra keys on the same line: `host_visible_ms_per_step` (the same step through the host-output entry point:
+       launch to PSD in host memory, SURVEY 8d's end point), `sweep_c4` (the N > 1 workload run on this one GPU, so
+       that the N-GPU speed-up is a plain division), `csd_c3` (BASELINE config 3: two-channel cross spectrum /
+       coherence, 2 x 2^26 samples, csd4096ws kernel, 16 B per sample pair), `scan_c5` (BASELINE config 5: 64 channel
+       streams x 2^22 samples, 16384-pt rectangular |X|^2/N^2 mean + the device decision stage, welch16k kernel),
+       each with its own `roofline`; `h2d_inclusive` (host buffer -> PSD through the streaming entry point);
+       `cpu_baseline` (+ `_parallel`, `_c5`).
 N > 1  workload "C4" (BASELINE config 4 = the north star's 8-segment sweep), STRONG scaling: a FIXED sweep of
        8 RF segments x 2^27 samples, segment i on rank i mod N, the same Welch parameters + fftshift + 256-bin
        trim + dB (spectrum_sweeper.py:260-276), then ONE all-gather (RCCL) of the 3584-bin rows into tune order
@@ -25,12 +30,19 @@ per-step event times (max over ranks), `value` follows from it; `wall_ms_per_ste
 / K (max over ranks).  Before the warm-up the same step runs untimed for --ramp-ms so that the device has left
 its idle clock level.
 
+Launching.  Under a launcher (WORLD_SIZE set) the process is one rank.  Typed as `python bench.py --gpus N` with
+N > 1 it spawns its N ranks itself - child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, started
+BEFORE this process makes any HIP call (a process that has touched the GPU is never re-executed) - waits for them,
+forwards rank 0's JSON line and exits non-zero if any rank failed.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -110,6 +122,96 @@ def cpu_baseline(nfft):
     return single, parallel
 
 
+def cpu_baseline_c5(nfft=16384, nch=4, log2_samples=22):
+    """SURVEY 8d baseline (iii): the GNU Radio chain of config 5 restated on the CPU in the arithmetic GNU Radio uses
+    (single precision: oracle.chain_sensor_v2_mean_c64 = stream_to_vector -> fft_vcc(rect, shift) -> |.|^2 -> 1/N^2,
+    multichannel_scanner.py:78-86, averaged per channel stream), one thread, on a bounded sample."""
+    from oracle import ref_cpu as R
+    S = 1 << log2_samples
+    xs = [R.synth_iq(S, 3000 + c) for c in range(nch)]
+    R.chain_sensor_v2_mean_c64(xs[0][:1 << 18], nfft)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for x in xs:
+            R.chain_sensor_v2_mean_c64(x, nfft)
+        times.append(time.perf_counter() - t0)
+    return {'value': nch * S / sorted(times)[1] / 1e6, 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d of the 64 channel streams of scan_c5 (2^%d samples each), %d-pt rect FFT + |X|^2/N^2 + mean in '
+                      'single precision (scipy.fft on complex64, one (rows, N) batch per stream), median of 3'
+                      % (nch, log2_samples, nfft)}
+
+
+def free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as child processes and forward rank
+    0's line.  Nothing here touches the GPU: torch.cuda.device_count() reads the device list without creating a HIP
+    context on this image, and the children are ordinary new processes (Popen), never an exec of this one."""
+    import torch
+    have = torch.cuda.device_count()
+    rehearse = os.environ.get('BENCH_REHEARSE') == '1'
+    if have == 0:
+        sys.exit('bench.py needs an MI355X: torch.cuda.device_count() is 0 (there is no CPU fallback)')
+    if have < args.gpus and not rehearse:
+        sys.exit('bench.py --gpus %d: only %d GPU(s) visible (BENCH_REHEARSE=1 rehearses the N-rank path on one '
+                 'device over gloo)' % (args.gpus, have))
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(args.gpus):
+        procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # rank 0's stdout is read to its end first (it prints one line); a rank that dies takes the others' collectives
+    # with it, so the first failure ends the rest (by their own PIDs)
+    failed = None
+    out0 = b''
+    pending = set(range(args.gpus))
+    import select
+    fd0 = procs[0].stdout
+    while pending:
+        r, _, _ = select.select([fd0], [], [], 0.2) if fd0 else ([], [], [])
+        if r:
+            chunk = os.read(fd0.fileno(), 65536)
+            if chunk:
+                out0 += chunk
+            else:
+                fd0 = None
+        for i in list(pending):
+            rc = procs[i].poll()
+            if rc is not None:
+                pending.discard(i)
+                if rc != 0 and failed is None:
+                    failed = (i, rc)
+        if failed is not None:
+            for i in pending:
+                procs[i].terminate()
+            for i in pending:
+                try:
+                    procs[i].wait(10)
+                except subprocess.TimeoutExpired:
+                    procs[i].kill()
+            break
+    if procs[0].stdout:
+        out0 += procs[0].stdout.read() or b''
+    if failed is not None:
+        sys.stderr.write('bench.py: rank %d exited with code %d\n' % failed)
+        return failed[1] if failed[1] > 0 else 1
+    lines = [ln for ln in out0.decode().splitlines() if ln.startswith('{')]
+    if not lines:
+        sys.stderr.write('bench.py: rank 0 printed no result line\n')
+        return 1
+    print(lines[-1])
+    return 0
+
+
 def timed_steps(torch, dist, dev, step, fence, steps, multi):
     """K steps between two fences; per-step events on the compute stream.  -> (wall seconds max over ranks,
     per-step ms list max-reduced over ranks)."""
@@ -141,15 +243,18 @@ def main():
     ap.add_argument('--sweep-log2-samples', type=int, default=SWEEP_LOG2_SAMPLES,
                     help='samples per RF segment of the 8-segment sweep (N > 1, and the sweep_c4 key at N = 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extras', action='store_true', help='N = 1: skip the sweep_c4 and h2d_inclusive keys')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='N = 1: skip the sweep_c4, csd_c3, scan_c5, host-visible and h2d_inclusive keys')
     args = ap.parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                 # before anything in this process touches the GPU
 
     # the pool's host driver only supports dmabuf IPC; RCCL needs this before the HIP runtime starts
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ofdm_tools import _hip, sweep, windows
+    from ofdm_tools import _hip, scan_batch, sweep, windows
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -265,8 +370,141 @@ def main():
         del seg
         return out, S
 
+    def ranks_seen():
+        """Who took part, as the collective backend sees it: every rank's PCI address (domain, bus, device) and
+        device index all-gathered through the process group (RCCL on a real run) - the distinct addresses must be
+        as many as the ranks unless this is a one-device rehearsal."""
+        pr = torch.cuda.get_device_properties(dev)
+        mine = torch.tensor([rank, local_rank, int(getattr(pr, 'pci_domain_id', 0)), int(getattr(pr, 'pci_bus_id', -1)),
+                             int(getattr(pr, 'pci_device_id', -1))], dtype=torch.int64,
+                            device=dev if not rehearse else 'cpu')
+        allr = torch.empty((world, 5), dtype=torch.int64, device=mine.device)
+        if world > 1 or force:
+            dist.all_gather_into_tensor(allr, mine)
+        else:
+            allr[0] = mine
+        rows = [[int(v) for v in r] for r in allr.cpu()]
+        return {'world_size': world, 'backend': dist.get_backend() if multi else None,
+                'devices': ['%04x:%02x:%02x.0 (rank %d, cuda:%d)' % (r[2], r[3], r[4], r[0], r[1]) for r in rows],
+                'distinct_devices': len({(r[2], r[3], r[4]) for r in rows})}
+
+    # ---------------------------------------------------------------- two-channel csd / coherence (C3) ----
+    def csd_bench(steps, warmup):
+        n = 1 << 26
+        x = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        y = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        ctx.synth_iq(x.data_ptr(), n, 1003, TONES, DC)
+        ctx.synth_iq(y.data_ptr(), n, 1004, (), 0j)
+        y.mul_(0.5).add_(torch.roll(x, 5, 0), alpha=0.7)      # SURVEY 8d: y = 0.7 x delayed by 5 samples + independent noise
+        plan = ctx.welch_plan(NFFT, window=hann, fs=1.0)
+        pxx, pyy, cxy = (torch.zeros(NFFT, dtype=torch.float32, device=dev) for _ in range(3))
+        pxy = torch.zeros((NFFT, 2), dtype=torch.float32, device=dev)
+
+        def step():
+            plan.csd_exec_dev(x.data_ptr(), y.data_ptr(), n, pxx.data_ptr(), pyy.data_ptr(), pxy.data_ptr(), cxy.data_ptr())
+
+        ramp(step)
+        for _ in range(warmup):
+            step()
+        ctx.set_timing(True)
+        ctx.get_timing(reset=True)
+        wall, per = timed_steps(torch, dist, dev, step, fence, steps, False)
+        kern_ms, launches = ctx.get_timing(reset=True)
+        ctx.set_timing(False)
+        assert bool(torch.isfinite(cxy).all())
+        from oracle import ref_cpu as R
+        m = 1 << 20
+        px = x[:m].cpu().numpy().view(np.complex64).reshape(-1)
+        py = y[:m].cpu().numpy().view(np.complex64).reshape(-1)
+        _, rc, rxx, ryy, rxy = R.coherence_np(px, py, nperseg=NFFT, nfft=NFFT)
+        gxx, gyy, gxy, gc = ctx.welch_plan(NFFT, window=hann, fs=1.0).csd(px, py)
+        err = {'pxx': float(np.max(np.abs(gxx - rxx) / rxx)), 'pyy': float(np.max(np.abs(gyy - ryy) / ryy)),
+               'pxy_over_sqrt_pxx_pyy': float(np.max(np.abs(gxy - rxy) / np.sqrt(rxx * ryy))),
+               'cxy_abs': float(np.max(np.abs(gc - rc)))}
+        med = statistics.median(per)
+        kavg = kern_ms / max(launches, 1)
+        ach = 16.0 * n / (kavg * 1e-3) / 1e9 if kavg else 0.0
+        return {'value': n / (med * 1e-3) / 1e6, 'unit': 'Msample-pairs/s', 'ms_per_step': med,
+                'wall_ms_per_step': 1e3 * wall / steps, 'steps': steps, 'kernel_avg_ms': kavg, 'launches': int(launches),
+                'config': {'workload': 'C3: two complex64 streams x 2^26 samples (y = 0.7 x delayed by 5 + noise), 4096-pt '
+                                       'Hann, 50% overlap, detrend constant -> Pxx, Pyy, Pxy, Cxy on the device'},
+                'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                             'frac': ach / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'csd4096ws_kernel',
+                             'kernel_avg_ms': kavg, 'launches': int(launches), 'algorithmic_bytes_per_launch': 16 * n,
+                             'whole_step_frac': 16.0 * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                'parity_prefix_max_err': err}
+
+    # ---------------------------------------------------------------- batched scanner (C5) -----------------
+    def scan_bench(steps, warmup):
+        nch, S, N = 64, 1 << 22, 16384
+        Sf = 1000000
+        iq = torch.empty((nch * S, 2), dtype=torch.float32, device=dev)
+        for c in range(nch):
+            ctx.synth_iq(iq.data_ptr() + 8 * c * S, S, 3000 + c, TONES, DC)
+        bp = scan_batch.BatchScanPlan(ctx, N, Sf, 15625.0, 10e3, thr_leveler=10)
+        lo, hi = bp._slices()
+        rows = torch.zeros((nch, N), dtype=torch.float32, device=dev)
+        noise = torch.zeros(nch, dtype=torch.float32, device=dev)
+        power = torch.zeros((nch, max(len(lo), 1)), dtype=torch.float32, device=dev)
+        mask = torch.zeros((nch, N), dtype=torch.uint8, device=dev)
+
+        def step():
+            bp.psd_rows_dev(iq.data_ptr(), S, nch, S, rows.data_ptr())
+            ctx.scan_decide_dev_out(rows.data_ptr(), nch, N, bp.scanner.srch_bins, bp.thr_leveler, lo, hi,
+                                    noise.data_ptr(), power.data_ptr(), mask.data_ptr())
+
+        ramp(step)
+        for _ in range(warmup):
+            step()
+        ctx.set_timing(True)
+        ctx.get_timing(reset=True)
+        wall, per = timed_steps(torch, dist, dev, step, fence, steps, False)
+        kern_ms, launches = ctx.get_timing(reset=True)
+        ctx.set_timing(False)
+        # parity of channel 0 (prefix of 2^20 samples: PSD row, noise floor, mask, channel sums) against the oracle
+        from oracle import ref_cpu as R
+        m = 1 << 20
+        pre = iq[:m].cpu().numpy().view(np.complex64).reshape(-1)
+        d_pre, d_row = ctx.alloc(m * 8), ctx.alloc(N * 4)
+        try:
+            ctx.h2d(d_pre, pre)
+            bp.psd_rows_dev(d_pre, m, 1, m, d_row)
+            got_mask, got_noise, got_pw = bp.decide_dev(d_row, 1)
+            got_row = ctx.d2h(d_row, (N,), np.float32)
+        finally:
+            ctx.free(d_pre)
+            ctx.free(d_row)
+        ref_row = R.chain_sensor_v2(pre, N).mean(axis=0)
+        ma = R.movingaverage(ref_row.astype(np.float32), bp.scanner.srch_bins)
+        ref_noise = float(ma.min())
+        ref_pw = np.array(R.src_power(ref_row.astype(np.float32), N, bp.scanner.Fr, Sf, bp.scanner.bb_freqs,
+                                      bp.scanner.srch_bins))
+        if bp.scanner.trunc > 0:
+            ref_pw = ref_pw[bp.scanner.trunc_ch:-bp.scanner.trunc_ch]
+        ref_mask = ref_row > bp.thr_leveler * ref_noise
+        margin = np.abs(ref_row - bp.thr_leveler * ref_noise) / (bp.thr_leveler * ref_noise)
+        err = {'psd_row': float(np.max(np.abs(got_row - ref_row) / ref_row)),
+               'noise_floor': abs(float(got_noise[0]) - ref_noise) / ref_noise,
+               'channel_power': float(np.max(np.abs(np.asarray(got_pw)[0] - ref_pw) / ref_pw)),
+               'mask_mismatches_beyond_1e-4_of_the_threshold': int(np.sum(((got_mask[0] != 0) != ref_mask) & (margin >= 1e-4)))}
+        med = statistics.median(per)
+        kavg = kern_ms / max(launches, 1)
+        total = nch * S
+        ach = 8.0 * total / (kavg * 1e-3) / 1e9 if kavg else 0.0
+        return {'value': total / (med * 1e-3) / 1e6, 'unit': 'Msamples/s', 'ms_per_step': med,
+                'wall_ms_per_step': 1e3 * wall / steps, 'steps': steps, 'kernel_avg_ms': kavg, 'launches': int(launches),
+                'config': {'workload': 'C5: 64 channel streams x 2^22 samples, 16384-pt rectangular |X|^2/N^2 mean per stream '
+                                       '(multichannel_scanner.py:78-86) + moving average, noise floor, per-bin mask and %d '
+                                       'channel sums on the device (oth_scan_decide_dev_out)' % len(lo)},
+                'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                             'frac': ach / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'welch16k_kernel',
+                             'kernel_avg_ms': kavg, 'launches': int(launches), 'algorithmic_bytes_per_launch': 8 * total,
+                             'whole_step_frac': 8.0 * total / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                'parity_prefix_max_rel_err': err}
+
     result = None
     if multi:
+        seen = ranks_seen()
         sw, S = sweep_bench(args.steps, args.warmup)
         if rank == 0:
             kavg = sw['kernel_avg_ms']
@@ -288,6 +526,9 @@ def main():
                              'kernel_avg_ms': kavg, 'launches': sw['launches'],
                              'algorithmic_bytes_per_launch': 8 * S},
                 'parity_prefix_max_rel_err': sw['parity_prefix_max_rel_err'],
+                'ranks_seen': seen,
+                'scaling_base': 'sweep_c4.value of the --gpus 1 line (the same fixed sweep on one GPU): speed-up at N = '
+                                'this value / that value',
                 'cpu_baseline': None, 'device': ctx.device_name(),
             }
     else:
@@ -355,6 +596,20 @@ def main():
             'device': ctx.device_name(),
         }
         if not args.no_extras:
+            # SURVEY 8d ends the metric at "PSD available on host": the same step through the host-output entry point
+            # (oth_welch_exec with a device source: kernels + 16 KiB D2H + stream synchronisation inside the call)
+            for _ in range(3):
+                plan.exec_device_src(iq.data_ptr(), n)
+            hv = []
+            for _ in range(max(10, args.steps // 4)):
+                t0 = time.perf_counter()
+                plan.exec_device_src(iq.data_ptr(), n)
+                hv.append((time.perf_counter() - t0) * 1e3)
+            result['host_visible_ms_per_step'] = statistics.median(hv)
+            result['host_visible_value'] = n / (statistics.median(hv) * 1e-3) / 1e6
+            result['host_visible_note'] = ('oth_welch_exec(src_is_device=1): launch -> float32[4096] PSD in host memory, '
+                                           'one blocking call per step (no overlap between steps), median of %d host-clock '
+                                           'times; `value` is the pipelined device-side rate' % len(hv))
             # host buffer -> PSD on the host through the streaming entry point (pinned staging ring, asynchronous
             # H2D + kernels): the PCIe-inclusive rate; never `value`
             # sixteen DISTINCT 32 MiB chunks (512 MiB of host memory: well past the CPU's last-level cache, so the
@@ -386,8 +641,14 @@ def main():
             torch.cuda.empty_cache()
             sw, _ = sweep_bench(max(10, args.steps // 4), max(3, args.warmup // 4))
             result['sweep_c4'] = sw
+            torch.cuda.empty_cache()
+            result['csd_c3'] = csd_bench(max(10, args.steps // 4), max(3, args.warmup // 4))
+            torch.cuda.empty_cache()
+            result['scan_c5'] = scan_bench(max(10, args.steps // 4), max(3, args.warmup // 4))
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             result['cpu_baseline'], result['cpu_baseline_parallel'] = cpu_baseline(NFFT)
+            result['cpu_baseline_c5'] = cpu_baseline_c5()
         else:
             result['cpu_baseline'] = None
     if multi:

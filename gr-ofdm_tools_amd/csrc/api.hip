@@ -39,6 +39,15 @@ struct oth_ctx {
     int queue_used = 0;                // counters the last averaging launch drew from
     unsigned char *scratch = nullptr;  // device scratch of the small ops (channel power, decision stage, xcorr): grown on
     size_t scratch_cap = 0;            // demand, never freed per call
+    // channel slice bounds of the decision stage (oth_scan_decide_dev*): a scanner passes the same lo / hi on every
+    // call, so they live on the device and are uploaded again only when their contents change - through a pinned
+    // staging buffer, so that the upload is a real asynchronous copy (from pageable memory hipMemcpyAsync may hold the
+    // host until the stream has drained, which would make the "asynchronous" entry points wait for the PSD kernels)
+    std::vector<int> bounds_host;      // lo[nch] then hi[nch], as last uploaded
+    int *d_bounds = nullptr;
+    int *h_bounds = nullptr;           // pinned
+    size_t bounds_cap = 0;             // ints
+    hipEvent_t bounds_ev = nullptr;    // behind the last upload: the pinned words may be rewritten after it
 };
 
 struct oth_plan {
@@ -783,10 +792,13 @@ int oth_ctx_destroy(oth_ctx *c) {
     if (c->acc4) hipFree(c->acc4);
     if (c->queue) hipFree(c->queue);
     if (c->scratch) hipFree(c->scratch);
+    if (c->d_bounds) hipFree(c->d_bounds);
+    if (c->h_bounds) hipHostFree(c->h_bounds);
+    if (c->bounds_ev) hipEventDestroy(c->bounds_ev);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return OTH_OK;
-    OTH_CATCH(c)
+    OTH_CATCH(nullptr)
 }
 
 const char *oth_last_error(oth_ctx *c) { return c ? c->err.c_str() : g_err.c_str(); }
@@ -1077,7 +1089,8 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
         return fail(p->ctx, OTH_ERR_INVALID, "bad tuning value");
     if (variant && *variant) {
         bool known = !strcmp(variant, "seg3") || !strcmp(variant, "seg4") || !strcmp(variant, "segws") ||   // 1024 / 2048
-                     !strcmp(variant, "csd1");                                  // the one-role two-channel kernel
+                     !strcmp(variant, "csd1") ||                                // the one-role two-channel kernel
+                     !strcmp(variant, "fd") || !strcmp(variant, "td");          // detrend form only (run_average)
         for (const auto &v : kVariants) known = known || !strcmp(variant, v.tag);
         if (!known) return fail(p->ctx, OTH_ERR_UNSUPPORTED, std::string("unknown kernel build: ") + variant);
     }
@@ -1942,6 +1955,39 @@ int oth_rows_group_mean(oth_ctx *c, const float *rows_host, size_t nrows, int nf
 
 static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// -> device pointers to the channel slice bounds, uploading them only when they differ from the cached copy
+static int channel_bounds_dev(oth_ctx *c, int nch, const int *lo, const int *hi, const int **dlo, const int **dhi) {
+    *dlo = *dhi = nullptr;
+    if (nch <= 0) return OTH_OK;
+    const size_t n = 2 * (size_t)nch;
+    bool same = c->d_bounds && c->bounds_host.size() == n;
+    for (int i = 0; same && i < nch; ++i) same = c->bounds_host[i] == lo[i] && c->bounds_host[nch + i] == hi[i];
+    if (!same) {
+        if (n > c->bounds_cap) {
+            if (c->bounds_ev) HIPCHK(c, hipEventSynchronize(c->bounds_ev));
+            HIPCHK(c, hipStreamSynchronize(c->stream));      // kernels may still read the old device copy
+            if (c->d_bounds) hipFree(c->d_bounds);
+            if (c->h_bounds) hipHostFree(c->h_bounds);
+            c->d_bounds = c->h_bounds = nullptr;
+            c->bounds_cap = 0;
+            c->bounds_host.clear();
+            if (hipMalloc(&c->d_bounds, sizeof(int) * n) != hipSuccess) return fail(c, OTH_ERR_NOMEM, "device allocation failed");
+            HIPCHK(c, hipHostMalloc((void **)&c->h_bounds, sizeof(int) * n, hipHostMallocDefault));
+            c->bounds_cap = n;
+        }
+        if (!c->bounds_ev) HIPCHK(c, hipEventCreateWithFlags(&c->bounds_ev, hipEventDisableTiming));
+        else HIPCHK(c, hipEventSynchronize(c->bounds_ev));      // the previous upload has read the pinned words
+        memcpy(c->h_bounds, lo, sizeof(int) * nch);
+        memcpy(c->h_bounds + nch, hi, sizeof(int) * nch);
+        HIPCHK(c, hipMemcpyAsync(c->d_bounds, c->h_bounds, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->bounds_ev, c->stream));
+        c->bounds_host.assign(c->h_bounds, c->h_bounds + n);
+    }
+    *dlo = c->d_bounds;
+    *dhi = c->d_bounds + nch;
+    return OTH_OK;
+}
+
 int oth_channel_power(oth_ctx *c, const float *psd_host, int nfft, double srch_bins, int nch, const int *lo,
                       const int *hi, float *power_out, float *movavg_out) {
     OTH_TRY
@@ -2009,17 +2055,14 @@ int oth_scan_decide_dev(oth_ctx *c, const float *psd_rows_dev, int nrows, int nf
     if (use_device(c)) return OTH_ERR_HIP;
     const size_t nb = (size_t)nrows * nfft;
     const size_t o_ma = 0, o_mask = up16(o_ma + sizeof(double) * nb), o_noise = up16(o_mask + nb),
-                 o_pw = up16(o_noise + sizeof(float) * nrows), o_lo = up16(o_pw + sizeof(float) * nrows * (nch + 1)),
-                 o_hi = up16(o_lo + sizeof(int) * (nch + 1)), bytes = up16(o_hi + sizeof(int) * (nch + 1));
+                 o_pw = up16(o_noise + sizeof(float) * nrows), bytes = up16(o_pw + sizeof(float) * nrows * (nch + 1));
     int rc = ensure(c, &c->scratch, &c->scratch_cap, bytes);
     if (rc) return rc;
     unsigned char *d = c->scratch;
-    if (nch) {
-        HIPCHK(c, hipMemcpyAsync(d + o_lo, lo, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d + o_hi, hi, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream));
-    }
-    HIPCHK(c, launch_scan_decide(psd_rows_dev, nrows, nfft, srch_bins, thr_leveler, nch, (const int *)(d + o_lo),
-                                 (const int *)(d + o_hi), (double *)(d + o_ma), mask_out ? d + o_mask : nullptr,
+    const int *dlo = nullptr, *dhi = nullptr;
+    if ((rc = channel_bounds_dev(c, nch, lo, hi, &dlo, &dhi))) return rc;
+    HIPCHK(c, launch_scan_decide(psd_rows_dev, nrows, nfft, srch_bins, thr_leveler, nch, dlo,
+                                 dhi, (double *)(d + o_ma), mask_out ? d + o_mask : nullptr,
                                  (float *)(d + o_noise), nch ? (float *)(d + o_pw) : nullptr, c->stream));
     if (mask_out) HIPCHK(c, hipMemcpyAsync(mask_out, d + o_mask, nb, hipMemcpyDeviceToHost, c->stream));
     if (noise_out)
@@ -2043,18 +2086,14 @@ int oth_scan_decide_dev_out(oth_ctx *c, const float *psd_rows_dev, int nrows, in
         if (lo[i] < 0 || hi[i] > nfft) return fail(c, OTH_ERR_INVALID, "channel slice outside [0, nfft]");
     if (use_device(c)) return OTH_ERR_HIP;
     const size_t nb = (size_t)nrows * nfft;
-    const size_t o_ma = 0, o_lo = up16(o_ma + sizeof(double) * nb), o_hi = up16(o_lo + sizeof(int) * (nch + 1)),
-                 bytes = up16(o_hi + sizeof(int) * (nch + 1));
+    const size_t bytes = up16(sizeof(double) * nb);
     int rc = ensure(c, &c->scratch, &c->scratch_cap, bytes);
     if (rc) return rc;
     unsigned char *d = c->scratch;
-    if (nch) {      // pageable host words: staged by the runtime before the call returns
-        HIPCHK(c, hipMemcpyAsync(d + o_lo, lo, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d + o_hi, hi, sizeof(int) * nch, hipMemcpyHostToDevice, c->stream));
-    }
-    HIPCHK(c, launch_scan_decide(psd_rows_dev, nrows, nfft, srch_bins, thr_leveler, nch, (const int *)(d + o_lo),
-                                 (const int *)(d + o_hi), (double *)(d + o_ma), mask_dev, noise_dev, nch ? power_dev : nullptr,
-                                 c->stream));
+    const int *dlo = nullptr, *dhi = nullptr;      // cached on the device: no host copy on the steady-state path
+    if ((rc = channel_bounds_dev(c, nch, lo, hi, &dlo, &dhi))) return rc;
+    HIPCHK(c, launch_scan_decide(psd_rows_dev, nrows, nfft, srch_bins, thr_leveler, nch, dlo, dhi, (double *)d, mask_dev,
+                                 noise_dev, nch ? power_dev : nullptr, c->stream));
     return OTH_OK;
     OTH_CATCH(c)
 }

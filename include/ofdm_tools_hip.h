@@ -156,7 +156,8 @@ int oth_plan_set_schedule(oth_plan *plan, int which);         /* OTH_SCHED_* */
 int oth_plan_out_len(oth_plan *plan, int *n);
 /* Launch tuning for A/B tools and the parity suite: which build of the 4096-point kernel ("dpp", "pipe", "ws") or
  * of the 256 ... 2048-point kernels ("seg3", "seg4": registers held to 3 / 4 waves per SIMD; NULL or "" = the
- * library's choice), a schedule override (-1 = the plan's), segments per chunk and per tail chunk
+ * library's choice), or only the detrend form of the size's default kernel ("fd": after the transform even below 8
+ * segments per stream; "td": before it at any length - what OTH_DETREND_CONSTANT_EXACT plans always do), a schedule override (-1 = the plan's), segments per chunk and per tail chunk
  * (0 = default).  The OTH_W4096_VARIANT / _SCHED / _CHUNK / _TAIL environment variables give the initial values
  * and are read once, in oth_welch_plan(). */
 int oth_plan_set_tuning(oth_plan *plan, const char *variant, int sched, int chunk, int tail_chunk);

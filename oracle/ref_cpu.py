@@ -232,6 +232,24 @@ def welch_np(x, fs=1.0, window='hann', nperseg=256, noverlap=None, nfft=None,
     return csd_np(x, None, fs, window, nperseg, noverlap, nfft, detrend, scaling)
 
 
+def welch_c64(x, fs=1.0, window='hann', nperseg=256, noverlap=None, nfft=None, y=None):
+    """The reference's arithmetic AS IT RUNS: GNU Radio hands ``sg.welch`` complex64 samples
+    (ofdm_cr_tools.py:214,322,342; spectrum_sweeper.py:263) and SciPy keeps complex64 in single precision - segment
+    mean, window product and pocketfft all in float32.  Tests use it to tell "differs from the float64 restatement
+    by what single precision costs the reference itself" from a defect: with a DC line far above the noise the
+    float32 REPRESENTATION of the segment mean (relative 6e-8, times sum(w) in bin 0) already costs the reference
+    1e-4 ... 5e-3 of bins 0, +-1 on a one-segment input.  ``y``: cross spectrum (sg.csd).  -> float64 copy of the
+    float32 / complex64 result."""
+    import scipy.signal as sg
+    x = np.asarray(x, np.complex64)
+    if y is None:
+        _, p = sg.welch(x, fs=fs, window=window, nperseg=nperseg, noverlap=noverlap, nfft=nfft, return_onesided=False)
+        return p.astype(np.float64)
+    _, p = sg.csd(x, np.asarray(y, np.complex64), fs=fs, window=window, nperseg=nperseg, noverlap=noverlap, nfft=nfft,
+                  return_onesided=False)
+    return p.astype(np.complex128)
+
+
 def coherence_np(x, y, fs=1.0, window='hann', nperseg=256, noverlap=None, nfft=None,
                  detrend='constant'):
     """|Pxy|^2 / (Pxx Pyy) - the semantics of ``scipy.signal.coherence``
@@ -453,6 +471,18 @@ def chain_sensor_v2(x, fft_len, decim=1):
     rectangular window, shifted FFT, |.|^2, x 1/N^2, per kept vector."""
     X = gr_fft_vcc(gr_kept_vectors(x, fft_len, decim), None, True)
     return (X.real ** 2 + X.imag ** 2) * (1.0 / float(fft_len ** 2))
+
+
+def chain_sensor_v2_mean_c64(x, fft_len):
+    """The same chain as GNU Radio RUNS it - single precision throughout (fft_vcc is FFTW3f, the magnitude and 1/N^2
+    blocks are float32 VOLK kernels) - averaged over all vectors of the stream: the CPU counterpart of BASELINE
+    config 5's per-channel PSD (multichannel_scanner.py:78-86 + the mean).  scipy.fft keeps complex64 in single
+    precision; one (rows, N) batch per call, rows accumulated in float64.  bench.py times this (cpu_baseline_c5)."""
+    import scipy.fft as sfft
+    v = gr_kept_vectors(np.asarray(x, np.complex64), fft_len, 1)
+    X = sfft.fft(v, axis=1)
+    p = (X.real * X.real + X.imag * X.imag) * np.float32(1.0 / float(fft_len ** 2))
+    return np.fft.fftshift(p.mean(axis=0, dtype=np.float64))
 
 
 def chain_psd_logger(x, fft_len, decim=1):

@@ -85,6 +85,22 @@ def test_exception_barrier_at_the_abi():
         assert body.lstrip().startswith('OTH_TRY') and 'OTH_CATCH(' in body.rstrip().splitlines()[-1], name
 
 
+def test_bench_gpus_n_without_a_gpu_exits_with_the_clear_message():
+    """`python bench.py --gpus N` is the driver's command shape: without a launcher it must decide BEFORE touching the
+    GPU whether it can spawn its ranks, and say why not."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip('GPU present')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    for extra in ([], ['--gpus', '2']):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1'] + extra, env=env,
+                           capture_output=True, timeout=300)
+        assert p.returncode != 0 and b'needs an MI355X' in p.stderr and b'no CPU fallback' in p.stderr, p.stderr
+        assert p.stdout.strip() == b''
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from ofdm_tools import _hip
     monkeypatch.setattr(_hip, '_lib', None)

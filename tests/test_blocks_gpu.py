@@ -785,3 +785,23 @@ def test_ascii_plot_block(ctx):
     assert len(got_rows) == len(want_rows) and got_rows[-2:] == want_rows[-2:]
     diff = sum(a != b for a, b in zip(blk.last_plot, want))
     assert diff <= 8, diff
+
+
+def test_bench_gpus_2_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` as typed (no launcher): the parent spawns two ranks before it touches the GPU, rank 0's
+    ONE JSON line comes back, rc 0.  Rehearsal form on this one-GPU box (both ranks on device 0, gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['BENCH_REHEARSE'] = '1'
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                        '--sweep-log2-samples', '22', '--ramp-ms', '20'], env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['steps'] == 5 and r['scaling'] == 'strong' and r['value'] > 0
+    assert r['ranks_seen']['world_size'] == 2 and len(r['ranks_seen']['devices']) == 2
+    assert 'sweep_c4.value' in r['scaling_base'] and r['parity_prefix_max_rel_err'] < RTOL
