@@ -378,12 +378,12 @@ def main():
         mine = torch.tensor([rank, local_rank, int(getattr(pr, 'pci_domain_id', 0)), int(getattr(pr, 'pci_bus_id', -1)),
                              int(getattr(pr, 'pci_device_id', -1))], dtype=torch.int64,
                             device=dev if not rehearse else 'cpu')
-        allr = torch.empty((world, 5), dtype=torch.int64, device=mine.device)
+        allr = torch.empty(world * 5, dtype=torch.int64, device=mine.device)
         if world > 1 or force:
             dist.all_gather_into_tensor(allr, mine)
         else:
-            allr[0] = mine
-        rows = [[int(v) for v in r] for r in allr.cpu()]
+            allr[:5] = mine
+        rows = [[int(v) for v in r] for r in allr.view(world, 5).cpu()]
         return {'world_size': world, 'backend': dist.get_backend() if multi else None,
                 'devices': ['%04x:%02x:%02x.0 (rank %d, cuda:%d)' % (r[2], r[3], r[4], r[0], r[1]) for r in rows],
                 'distinct_devices': len({(r[2], r[3], r[4]) for r in rows})}
