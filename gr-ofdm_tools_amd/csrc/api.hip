@@ -59,6 +59,7 @@ struct oth_plan {
     const float2 *d_tw = nullptr;
     float4 *d_fd = nullptr;            // window spectrum for the frequency-domain detrend (welch4096ws), or nullptr
     bool exact_detrend = false;        // OTH_DETREND_CONSTANT_EXACT: time-domain detrend only (d_fd stays nullptr)
+    bool rect_window = false;          // every window value is 1 (window == NULL or boxcar): builds without the multiply
     float *d_partial = nullptr;
     size_t partial_cap = 0;
     int last_W = 0;
@@ -523,6 +524,10 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     const bool tuned_16k = !csd && (p->nfft == 16384 || p->nfft == 8192) &&
                            (p->nperseg == p->nfft || p->nperseg * 4 == p->nfft) &&      // (nfft / 4: the sweeper's zero padding)
                            p->kernel != OTH_KERNEL_GENERIC;
+    // welch16k1x.hip: 16384-point vectors that do not overlap, no detrend (the scanner of BASELINE config 5): one
+    // cross-wave exchange per segment instead of two; "16k4" keeps the 4 x 4096 kernel (A/B, parity suite)
+    const bool tuned_16k1x = tuned_16k && p->nfft == 16384 && p->nperseg == 16384 && p->step >= 16384 &&
+                             p->detrend == OTH_DETREND_NONE && p->tune_variant != "16k4";
     // segfft.hip: nperseg = nfft = 256 / 512 / 1024 / 2048, any step (team of nfft / 16 threads per segment)
     // ... and zero-padded segments nperseg = nfft / 4 (the sweeper's call, spectrum_sweeper.py:263) or nfft / 2 at 1024 / 2048
     const bool seg_pad = !csd && seg_padded_supported(p->nfft, p->nperseg) && p->kernel != OTH_KERNEL_GENERIC;
@@ -621,6 +626,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
             a.sched = OTH_SCHED_CONTIGUOUS;
         a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 16 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : ((p->nfft == 1024 && !seg_ws) || (p->nfft == 2048 && seg_ws) ? 32 : 16)) : 8)));
         if (a.chunk < 1) a.chunk = 1;
+        if (tuned_16k1x && a.chunk < 2) a.chunk = 2;      // its ticket for the NEXT chunk is published with a chunk's first
+                                                          // segment and read at its last: chunks of at least two segments
         a.tail_chunk = a.chunk;
         a.nbig = nseg_run / a.chunk;
         if (a.sched < 0 || a.sched > 2) a.sched = 0;
@@ -631,6 +638,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
                 // guided tail: the last half round of work goes out in quarter-size chunks
                 a.tail_chunk = p->tune_tail > 0 ? p->tune_tail : (a.chunk >= 4 ? a.chunk / 4 : 1);
                 if (a.tail_chunk < 1) a.tail_chunk = 1;
+                if (tuned_16k1x && a.tail_chunk < 2) a.tail_chunk = 2;
                 const long long tail_segs = (long long)W * a.chunk / 2;
                 a.nbig = nseg_run > tail_segs ? (nseg_run - tail_segs) / a.chunk : 0;
                 if (!c->queue_clean) HIPCHK(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned) * 64, c->stream));
@@ -666,12 +674,13 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         Timed tm(c);
         HIPCHK(c, tuned ? var->launch(a, c->stream)
                         : (tuned_csd ? (csd_ws ? launch_csd_tuned4096ws(a, c->stream) : launch_csd_tuned4096(a, c->stream))
-                                     : (tuned_16k ? launch_welch_tuned16k(p->nfft, a, c->stream)
+                                     : (tuned_16k ? (tuned_16k1x ? launch_welch_tuned16k1x(a, !p->rect_window, p->tune_variant == "16kplain", c->stream)
+                                                                 : launch_welch_tuned16k(p->nfft, a, c->stream))
                                                   : launch_welch_generic(p->nfft, a, c->stream))));
     }
     *nseg_out = nseg;
     *W_out = W * rows;
-    *layout_out = (tuned || tuned_csd) ? 1 : (tuned_16k ? (p->nfft == 16384 ? 2 : 3) : 0);
+    *layout_out = (tuned || tuned_csd) ? 1 : (tuned_16k ? (tuned_16k1x ? 4 : (p->nfft == 16384 ? 2 : 3)) : 0);
     return OTH_OK;
 }
 
@@ -989,8 +998,10 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     if (const char *e = getenv("OTH_W4096_TAIL")) p->tune_tail = atoi(e);
     std::vector<float> w(nfft, 0.f);   // zero-extended so that kernels may index [0, nfft)
     double s1 = 0.0, s2 = 0.0;
+    p->rect_window = true;
     for (int i = 0; i < nperseg; ++i) {
         w[i] = window ? window[i] : 1.0f;
+        if (w[i] != 1.0f) p->rect_window = false;
         s1 += (double)w[i];
         s2 += (double)w[i] * (double)w[i];
     }
@@ -1090,7 +1101,9 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
     if (variant && *variant) {
         bool known = !strcmp(variant, "seg3") || !strcmp(variant, "seg4") || !strcmp(variant, "segws") ||   // 1024 / 2048
                      !strcmp(variant, "csd1") ||                                // the one-role two-channel kernel
-                     !strcmp(variant, "fd") || !strcmp(variant, "td");          // detrend form only (run_average)
+                     !strcmp(variant, "fd") || !strcmp(variant, "td") ||        // detrend form only (run_average)
+                     !strcmp(variant, "16k4") || !strcmp(variant, "16kplain");  // 16384 points: the 4 x 4096 build / the
+                                                                                // un-pipelined one-exchange build
         for (const auto &v : kVariants) known = known || !strcmp(variant, v.tag);
         if (!known) return fail(p->ctx, OTH_ERR_UNSUPPORTED, std::string("unknown kernel build: ") + variant);
     }

@@ -11,8 +11,11 @@ namespace oth {
 //   layout 0: natural order (generic kernels)
 //   layout 1: welch4096 / csd4096 leave bin k0 + 16 k1 + 256 k2 at 16 k0 + k1 + 256 k2
 //   layout 2: welch16k leaves bin k' + 4 q at 4096 k' + (layout-1 position of q); layout 3 (8192 points): k' + 2 q
+//   layout 4: welch16k1x leaves bin k0 + 16 k1 + 256 k2 + 4096 bitrev2(q) at 1024 k2 + 64 k0 + 4 k1 + q
 __device__ __forceinline__ int bin_pos(int pos, int layout) {
     if (layout == 0) return pos;
+    if (layout == 4)
+        return ((pos >> 6) & 15) + 16 * ((pos >> 2) & 15) + 256 * (pos >> 10) + 4096 * (((pos & 1) << 1) | ((pos >> 1) & 1));
     const int r = pos & 4095;
     const int q = ((r & 15) << 4) | ((r >> 4) & 15) | (r & ~255);
     return layout == 1 ? q : (pos >> 12) + (layout == 2 ? 4 : 2) * q;
@@ -140,8 +143,54 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *parti
     *reinterpret_cast<float4 *>(scratch + ((((size_t)stream * G) + g) * nch + ch) * nfft + col) = o;
 }
 
+// Layout 4 (welch16k1x, 16384 points, one channel): position 1024 k2 + 4 (16 k0 + k1) + q holds bin
+// k0 + 16 k1 + 256 k2 + 4096 bitrev2(q), so ONE float4 at position 1024 k2 + 4 t (t = 16 k0 + k1) carries the four k3 of
+// (k0, k1, k2).  A block takes one k2: 256 threads read W rows of 4 KiB each as float4 (coalesced), sum in double (fixed
+// order), turn t = 16 k0 + k1 into k0 + 16 k1 through LDS and write four runs of 256 consecutive bins (1 KiB each) -
+// reads and writes both coalesced.  The general finalize_kernel scatters 4-byte stores across the row for this layout:
+// 21-24 us for the 64 x 16384 rows of BASELINE config 5 next to a 450 us transform kernel; this one 4-5 us.
+__global__ __launch_bounds__(256) void finalize_l4_kernel(FinalizeArgs a) {
+    __shared__ double red[4][256];
+    if (a.queue_reset && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < a.queue_n) a.queue_reset[threadIdx.x] = 0u;
+    const int t = threadIdx.x, k2 = blockIdx.x, stream = blockIdx.y;
+    const float *base = a.partial + (size_t)stream * a.W * a.nfft + 1024 * k2 + 4 * t;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int w = 0; w < a.W; ++w) {
+        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)w * a.nfft);
+        s0 += v.x;
+        s1 += v.y;
+        s2 += v.z;
+        s3 += v.w;
+    }
+    const int u = (t >> 4) + 16 * (t & 15);      // k0 + 16 k1
+    red[0][u] = s0;                              // q = 0 -> k3 = 0
+    red[2][u] = s1;                              // q = 1 -> k3 = 2
+    red[1][u] = s2;                              // q = 2 -> k3 = 1
+    red[3][u] = s3;                              // q = 3 -> k3 = 3
+    __syncthreads();
+#pragma unroll
+    for (int k3 = 0; k3 < 4; ++k3) {
+        const int k = t + 256 * k2 + 4096 * k3;
+        const int ks = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;
+        const int i = ks - a.trim;
+        if (i < 0 || i >= a.nout) continue;
+        const size_t o = (size_t)stream * a.nout + i;
+        const double sum = red[k3][t];
+        if (a.accumulate) {
+            a.out0[o] += (float)sum;
+        } else {
+            const double v = sum * a.scale;
+            a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
+        }
+    }
+}
+
 hipError_t launch_finalize(const FinalizeArgs &a_in, int nstreams, hipStream_t s) {
     FinalizeArgs a = a_in;
+    if (a.layout == 4 && a.nch == 1 && a.nfft == 16384 && a.W <= 64) {
+        hipLaunchKernelGGL(finalize_l4_kernel, dim3(16, nstreams), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.nch == 1 && a.W >= 64 && (a.nfft % 16) == 0) {
         // 16 positions per block: 5.2 us for 512 rows of 4096 against 6.8 us with 32 (half as many blocks)
         hipLaunchKernelGGL(finalize_wide_kernel<16>, dim3(a.nfft / 16, nstreams), dim3(256), 0, s, a);

@@ -90,7 +90,8 @@ struct FinalizeArgs {
     int W;
     int nfft;
     int nch;                // 1 or 4
-    int layout;             // 0 natural, 1 welch4096 digit order, 2 / 3 welch16k order at 16384 / 8192 (kernels_misc.hip bin_pos)
+    int layout;             // 0 natural, 1 welch4096 digit order, 2 / 3 welch16k order at 16384 / 8192, 4 welch16k1x order
+                            // (kernels_misc.hip bin_pos)
     int fftshift;
     int trim;
     int db;
@@ -135,6 +136,9 @@ hipError_t launch_csd_tuned4096ws(const WelchArgs &a, hipStream_t s);
 int csd4096ws_blocks_per_cu();
 // welch16k.hip: nfft = nperseg = 16384 (one 1024-thread workgroup per CU) or 8192 (two 512-thread workgroups)
 hipError_t launch_welch_tuned16k(int nfft, const WelchArgs &a, hipStream_t s);
+// welch16k1x.hip: nfft = nperseg = 16384, no detrend, whole-segment loads (the scanner's non-overlapping vectors): one
+// cross-wave exchange, two workgroup barriers per segment; partial rows in finalize layout 4
+hipError_t launch_welch_tuned16k1x(const WelchArgs &a, bool window, bool plain, hipStream_t s);
 // the fused periodogram chain at 8192 / 16384 points (one workgroup per segment; workgroups per CU: 2 / 1)
 hipError_t launch_chain16k(int nfft, const SegArgs &a, bool rect, hipStream_t s);
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);

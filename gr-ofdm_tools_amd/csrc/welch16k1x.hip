@@ -1,0 +1,576 @@
+// welch16k1x: segment-averaged |FFT_16384(x * w)|^2 for non-overlapping 16384-point vectors - BASELINE config 5, the
+// multichannel_scanner chain (python/multichannel_scanner.py:78-86: stream_to_vector -> fft_vcc(rect, shift) ->
+// |.|^2 -> 1/N^2) averaged over the kept vectors of each channel stream; also any scipy.signal.welch call with
+// nperseg = nfft = 16384, detrend=False and no overlap.
+//
+// One 1024-thread workgroup (16 waves) per segment, 16 points per thread, N = 16 x 16 x 16 x 4 decimation in
+// frequency with the index bits placed so that only ONE of the three exchanges crosses waves:
+//
+//   n = tid + 1024 r           tid = 64 w + l (wave w, lane l),  l = 4 g + q
+//   k = k0 + 16 k1 + 256 k2 + 4096 k3
+//   pass 1  thread (w, l) holds r = 0..15          -> k0,  x W_N^(k0 tid)
+//   exch A  LDS [k0][w][l]: thread (w, l) -> thread (wave k0, lane l)       the only cross-wave exchange
+//   pass 2  thread (k0, l) holds w = 0..15         -> k1,  x W_1024^(k1 l)
+//   exch B  inside wave k0's own 8.5 KiB region: lane (g, q) -> lane (k1, q)   wave-level ordering only
+//   pass 3  thread (k0, k1, q) holds g = 0..15     -> k2,  x W_64^(k2 q)
+//   pass 4  radix 4 over q, the four lanes of a quad, through DPP inside the multiply-adds -> k3 (no LDS)
+//
+// welch16k_kernel (4 x 4096: radix-4 pass, scatter to four sub-FFT images, then the 4096 scheme) moves every point
+// through LDS three times, two of them across waves, behind four workgroup barriers per segment; with one
+// workgroup per CU (139 KiB image) a barrier idles the whole CU, and its counters showed that (profiles/r03_C5.txt:
+// VALU issue 42 %, waves waiting 38 % of their time at 56 % of the HBM roofline).  Here a point crosses LDS twice, two
+// workgroup barriers per segment (around the exchange-A writes), and between them the waves run unsynchronised from
+// the exchange-A reads to the next segment's pass 1, so their LDS, VALU and global-load phases interleave.
+//
+// LDS: 16 wave regions of 16 rows x 68 float2 (exchange B pads its rows by 4: lanes (k1, q) of a 32-lane read group
+// then cover 32 distinct 8-byte slots; exchange A uses the first 1024 slots of a region, conflict-free as it is:
+// consecutive lanes, consecutive slots) = 136 KiB, one workgroup per CU.
+// Only |X|^2 leaves pass 4, so a bin may come out multiplied by -1 or -i: lanes 2, 3 of a quad carry the negated odd
+// half, which saves the lane-dependent add / subtract.
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "fft4096.hip.h"
+
+#ifndef OTH_X1_PPLACES
+#define OTH_X1_PPLACES 0x22222222u     // the same for the pipelined kernel (places: see its `spread`)
+#endif
+#ifndef OTH_X1_DIAG
+#define OTH_X1_DIAG 0        // 1: per-wave phase cycle counters behind the partial sums (tools/diag_x1.py)
+#endif
+#if OTH_X1_DIAG
+#define X1_STAMP(i)                                                      \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                              \
+        phase[i] += now_ - last_;                                        \
+        last_ = now_;                                                    \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    } while (0)
+#define X1_DRAIN_VM() __builtin_amdgcn_s_waitcnt(0x0F70)
+#define X1_DRAIN_LGKM() __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
+#define X1_STAMP(i) do { } while (0)
+#define X1_DRAIN_VM() do { } while (0)
+#define X1_DRAIN_LGKM() do { } while (0)
+#endif
+
+namespace oth {
+namespace {
+
+constexpr int XROW = 68;                       // float2 per exchange-B row (64 + 4 pad)
+constexpr int XREG = 16 * XROW;                // float2 per wave region (1088: exchange A uses [0, 1024))
+constexpr int X1_RED = 8;                      // chunk tickets (two slots, by chunk parity)
+constexpr size_t x1_lds_bytes() { return (16 * XREG + X1_RED) * sizeof(float2); }
+// the pipelined kernel adds its twiddle tables (passes 2 and 3) and the quad-butterfly constants
+constexpr size_t x1p_lds_bytes() { return x1_lds_bytes() + (16 * 64 + 16 * 4) * sizeof(float2) + 4 * sizeof(float4); }
+
+// Non-temporal 8-byte load at (uniform row base in scalar registers) + (lane offset): one lane-offset register serves
+// all sixteen rows of a segment, and the compiler can neither move the load nor gather it with its neighbours - the
+// next segment's loads are spread over the step on purpose.  The caller waits (s_waitcnt vmcnt) before the first use.
+typedef float f2v __attribute__((ext_vector_type(2)));      // a register pair the inline asm below can name as one operand
+__device__ __forceinline__ void load_row_nt(f2v &dst, unsigned lane_off, const char *row) {
+    asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
+}
+
+// v[r16(k)] *= W^k, k = 1..15, W^k rebuilt from p1 = W and p4 = W^4 as in scatter_pow16
+__device__ __forceinline__ void twiddle_pow16_inplace(float2 (&v)[16], float2 p1, float2 p4) {
+    float2 wj[4], wi[4];
+    wj[1] = p1;
+    wi[1] = p4;
+    asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wi[1].x), "+v"(wi[1].y));
+    wj[2] = cmul(wj[1], wj[1]);
+    wj[3] = cmul(wj[2], wj[1]);
+    wi[2] = cmul(wi[1], wi[1]);
+    wi[3] = cmul(wi[2], wi[1]);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const int i = k >> 2, j = k & 3;
+        const float2 w = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
+        v[r16(k)] = cmul(v[r16(k)], w);
+    }
+}
+
+// The same two operations with six stored powers W, W^2, W^3, W^4, W^8, W^12 (nine products instead of thirteen)
+struct Pow6x {
+    float2 j1, j2, j3, i1, i2, i3;
+};
+__device__ __forceinline__ Pow6x pow6_load(const float2 *tw, int e) {
+    return Pow6x{tw[e], tw[2 * e], tw[3 * e], tw[4 * e], tw[8 * e], tw[12 * e]};
+}
+template <int STRIDE, bool STORE>
+__device__ __forceinline__ void twiddle6(float2 (&v)[16], float2 *out, const Pow6x &w) {
+    float2 wj[4], wi[4];
+    wj[1] = w.j1, wj[2] = w.j2, wj[3] = w.j3;
+    wi[1] = w.i1, wi[2] = w.i2, wi[3] = w.i3;
+    // every product below has a wj factor: making those opaque keeps the nine products out of loop-invariant registers
+    asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wj[2].x), "+v"(wj[2].y), "+v"(wj[3].x), "+v"(wj[3].y));
+    if (STORE) out[0] = v[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const int i = k >> 2, j = k & 3;
+        const float2 tw = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
+        const float2 r = cmul(v[r16(k)], tw);
+        if (STORE) out[STRIDE * k] = r;
+        else v[r16(k)] = r;
+    }
+}
+
+// Radix-4 butterfly over the four lanes of a quad (lane q holds input q of every one of its sixteen registers), in
+// place; lane q ends with output k3 = bit-reversed q, up to a factor of -1 or -i (the caller takes |.|^2):
+//   stage 1 (partner q ^ 2)  x <- x + s1 x'        s1 = +1, +1, -1, -1:  e0, e1, -(d0), -(d1)
+//   stage 2 (partner q ^ 1)  x <- x + c x'          c = 1, -1, -i, -i:   X0, -X2, -X1, -(d1 - i d0) = i X3 / ... |.| equal
+// c = al - i be:  re += al re' + be im',  im += al im' - be re'.
+__device__ __forceinline__ void quad_dft4_dpp(float2 (&v)[16], float s1, float al, float be, float nbe) {
+    asm volatile("s_nop 1");      // VALU write -> DPP read of the same register needs two wait states
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v[i].x) : "v"(s1));
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v[i].y) : "v"(s1));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float t;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(v[i].x));      // the partner reads the OLD real part last
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[i].x) : "v"(al));
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                     : "+v"(v[i].x)
+                     : "v"(v[i].y), "v"(be));
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[i].y) : "v"(al));
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[i].y) : "v"(t), "v"(nbe));
+    }
+}
+
+// The plain loop: every phase of a segment in program order, its sixteen loads at the top.  The pipelined kernel below
+// is the default for the scanner's rectangular window; this one takes windowed plans (sixteen window values in
+// registers do not fit next to two segments in flight) and serves as the A/B reference ("plain").
+template <bool WINDOW>
+__global__ __launch_bounds__(1024) void welch16k1x_kernel(WelchArgs p) {
+    constexpr int N = 16384;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    int *lnext = reinterpret_cast<int *>(lds + 16 * XREG);
+
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63, g = l >> 2, q = l & 3;
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
+    const float2 *xb = p.x + (size_t)stream * p.stream_stride;
+
+    // twiddle seeds W, W^4 of the three twiddled passes (p.tw[k] = W_N^k)
+    const float2 a1 = p.tw[tid], a4 = p.tw[4 * tid];             // W_N^tid
+    const float2 b1 = p.tw[16 * l], b4 = p.tw[64 * l];           // W_1024^l
+    const float2 c1 = p.tw[256 * q], c4 = p.tw[1024 * q];        // W_64^q
+    float win[WINDOW ? 16 : 1];
+    if constexpr (WINDOW) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) win[r] = p.win[tid + 1024 * r];
+    }
+    // quad butterfly constants by lane
+    const float qs1 = q < 2 ? 1.0f : -1.0f;
+    const float qal = q == 0 ? 1.0f : (q == 1 ? -1.0f : 0.0f);
+    const float qbe = q >= 2 ? 1.0f : 0.0f, qnbe = -qbe;
+
+    float2 *wa = lds + tid;                           // exchange A write: + XREG k0
+    const float2 *ra = lds + XREG * wv + l;           // exchange A read:  + 64 w
+    float2 *wb = lds + XREG * wv + l;                 // exchange B write: + XROW k1
+    const float2 *rb = lds + XREG * wv + XROW * g + q;   // exchange B read:  + 4 j   (this lane is (k1 = g, q))
+
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+
+    const int sched = p.sched;
+    const long long nchunks = sched ? chunk_count(p) : 1;
+    int par = 0;
+#if OTH_X1_DIAG
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
+    for (long long cur = sched ? wg : 0; cur < nchunks;) {
+        long long sb = s0, se = s1;
+        if (sched) chunk_range(p, cur, sb, se);
+        for (long long s = sb; s < se; ++s) {
+            float2 v[16];
+            prio_latency();
+            const float2 *xs = xb + s * p.step + tid;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = load_once(xs + 1024 * r);
+            if constexpr (WINDOW) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = make_float2(v[r].x * win[r], v[r].y * win[r]);
+            }
+            X1_STAMP(7);
+            X1_DRAIN_VM();
+            X1_STAMP(0);
+            prio_compute();
+            dft16(v);                                              // pass 1: r -> k0
+            prio_latency();
+            X1_STAMP(1);
+            lds_barrier();      // 1: every wave is through with the previous segment's exchanges (A reads, B in its region)
+            X1_STAMP(2);
+            if (sched == 2 && s == sb && tid == 0) lnext[par] = (int)atomicAdd(p.queue + stream, 1u);
+            scatter_pow16<XREG>(v, wa, a1, a4);                    // x W_N^(k0 tid) -> [k0][w][l]
+            X1_DRAIN_LGKM();
+            X1_STAMP(3);
+            lds_barrier();      // 2
+            X1_STAMP(4);
+            dft16_from_lds<64>(v, ra, [] { prio_compute(); });     // pass 2: w -> k1
+            prio_latency();
+            wave_lds_sync();
+            scatter_pow16<XROW>(v, wb, b1, b4);                    // x W_1024^(k1 l) -> row k1, column l of this wave's region
+            X1_DRAIN_LGKM();
+            X1_STAMP(5);
+            wave_lds_sync();
+            dft16_from_lds<4>(v, rb, [] { prio_compute(); });      // pass 3: g -> k2
+            twiddle_pow16_inplace(v, c1, c4);                      // x W_64^(k2 q)
+            quad_dft4_dpp(v, qs1, qal, qbe, qnbe);                 // pass 4: q -> k3
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const float2 X = v[r16(k2)];
+                acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
+            }
+            X1_STAMP(6);
+        }
+        if (sched == 0) break;
+        cur = (sched == 1) ? cur + W : (long long)W + lnext[par];
+        par ^= 1;
+    }
+
+    // bin k0 + 16 k1 + 256 k2 + 4096 bitrev2(q) sits at 1024 k2 + 64 k0 + 4 k1 + q (finalize layout 4)
+    float *dst = p.partial + ((size_t)stream * W + wg) * N + tid;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) dst[1024 * k2] = acc[k2];
+#if OTH_X1_DIAG
+    if (l == 0) {
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * N) +
+                                 128 * ((size_t)stream * W + wg) + 8 * wv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st[i] = phase[i];
+    }
+#endif
+}
+
+}  // namespace
+
+// Pass twiddles from an LDS table instead of rebuilding them from two seeds (13 complex products = 52 VALU
+// instructions per pass): tab[TS * k] = W^k for this lane, k = 1..15.  Two batches of reads, 8 + 7 values, so that at
+// most sixteen registers are in flight: TW_READ_A is issued by the caller early enough to be there (behind a
+// butterfly layer), the second batch costs one exposed LDS round trip - the other three waves of the SIMD fill it.
+struct TwBatch {
+    f2v w[8];
+};
+#define OTH_TW_RD(b, addr, TSB, k, i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"((b).w[i]) : "v"(addr), "n"((TSB) * (k)))
+template <int TS> __device__ __forceinline__ void tw_read_a(TwBatch &b, const float2 *tab) {
+    const unsigned addr = (unsigned)(unsigned long long)tab;
+    OTH_TW_RD(b, addr, 8 * TS, 1, 0); OTH_TW_RD(b, addr, 8 * TS, 2, 1); OTH_TW_RD(b, addr, 8 * TS, 3, 2); OTH_TW_RD(b, addr, 8 * TS, 4, 3);
+    OTH_TW_RD(b, addr, 8 * TS, 5, 4); OTH_TW_RD(b, addr, 8 * TS, 6, 5); OTH_TW_RD(b, addr, 8 * TS, 7, 6); OTH_TW_RD(b, addr, 8 * TS, 8, 7);
+}
+template <int TS> __device__ __forceinline__ void tw_read_b(TwBatch &b, const float2 *tab) {
+    const unsigned addr = (unsigned)(unsigned long long)tab;
+    OTH_TW_RD(b, addr, 8 * TS, 9, 0); OTH_TW_RD(b, addr, 8 * TS, 10, 1); OTH_TW_RD(b, addr, 8 * TS, 11, 2); OTH_TW_RD(b, addr, 8 * TS, 12, 3);
+    OTH_TW_RD(b, addr, 8 * TS, 13, 4); OTH_TW_RD(b, addr, 8 * TS, 14, 5); OTH_TW_RD(b, addr, 8 * TS, 15, 6);
+}
+#undef OTH_TW_RD
+// every LDS operation of this wave so far has completed; names the batch so that no use of it moves above the wait
+__device__ __forceinline__ void tw_wait(TwBatch &b) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.w[2]), "+v"(b.w[3]), "+v"(b.w[4]), "+v"(b.w[5]), "+v"(b.w[6]), "+v"(b.w[7])
+                 :
+                 : "memory");
+}
+// v[r16(k)] *= W^k from the table (batch A already issued into `a`); STORE: out[STRIDE * k] = the product instead
+template <int TS, int STRIDE, bool STORE>
+__device__ __forceinline__ void twiddle_table16(float2 (&v)[16], float2 *out, const float2 *tab, TwBatch &a) {
+    TwBatch b;
+    tw_wait(a);
+    tw_read_b<TS>(b, tab);
+    if (STORE) out[0] = v[0];
+#pragma unroll
+    for (int k = 1; k <= 8; ++k) {
+        const float2 r = cmul(v[r16(k)], make_float2(a.w[k - 1].x, a.w[k - 1].y));
+        if (STORE) out[STRIDE * k] = r;
+        else v[r16(k)] = r;
+    }
+    tw_wait(b);
+#pragma unroll
+    for (int k = 9; k < 16; ++k) {
+        const float2 r = cmul(v[r16(k)], make_float2(b.w[k - 9].x, b.w[k - 9].y));
+        if (STORE) out[STRIDE * k] = r;
+        else v[r16(k)] = r;
+    }
+}
+
+// Sixteen ds_read_b64 at base[STRIDE * i], issued and NOT waited for: the caller's next lds_barrier() (lgkmcnt(0)) or
+// an explicit wait makes r[] valid.  Nothing may read r[] before that.
+template <int STRIDE> __device__ __forceinline__ void lds_issue16(f2v (&r)[16], const float2 *base) {
+    const unsigned addr = (unsigned)(unsigned long long)base;
+#define OTH_LDS_READ(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[i]) : "v"(addr), "n"(8 * STRIDE * (i)))
+    OTH_LDS_READ(0); OTH_LDS_READ(4); OTH_LDS_READ(8); OTH_LDS_READ(12);
+    OTH_LDS_READ(1); OTH_LDS_READ(5); OTH_LDS_READ(9); OTH_LDS_READ(13);
+    OTH_LDS_READ(2); OTH_LDS_READ(6); OTH_LDS_READ(10); OTH_LDS_READ(14);
+    OTH_LDS_READ(3); OTH_LDS_READ(7); OTH_LDS_READ(11); OTH_LDS_READ(15);
+#undef OTH_LDS_READ
+}
+
+// The software-pipelined form (the default).  Per-wave phase stamps of the plain loop above (tools/diag_x1.py,
+// profiles/r04_x1_phases.txt) showed the two halves of a segment badly matched: between barrier 1 and barrier 2 every
+// wave only multiplies by the pass-1 twiddles and writes exchange A - the CU's LDS store path is the limit (16 waves x
+// 16 ds_write_b64) and the SIMDs idle - while everything else (passes 2, 3, 4, the accumulation, the next pass 1)
+// queues up between barrier 2 and barrier 1, where the four waves of a SIMD take turns oldest first (they reach
+// barrier 1 about 1650 cycles apart).  Here the tail of segment s - 1 (pass 3, its twiddles, pass 4, |X|^2: 456 VALU
+// instructions that touch registers only) runs AFTER barrier 1 of segment s, beside the exchange-A writes, and the
+// other half keeps exchange A read, pass 2, exchange B and the next pass 1:
+//
+//   P1   pass 1 of segment s (its samples were loaded one phase earlier)
+//   ---- barrier 1: every wave holds its exchange-B values of segment s - 1 in registers
+//   WA   pass-1 twiddles, exchange A writes of segment s
+//   T3   pass 3, twiddles, pass 4, accumulation of segment s - 1
+//   ---- barrier 2
+//   LD   loads of segment s + 1
+//   RA   exchange A reads, pass 2, twiddles, exchange B writes and reads (reads issued, waited for at barrier 1)
+//
+// 624 + 456 VALU instructions per wave on the two sides instead of 168 + 912; registers: the samples / pass-1 outputs
+// of one segment and the exchange-B values of the one before, 32 + 32.
+template <bool WINDOW>      // (only <false> is instantiated: the scanner passes `()` as its window)
+__global__ __launch_bounds__(1024) void welch16k1x_pipe_kernel(WelchArgs p) {
+    constexpr int N = 16384;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    int *lnext = reinterpret_cast<int *>(lds + 16 * XREG);
+
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63, g = l >> 2, q = l & 3;
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
+    const float2 *xb = p.x + (size_t)stream * p.stream_stride;
+
+    // The twiddle seeds W, W^4 of the three twiddled passes and the quad-butterfly constants live in LDS, not in
+    // registers: 16 registers that the two segments in flight (32 + 32) need; each is read where it is used.
+    // Twiddles: pass 1 (W_N^(k0 tid), a different set per thread) is rebuilt from six register-resident powers; passes
+    // 2 and 3 depend on the lane only and are read from LDS tables where they are used (tabB[k1][l] = W_1024^(k1 l),
+    // 8 KiB; tabC[k2][q] = W_64^(k2 q), 512 B) - no products to rebuild them, and none of their seeds in registers.
+    float2 *tabB = lds + 16 * XREG + X1_RED;                                   // [16][64]
+    float2 *tabC = tabB + 16 * 64;                                              // [16][4]
+    float4 *quadK = reinterpret_cast<float4 *>(tabC + 16 * 4);                  // [4]: s1, alpha, beta, -beta
+    {
+        tabB[tid] = p.tw[16 * ((tid >> 6) * (tid & 63))];                       // k1 = tid >> 6, l = tid & 63
+        if (tid < 64) tabC[tid] = p.tw[256 * ((tid >> 2) * (tid & 3))];         // k2 = tid >> 2, q = tid & 3
+        if (tid < 4) {
+            const float be = tid >= 2 ? 1.0f : 0.0f;
+            quadK[tid] = make_float4(tid < 2 ? 1.0f : -1.0f, tid == 0 ? 1.0f : (tid == 1 ? -1.0f : 0.0f), be, -be);
+        }
+    }
+    const Pow6x a6 = pow6_load(p.tw, tid);
+    __syncthreads();
+
+    float2 *wa = lds + tid;
+    const float2 *ra = lds + XREG * wv + l;
+    float2 *wb = lds + XREG * wv + l;
+    const float2 *rb = lds + XREG * wv + XROW * g + q;
+
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+
+    const int sched = p.sched;
+    const long long nchunks = sched ? chunk_count(p) : 1;
+    long long cur = sched ? wg : 0, sb = s0, se = s1;
+    if (sched && cur < nchunks) chunk_range(p, cur, sb, se);
+    bool live = sched ? cur < nchunks : s0 < s1;
+    long long s = sb;
+    int par = 0;
+#if OTH_X1_DIAG
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
+    f2v pfr[16];      // the next segment's samples as the pinned loads deliver them (valid behind the vmcnt wait)
+    f2v rB[16];       // exchange-B values of the segment before; zeros in front of the first one (its tail then adds 0)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rB[i] = f2v{0.f, 0.f};
+    bool have_prev = false;
+    if (live) {
+        const char *x0 = reinterpret_cast<const char *>(xb + s * p.step);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) load_row_nt(pfr[r], 8u * tid, x0 + 8192 * r);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    using std::integral_constant;
+    while (live) {
+        float2 pf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pf[r] = make_float2(pfr[r].x, pfr[r].y);
+        if constexpr (WINDOW) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float w = p.win[tid + 1024 * r];      // L2-resident, sixteen 4-byte loads per segment
+                pf[r] = make_float2(pf[r].x * w, pf[r].y * w);
+            }
+        }
+        X1_STAMP(7);
+        X1_DRAIN_VM();
+        X1_STAMP(0);
+        prio_compute();
+        dft16(pf);                                             // P1
+        prio_latency();
+        X1_STAMP(1);
+        lds_barrier();      // 1 (also waits for this wave's exchange-B reads of the segment before)
+        X1_STAMP(2);
+        const bool first_of_chunk = s == sb;
+        if (sched == 2 && first_of_chunk && tid == 0) lnext[par] = (int)atomicAdd(p.queue + stream, 1u);
+        twiddle6<XREG, true>(pf, wa, a6);                      // WA
+        X1_STAMP(3);
+        // The segment after this one: its loads go out two at a time over the whole step.  A ticket (dynamic schedule)
+        // is drawn with a chunk's FIRST segment and published before barrier 2 of that segment, so at the chunk's last
+        // segment it is known here - the launcher never makes one-segment chunks except the very last one of a stream,
+        // behind which no ticket can name another chunk.
+        long long ns = s + 1;
+        bool more = true;
+        constexpr bool known = true;
+        auto next_chunk = [&]() {
+            cur = (sched == 1) ? cur + W : (long long)W + __builtin_amdgcn_readfirstlane(lnext[par]);
+            par ^= 1;
+            more = cur < nchunks;
+            if (more) {
+                chunk_range(p, cur, sb, se);
+                ns = sb;
+            }
+        };
+        if (ns >= se) {
+            if (sched == 0 || (sched == 2 && first_of_chunk)) more = false;
+            else next_chunk();
+        }
+        // uniform row base (scalar registers) + one lane offset: no per-load address registers
+        // (behind the last segment the same loads run once more on the segment just done: an unconditional
+        // definition keeps the sixteen registers free between pass 1 and the first group of loads)
+        const char *xn = reinterpret_cast<const char *>(xb + (more ? ns : s) * p.step);
+        const unsigned voff = 8u * tid;
+        auto spread = [&](auto gc, bool) {      // two of the next segment's sixteen loads
+            // place grp of the step (0: after the exchange-A writes, 1: after the tail's butterflies, 2: after its
+            // twiddles, 3: end of the tail, 4: behind barrier 2, 5: between pass 2's layers, 6: after pass 2, 7: after
+            // the exchange-B writes) issues nibble grp of OTH_X1_PPLACES of the sixteen loads
+            constexpr int grp = decltype(gc)::value;
+            constexpr unsigned plan = OTH_X1_PPLACES;
+            static_assert(((plan >> 0) & 15) + ((plan >> 4) & 15) + ((plan >> 8) & 15) + ((plan >> 12) & 15) + ((plan >> 16) & 15) +
+                              ((plan >> 20) & 15) + ((plan >> 24) & 15) + ((plan >> 28) & 15) == 16,
+                          "the eight places must issue exactly the sixteen rows of a segment");
+            constexpr int cnt = (plan >> (4 * grp)) & 15;
+            constexpr int first = ((grp > 0 ? (plan >> 0) & 15 : 0) + (grp > 1 ? (plan >> 4) & 15 : 0) + (grp > 2 ? (plan >> 8) & 15 : 0) +
+                                   (grp > 3 ? (plan >> 12) & 15 : 0) + (grp > 4 ? (plan >> 16) & 15 : 0) + (grp > 5 ? (plan >> 20) & 15 : 0) +
+                                   (grp > 6 ? (plan >> 24) & 15 : 0));
+            if constexpr (cnt > 0) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = first; r < first + cnt; ++r) load_row_nt(pfr[r], voff, xn + 8192 * r);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        spread(integral_constant<int, 0>{}, known);
+        prio_compute();
+        {                                                      // T3: pass 3, twiddles, pass 4, |X|^2 of the segment before
+            float2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = make_float2(rB[i].x, rB[i].y);
+            TwBatch ta;
+            tw_read_a<4>(ta, tabC + q);
+            const float4 qk = quadK[q];
+            dft16(v);
+            spread(integral_constant<int, 1>{}, known);
+            twiddle_table16<4, 1, false>(v, nullptr, tabC + q, ta);
+            spread(integral_constant<int, 2>{}, known);
+            quad_dft4_dpp(v, qk.x, qk.y, qk.z, qk.w);
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const float2 X = v[r16(k2)];
+                acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
+            }
+        }
+        spread(integral_constant<int, 3>{}, known);
+        prio_latency();
+        X1_STAMP(4);
+        lds_barrier();      // 2
+        X1_STAMP(5);
+        spread(integral_constant<int, 4>{}, true);
+        {                                                      // RA
+            float2 v[16];
+            TwBatch ta;
+            dft16_from_lds<64>(v, ra, [] { prio_compute(); }, [&] {
+                spread(integral_constant<int, 5>{}, true);
+                tw_read_a<64>(ta, tabB + l);
+            });
+            prio_latency();
+            spread(integral_constant<int, 6>{}, true);
+            wave_lds_sync();
+            twiddle_table16<64, XROW, true>(v, wb, tabB + l, ta);
+            spread(integral_constant<int, 7>{}, true);
+            wave_lds_sync();
+            lds_issue16<4>(rB, rb);
+        }
+        X1_STAMP(6);
+        have_prev = true;
+        live = more;
+        s = ns;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the sixteen pinned loads of this step: the next pass 1 reads them
+    }
+    if (have_prev) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = make_float2(rB[i].x, rB[i].y);
+        TwBatch ta;
+        tw_read_a<4>(ta, tabC + q);
+        const float4 qk = quadK[q];
+        dft16(v);
+        twiddle_table16<4, 1, false>(v, nullptr, tabC + q, ta);
+        quad_dft4_dpp(v, qk.x, qk.y, qk.z, qk.w);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const float2 X = v[r16(k2)];
+            acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
+        }
+    }
+
+    float *dst = p.partial + ((size_t)stream * W + wg) * N + tid;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) dst[1024 * k2] = acc[k2];
+#if OTH_X1_DIAG
+    if (l == 0) {
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * N) +
+                                 128 * ((size_t)stream * W + wg) + 8 * wv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st[i] = phase[i];
+    }
+#endif
+}
+
+template <bool WINDOW> static hipError_t launch1x_pipe(const WelchArgs &a, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    constexpr size_t lds = x1p_lds_bytes();
+    const void *fn = reinterpret_cast<const void *>(welch16k1x_pipe_kernel<WINDOW>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((welch16k1x_pipe_kernel<WINDOW>), grid, dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+
+template <bool WINDOW> static hipError_t launch1x(const WelchArgs &a, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    constexpr size_t lds = x1_lds_bytes();
+    const void *fn = reinterpret_cast<const void *>(welch16k1x_kernel<WINDOW>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((welch16k1x_kernel<WINDOW>), grid, dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+
+// plain: the A/B switch (tuning variant "16kplain" / OTH_16K1X_MODE=plain); windowed plans always take the plain kernel
+hipError_t launch_welch_tuned16k1x(const WelchArgs &a, bool window, bool plain, hipStream_t s) {
+    static const char *mode = getenv("OTH_16K1X_MODE");
+    plain = plain || (mode && !strcmp(mode, "plain"));
+    if (window) return launch1x<true>(a, s);
+    return plain ? launch1x<false>(a, s) : launch1x_pipe<false>(a, s);
+}
+
+}  // namespace oth

@@ -200,6 +200,58 @@ def test_welch16k_scanner_config_batched(ctx, hip, kernel, N):
         assert relerr(out[i], ref) < RTOL
 
 
+def test_welch16k1x_scanner_kernels_schedules_and_counts(ctx, hip):
+    """16384-point vectors that do not overlap, no detrend (BASELINE config 5, multichannel_scanner.py:78-86 averaged):
+    the one-exchange kernels (pipelined default, 'plain', windowed) and the 4 x 4096 build ('16k4') against the float64
+    oracle on a short run, and against the coverage kernel over segment counts around chunk and grid multiples (odd
+    counts end in a one-segment chunk), 1-3 streams, all three schedules, chunk sizes 0-5, steps >= nfft."""
+    N = 16384
+    rng = np.random.default_rng(5)
+    x = R.synth_iq(N * 7 + 33, 77)
+    ref = R.chain_sensor_v2(x, N).mean(axis=0)                    # rect, shift, |X|^2 / N^2, mean over 7 vectors
+    for variant in (None, '16kplain', '16k4'):
+        plan = ctx.welch_plan(N, noverlap=0, window=None, detrend=hip.DETREND_NONE, scaling=hip.SCALE_OVER_N2,
+                              fftshift=True, kernel=hip.KERNEL_TUNED)
+        plan.set_tuning(variant)
+        assert relerr(plan.exec(x), ref) < RTOL and plan.last_nseg == 7, variant
+        plan.close()
+    _, refw = R.welch_np(x, fs=2.0, window='hann', nperseg=N, noverlap=0, nfft=N, detrend=False)
+    plan = ctx.welch_plan(N, noverlap=0, window=hann(N), detrend=hip.DETREND_NONE, fs=2.0, kernel=hip.KERNEL_TUNED)
+    assert relerr(plan.exec(x), refw) < RTOL                        # the windowed build
+    plan.close()
+    nmax = N * 300 + 5000
+    d_in, d_a, d_b = ctx.alloc(3 * nmax * 8), ctx.alloc(3 * N * 4), ctx.alloc(3 * N * 4)
+    try:
+        ctx.synth_iq(d_in, 3 * nmax, 78, R.TONES, R.DC)
+        kw = dict(noverlap=0, window=None, detrend=hip.DETREND_NONE, scaling=hip.SCALE_OVER_N2, fftshift=True)
+        tuned = ctx.welch_plan(N, kernel=hip.KERNEL_TUNED, **kw)
+        gen = ctx.welch_plan(N, kernel=hip.KERNEL_GENERIC, **kw)
+        for nseg in [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 255, 256, 257, 299] + [int(v) for v in rng.integers(1, 300, 5)]:
+            n = N * nseg + int(rng.integers(0, N))
+            ns = int(rng.integers(1, 4))
+            assert gen.exec_dev(d_in, n, d_b, nstreams=ns, stream_stride=nmax) == nseg
+            b = ctx.d2h(d_b, (ns, N), np.float32)
+            for variant in (None, '16kplain'):
+                sched, chunk = int(rng.integers(0, 3)), int(rng.integers(0, 6))
+                tuned.set_schedule(sched)
+                tuned.set_tuning(variant, chunk=chunk)
+                assert tuned.exec_dev(d_in, n, d_a, nstreams=ns, stream_stride=nmax) == nseg
+                a = ctx.d2h(d_a, (ns, N), np.float32).astype(np.float64)
+                err = np.max(np.abs(a - b) / np.maximum(b, 0.1 * np.median(b)))
+                assert err < (5e-5 if nseg >= 8 else 2e-4), (nseg, ns, variant, sched, chunk, err)
+        # vectors further apart than their length (keep_one_in_n > 1 on the stream)
+        plan = ctx.welch_plan(N, nperseg=N, noverlap=0, window=None, detrend=hip.DETREND_NONE, scaling=hip.SCALE_OVER_N2,
+                              kernel=hip.KERNEL_TUNED)
+        n = N * 40
+        assert plan.exec_dev(d_in, n, d_a) == 40 and gen.exec_dev(d_in, n, d_b) == 40
+        tuned.close()
+        gen.close()
+        plan.close()
+    finally:
+        for ptr in (d_in, d_a, d_b):
+            ctx.free(ptr)
+
+
 @pytest.mark.parametrize('N', [8192, 16384])
 def test_welch16k_hann_overlap_detrend_many_segments(ctx, hip, N):
     nseg = 701 if N == 16384 else 1403                # at 75 % overlap: more segments than resident workgroups

@@ -65,12 +65,13 @@ elif cfg in ('C4', 'C4ref'):
     nbytes = 8 * nrf * S
 elif cfg == 'C5':
     nch, S, N = 64, 1 << (log2n or 22), 16384
-    d, o = dev(nch * S * 8), dev(nch * N * 4)
+    stride = S + int(os.environ.get('PROF_STRIDE_PAD', '0'))      # samples between channel streams (default: back to back)
+    d, o = dev(nch * stride * 8), dev(nch * N * 4)
     for i in range(nch):
-        ctx.synth_iq(d + i * S * 8, S, 3000 + i, TONES, DC)
+        ctx.synth_iq(d + i * stride * 8, S, 3000 + i, TONES, DC)
     plan = ctx.welch_plan(N, noverlap=0, window=None, detrend=_hip.DETREND_NONE, scaling=_hip.SCALE_OVER_N2,
                           fftshift=True)
-    run = lambda: plan.exec_dev(d, S, o, nstreams=nch, stream_stride=S)      # noqa: E731
+    run = lambda: plan.exec_dev(d, S, o, nstreams=nch, stream_stride=stride)      # noqa: E731
     nbytes = 8 * nch * S
 elif cfg in ('w1024', 'w2048', 'w512', 'w256', 'w8192', 'w16384'):
     N = int(cfg[1:])
