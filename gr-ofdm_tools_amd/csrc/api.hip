@@ -58,6 +58,7 @@ struct oth_plan {
     float *d_win = nullptr;
     const float2 *d_tw = nullptr;
     float4 *d_fd = nullptr;            // window spectrum for the frequency-domain detrend (welch4096ws), or nullptr
+    float4 *d_fd1x = nullptr;          // the same for welch16k1x_half_kernel (16384 points, spectrum confined to |k| < 16)
     bool exact_detrend = false;        // OTH_DETREND_CONSTANT_EXACT: time-domain detrend only (d_fd stays nullptr)
     bool rect_window = false;          // every window value is 1 (window == NULL or boxcar): builds without the multiply
     float *d_partial = nullptr;
@@ -479,6 +480,46 @@ bool window_spectrum_table_16k(const std::vector<float> &w, int n, std::vector<f
     return true;
 }
 
+// The table for welch16k1x_half_kernel (N = 16384): thread tid = 64 k0 + 4 k1 + q corrects register k2 = 0 - bin k0 when
+// k1 = 0, q = 0 - and register k2 = 15 - bin N - 16 + k0 when k1 = 15, q = 3, where the quad butterfly leaves i X - so the
+// table exists when the window's spectrum is confined to |k| < 16 (all periodic cosine-sum windows; boxcar).
+bool window_spectrum_table_16k1x(const std::vector<float> &w, std::vector<float> &fd) {
+    const int n = 16384, lg = 14;
+    std::vector<double> re(n), im(n, 0.0);
+    double s2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        int r = 0;
+        for (int b = 0; b < lg; ++b) r |= ((i >> b) & 1) << (lg - 1 - b);
+        re[r] = (double)w[i];
+        s2 += (double)w[i] * (double)w[i];
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / len;
+        for (int i = 0; i < n; i += len)
+            for (int j = 0; j < len / 2; ++j) {
+                const double c = cos(ang * j), s = sin(ang * j);
+                const int a = i + j, b = a + len / 2;
+                const double tr = re[b] * c - im[b] * s, ti = re[b] * s + im[b] * c;
+                re[b] = re[a] - tr;
+                im[b] = im[a] - ti;
+                re[a] += tr;
+                im[a] += ti;
+            }
+    }
+    for (int k = 16; k < n - 16; ++k)
+        if (re[k] * re[k] + im[k] * im[k] > 1e-10 * s2) return false;
+    fd.assign((size_t)4 * 1024, 0.f);
+    for (int k0 = 0; k0 < 16; ++k0) {
+        const int lo = 64 * k0 + 4 * 0 + 0, hi = 64 * k0 + 4 * 15 + 3;
+        fd[4 * lo] = (float)re[k0];
+        fd[4 * lo + 1] = (float)im[k0];
+        const int kh = n - 16 + k0;                       // i (re + i im) = -im + i re
+        fd[4 * hi + 2] = (float)(-im[kh]);
+        fd[4 * hi + 3] = (float)re[kh];
+    }
+    return true;
+}
+
 int segments(const oth_plan *p, size_t nsamples, long long *nseg) {
     if (nsamples < (size_t)p->nperseg) return OTH_ERR_INVALID;
     *nseg = (long long)((nsamples - (size_t)p->noverlap) / (size_t)p->step);
@@ -528,6 +569,11 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     // cross-wave exchange per segment instead of two; "16k4" keeps the 4 x 4096 kernel (A/B, parity suite)
     const bool tuned_16k1x = tuned_16k && p->nfft == 16384 && p->nperseg == 16384 && p->step >= 16384 &&
                              p->detrend == OTH_DETREND_NONE && p->tune_variant != "16k4";
+    // ... and the same transform at 50 % overlap (the kept half in registers); a constant detrend needs its own
+    // window-spectrum table (d_fd1x: spectrum confined to |k| < 16) and follows the few-segment routing above
+    const float4 *fd1x = (fd_tab && p->d_fd1x) ? p->d_fd1x : nullptr;
+    const bool tuned_16k1x_half = tuned_16k && p->nfft == 16384 && p->nperseg == 16384 && p->step == 8192 &&
+                                  (p->detrend == OTH_DETREND_NONE || fd1x) && p->tune_variant != "16k4";
     // segfft.hip: nperseg = nfft = 256 / 512 / 1024 / 2048, any step (team of nfft / 16 threads per segment)
     // ... and zero-padded segments nperseg = nfft / 4 (the sweeper's call, spectrum_sweeper.py:263) or nfft / 2 at 1024 / 2048
     const bool seg_pad = !csd && seg_padded_supported(p->nfft, p->nperseg) && p->kernel != OTH_KERNEL_GENERIC;
@@ -591,7 +637,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.tail_chunk = 1;
     a.nbig = 0;
     a.queue = nullptr;
-    a.fd = fd_tab;
+    a.fd = tuned_16k1x_half ? fd1x : fd_tab;
     if (tuned || tuned_csd || tuned_16k || tuned_seg) {
         a.sched = p->tune_sched >= 0 ? p->tune_sched : p->sched;
         // one 1024-thread workgroup per CU and equal work per segment: contiguous runs beat the ticket queue (+3 %)
@@ -626,7 +672,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
             a.sched = OTH_SCHED_CONTIGUOUS;
         a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 16 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : ((p->nfft == 1024 && !seg_ws) || (p->nfft == 2048 && seg_ws) ? 32 : 16)) : 8)));
         if (a.chunk < 1) a.chunk = 1;
-        if (tuned_16k1x && a.chunk < 2) a.chunk = 2;      // its ticket for the NEXT chunk is published with a chunk's first
+        if ((tuned_16k1x) && a.chunk < 2) a.chunk = 2;      // its ticket for the NEXT chunk is published with a chunk's first
                                                           // segment and read at its last: chunks of at least two segments
         a.tail_chunk = a.chunk;
         a.nbig = nseg_run / a.chunk;
@@ -674,13 +720,14 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         Timed tm(c);
         HIPCHK(c, tuned ? var->launch(a, c->stream)
                         : (tuned_csd ? (csd_ws ? launch_csd_tuned4096ws(a, c->stream) : launch_csd_tuned4096(a, c->stream))
-                                     : (tuned_16k ? (tuned_16k1x ? launch_welch_tuned16k1x(a, !p->rect_window, p->tune_variant == "16kplain", c->stream)
+                                     : (tuned_16k ? (tuned_16k1x_half ? launch_welch_tuned16k1x_half(a, c->stream)
+                                                     : tuned_16k1x ? launch_welch_tuned16k1x(a, !p->rect_window, p->tune_variant == "16kplain", c->stream)
                                                                  : launch_welch_tuned16k(p->nfft, a, c->stream))
                                                   : launch_welch_generic(p->nfft, a, c->stream))));
     }
     *nseg_out = nseg;
     *W_out = W * rows;
-    *layout_out = (tuned || tuned_csd) ? 1 : (tuned_16k ? (tuned_16k1x ? 4 : (p->nfft == 16384 ? 2 : 3)) : 0);
+    *layout_out = (tuned || tuned_csd) ? 1 : (tuned_16k ? ((tuned_16k1x || tuned_16k1x_half) ? 4 : (p->nfft == 16384 ? 2 : 3)) : 0);
     return OTH_OK;
 }
 
@@ -1029,6 +1076,13 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
         if (e == hipSuccess)
             e = hipMemcpyAsync(p->d_fd, fd.data(), sizeof(float) * fd.size(), hipMemcpyHostToDevice, c->stream);
     }
+    std::vector<float> fd1x;
+    if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT && !exact_detrend && nfft == 16384 && nperseg == 16384 &&
+        window_spectrum_table_16k1x(w, fd1x)) {
+        e = hipMalloc(&p->d_fd1x, sizeof(float) * fd1x.size());
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(p->d_fd1x, fd1x.data(), sizeof(float) * fd1x.size(), hipMemcpyHostToDevice, c->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         oth_plan_destroy(p);
@@ -1048,6 +1102,7 @@ int oth_plan_destroy(oth_plan *p) {
     hipStreamSynchronize(c->stream);
     if (p->d_win) hipFree(p->d_win);
     if (p->d_fd) hipFree(p->d_fd);
+    if (p->d_fd1x) hipFree(p->d_fd1x);
     if (p->d_partial) hipFree(p->d_partial);
     if (p->d_reduce) hipFree(p->d_reduce);
     if (p->d_out) hipFree(p->d_out);

@@ -139,6 +139,8 @@ hipError_t launch_welch_tuned16k(int nfft, const WelchArgs &a, hipStream_t s);
 // welch16k1x.hip: nfft = nperseg = 16384, no detrend, whole-segment loads (the scanner's non-overlapping vectors): one
 // cross-wave exchange, two workgroup barriers per segment; partial rows in finalize layout 4
 hipError_t launch_welch_tuned16k1x(const WelchArgs &a, bool window, bool plain, hipStream_t s);
+// the same transform at step = 8192 (50 % overlap, the kept half in registers); WelchArgs.fd = window_spectrum_table_16k1x
+hipError_t launch_welch_tuned16k1x_half(const WelchArgs &a, hipStream_t s);
 // the fused periodogram chain at 8192 / 16384 points (one workgroup per segment; workgroups per CU: 2 / 1)
 hipError_t launch_chain16k(int nfft, const SegArgs &a, bool rect, hipStream_t s);
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);

@@ -555,6 +555,164 @@ template <bool WINDOW> static hipError_t launch1x_pipe(const WelchArgs &a, hipSt
     return hipGetLastError();
 }
 
+// 50 % overlap (scipy.signal.welch's default noverlap at nperseg = nfft = 16384, ofdm_cr_tools.py:214,322,342 with
+// nFFT = 16384): the second half of a segment (rows r = 8..15 of this thread) is the first half of the next one, so it
+// stays in registers (raw) and every sample is read once; two transforms per new sample.  DET = 2: constant detrend
+// after the transform, X[k] -= mean FFT(w)[k], for windows whose spectrum is confined to |k| < 16 (every periodic
+// cosine-sum window): those bins are register k2 = 0 of lanes (k1 = 0, q = 0) and register k2 = 15 of lanes (k1 = 15,
+// q = 3) of each wave k0, so every thread corrects v[0] and v[15] with its own pair of table values (WelchArgs.fd,
+// zero for all but 32 threads; the q = 3 entries carry the factor i the quad butterfly leaves on that lane).  The
+// per-wave sums of the new half go to LDS by step parity, wave 0 adds them up behind barrier 1 and every thread picks
+// the segment total up at the end of the step (as welch16k_kernel<2, ...>).  Twiddles of passes 2 and 3 from LDS tables.
+constexpr int XH_RED = 48;      // 16 wave sums x 2 parities, tickets [32..33], segment totals [40..41]
+constexpr size_t x1h_lds_bytes() { return (16 * XREG + XH_RED + 16 * 64 + 16 * 4) * sizeof(float2) + 4 * sizeof(float4); }
+
+template <int DET>
+__global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
+    constexpr int N = 16384;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    float2 *red = lds + 16 * XREG;
+    int *lnext = reinterpret_cast<int *>(red + 32);
+    float2 *tabB = red + XH_RED;                                                // [16][64]: W_1024^(k1 l)
+    float2 *tabC = tabB + 16 * 64;                                              // [16][4]:  W_64^(k2 q)
+    float4 *quadK = reinterpret_cast<float4 *>(tabC + 16 * 4);
+
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63, g = l >> 2, q = l & 3;
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
+    const float2 *xb = p.x + (size_t)stream * p.stream_stride;
+
+    {
+        tabB[tid] = p.tw[16 * ((tid >> 6) * (tid & 63))];
+        if (tid < 64) tabC[tid] = p.tw[256 * ((tid >> 2) * (tid & 3))];
+        if (tid < 4) {
+            const float be = tid >= 2 ? 1.0f : 0.0f;
+            quadK[tid] = make_float4(tid < 2 ? 1.0f : -1.0f, tid == 0 ? 1.0f : (tid == 1 ? -1.0f : 0.0f), be, -be);
+        }
+    }
+    const float2 a1 = p.tw[tid], a4 = p.tw[4 * tid];
+    float win[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) win[r] = p.win[tid + 1024 * r];
+    float4 fd = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DET == 2) fd = p.fd[tid];
+    __syncthreads();
+
+    float2 *wa = lds + tid;
+    const float2 *ra = lds + XREG * wv + l;
+    float2 *wb = lds + XREG * wv + l;
+    const float2 *rb = lds + XREG * wv + XROW * g + q;
+
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+
+    const int sched = p.sched;
+    const long long nchunks = sched ? chunk_count(p) : 1;
+    int cpar = 0;
+    float2 keep[8];
+    for (long long cur = sched ? wg : 0; cur < nchunks;) {
+        long long sb = s0, se = s1;
+        if (sched) chunk_range(p, cur, sb, se);
+        for (long long s = sb; s < se; ++s) {
+            float2 v[16];
+            prio_latency();
+            const float2 *xs = xb + s * p.step + tid;
+            float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
+            if (s == sb) {      // the chunk's first segment brings its own first half
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    keep[r] = load_once(xs + 1024 * r);
+                    sumf = cadd(sumf, keep[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float2 nw = load_once(xs + 1024 * (8 + r));
+                v[r] = keep[r];
+                v[8 + r] = nw;
+                keep[r] = nw;
+                sum = cadd(sum, nw);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = make_float2(v[r].x * win[r], v[r].y * win[r]);
+            const int par = (int)(s & 1);
+            if (DET == 2) {
+                sum.x = wave_total_lane63(sum.x);
+                sum.y = wave_total_lane63(sum.y);
+                if (s == sb) {
+                    sumf.x = wave_total_lane63(sumf.x);
+                    sumf.y = wave_total_lane63(sumf.y);
+                }
+                if (l == 63) {
+                    red[16 * par + wv] = sum;
+                    if (s == sb) red[16 * (par ^ 1) + wv] = sumf;
+                }
+            }
+            prio_compute();
+            dft16(v);                                              // pass 1: r -> k0
+            prio_latency();
+            lds_barrier();      // 1
+            if (sched == 2 && s == sb && tid == 0) lnext[cpar] = (int)atomicAdd(p.queue + stream, 1u);
+            if (DET == 2 && tid < 64) {      // wave 0: the 32 per-wave sums of this segment's two halves -> its total
+                float2 part = make_float2(0.f, 0.f);
+                if (tid < 32) part = red[tid];
+                part.x = wave_total_lane63(part.x);
+                part.y = wave_total_lane63(part.y);
+                if (tid == 63) red[40 + par] = part;      // read behind barrier 2, at the end of the step
+            }
+            scatter_pow16<XREG>(v, wa, a1, a4);                    // x W_N^(k0 tid) -> [k0][w][l]
+            lds_barrier();      // 2
+            TwBatch ta;
+            dft16_from_lds<64>(v, ra, [] { prio_compute(); }, [&] { tw_read_a<64>(ta, tabB + l); });     // pass 2
+            prio_latency();
+            wave_lds_sync();
+            twiddle_table16<64, XROW, true>(v, wb, tabB + l, ta);
+            wave_lds_sync();
+            TwBatch tc;
+            dft16_from_lds<4>(v, rb, [] { prio_compute(); }, [&] { tw_read_a<4>(tc, tabC + q); });        // pass 3
+            const float4 qk = quadK[q];
+            twiddle_table16<4, 1, false>(v, nullptr, tabC + q, tc);
+            quad_dft4_dpp(v, qk.x, qk.y, qk.z, qk.w);              // pass 4
+            if (DET == 2) {
+                const float2 tot = red[40 + par];
+                const float2 mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
+                v[0] = make_float2(v[0].x - (mean.x * fd.x - mean.y * fd.y), v[0].y - (mean.x * fd.y + mean.y * fd.x));
+                v[15] = make_float2(v[15].x - (mean.x * fd.z - mean.y * fd.w), v[15].y - (mean.x * fd.w + mean.y * fd.z));
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const float2 X = v[r16(k2)];
+                acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
+            }
+        }
+        if (sched == 0) break;
+        cur = (sched == 1) ? cur + W : (long long)W + lnext[cpar];
+        cpar ^= 1;
+    }
+
+    float *dst = p.partial + ((size_t)stream * W + wg) * N + tid;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) dst[1024 * k2] = acc[k2];
+}
+
+template <int DET> static hipError_t launch1x_half(const WelchArgs &a, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    constexpr size_t lds = x1h_lds_bytes();
+    const void *fn = reinterpret_cast<const void *>(welch16k1x_half_kernel<DET>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((welch16k1x_half_kernel<DET>), grid, dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+
+// step = N / 2; detrend none, or constant through the frequency-domain form (a.fd = the table described above)
+hipError_t launch_welch_tuned16k1x_half(const WelchArgs &a, hipStream_t s) {
+    return (a.detrend && a.fd) ? launch1x_half<2>(a, s) : launch1x_half<0>(a, s);
+}
+
 template <bool WINDOW> static hipError_t launch1x(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
     constexpr size_t lds = x1_lds_bytes();
