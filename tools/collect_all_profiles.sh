@@ -7,14 +7,16 @@
 set -u
 TAG=$1; shift
 ONLY=" $* "
-for spec in "C2:welch4096ws" "C3:csd4096ws" "C4:welch4096ws" "C4ref:welch4096_kernel" "C5:welch16k" \
+for spec in "C2:welch4096ws" "C3:csd4096ws" "C4:welch4096ws" "C4ref:welch4096_kernel" "C5:welch16k1x_pipe" "C5old:welch16k_kernel" \
             "w256:seg_kernel" "w512:seg_kernel" "w1024:segws_kernel" "w2048:segws_kernel" "w8192:welch16k" \
-            "w16384:welch16k" "p1024:seg_kernel" "p2048:seg_kernel" \
+            "w16384:welch16k1x_half" "p1024:seg_kernel" "p2048:seg_kernel" "p8192:welch16k" "p16384:welch16k" \
             "chain256:seg_kernel" "chain512:seg_kernel" "chain1024:seg_kernel" "chain2048:seg_kernel" "chain4096:seg_kernel" \
             "chain8192:chain16k" "chain16384:chain16k"; do
     cfg=${spec%%:*}; pat=${spec##*:}
     if [ "$ONLY" != "  " ] && [[ "$ONLY" != *" $cfg "* ]]; then continue; fi
-    tools/pmc_passes.sh prof_${TAG}_${cfg} $cfg 5 $pat > /dev/null 2>&1
+    drv=$cfg; var=
+    if [ "$cfg" = "C5old" ]; then drv=C5; var=16k4; fi
+    OTH_W4096_VARIANT=$var tools/pmc_passes.sh prof_${TAG}_${cfg} $drv 5 $pat > /dev/null 2>&1
     echo "== $cfg"; grep -E "GB/s" $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${cfg}/trace.log | tail -1
 done
 if [ -n "${PUBLISH_ROUND:-}" ]; then

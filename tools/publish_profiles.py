@@ -25,13 +25,17 @@ CONFIGS = {
     'C4': ('welch4096ws', 8 * 8 * 2 ** 25, 'C4: sweep of 8 x 2^25 samples on one GPU, Hann 4096, shift + trim + dB'),
     'C4ref': ('welch4096_kernel', 8 * 8 * 2 ** 25, 'C4 reference-faithful: flattop, nperseg 1024 zero-padded to 4096 '
               '(spectrum_sweeper.py:263): 4 transforms per 2048 new samples'),
-    'C5': ('welch16k', 8 * 64 * 2 ** 22, 'C5: 64 channel streams x 2^22 samples, 16384-pt rect |X|^2/N^2 mean'),
+    'C5': ('welch16k1x_pipe', 8 * 64 * 2 ** 22, 'C5: 64 channel streams x 2^22 samples, 16384-pt rect |X|^2/N^2 mean (welch16k1x_pipe_kernel: '
+           'one cross-wave exchange, software-pipelined, loads spread over the step)'),
+    'C5old': ('welch16k_kernel', 8 * 64 * 2 ** 22, 'C5 on the round-3 kernel (welch16k_kernel<0, 4>: 4 x 4096, variant 16k4), same box and passes'),
     'w256': ('seg_kernel', 8 * 2 ** 27, 'Welch 256-pt Hann 50 % overlap, 2^27 samples (four 16-thread teams per wave)'),
     'w512': ('seg_kernel', 8 * 2 ** 27, 'Welch 512-pt Hann 50 % overlap, 2^27 samples (two 32-thread teams per wave)'),
     'w1024': ('segws_kernel', 8 * 2 ** 27, 'Welch 1024-pt Hann 50 % overlap, 2^27 samples'),
     'w2048': ('segws_kernel', 8 * 2 ** 27, 'Welch 2048-pt Hann 50 % overlap, 2^27 samples'),
     'w8192': ('welch16k', 8 * 2 ** 27, 'Welch 8192-pt Hann 50 % overlap, 2^27 samples (welch16k_kernel<2, 2, HALF>: frequency-domain detrend, overlapped half kept in registers; two transforms per sample)'),
-    'w16384': ('welch16k', 8 * 2 ** 27, 'Welch 16384-pt Hann 50 % overlap + detrend, 2^27 samples (welch16k_kernel<2, 4, HALF>: frequency-domain detrend, overlapped half kept in registers; two transforms per sample)'),
+    'w16384': ('welch16k1x_half', 8 * 2 ** 27, 'Welch 16384-pt Hann 50 % overlap + detrend, 2^27 samples (welch16k1x_half_kernel<2>: one cross-wave exchange, frequency-domain detrend, overlapped half kept in registers; two transforms per sample)'),
+    'p8192': ('welch16k', 8 * 2 ** 27, 'the sweeper call at fft_len 8192: flattop, nperseg 2048 zero-padded to 8192, step 1024: 8 transforms per 8192 new samples (welch16k_kernel<1, 2, false, PAD>)'),
+    'p16384': ('welch16k', 8 * 2 ** 27, 'the sweeper call at fft_len 16384: flattop, nperseg 4096 zero-padded to 16384, step 2048 (welch16k_kernel<1, 4, false, PAD>)'),
     'p1024': ('seg_kernel', 8 * 2 ** 27, 'the sweeper call at fft_len 1024 (spectrum_sweeper.py:263): flattop, nperseg 256 zero-padded to 1024, step 128: 8 transforms per 1024 new samples (seg_kernel<4, HALF, ., NA=4>)'),
     'p2048': ('seg_kernel', 8 * 2 ** 27, 'the sweeper call at fft_len 2048: flattop, nperseg 512 zero-padded to 2048, step 256 (seg_kernel<8, HALF, ., NA=4>)'),
     'chain256': ('seg_kernel', 8 * 2 ** 26, 'periodogram chain 256, 2^26 samples'),
