@@ -666,6 +666,11 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         // tail has nothing to even out and costs 5-20 % (2048 points, 2^22 samples: 17.3 % against 14.0 %)
         if ((tuned || seg_ws) && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC && per_team < 32)
             a.sched = OTH_SCHED_CONTIGUOUS;
+        // the one-exchange 16384-point scanner kernel: one workgroup per CU, equal work per segment, no chunk head to
+        // re-read - contiguous runs (0.417-0.418 against 0.421-0.424 ms with tickets, same box) unless a workgroup gets so
+        // few segments that an uneven split shows
+        if (tuned_16k1x && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC && nseg_run / (W > 0 ? W : 1) >= 8)
+            a.sched = OTH_SCHED_CONTIGUOUS;
         // 16384 points at 50 % overlap: one workgroup per CU and equal work per segment - contiguous runs (no chunk head
         // is read twice): 30.8 % against 29.3 % with tickets; 8192: tickets over chunks of 16 (33.4 % against 32.5 % at 8)
         if (tuned_16k && p->nfft == 16384 && p->step * 2 == p->nfft && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC)
