@@ -3,6 +3,8 @@
 // epilogues (single_pole_iir_filter_ff + nlog10_ff of local_worker.py:66-69,
 // peak hold of psd_logger.py:85), channel power (ofdm_cr_tools.py:168-170,
 // 232-249), the synthetic IQ generator and the measurement probes.
+#include <cstdint>
+
 #include "oth_internal.h"
 
 namespace oth {
@@ -556,9 +558,96 @@ __global__ __launch_bounds__(256) void bin_threshold_ma_kernel(const float *psd,
     for (int i = threadIdx.x; i < nfft; i += 256) mask[(size_t)blockIdx.x * nfft + i] = row[i] > level ? 1 : 0;
 }
 
+// ---- decision stage of the batched scanner, many rows (oth_scan_decide_dev*) ------------------------------------------
+// movingaverage (ofdm_cr_tools.py:168-170) as a SLIDING sum: a thread forms the M-tap sum of its first output directly
+// and moves on by + x[in] - x[out] for the other 15.  Sums of a few hundred float32 values in double are exact
+// (24-bit mantissas, 53-bit accumulator), so the sliding sum IS the direct one, not an approximation of it; 12 adds
+// per output instead of M = 163 at config 5's search bandwidth.  The row minimum (the noise floor of
+// spectrum_sensor_v2.py:465-467, per row) is taken on the way: non-negative floats order like their bit patterns, so
+// one atomicMin per block on the row's word, which the launcher presets to 0x7F7F7F7F (3.39e38).
+// The 4096 + M - 1 inputs of a block's 4096 outputs are staged in LDS first (coalesced; one pad word per 16 so that
+// the per-thread runs, 16 apart, fall into different banks): the taps then cost LDS reads, not dependent global loads
+// (35 us -> 5 us for 64 rows of 16384 at M = 163).
+constexpr int kMaTile = 4096, kMaRun = 16, kMaMaxM = 1024;
+__device__ __forceinline__ int ma_pad(int k) { return k + (k >> 4); }
+__global__ __launch_bounds__(256) void movavg_run_kernel(const float *psd, int nfft, double srch_bins, double *movavg,
+                                                         unsigned *noise_bits) {
+    __shared__ float xs[(kMaTile + kMaMaxM) + (kMaTile + kMaMaxM) / 16 + 1];
+    __shared__ double ys[kMaTile + kMaTile / 16];      // the outputs, written back coalesced (a thread's own run of 16
+                                                       // doubles is 64 different cache lines per store instruction)
+    __shared__ float red[4];
+    const float *x = psd + (size_t)blockIdx.y * nfft;
+    double *out = movavg + (size_t)blockIdx.y * nfft;
+    const int M = (int)srch_bins, half = (M - 1) / 2;
+    const double inv = 1.0 / srch_bins;      // np.convolve(x, ones(M) / sb): the taps are 1 / sb there too; 16 double divisions less
+    const int base = blockIdx.x * kMaTile;
+    const int lo = base + half - M + 1, count = kMaTile + M - 1;      // inputs n = lo + k, k in [0, count)
+    for (int k = threadIdx.x; k < count; k += 256) {
+        const int n = lo + k;
+        xs[ma_pad(k)] = (n >= 0 && n < nfft) ? x[n] : 0.f;            // out-of-range taps are skipped = add 0
+    }
+    __syncthreads();
+    const int t0 = threadIdx.x * kMaRun, i0 = base + t0;              // output i0 + r takes xs[t0 + r .. t0 + r + M - 1]
+    float mn = 3.4e38f;
+    if (i0 < nfft) {
+        double s = 0.0;
+        for (int j = 0; j < M; ++j) s += (double)xs[ma_pad(t0 + j)];
+        double v = fabs(s * inv);
+        ys[ma_pad(t0)] = v;
+        mn = (float)v;
+#pragma unroll 4
+        for (int r = 1; r < kMaRun && i0 + r < nfft; ++r) {
+            s += (double)xs[ma_pad(t0 + r + M - 1)];
+            s -= (double)xs[ma_pad(t0 + r - 1)];
+            v = fabs(s * inv);
+            ys[ma_pad(t0 + r)] = v;
+            mn = fminf(mn, (float)v);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kMaTile && base + k < nfft; k += 256) out[base + k] = ys[ma_pad(k)];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMin(noise_bits + blockIdx.y, __float_as_uint(fminf(fminf(red[0], red[1]), fminf(red[2], red[3]))));
+}
+
+// mask[k] = psd[k] > thr * noise[row]: 1024 bins per block (the one-workgroup-per-row form left 192 of 256 CUs idle at
+// 64 rows)
+__global__ __launch_bounds__(256) void row_mask_kernel(const float *psd, const float *noise, int nfft, float thr,
+                                                       unsigned char *mask) {
+    const size_t row = (size_t)blockIdx.y * nfft;
+    const float level = noise[blockIdx.y] * thr;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < nfft) {
+        const float4 v = *reinterpret_cast<const float4 *>(psd + row + i);
+        uchar4 m;
+        m.x = v.x > level ? 1 : 0;
+        m.y = v.y > level ? 1 : 0;
+        m.z = v.z > level ? 1 : 0;
+        m.w = v.w > level ? 1 : 0;
+        *reinterpret_cast<uchar4 *>(mask + row + i) = m;
+    } else {
+        for (int k = i; k < nfft; ++k) mask[row + k] = psd[row + k] > level ? 1 : 0;
+    }
+}
+
 hipError_t launch_scan_decide(const float *psd, int nrows, int nfft, double srch_bins, float thr, int nch, const int *lo,
                               const int *hi, double *movavg, unsigned char *mask, float *noise, float *power,
                               hipStream_t s) {
+    if ((nfft & 3) == 0 && (reinterpret_cast<uintptr_t>(psd) & 15) == 0 && (!mask || (reinterpret_cast<uintptr_t>(mask) & 3) == 0) &&
+        (int)srch_bins <= kMaMaxM) {
+        hipError_t e = hipMemsetAsync(noise, 0x7F, sizeof(float) * (size_t)nrows, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(movavg_run_kernel, dim3((nfft + kMaTile - 1) / kMaTile, nrows), dim3(256), 0, s, psd, nfft, srch_bins,
+                           movavg, reinterpret_cast<unsigned *>(noise));
+        if (nch > 0 && power)
+            hipLaunchKernelGGL(channel_sum_kernel, dim3(nch, nrows), dim3(64), 0, s, movavg, nfft, nch, lo, hi, power);
+        if (mask)
+            hipLaunchKernelGGL(row_mask_kernel, dim3((nfft + 1023) / 1024, nrows), dim3(256), 0, s, psd, noise, nfft, thr, mask);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(movavg_kernel, dim3((nfft + 255) / 256, nrows), dim3(256), 0, s, psd, nfft, srch_bins, movavg,
                        (float *)nullptr);
     if (nch > 0 && power)

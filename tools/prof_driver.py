@@ -73,6 +73,20 @@ elif cfg == 'C5':
                           fftshift=True)
     run = lambda: plan.exec_dev(d, S, o, nstreams=nch, stream_stride=stride)      # noqa: E731
     nbytes = 8 * nch * S
+elif cfg == 'C5d':      # config 5 as bench.py's scan_c5 runs it: PSD rows + the device decision stage (device outputs)
+    from ofdm_tools import scan_batch
+    nch, S, N = 64, 1 << (log2n or 22), 16384
+    d, o = dev(nch * S * 8), dev(nch * N * 4)
+    for i in range(nch):
+        ctx.synth_iq(d + i * S * 8, S, 3000 + i, TONES, DC)
+    bp = scan_batch.BatchScanPlan(ctx, N, 1000000, 15625.0, 10e3, thr_leveler=10)
+    lo, hi = bp._slices()
+    noise, power, mask = dev(nch * 4), dev(nch * max(len(lo), 1) * 4), dev(nch * N)
+
+    def run():
+        bp.psd_rows_dev(d, S, nch, S, o)
+        ctx.scan_decide_dev_out(o, nch, N, bp.scanner.srch_bins, bp.thr_leveler, lo, hi, noise, power, mask)
+    nbytes = 8 * nch * S
 elif cfg in ('w1024', 'w2048', 'w512', 'w256', 'w8192', 'w16384'):
     N = int(cfg[1:])
     n = 1 << (log2n or 27)
