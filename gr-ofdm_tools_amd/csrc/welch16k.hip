@@ -188,13 +188,19 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int a = 0; a < F; ++a) {
-                        if (PAD && (a != 0 || j >= 4)) {
-                            v[F * j + a] = make_float2(0.f, 0.f);
-                        } else {
-                            v[F * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
-                            sum = cadd(sum, v[F * j + a]);
-                        }
+                        if (PAD && (a != 0 || j >= 4)) v[F * j + a] = make_float2(0.f, 0.f);
+                        else v[F * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
                     }
+                if (DETREND) {
+                    // pairwise, like NumPy's float32 mean: with a DC line far above the signal the ORDER of the adds is
+                    // what separates 1e-4 from 4e-4 in bins 0, +-1 of a few-segment result (the padding zeros add exactly)
+                    float2 t8[8], t4[4];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t8[i] = cadd(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t4[i] = cadd(t8[2 * i], t8[2 * i + 1]);
+                    sum = cadd(cadd(t4[0], t4[1]), cadd(t4[2], t4[3]));
+                }
             }
             float2 mean = make_float2(0.f, 0.f);
             if (DET == 2) {      // windowed before the barrier: the mean comes off in the frequency domain
@@ -243,9 +249,18 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
                 if (tid == 63) red[40 + par] = part;      // read behind the barriers of the transform
             }
             if (DET == 1) {
-                float2 tot = red[0];
+                float2 tot;      // the T16 / 64 wave sums, pairwise as well
+                {
+                    constexpr int NW = T16 / 64;
+                    float2 t[NW];
 #pragma unroll
-                for (int w = 1; w < T16 / 64; ++w) tot = cadd(tot, red[w]);
+                    for (int w = 0; w < NW; ++w) t[w] = red[w];
+#pragma unroll
+                    for (int n = NW / 2; n >= 1; n /= 2)
+#pragma unroll
+                        for (int w = 0; w < n; ++w) t[w] = cadd(t[2 * w], t[2 * w + 1]);
+                    tot = t[0];
+                }
                 if (HALF) {
                     if (s == sb) {
                         float2 ft = red[16];
