@@ -124,23 +124,41 @@ __device__ __forceinline__ void twiddle6(float2 (&v)[16], float2 *out, const Pow
 //   stage 2 (partner q ^ 1)  x <- x + c x'          c = 1, -1, -i, -i:   X0, -X2, -X1, -(d1 - i d0) = i X3 / ... |.| equal
 // c = al - i be:  re += al re' + be im',  im += al im' - be re'.
 __device__ __forceinline__ void quad_dft4_dpp(float2 (&v)[16], float s1, float al, float be, float nbe) {
-    asm volatile("s_nop 1");      // VALU write -> DPP read of the same register needs two wait states
+    // Each asm block is ONE statement: the compiler cannot put a VALU write of a register between the wait states and
+    // the DPP read of it (VALU write -> DPP read needs two wait states, which its hazard recognizer does not see inside
+    // inline asm).  Stage 1 blocks open with s_nop 1; in the stage 2 blocks the four copies come first - four VALU
+    // instructions between the block's start and its first DPP read, and between each copy and the DPP read of it.
+#define OTH_Q1 "v_fmac_f32_dpp %0, %0, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+               "v_fmac_f32_dpp %1, %1, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+               "v_fmac_f32_dpp %2, %2, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+               "v_fmac_f32_dpp %3, %3, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+               "v_fmac_f32_dpp %4, %4, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+               "v_fmac_f32_dpp %5, %5, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+               "v_fmac_f32_dpp %6, %6, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+               "v_fmac_f32_dpp %7, %7, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v[i].x) : "v"(s1));
-        asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v[i].y) : "v"(s1));
-    }
+    for (int i = 0; i < 16; i += 4)
+        asm volatile("s_nop 1\n\t" OTH_Q1
+                     : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i + 1].x), "+v"(v[i + 1].y), "+v"(v[i + 2].x), "+v"(v[i + 2].y),
+                       "+v"(v[i + 3].x), "+v"(v[i + 3].y)
+                     : "v"(s1));
+#undef OTH_Q1
+    // x = %0/%2/%4/%6, y = %1/%3/%5/%7, old-x copies %8..%11, al %12, be %13, -be %14
+#define OTH_Q2(x, y, t)                                                                            \
+    "v_fmac_f32_dpp " x ", " x ", %12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_fmac_f32_dpp " x ", " y ", %13 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_fmac_f32_dpp " y ", " y ", %12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_fmac_f32_dpp " y ", " t ", %14 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float t;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(v[i].x));      // the partner reads the OLD real part last
-        asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[i].x) : "v"(al));
-        asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-                     : "+v"(v[i].x)
-                     : "v"(v[i].y), "v"(be));
-        asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[i].y) : "v"(al));
-        asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[i].y) : "v"(t), "v"(nbe));
+    for (int i = 0; i < 16; i += 4) {
+        float t0, t1, t2, t3;
+        asm volatile("v_mov_b32 %8, %0\n\tv_mov_b32 %9, %2\n\tv_mov_b32 %10, %4\n\tv_mov_b32 %11, %6\n\t"      // the partner reads the OLD real part last
+                     OTH_Q2("%0", "%1", "%8") OTH_Q2("%2", "%3", "%9") OTH_Q2("%4", "%5", "%10") OTH_Q2("%6", "%7", "%11")
+                     : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i + 1].x), "+v"(v[i + 1].y), "+v"(v[i + 2].x), "+v"(v[i + 2].y),
+                       "+v"(v[i + 3].x), "+v"(v[i + 3].y), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                     : "v"(al), "v"(be), "v"(nbe));
     }
+#undef OTH_Q2
 }
 
 // The plain loop: every phase of a segment in program order, its sixteen loads at the top.  The pipelined kernel below
