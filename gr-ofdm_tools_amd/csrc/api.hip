@@ -1717,11 +1717,15 @@ static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec
         groups = chain_tail_groups((int)W, N);
         if (groups && (rc = ensure(c, &h->d_tail, &h->tail_cap, sizeof(float) * (size_t)groups * N))) return rc;
     }
+    // 16384 points: the one-exchange pipelined loop (welch16k1x.hip, round 4); OTH_CHAIN16K=old keeps the 4 x 4096 build (A/B)
+    static const char *chain16k_mode = getenv("OTH_CHAIN16K");
+    const bool x1 = N == 16384 && !(chain16k_mode && !strcmp(chain16k_mode, "old"));
     {
         Timed tm(c);      // the whole push: transform kernel + cross-team reduction + state / rows
-        HIPCHK(c, big ? launch_chain16k(N, a, h->rect, c->stream) : launch_seg(N, a, 2, false, c->stream));
+        HIPCHK(c, big ? (x1 ? launch_chain16k1x(a, h->rect, c->stream) : launch_chain16k(N, a, h->rect, c->stream))
+                      : launch_seg(N, a, 2, false, c->stream));
         if (a.acc_mode != 3)
-            HIPCHK(c, launch_chain_tail(h->d_partial, groups ? h->d_tail : nullptr, (int)W, N, big ? (N == 16384 ? 2 : 3) : 0,
+            HIPCHK(c, launch_chain_tail(h->d_partial, groups ? h->d_tail : nullptr, (int)W, N, big ? (x1 ? 4 : (N == 16384 ? 2 : 3)) : 0,
                                         h->fftshift, a.acc_mode, a.acc_end,
                                         h->alpha, h->kdb, h->d_iir, h->d_peak, h->d_rows, h->do_iir ? give : 0, rows_last,
                                         c->stream));

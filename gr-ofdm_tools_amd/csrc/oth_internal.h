@@ -143,6 +143,9 @@ hipError_t launch_welch_tuned16k1x(const WelchArgs &a, bool window, bool plain, 
 hipError_t launch_welch_tuned16k1x_half(const WelchArgs &a, hipStream_t s);
 // the fused periodogram chain at 8192 / 16384 points (one workgroup per segment; workgroups per CU: 2 / 1)
 hipError_t launch_chain16k(int nfft, const SegArgs &a, bool rect, hipStream_t s);
+// the same chain at 16384 points on the one-exchange pipelined loop (welch16k1x.hip); partial rows in layout 4; needs
+// chunks of at least two segments
+hipError_t launch_chain16k1x(const SegArgs &a, bool rect, hipStream_t s);
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
 // segfft.hip
 bool seg_supported(int nfft);

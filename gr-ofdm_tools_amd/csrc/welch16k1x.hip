@@ -352,36 +352,45 @@ template <int STRIDE> __device__ __forceinline__ void lds_issue16(f2v (&r)[16], 
 //
 // 624 + 456 VALU instructions per wave on the two sides instead of 168 + 912; registers: the samples / pass-1 outputs
 // of one segment and the exchange-B values of the one before, 32 + 32.
-template <bool WINDOW>      // (only <false> is instantiated: the scanner passes `()` as its window)
-__global__ __launch_bounds__(1024) void welch16k1x_pipe_kernel(WelchArgs p) {
-    constexpr int N = 16384;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2 *lds = reinterpret_cast<float2 *>(smem);
-    int *lnext = reinterpret_cast<int *>(lds + 16 * XREG);
+// The segment schedule as the body below takes it (WelchArgs and SegArgs both carry these fields)
+struct X1Sched {
+    long long nseg, nbig;
+    int chunk, tail_chunk, sched;
+    unsigned *queue;      // this stream's ticket word (dynamic schedule) or nullptr
+};
 
+// 4-byte non-temporal-free load of a window value at (uniform row base) + (lane offset), pinned like load_row_nt: the
+// compiler would hoist sixteen loop-invariant window loads into sixteen registers the two segments in flight need
+__device__ __forceinline__ void load_win(float &dst, unsigned lane_off, const char *row) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
+}
+
+// The pipelined transform loop.  `epi.take(v, s)` receives segment s after pass 4 (v[r16(k2)] = bin k0 + 16 k1 + 256 k2
+// + 4096 bitrev2(q) of thread (wave k0, lane 4 k1 + q), times 1, -1, -1 or i); the first call has s = -1 and zeros.
+template <bool WINDOW, class Epi>
+__device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, const X1Sched &sc, int wg, int W, const float *win,
+                                             const float2 *tw, float2 *lds, Epi &epi, unsigned long long *diag_out) {
+    int *lnext = reinterpret_cast<int *>(lds + 16 * XREG);
     const int tid = threadIdx.x;
     const int wv = tid >> 6, l = tid & 63, g = l >> 2, q = l & 3;
-    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
-    const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
-    const float2 *xb = p.x + (size_t)stream * p.stream_stride;
+    const long long s0 = (sc.nseg * wg) / W, s1 = (sc.nseg * (wg + 1)) / W;
 
-    // The twiddle seeds W, W^4 of the three twiddled passes and the quad-butterfly constants live in LDS, not in
-    // registers: 16 registers that the two segments in flight (32 + 32) need; each is read where it is used.
     // Twiddles: pass 1 (W_N^(k0 tid), a different set per thread) is rebuilt from six register-resident powers; passes
     // 2 and 3 depend on the lane only and are read from LDS tables where they are used (tabB[k1][l] = W_1024^(k1 l),
-    // 8 KiB; tabC[k2][q] = W_64^(k2 q), 512 B) - no products to rebuild them, and none of their seeds in registers.
+    // 8 KiB; tabC[k2][q] = W_64^(k2 q), 512 B) - no products to rebuild them, none of their seeds in registers; the
+    // quad-butterfly constants sit there too.
     float2 *tabB = lds + 16 * XREG + X1_RED;                                   // [16][64]
     float2 *tabC = tabB + 16 * 64;                                              // [16][4]
     float4 *quadK = reinterpret_cast<float4 *>(tabC + 16 * 4);                  // [4]: s1, alpha, beta, -beta
     {
-        tabB[tid] = p.tw[16 * ((tid >> 6) * (tid & 63))];                       // k1 = tid >> 6, l = tid & 63
-        if (tid < 64) tabC[tid] = p.tw[256 * ((tid >> 2) * (tid & 3))];         // k2 = tid >> 2, q = tid & 3
+        tabB[tid] = tw[16 * ((tid >> 6) * (tid & 63))];                         // k1 = tid >> 6, l = tid & 63
+        if (tid < 64) tabC[tid] = tw[256 * ((tid >> 2) * (tid & 3))];           // k2 = tid >> 2, q = tid & 3
         if (tid < 4) {
             const float be = tid >= 2 ? 1.0f : 0.0f;
             quadK[tid] = make_float4(tid < 2 ? 1.0f : -1.0f, tid == 0 ? 1.0f : (tid == 1 ? -1.0f : 0.0f), be, -be);
         }
     }
-    const Pow6x a6 = pow6_load(p.tw, tid);
+    const Pow6x a6 = pow6_load(tw, tid);
     __syncthreads();
 
     float2 *wa = lds + tid;
@@ -389,43 +398,60 @@ __global__ __launch_bounds__(1024) void welch16k1x_pipe_kernel(WelchArgs p) {
     float2 *wb = lds + XREG * wv + l;
     const float2 *rb = lds + XREG * wv + XROW * g + q;
 
-    float acc[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-
-    const int sched = p.sched;
-    const long long nchunks = sched ? chunk_count(p) : 1;
+    const int sched = sc.sched;
+    const long long nchunks = sched ? chunk_count_of(sc.nseg, sc.nbig, sc.chunk, sc.tail_chunk) : 1;
     long long cur = sched ? wg : 0, sb = s0, se = s1;
-    if (sched && cur < nchunks) chunk_range(p, cur, sb, se);
+    if (sched && cur < nchunks) chunk_range_of(sc.nseg, sc.nbig, sc.chunk, sc.tail_chunk, cur, sb, se);
     bool live = sched ? cur < nchunks : s0 < s1;
-    long long s = sb;
+    long long s = sb, sp = -1;      // this segment, the one before (whose tail runs in this step)
     int par = 0;
 #if OTH_X1_DIAG
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
     f2v pfr[16];      // the next segment's samples as the pinned loads deliver them (valid behind the vmcnt wait)
-    f2v rB[16];       // exchange-B values of the segment before; zeros in front of the first one (its tail then adds 0)
+    f2v rB[16];       // exchange-B values of the segment before; zeros in front of the first one
 #pragma unroll
     for (int i = 0; i < 16; ++i) rB[i] = f2v{0.f, 0.f};
     bool have_prev = false;
     if (live) {
-        const char *x0 = reinterpret_cast<const char *>(xb + s * p.step);
+        const char *x0 = reinterpret_cast<const char *>(xb + s * step);
 #pragma unroll
         for (int r = 0; r < 16; ++r) load_row_nt(pfr[r], 8u * tid, x0 + 8192 * r);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    auto tail = [&](auto hook1, auto hook2) {      // pass 3, twiddles, pass 4 of the segment whose exchange-B values sit in rB
+        float2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = make_float2(rB[i].x, rB[i].y);
+        TwBatch ta;
+        tw_read_a<4>(ta, tabC + q);
+        const float4 qk = quadK[q];
+        dft16(v);
+        hook1();
+        twiddle_table16<4, 1, false>(v, nullptr, tabC + q, ta);
+        hook2();
+        quad_dft4_dpp(v, qk.x, qk.y, qk.z, qk.w);
+        epi.take(v, sp);
+    };
     using std::integral_constant;
     while (live) {
         float2 pf[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) pf[r] = make_float2(pfr[r].x, pfr[r].y);
-        if constexpr (WINDOW) {
+        if constexpr (WINDOW) {      // sixteen L2-resident window values, loaded where they are used (see load_win)
+            float wv16[16];
+            const char *wbase = reinterpret_cast<const char *>(win);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float w = p.win[tid + 1024 * r];      // L2-resident, sixteen 4-byte loads per segment
-                pf[r] = make_float2(pf[r].x * w, pf[r].y * w);
-            }
+            for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * tid, wbase + 4096 * r);
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(wv16[0]), "+v"(wv16[1]), "+v"(wv16[2]), "+v"(wv16[3]), "+v"(wv16[4]), "+v"(wv16[5]), "+v"(wv16[6]),
+                           "+v"(wv16[7]), "+v"(wv16[8]), "+v"(wv16[9]), "+v"(wv16[10]), "+v"(wv16[11]), "+v"(wv16[12]), "+v"(wv16[13]),
+                           "+v"(wv16[14]), "+v"(wv16[15])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pf[r] = make_float2(pf[r].x * wv16[r], pf[r].y * wv16[r]);
         }
         X1_STAMP(7);
         X1_DRAIN_VM();
@@ -437,7 +463,7 @@ __global__ __launch_bounds__(1024) void welch16k1x_pipe_kernel(WelchArgs p) {
         lds_barrier();      // 1 (also waits for this wave's exchange-B reads of the segment before)
         X1_STAMP(2);
         const bool first_of_chunk = s == sb;
-        if (sched == 2 && first_of_chunk && tid == 0) lnext[par] = (int)atomicAdd(p.queue + stream, 1u);
+        if (sched == 2 && first_of_chunk && tid == 0) lnext[par] = (int)atomicAdd(sc.queue, 1u);
         twiddle6<XREG, true>(pf, wa, a6);                      // WA
         X1_STAMP(3);
         // The segment after this one: its loads go out two at a time over the whole step.  A ticket (dynamic schedule)
@@ -446,29 +472,28 @@ __global__ __launch_bounds__(1024) void welch16k1x_pipe_kernel(WelchArgs p) {
         // behind which no ticket can name another chunk.
         long long ns = s + 1;
         bool more = true;
-        constexpr bool known = true;
-        auto next_chunk = [&]() {
-            cur = (sched == 1) ? cur + W : (long long)W + __builtin_amdgcn_readfirstlane(lnext[par]);
-            par ^= 1;
-            more = cur < nchunks;
-            if (more) {
-                chunk_range(p, cur, sb, se);
-                ns = sb;
-            }
-        };
         if (ns >= se) {
-            if (sched == 0 || (sched == 2 && first_of_chunk)) more = false;
-            else next_chunk();
+            if (sched == 0 || (sched == 2 && first_of_chunk)) {
+                more = false;
+            } else {
+                cur = (sched == 1) ? cur + W : (long long)W + __builtin_amdgcn_readfirstlane(lnext[par]);
+                par ^= 1;
+                more = cur < nchunks;
+                if (more) {
+                    chunk_range_of(sc.nseg, sc.nbig, sc.chunk, sc.tail_chunk, cur, sb, se);
+                    ns = sb;
+                }
+            }
         }
-        // uniform row base (scalar registers) + one lane offset: no per-load address registers
-        // (behind the last segment the same loads run once more on the segment just done: an unconditional
-        // definition keeps the sixteen registers free between pass 1 and the first group of loads)
-        const char *xn = reinterpret_cast<const char *>(xb + (more ? ns : s) * p.step);
+        // uniform row base (scalar registers) + one lane offset: no per-load address registers.  Behind the last
+        // segment the same loads run once more on the segment just done: an unconditional definition keeps the sixteen
+        // registers free between pass 1 and the first group of loads (a conditional one keeps their OLD values alive).
+        const char *xn = reinterpret_cast<const char *>(xb + (more ? ns : s) * step);
         const unsigned voff = 8u * tid;
-        auto spread = [&](auto gc, bool) {      // two of the next segment's sixteen loads
+        auto spread = [&](auto gc) {
             // place grp of the step (0: after the exchange-A writes, 1: after the tail's butterflies, 2: after its
             // twiddles, 3: end of the tail, 4: behind barrier 2, 5: between pass 2's layers, 6: after pass 2, 7: after
-            // the exchange-B writes) issues nibble grp of OTH_X1_PPLACES of the sixteen loads
+            // the exchange-B writes) issues nibble grp of OTH_X1_PPLACES of the next segment's sixteen loads
             constexpr int grp = decltype(gc)::value;
             constexpr unsigned plan = OTH_X1_PPLACES;
             static_assert(((plan >> 0) & 15) + ((plan >> 4) & 15) + ((plan >> 8) & 15) + ((plan >> 12) & 15) + ((plan >> 16) & 15) +
@@ -485,82 +510,148 @@ __global__ __launch_bounds__(1024) void welch16k1x_pipe_kernel(WelchArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        spread(integral_constant<int, 0>{}, known);
+        spread(integral_constant<int, 0>{});
         prio_compute();
-        {                                                      // T3: pass 3, twiddles, pass 4, |X|^2 of the segment before
-            float2 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = make_float2(rB[i].x, rB[i].y);
-            TwBatch ta;
-            tw_read_a<4>(ta, tabC + q);
-            const float4 qk = quadK[q];
-            dft16(v);
-            spread(integral_constant<int, 1>{}, known);
-            twiddle_table16<4, 1, false>(v, nullptr, tabC + q, ta);
-            spread(integral_constant<int, 2>{}, known);
-            quad_dft4_dpp(v, qk.x, qk.y, qk.z, qk.w);
-#pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) {
-                const float2 X = v[r16(k2)];
-                acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
-            }
-        }
-        spread(integral_constant<int, 3>{}, known);
+        tail([&] { spread(integral_constant<int, 1>{}); }, [&] { spread(integral_constant<int, 2>{}); });      // T3
+        spread(integral_constant<int, 3>{});
         prio_latency();
         X1_STAMP(4);
         lds_barrier();      // 2
         X1_STAMP(5);
-        spread(integral_constant<int, 4>{}, true);
+        spread(integral_constant<int, 4>{});
         {                                                      // RA
             float2 v[16];
             TwBatch ta;
             dft16_from_lds<64>(v, ra, [] { prio_compute(); }, [&] {
-                spread(integral_constant<int, 5>{}, true);
+                spread(integral_constant<int, 5>{});
                 tw_read_a<64>(ta, tabB + l);
             });
             prio_latency();
-            spread(integral_constant<int, 6>{}, true);
+            spread(integral_constant<int, 6>{});
             wave_lds_sync();
             twiddle_table16<64, XROW, true>(v, wb, tabB + l, ta);
-            spread(integral_constant<int, 7>{}, true);
+            spread(integral_constant<int, 7>{});
             wave_lds_sync();
             lds_issue16<4>(rB, rb);
         }
         X1_STAMP(6);
         have_prev = true;
         live = more;
+        sp = s;
         s = ns;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the sixteen pinned loads of this step: the next pass 1 reads them
     }
     if (have_prev) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float2 v[16];
+        tail([] {}, [] {});
+    }
+#if OTH_X1_DIAG
+    if (l == 0 && diag_out) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = make_float2(rB[i].x, rB[i].y);
-        TwBatch ta;
-        tw_read_a<4>(ta, tabC + q);
-        const float4 qk = quadK[q];
-        dft16(v);
-        twiddle_table16<4, 1, false>(v, nullptr, tabC + q, ta);
-        quad_dft4_dpp(v, qk.x, qk.y, qk.z, qk.w);
+        for (int i = 0; i < 8; ++i) diag_out[8 * wv + i] = phase[i];
+    }
+#endif
+}
+
+// Welch average: sum of |X|^2 per bin; partial rows in finalize layout 4
+struct X1WelchEpi {
+    float acc[16];
+    __device__ __forceinline__ void take(const float2 (&v)[16], long long) {      // (the priming call adds zeros)
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             const float2 X = v[r16(k2)];
             acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
         }
     }
+};
 
-    float *dst = p.partial + ((size_t)stream * W + wg) * N + tid;
+template <bool WINDOW>      // (the scanner passes `()` as its window; windowed Welch plans take the plain kernel)
+__global__ __launch_bounds__(1024) void welch16k1x_pipe_kernel(WelchArgs p) {
+    constexpr int N = 16384;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    X1WelchEpi epi;
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) dst[1024 * k2] = acc[k2];
+    for (int k = 0; k < 16; ++k) epi.acc[k] = 0.f;
+    const X1Sched sc{p.nseg, p.nbig, p.chunk, p.tail_chunk, p.sched, p.queue ? p.queue + stream : nullptr};
+    unsigned long long *diag = nullptr;
 #if OTH_X1_DIAG
-    if (l == 0) {
-        unsigned long long *st = reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * N) +
-                                 128 * ((size_t)stream * W + wg) + 8 * wv;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) st[i] = phase[i];
-    }
+    diag = reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * N) + 128 * ((size_t)stream * W + wg);
 #endif
+    x1_pipe_body<WINDOW>(p.x + (size_t)stream * p.stream_stride, p.step, sc, wg, W, p.win, p.tw, lds, epi, diag);
+    float *dst = p.partial + ((size_t)stream * W + wg) * N + threadIdx.x;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) dst[1024 * k2] = epi.acc[k2];
+}
+
+// The fused periodogram chain (stream_to_vector -> keep_one_in_n -> fft_vcc(window, shift) -> |X| or |X|^2 [x 1/N^2] -> IIR
+// weights / peak maximum / rows, python/spectrum_sensor_v2.py:85-93, psd_logger.py:43-53, local_worker.py:58-69,
+// multichannel_scanner.py:78-86 at fft_len 16384) on the same loop: what chain16k_kernel<4, ...> (welch16k.hip) does,
+// same SegArgs, partial rows in layout 4 for chain_reduce / chain_state.
+struct X1ChainEpi {
+    float acc[16];
+    const SegArgs *p;
+    int kb;              // bin of register k2: kb + 256 k2
+    size_t row_base;     // stream offset into p->rows, in rows
+    __device__ __forceinline__ void take(const float2 (&v)[16], long long s) {
+        if (s < 0) return;      // the priming call
+        const SegArgs &a = *p;
+        float val[16];
+        if (a.epilogue == 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const float2 X = v[r16(k2)];
+                val[k2] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));
+            }
+        } else {
+            const float sc = a.scale;
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const float2 X = v[r16(k2)];
+                val[k2] = fmaf(X.x, X.x, X.y * X.y) * sc;
+            }
+        }
+        if (s >= a.store_from) {
+            float *row = a.rows + (row_base + (size_t)(s - a.store_from)) * 16384;
+            const int sh = a.fftshift ? 8192 : 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) row[(kb + 256 * k2 + sh) & 16383] = val[k2];
+        }
+        if (s < a.acc_end) {
+            if (a.acc_mode == 1) {
+                const long long kk = a.acc_end - 1 - s;
+                const float w = kk == 0 ? 1.0f : exp2f(a.l2 * (float)kk);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = fmaf(w, val[k], acc[k]);
+            } else if (a.acc_mode == 2) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = fmaxf(acc[k], val[k]);
+            }
+        }
+    }
+};
+
+template <bool WINDOW>
+__global__ __launch_bounds__(1024) void chain16k1x_kernel(SegArgs p) {
+    constexpr int N = 16384;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x, l = tid & 63, q = l & 3;
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    X1ChainEpi epi;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) epi.acc[k] = 0.f;
+    epi.p = &p;
+    epi.kb = (tid >> 6) + 16 * (l >> 2) + 4096 * (((q & 1) << 1) | (q >> 1));
+    epi.row_base = (size_t)stream * (size_t)(p.nseg - p.store_from);
+    const X1Sched sc{p.nseg, p.nbig, p.chunk, p.tail_chunk, p.sched, p.queue ? p.queue + stream : nullptr};
+    x1_pipe_body<WINDOW>(p.x + (size_t)stream * p.stream_stride + p.first, p.step, sc, wg, W, p.win, p.tw, lds, epi, nullptr);
+    if (p.partial) {
+        float *dst = p.partial + ((size_t)stream * W + wg) * N + tid;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) dst[1024 * k2] = epi.acc[k2];
+    }
 }
 
 template <bool WINDOW> static hipError_t launch1x_pipe(const WelchArgs &a, hipStream_t s) {
@@ -738,6 +829,19 @@ template <bool WINDOW> static hipError_t launch1x(const WelchArgs &a, hipStream_
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((welch16k1x_kernel<WINDOW>), grid, dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain16k1x(const SegArgs &a, bool rect, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    constexpr size_t lds = x1p_lds_bytes();
+    const void *fn = rect ? reinterpret_cast<const void *>(chain16k1x_kernel<false>) : reinterpret_cast<const void *>(chain16k1x_kernel<true>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (rect)
+        hipLaunchKernelGGL((chain16k1x_kernel<false>), grid, dim3(1024), lds, s, a);
+    else
+        hipLaunchKernelGGL((chain16k1x_kernel<true>), grid, dim3(1024), lds, s, a);
     return hipGetLastError();
 }
 
