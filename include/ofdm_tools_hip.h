@@ -236,6 +236,9 @@ int oth_chain_push_dev(oth_chain *chain, const void *iq_dev, size_t nsamples, fl
  * the D2H copy of the LATEST row are enqueued, an event is recorded and the call returns a ticket.  poll() is
  * non-blocking (ready = 0 while the GPU is still working); wait() blocks without holding the context.  The ring
  * keeps the last four tickets: an older one returns OTH_ERR_STATE (it lost against newer vectors). */
+/* (Pushes above 1 MiB of PAGEABLE host memory skip the pinned slot and use the runtime's staged copy, which returns once
+ * the caller's buffer has been read but may hold the host until the stream reaches the copy; GNU Radio's work() chunks
+ * are far smaller.) */
 int oth_chain_push_async(oth_chain *chain, const void *iq_host, size_t nsamples, uint64_t *ticket_out);
 int oth_chain_poll(oth_chain *chain, uint64_t ticket, float *row_out, uint64_t *nrows_out, int *ready);
 int oth_chain_wait(oth_chain *chain, uint64_t ticket, float *row_out, uint64_t *nrows_out);

@@ -252,6 +252,45 @@ def test_welch16k1x_scanner_kernels_schedules_and_counts(ctx, hip):
             ctx.free(ptr)
 
 
+def test_welch16k1x_kernels_repeat_without_drift(ctx, hip):
+    """200 launches of the 16384-point one-exchange kernels on one input (the pipelined scanner kernel, the plain one,
+    the 50 %-overlap form), schedules and chunk sizes drawn at random, two streams: every result must stay within
+    rounding of the first (a missed barrier, a stale ticket or a load that is read before it has landed shows up as an
+    occasional outlier, not as a steady error)."""
+    N = 16384
+    rng = np.random.default_rng(123)
+    n = N * 131 + 777
+    d_in = ctx.alloc(2 * n * 8)
+    d_a, d_b = ctx.alloc(2 * N * 4), ctx.alloc(2 * N * 4)
+    try:
+        ctx.synth_iq(d_in, 2 * n, 9, R.TONES, R.DC)
+        scan = ctx.welch_plan(N, noverlap=0, window=None, detrend=hip.DETREND_NONE, scaling=hip.SCALE_OVER_N2,
+                              kernel=hip.KERNEL_TUNED)
+        half = ctx.welch_plan(N, window=hann(N), kernel=hip.KERNEL_TUNED)
+        gens = {}
+        for name, plan, kw in (('scan', scan, dict(noverlap=0, window=None, detrend=hip.DETREND_NONE, scaling=hip.SCALE_OVER_N2)),
+                               ('half', half, dict(window=hann(N)))):
+            g = ctx.welch_plan(N, kernel=hip.KERNEL_GENERIC, **kw)
+            g.exec_dev(d_in, n, d_b, nstreams=2, stream_stride=n)
+            gens[name] = ctx.d2h(d_b, (2, N), np.float32).astype(np.float64)
+            g.close()
+        worst = 0.0
+        for it in range(200):
+            name, plan = (('scan', scan), ('half', half))[it % 2]
+            variant = None if name == 'half' else (None, '16kplain')[(it // 2) % 2]
+            plan.set_tuning(variant, chunk=int(rng.choice([0, 2, 3, 5, 8, 16])))
+            plan.set_schedule(int(rng.integers(0, 3)))
+            nseg = plan.exec_dev(d_in, n, d_a, nstreams=2, stream_stride=n)
+            assert nseg == (131 if name == 'scan' else 261)
+            got = ctx.d2h(d_a, (2, N), np.float32)
+            err = float(np.max(np.abs(got - gens[name]) / gens[name]))
+            worst = max(worst, err)
+            assert err < 2e-5, (it, name, variant, err)
+    finally:
+        for ptr in (d_in, d_a, d_b):
+            ctx.free(ptr)
+
+
 @pytest.mark.parametrize('N', [8192, 16384])
 def test_welch16k_hann_overlap_detrend_many_segments(ctx, hip, N):
     nseg = 701 if N == 16384 else 1403                # at 75 % overlap: more segments than resident workgroups
