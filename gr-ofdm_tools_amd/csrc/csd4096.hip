@@ -50,9 +50,14 @@ __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
         for (int a = 0; a < 16; ++a) v[a] = xs[256 * a];
         float2 mean = make_float2(0.f, 0.f);
         if (DETREND) {
-            float2 sum = v[0];
+            // pairwise, like NumPy's float32 mean (section 2 of DESIGN.md: with a DC line far above the signal the order
+            // of these adds shows in bins 0, +-1 of a few-segment result)
+            float2 t8[8], t4[4];
 #pragma unroll
-            for (int a = 1; a < 16; ++a) sum = cadd(sum, v[a]);
+            for (int i = 0; i < 8; ++i) t8[i] = cadd(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t4[i] = cadd(t8[2 * i], t8[2 * i + 1]);
+            float2 sum = cadd(cadd(t4[0], t4[1]), cadd(t4[2], t4[3]));
             sum.x = wave_total(sum.x);
             sum.y = wave_total(sum.y);
             if ((t & 63) == 0) red[t >> 6] = sum;

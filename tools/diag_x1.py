@@ -23,7 +23,7 @@ ctx.sync()
 fn = ctx.lib.oth__debug_partial_raw
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
-pipe = os.environ.get('OTH_16K1X_MODE', '') not in ('plain', 'pf', 'p6')
+pipe = os.environ.get('OTH_16K1X_MODE', '') != 'plain'
 names = ['load wait', 'pass 1', 'barrier 1', 'tw + exch A write', 'tail (pass 3, 4, acc) of the segment before', 'barrier 2',
          'loads + A read + pass 2 + B write + B read issue', 'loop'] if pipe else ['load wait', 'pass 1', 'barrier 1', 'tw + exch A write', 'barrier 2', 'A read + pass 2 + tw + B write',
          'B read + pass 3 + tw + pass 4 + acc', 'loop + load issue']
