@@ -68,6 +68,8 @@ struct oth_plan {
     size_t reduce_cap = 0;
     float *d_out = nullptr;            // [4][nfft] + pxy extra
     size_t out_cap = 0;
+    float *h_out = nullptr;            // pinned, device-visible [nfft]: oth_welch_exec's finalize launch writes the PSD straight
+                                       // into host memory (no copy-engine hop between the last kernel and the synchronisation)
     float2 *d_stage = nullptr;         // host-input staging (x then y)
     size_t stage_cap = 0;
     // streaming state
@@ -1116,6 +1118,7 @@ int oth_plan_destroy(oth_plan *p) {
     if (p->d_partial) hipFree(p->d_partial);
     if (p->d_reduce) hipFree(p->d_reduce);
     if (p->d_out) hipFree(p->d_out);
+    if (p->h_out) hipHostFree(p->h_out);
     if (p->d_stage) hipFree(p->d_stage);
     if (p->d_sum) hipFree(p->d_sum);
     if (p->d_stream) hipFree(p->d_stream);
@@ -1248,10 +1251,24 @@ int oth_welch_exec(oth_plan *p, const void *iq, size_t nsamples, int src_is_devi
     int rc;
     if (!src_is_device && (rc = stage_host(p, iq, nullptr, nsamples, &dx, &dy))) return rc;
     const int nout = p->nfft - 2 * p->trim;
-    if ((rc = ensure(c, &p->d_out, &p->out_cap, sizeof(float) * 5 * p->nfft))) return rc;
-    if ((rc = oth_welch_exec_dev(p, dx, nsamples, 1, nsamples, p->d_out, nseg_out))) return rc;
-    HIPCHK(c, hipMemcpyAsync(psd_out, p->d_out, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+    if (!p->h_out) {
+        if (hipHostMalloc((void **)&p->h_out, sizeof(float) * p->nfft, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            p->h_out = nullptr;
+            return fail(c, OTH_ERR_NOMEM, "pinned host allocation failed");
+        }
+    }
+    static const char *hostout = getenv("OTH_HOSTOUT");      // A/B: "copy" = device row + hipMemcpyAsync (rounds 1-3)
+    if (hostout && !strcmp(hostout, "copy")) {
+        if ((rc = ensure(c, &p->d_out, &p->out_cap, sizeof(float) * 5 * p->nfft))) return rc;
+        if ((rc = oth_welch_exec_dev(p, dx, nsamples, 1, nsamples, p->d_out, nseg_out))) return rc;
+        HIPCHK(c, hipMemcpyAsync(psd_out, p->d_out, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return OTH_OK;
+    }
+    if ((rc = oth_welch_exec_dev(p, dx, nsamples, 1, nsamples, p->h_out, nseg_out))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(psd_out, p->h_out, sizeof(float) * nout);
     return OTH_OK;
     OTH_CATCH((p ? p->ctx : nullptr))
 }
