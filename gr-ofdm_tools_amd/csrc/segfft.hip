@@ -571,6 +571,9 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
 //      2 frequency domain in the consumer, X -= mean FFT(w) on the bins |k| < 256 (SegArgs.fd; needs a window whose
 //        spectrum is confined to those bins, as welch4096ws.hip).
 enum { WS_STOP = 0, WS_DATA = 1 };
+#ifndef OTH_SEGWS_SPREAD
+#define OTH_SEGWS_SPREAD 0      // A/B (round 4): two loads at four places of the producer step: +3.5 % time at 1024, +0.8 % at 2048 - not the scanner kernel (whose 16 waves x 16 loads per step fill the queue)
+#endif
 #ifndef OTH_SEGWS_DEEP
 #define OTH_SEGWS_DEEP 0
 #endif
@@ -648,12 +651,25 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                 sum = cadd(sum, r);
             }
 #ifndef OTH_SEGWS_NOLOAD      // (timing experiment: -DOTH_SEGWS_NOLOAD keeps re-using the first loaded halves)
-            {
-                const float2 *xn = half(s + (OTH_SEGWS_DEEP ? 3 : 2));
+            const float2 *xn = half(s + (OTH_SEGWS_DEEP ? 3 : 2));
+            // the next half's eight loads, two at each of four places of the step instead of one burst (round 4: the
+            // scanner kernel's lesson - a burst fills the memory pipeline's queue and the issuing wave stands still)
+            auto spread = [&](int grp) {
+#if OTH_SEGWS_SPREAD
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int a = 0; a < 8; ++a) nxt[a] = load_once(xn + T * a);
-            }
+                for (int a = 2 * grp; a < 2 * grp + 2; ++a) nxt[a] = load_once(xn + T * a);
+                __builtin_amdgcn_sched_barrier(0);
 #else
+                if (grp == 0) {
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) nxt[a] = load_once(xn + T * a);
+                }
+#endif
+            };
+            spread(0);
+#else
+            auto spread = [&](int) {};
 #pragma unroll
             for (int a = 0; a < 8; ++a) asm volatile("" : "+v"(nxt[a].x), "+v"(nxt[a].y));
 #endif
@@ -677,9 +693,11 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                 if ((t & 63) == 63) red[q * 4 + (t >> 6)] = cadd(sum, other);
                 prev_new = sum;
             }
+            spread(1);
             prio_compute();
             dft16(v);
             prio_latency();
+            spread(2);
 #if OTH_SEGWS_STORED_TW1
             static_for<0, 16>([&](auto kc) {
                 constexpr int k0 = decltype(kc)::value;
@@ -692,6 +710,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                 lds_write_imm<8 * (512 * (k0 >> P) + R * (k0 & KP & ~KM))>((img + b_w1) ^ (8u * R * (k0 & KM)), val);
             });
 #endif
+            spread(3);
             if (t == 0) ctrl[q] = WS_DATA;
             lds_barrier();
             ++it;
