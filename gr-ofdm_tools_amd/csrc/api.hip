@@ -59,7 +59,9 @@ struct oth_plan {
     const float2 *d_tw = nullptr;
     float4 *d_fd = nullptr;            // window spectrum for the frequency-domain detrend (welch4096ws), or nullptr
     float4 *d_fd1x = nullptr;          // the same for welch16k1x_half_kernel (16384 points, spectrum confined to |k| < 16)
-    bool exact_detrend = false;        // OTH_DETREND_CONSTANT_EXACT: time-domain detrend only (d_fd stays nullptr)
+    float2 *d_pilot = nullptr;         // per-stream pilots of the frequency-domain detrend (WelchArgs.pilot)
+    size_t pilot_cap = 0;
+    bool fast_detrend = false;         // OTH_DETREND_CONSTANT_FAST: the builds without the pilot (WelchArgs.pilot)
     bool rect_window = false;          // every window value is 1 (window == NULL or boxcar): builds without the multiply
     float *d_partial = nullptr;
     size_t partial_cap = 0;
@@ -138,7 +140,7 @@ constexpr size_t kPinnedRingMax = 64u << 20;
 
 thread_local std::string g_err = "no error";
 
-// fewest segments per stream for which the frequency-domain detrend builds are chosen (run_average)
+// fewest segments per stream for which OTH_DETREND_CONSTANT_FAST picks the frequency-domain detrend builds (run_average)
 constexpr long long kFdMinSegments = 8;
 
 // A host buffer the runtime can DMA from directly (hipHostMalloc / hipHostRegister'd, e.g. a torch pinned tensor or a
@@ -550,14 +552,18 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
     const bool csd = (y != nullptr);
     // Which detrend form.  The role-split / half-keeping builds remove the segment mean AFTER the transform,
-    // FFT((x - m) w) = FFT(x w) - m FFT(w): the fp32 transform then carries the rounding of a DC line m sum(w) into bins
-    // 0, +-1 that the time-domain form never sees - per segment about 1e-7 * sqrt(nfft) * |m| / sigma relative to the
-    // detrended power (measured: tests/test_hip_parity.py::test_detrend_forms_few_segments_and_large_dc).
-    // Averaging takes it down by sqrt(nseg), so launches with fewer than kFdMinSegments segments per stream - which do
-    // not need those builds' throughput either - take the time-domain builds.  A variant forced through
-    // oth_plan_set_tuning (parity suite, A/B tools) is honoured; "td" forces the time-domain builds at any length.
+    // FFT((x - m) w) = FFT(x w) - m FFT(w).  OTH_DETREND_CONSTANT plans run the PILOT builds of whichever form
+    // (WelchArgs.pilot): they transform x - pilot, there is no DC line, and the form after the transform is then the most
+    // accurate one at any segment count - so it is chosen whenever the window's spectrum is confined.
+    // OTH_DETREND_CONSTANT_FAST plans work on the raw samples: the fp32 transform then carries the rounding of the DC
+    // line m sum(w) into every bin - per segment about 1e-7 sqrt(nfft) |m| / sigma of the detrended power (measured:
+    // tests/test_hip_parity.py::test_detrend_forms_few_segments_and_large_dc).  Averaging takes it down by
+    // sqrt(nseg), so their launches of fewer than kFdMinSegments segments per stream - which do not need those builds'
+    // throughput either - take the time-domain builds.  A variant forced through oth_plan_set_tuning (parity suite,
+    // A/B tools) is honoured; "td" forces the time-domain builds at any length.
     const bool fd_forced = !p->tune_variant.empty() && p->tune_variant != "td";
-    const float4 *fd_tab = (p->d_fd && p->tune_variant != "td" && (fd_forced || nseg >= kFdMinSegments)) ? p->d_fd : nullptr;
+    const float4 *fd_tab = (p->d_fd && p->tune_variant != "td" && (fd_forced || !p->fast_detrend || nseg >= kFdMinSegments))
+                               ? p->d_fd : nullptr;
     // welch4096 covers nperseg = 256, 512, ..., 4096 (zero-padded to 4096)
     bool tuned = p->nfft == 4096 && p->nperseg >= 256 && (p->nperseg & (p->nperseg - 1)) == 0 && !csd;
     const bool tuned_csd = csd && p->nfft == 4096 && p->nperseg == 4096 && p->kernel != OTH_KERNEL_GENERIC;
@@ -640,6 +646,14 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.nbig = 0;
     a.queue = nullptr;
     a.fd = tuned_16k1x_half ? fd1x : fd_tab;
+    // the pilot of every stream, then the PILOT build of whichever kernel runs (OTH_DETREND_CONSTANT_FAST: without)
+    a.pilot = nullptr;
+    if (p->detrend != OTH_DETREND_NONE && !p->fast_detrend) {
+        rc = ensure(c, &p->d_pilot, &p->pilot_cap, sizeof(float2) * 2 * (size_t)nstreams);
+        if (rc) return rc;
+        HIPCHK(c, launch_pilot_mean(x, csd ? y : nullptr, stride, p->nperseg, nstreams, p->d_pilot, c->stream));
+        a.pilot = p->d_pilot;
+    }
     if (tuned || tuned_csd || tuned_16k || tuned_seg) {
         a.sched = p->tune_sched >= 0 ? p->tune_sched : p->sched;
         // one 1024-thread workgroup per CU and equal work per segment: contiguous runs beat the ticket queue (+3 %)
@@ -725,6 +739,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         g.nbig = a.nbig;
         g.queue = a.queue;
         g.fd = fd_tab;
+        g.pilot = a.pilot;
         Timed tm(c);
         HIPCHK(c, seg_pad ? launch_seg_padded(p->nfft, p->nperseg, g, seg_kind, c->stream)
                           : (seg_ws ? launch_segws(p->nfft, g, seg_det, c->stream) : launch_seg(p->nfft, g, seg_kind, seg_wps4, c->stream)));
@@ -1030,10 +1045,11 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
         return fail(c, OTH_ERR_UNSUPPORTED, "nfft must be a power of two in [64, 16384]");
     if (nperseg < 1 || nperseg > nfft) return fail(c, OTH_ERR_INVALID, "need 1 <= nperseg <= nfft");
     if (noverlap < 0 || noverlap >= nperseg) return fail(c, OTH_ERR_INVALID, "need 0 <= noverlap < nperseg");
-    if (detrend != OTH_DETREND_NONE && detrend != OTH_DETREND_CONSTANT && detrend != OTH_DETREND_CONSTANT_EXACT)
+    if (detrend != OTH_DETREND_NONE && detrend != OTH_DETREND_CONSTANT && detrend != OTH_DETREND_CONSTANT_EXACT &&
+        detrend != OTH_DETREND_CONSTANT_FAST)
         return fail(c, OTH_ERR_INVALID, "unknown detrend");
-    const bool exact_detrend = detrend == OTH_DETREND_CONSTANT_EXACT;
-    if (exact_detrend) detrend = OTH_DETREND_CONSTANT;      // the kernels know two forms of one operation
+    const bool fast_detrend = detrend == OTH_DETREND_CONSTANT_FAST;
+    if (detrend != OTH_DETREND_NONE) detrend = OTH_DETREND_CONSTANT;      // one operation: forms and builds are run_average's choice
     if (scaling < OTH_SCALE_RAW || scaling > OTH_SCALE_SPECTRUM) return fail(c, OTH_ERR_INVALID, "unknown scaling");
     if (trim_bins < 0 || 2 * trim_bins >= nfft) return fail(c, OTH_ERR_INVALID, "trim_bins out of range");
     if (!(fs > 0.0)) return fail(c, OTH_ERR_INVALID, "fs must be positive");
@@ -1046,7 +1062,7 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     p->noverlap = noverlap;
     p->step = nperseg - noverlap;
     p->detrend = detrend;
-    p->exact_detrend = exact_detrend;
+    p->fast_detrend = fast_detrend;
     p->scaling = scaling;
     p->fs = fs;
     p->fftshift = fftshift != 0;
@@ -1080,7 +1096,7 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_win, w.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_sum, 0, sizeof(float) * nfft, c->stream);
     std::vector<float> fd;
-    if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT && !exact_detrend &&
+    if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT &&
         ((nfft == 4096 && nperseg == 4096 && window_spectrum_table(w, fd)) ||
          (nfft == 2048 && nperseg == 2048 && window_spectrum_table_seg(w, nfft, fd)) ||
          ((nfft == 8192 || nfft == 16384) && nperseg == nfft && window_spectrum_table_16k(w, nfft, fd)))) {
@@ -1089,7 +1105,7 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
             e = hipMemcpyAsync(p->d_fd, fd.data(), sizeof(float) * fd.size(), hipMemcpyHostToDevice, c->stream);
     }
     std::vector<float> fd1x;
-    if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT && !exact_detrend && nfft == 16384 && nperseg == 16384 &&
+    if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT && nfft == 16384 && nperseg == 16384 &&
         window_spectrum_table_16k1x(w, fd1x)) {
         e = hipMalloc(&p->d_fd1x, sizeof(float) * fd1x.size());
         if (e == hipSuccess)
@@ -1115,6 +1131,7 @@ int oth_plan_destroy(oth_plan *p) {
     if (p->d_win) hipFree(p->d_win);
     if (p->d_fd) hipFree(p->d_fd);
     if (p->d_fd1x) hipFree(p->d_fd1x);
+    if (p->d_pilot) hipFree(p->d_pilot);
     if (p->d_partial) hipFree(p->d_partial);
     if (p->d_reduce) hipFree(p->d_reduce);
     if (p->d_out) hipFree(p->d_out);

@@ -18,8 +18,9 @@ namespace {
 constexpr int LDS_WIN = 4096;   // floats
 constexpr size_t CSD_LDS_BYTES = LDS_BYTES + LDS_WIN * sizeof(float);
 
-template <bool DETREND>
+template <bool DETREND, bool PILOT = false>
 __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
+    static_assert(DETREND || !PILOT, "the pilot belongs to the detrend");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lx = reinterpret_cast<float2 *>(smem);
     float2 *red = lx + LDS_X;
@@ -42,12 +43,15 @@ __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
     for (int k = 0; k < 16; ++k) axx[k] = ayy[k] = are[k] = aim[k] = 0.f;
 
     const int w1 = hi * 17 + lo, r1 = hi * RS + lo, w2 = hi * RS + lo, r2 = hi * RS + lo * 17;
+    // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot of either channel comes off every sample as it arrives
+    const float2 px = load_pilot(PILOT ? p.pilot : nullptr, stream);
+    const float2 py = load_pilot(PILOT ? p.pilot : nullptr, p.nstreams + stream);
 
     // One 4096-point transform of the segment at xs; result bins k0 + 16 k1 + 256 k2 in v[r16(k2)].
-    auto transform = [&](const float2 *xs, float2(&v)[16]) {
+    auto transform = [&](const float2 *xs, float2 pv, float2(&v)[16]) {      // pv: WelchArgs.pilot of the channel
         prio_latency();
 #pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = xs[256 * a];
+        for (int a = 0; a < 16; ++a) v[a] = PILOT ? csub(xs[256 * a], pv) : xs[256 * a];
         float2 mean = make_float2(0.f, 0.f);
         if (DETREND) {
             // pairwise, like NumPy's float32 mean (section 2 of DESIGN.md: with a DC line far above the signal the order
@@ -94,12 +98,12 @@ __global__ __launch_bounds__(T4, 3) void csd4096_kernel(WelchArgs p) {
         if (sched) chunk_range(p, cur, sb, se);
         for (long long s = sb; s < se; ++s) {
             float2 X[16], v[16];
-            transform(xb + s * p.step + t, X);
+            transform(xb + s * p.step + t, px, X);
             if (sched == 2 && t == 0) {   // after barrier B of the x transform, before barrier A of the y one
                 if (s == sb) ticket = atomicAdd(p.queue + stream, 1u);
                 if (s == se - 1) *lnext = (int)ticket;
             }
-            transform(yb + s * p.step + t, v);
+            transform(yb + s * p.step + t, py, v);
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 const float2 x = X[r16(k2)], y = v[r16(k2)];
@@ -137,7 +141,9 @@ int csd4096_blocks_per_cu() {
 
 hipError_t launch_csd_tuned4096(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
-    if (a.detrend)
+    if (a.detrend && a.pilot)
+        hipLaunchKernelGGL((csd4096_kernel<true, true>), grid, dim3(T4), CSD_LDS_BYTES, s, a);
+    else if (a.detrend)
         hipLaunchKernelGGL((csd4096_kernel<true>), grid, dim3(T4), CSD_LDS_BYTES, s, a);
     else
         hipLaunchKernelGGL((csd4096_kernel<false>), grid, dim3(T4), CSD_LDS_BYTES, s, a);

@@ -80,8 +80,9 @@ enum { CS_STOP = 0, CS_DATA = 1, CS_BUBBLE = 2 };
 #define CS_STAMP(i)
 #endif
 
-template <bool DETREND>
+template <bool DETREND, bool PILOT = false>
 __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
+    static_assert(DETREND || !PILOT, "the pilot belongs to the detrend");
 #if OTH_CSDWS_DIAG
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
@@ -115,6 +116,8 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
         const float2 b1 = p.tw[t], b4 = p.tw[4 * t];
         float2 kw[8], nxt[8];
         float2 prev_new = make_float2(0.f, 0.f);
+        // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot of this team's channel comes off every sample as it arrives
+        const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, pair * p.nstreams + stream);
         int it = 0;
         unsigned ticket = 0;
         using std::false_type;
@@ -161,13 +164,14 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
             if (FIRST) {
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
+                    if (PILOT) kw[a] = csub(kw[a], pv);
                     sumf = cadd(sumf, kw[a]);
                     kw[a] = make_float2(kw[a].x * win[a], kw[a].y * win[a]);
                 }
             }
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
-                const float2 r = nxt[a];
+                const float2 r = PILOT ? csub(nxt[a], pv) : nxt[a];
                 v[a] = kw[a];
                 v[8 + a] = make_float2(r.x * win[8 + a], r.y * win[8 + a]);
                 if (MODE == 0) kw[a] = make_float2(r.x * win[a], r.y * win[a]);
@@ -455,7 +459,7 @@ int csd4096ws_blocks_per_cu() {
     static int cached = 0;
     if (cached) return cached;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, csd4096ws_kernel<true>, TCS, CS_LDS_BYTES) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, csd4096ws_kernel<true, false>, TCS, CS_LDS_BYTES) != hipSuccess || n < 1)
         n = 1;
     return cached = n;
 }
@@ -467,18 +471,20 @@ hipError_t launch_csd_tuned4096ws(const WelchArgs &a, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63, armed[63] = false;
     bool &big_lds = armed[dev];
     if (!big_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(csd4096ws_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(csd4096ws_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_LDS_BYTES);
+        hipError_t e = hipSuccess;
+        for (const void *fn : {reinterpret_cast<const void *>(csd4096ws_kernel<true, true>),
+                               reinterpret_cast<const void *>(csd4096ws_kernel<true, false>),
+                               reinterpret_cast<const void *>(csd4096ws_kernel<false, false>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_LDS_BYTES);
         if (e != hipSuccess) return e;
         big_lds = true;
     }
-    if (a.detrend)
-        hipLaunchKernelGGL((csd4096ws_kernel<true>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
+    if (a.detrend && a.pilot)
+        hipLaunchKernelGGL((csd4096ws_kernel<true, true>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
+    else if (a.detrend)
+        hipLaunchKernelGGL((csd4096ws_kernel<true, false>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
     else
-        hipLaunchKernelGGL((csd4096ws_kernel<false>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
+        hipLaunchKernelGGL((csd4096ws_kernel<false, false>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
     return hipGetLastError();
 }
 

@@ -20,6 +20,14 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// WelchArgs.pilot / SegArgs.pilot of one stream as a wave-uniform value (two scalar registers; zero without a table)
+__device__ __forceinline__ float2 load_pilot(const float2 *pilot, int idx) {
+    float2 pv = make_float2(0.f, 0.f);
+    if (pilot) pv = pilot[idx];
+    pv.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pv.x)));
+    pv.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pv.y)));
+    return pv;
+}
 // multiply by -i (forward) / +i (inverse)
 template <bool INV> __device__ __forceinline__ float2 rot90(float2 a) {
     return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);

@@ -36,14 +36,14 @@ template <int T> __device__ __forceinline__ float2 block_sum(float2 v, float2 *r
 // apply the window and leave it in buf.  Ends with a barrier.
 template <int N, int T>
 __device__ __forceinline__ void stage_segment(const float2 *__restrict__ xs, const float *__restrict__ win,
-                                              int nperseg, int detrend, float2 *buf, float2 *red, int tid) {
+                                              int nperseg, int detrend, float2 pilot, float2 *buf, float2 *red, int tid) {
     constexpr int NQ = N / T;
     float2 v[NQ];
     float2 sum = make_float2(0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int n = tid + q * T;
-        v[q] = (n < nperseg) ? xs[n] : make_float2(0.f, 0.f);
+        v[q] = (n < nperseg) ? csub(xs[n], pilot) : make_float2(0.f, 0.f);      // pilot: WelchArgs.pilot, or zero (x - 0 is exact)
         sum = cadd(sum, v[q]);
     }
     float2 mean = make_float2(0.f, 0.f);
@@ -84,8 +84,10 @@ __global__ __launch_bounds__(T) void welch_generic_kernel(WelchArgs p) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[c][q] = 0.f;
 
+    const float2 px = load_pilot(p.detrend ? p.pilot : nullptr, stream);
+    const float2 py = load_pilot(CSD && p.detrend ? p.pilot : nullptr, p.nstreams + stream);
     for (long long s = s0; s < s1; ++s) {
-        stage_segment<N, T>(xb + s * p.step, p.win, p.nperseg, p.detrend, buf, red, tid);
+        stage_segment<N, T>(xb + s * p.step, p.win, p.nperseg, p.detrend, px, buf, red, tid);
         fft_lds<N, T>(buf, p.tw, tid);
         if constexpr (!CSD) {
 #pragma unroll
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(T) void welch_generic_kernel(WelchArgs p) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) X[q] = buf[tid + q * T];
             __syncthreads();
-            stage_segment<N, T>(yb + s * p.step, p.win, p.nperseg, p.detrend, buf, red, tid);
+            stage_segment<N, T>(yb + s * p.step, p.win, p.nperseg, p.detrend, py, buf, red, tid);
             fft_lds<N, T>(buf, p.tw, tid);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -128,7 +130,7 @@ template <int N, int T> __global__ __launch_bounds__(T) void pgram_kernel(PgramA
     const int tid = threadIdx.x;
     for (long long r = blockIdx.x; r < p.nrows; r += gridDim.x) {
         const float2 *xs = p.x + (size_t)(p.first_vec + r * p.keep_n) * N;
-        stage_segment<N, T>(xs, p.win, N, 0, buf, red, tid);
+        stage_segment<N, T>(xs, p.win, N, 0, make_float2(0.f, 0.f), buf, red, tid);
         fft_lds<N, T>(buf, p.tw, tid);
         float *row = p.rows + (size_t)r * N;
 #pragma unroll

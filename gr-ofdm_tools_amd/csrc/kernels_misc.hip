@@ -788,6 +788,42 @@ __global__ void iq_power_kernel(const float2 *iq, size_t n, double *acc4) {
     }
 }
 
+// Pilot of the constant detrend (WelchArgs.pilot): the mean of a stream's first n samples, one block per stream
+// (and per channel of a pair), double accumulation; ~2 us.  Its value only has to be NEAR the stream's mean.
+__global__ __launch_bounds__(256) void pilot_mean_kernel(const float2 *x, const float2 *y, size_t stream_stride, int n,
+                                                         int nstreams, float2 *out) {
+    __shared__ double red[2][4];
+    const int stream = blockIdx.x % nstreams, ch = blockIdx.x / nstreams;
+    const float2 *src = (ch ? y : x) + (size_t)stream * stream_stride;
+    double sr = 0.0, si = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float2 v = src[i];
+        sr += v.x;
+        si += v.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_xor(sr, off, 64);
+        si += __shfl_xor(si, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sr;
+        red[1][threadIdx.x >> 6] = si;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double inv = 1.0 / n;
+        out[blockIdx.x] = make_float2((float)((red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv),
+                                      (float)((red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv));
+    }
+}
+
+hipError_t launch_pilot_mean(const float2 *x, const float2 *y, size_t stream_stride, int n, int nstreams, float2 *out,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(pilot_mean_kernel, dim3(nstreams * (y ? 2 : 1)), dim3(256), 0, s, x, y, stream_stride, n, nstreams, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_iq_power(const float2 *iq, size_t n, double *acc4, hipStream_t s) {
     hipLaunchKernelGGL(iq_power_kernel, dim3(2048), dim3(256), 0, s, iq, n, acc4);
     return hipGetLastError();

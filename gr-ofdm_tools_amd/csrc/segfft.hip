@@ -161,8 +161,9 @@ template <int T> __device__ __forceinline__ float team_total(float v) {
 // zero padding of scipy.signal.welch(nperseg < nfft) - the sweeper's call is nperseg = nfft / 4 for whatever fft_len
 // the flowgraph passes (spectrum_sweeper.py:263): NA = 4.  Rows a >= NA are compile-time zeros, so loads, window
 // products and the first butterfly layer of pass 1 shrink with NA; LOAD_HALF keeps NA / 2 rows (step = nperseg / 2).
-template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS, int NA = 16>
+template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS, int NA = 16, bool PILOT = false>
 __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
+    static_assert(DETREND || !PILOT, "the pilot belongs to the detrend");
     static_assert(NA == 16 || (!CHAIN && R >= 4 && (NA == 4 || NA == 8)), "zero-padded builds: Welch at 1024 / 2048 points");
     constexpr int NHALF = NA / 2;
     using G = Geo<R>;
@@ -246,6 +247,8 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
     constexpr int NH = (LOAD == LOAD_HALF) ? NHALF : NA;
     float2 kw[LOAD == LOAD_HALF ? NHALF : 1], nxt[NH];
     float2 prev_tot = make_float2(0.f, 0.f);
+    // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): SegArgs.pilot comes off every sample as it arrives
+    const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, stream);
 
     const int sched = p.sched;
     const long long nchunks = sched ? chunk_count_of(p.nseg, p.nbig, p.chunk, p.tail_chunk) : 1;
@@ -295,13 +298,14 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                 if (s == sb) {
 #pragma unroll
                     for (int a = 0; a < NHALF; ++a) {      // kw holds the raw first half of the chunk's first segment
+                        if (PILOT) kw[a] = csub(kw[a], pv);
                         sumf = cadd(sumf, kw[a]);
                         kw[a] = make_float2(kw[a].x * win[a], kw[a].y * win[a]);
                     }
                 }
 #pragma unroll
                 for (int a = 0; a < NHALF; ++a) {
-                    const float2 r = nxt[a];
+                    const float2 r = PILOT ? csub(nxt[a], pv) : nxt[a];
                     v[a] = kw[a];
                     v[NHALF + a] = make_float2(r.x * win[NHALF + a], r.y * win[NHALF + a]);
                     kw[a] = make_float2(r.x * win[a], r.y * win[a]);
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
             } else {
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
-                    const float2 r = nxt[a];
+                    const float2 r = PILOT ? csub(nxt[a], pv) : nxt[a];
                     v[a] = make_float2(r.x * win[a], r.y * win[a]);
                     sum = cadd(sum, r);
                 }
@@ -581,8 +585,9 @@ enum { WS_STOP = 0, WS_DATA = 1 };
 #define OTH_SEGWS_STORED_TW1 (!OTH_SEGWS_DEEP)
 #endif
 
-template <int R, int DET>
+template <int R, int DET, bool PILOT = false>
 __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
+    static_assert(DET != 0 || !PILOT, "the pilot belongs to the detrend");
     using G = Geo<R>;
     constexpr int T = G::T, N = G::N, Q = G::Q, LR = G::LR, P = G::P, KP = G::KP, KM = G::KM, WV = G::WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -622,6 +627,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
         float2 nB[8];
 #endif
         float2 prev_new = make_float2(0.f, 0.f);
+        const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, stream);      // PILOT: off every sample as it arrives
         const int sched = p.sched;
         const long long nchunks = sched ? chunk_count_of(p.nseg, p.nbig, p.chunk, p.tail_chunk) : 1;
         const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
@@ -638,13 +644,14 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
             if (s == sb) {
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
+                    if (PILOT) kw[a] = csub(kw[a], pv);
                     sumf = cadd(sumf, kw[a]);
                     kw[a] = make_float2(kw[a].x * win[a], kw[a].y * win[a]);
                 }
             }
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
-                const float2 r = nxt[a];
+                const float2 r = PILOT ? csub(nxt[a], pv) : nxt[a];
                 v[a] = kw[a];
                 v[8 + a] = make_float2(r.x * win[8 + a], r.y * win[8 + a]);
                 kw[a] = make_float2(r.x * win[a], r.y * win[a]);
@@ -862,6 +869,12 @@ template <int R> constexpr size_t segws_lds_bytes() { return 256 + 2 * (size_t)G
 
 template <int R, int DET> hipError_t launch_ws_one(const SegArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
+    if constexpr (DET != 0) {
+        if (a.pilot) {
+            hipLaunchKernelGGL((segws_kernel<R, DET, true>), grid, dim3(2 * Geo<R>::T), segws_lds_bytes<R>(), s, a);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((segws_kernel<R, DET>), grid, dim3(2 * Geo<R>::T), segws_lds_bytes<R>(), s, a);
     return hipGetLastError();
 }
@@ -881,6 +894,12 @@ template <int R, bool CHAIN> constexpr size_t seg_lds_bytes() {
 template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS, int NA = 16> hipError_t launch_one(const SegArgs &a, hipStream_t s) {
     const dim3 grid((a.wg_per_stream + Geo<R>::TPB - 1) / Geo<R>::TPB, a.nstreams);
     constexpr size_t lds = seg_lds_bytes<R, CHAIN>();
+    if constexpr (DETREND) {
+        if (a.pilot) {
+            hipLaunchKernelGGL((seg_kernel<R, LOAD, DETREND, CHAIN, WPS, NA, true>), grid, dim3(Geo<R>::BLOCK), lds, s, a);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((seg_kernel<R, LOAD, DETREND, CHAIN, WPS, NA>), grid, dim3(Geo<R>::BLOCK), lds, s, a);
     return hipGetLastError();
 }

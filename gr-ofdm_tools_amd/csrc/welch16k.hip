@@ -111,7 +111,7 @@ __device__ __forceinline__ void transform16k(float2 (&v)[16], const float2 (&wt)
 // PAD: nperseg = N / 4 zero-padded to N (the sweeper's call at these sizes, spectrum_sweeper.py:263): samples only at
 // a' = 0, j < 4 - four loads per thread, the rest compile-time zeros (the window array is zero-extended, so the
 // detrended, windowed padding is exactly 0 as well); the mean is over nperseg.  Whole-segment loads, any step.
-template <int DET, int F, bool HALF, bool PAD = false>
+template <int DET, int F, bool HALF, bool PAD = false, bool PILOT = false>
 __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
     static_assert(!PAD || (!HALF && DET != 2), "zero-padded build: whole-segment loads, time-domain detrend");
     constexpr bool DETREND = DET != 0;
@@ -154,6 +154,9 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
     unsigned ticket = 0;
     float2 keep[HALF ? 8 : 1];
     float2 prev_tot = make_float2(0.f, 0.f);
+    static_assert(DET != 0 || !PILOT, "the pilot belongs to the detrend");
+    // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot comes off every sample as it arrives
+    const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, stream);
     for (long long cur = sched ? wg : 0; cur < nchunks;) {
         long long sb = s0, se = s1;
         if (sched) chunk_range(p, cur, sb, se);
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
 #pragma unroll
                         for (int a = 0; a < H; ++a) {
                             keep[H * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
+                            if (PILOT) keep[H * j + a] = csub(keep[H * j + a], pv);
                             sumf = cadd(sumf, keep[H * j + a]);
                         }
                 }
@@ -177,7 +181,8 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int a = 0; a < H; ++a) {
-                        const float2 r = OTH_16K_LOAD(xs + 4096 * (H + a) + T16 * j);
+                        float2 r = OTH_16K_LOAD(xs + 4096 * (H + a) + T16 * j);
+                        if (PILOT) r = csub(r, pv);
                         v[F * j + a] = keep[H * j + a];
                         v[F * j + H + a] = r;
                         keep[H * j + a] = r;
@@ -189,7 +194,10 @@ __global__ __launch_bounds__(256 * F) void welch16k_kernel(WelchArgs p) {
 #pragma unroll
                     for (int a = 0; a < F; ++a) {
                         if (PAD && (a != 0 || j >= 4)) v[F * j + a] = make_float2(0.f, 0.f);
-                        else v[F * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
+                        else {
+                            v[F * j + a] = OTH_16K_LOAD(xs + 4096 * a + T16 * j);
+                            if (PILOT) v[F * j + a] = csub(v[F * j + a], pv);      // (the padding zeros stay zeros)
+                        }
                     }
                 if (DETREND) {
                     // pairwise, like NumPy's float32 mean: with a DC line far above the signal the ORDER of the adds is
@@ -467,14 +475,19 @@ hipError_t launch_chain16k(int nfft, const SegArgs &a, bool rect, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
-template <int DET, int F, bool HALF, bool PAD = false> hipError_t launch16k(const WelchArgs &a, hipStream_t s) {
+template <int DET, int F, bool HALF, bool PAD, bool PILOT> hipError_t launch16k_p(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
     constexpr size_t lds = lds16_bytes<F>();
-    const void *fn = reinterpret_cast<const void *>(welch16k_kernel<DET, F, HALF, PAD>);
+    const void *fn = reinterpret_cast<const void *>(welch16k_kernel<DET, F, HALF, PAD, PILOT>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((welch16k_kernel<DET, F, HALF, PAD>), grid, dim3(256 * F), lds, s, a);
+    hipLaunchKernelGGL((welch16k_kernel<DET, F, HALF, PAD, PILOT>), grid, dim3(256 * F), lds, s, a);
     return hipGetLastError();
+}
+template <int DET, int F, bool HALF, bool PAD = false> hipError_t launch16k(const WelchArgs &a, hipStream_t s) {
+    if constexpr (DET != 0)
+        if (a.pilot) return launch16k_p<DET, F, HALF, PAD, true>(a, s);
+    return launch16k_p<DET, F, HALF, PAD, false>(a, s);
 }
 
 template <int F> hipError_t launch16k_f(const WelchArgs &a, hipStream_t s) {

@@ -676,8 +676,9 @@ template <bool WINDOW> static hipError_t launch1x_pipe(const WelchArgs &a, hipSt
 constexpr int XH_RED = 48;      // 16 wave sums x 2 parities, tickets [32..33], segment totals [40..41]
 constexpr size_t x1h_lds_bytes() { return (16 * XREG + XH_RED + 16 * 64 + 16 * 4) * sizeof(float2) + 4 * sizeof(float4); }
 
-template <int DET>
+template <int DET, bool PILOT = false>
 __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
+    static_assert(DET == 2 || !PILOT, "the pilot belongs to the detrend");
     constexpr int N = 16384;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
@@ -722,6 +723,8 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
     const long long nchunks = sched ? chunk_count(p) : 1;
     int cpar = 0;
     float2 keep[8];
+    // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot comes off every sample as it arrives
+    const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, blockIdx.y);
     for (long long cur = sched ? wg : 0; cur < nchunks;) {
         long long sb = s0, se = s1;
         if (sched) chunk_range(p, cur, sb, se);
@@ -734,12 +737,14 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     keep[r] = load_once(xs + 1024 * r);
+                    if (PILOT) keep[r] = csub(keep[r], pv);
                     sumf = cadd(sumf, keep[r]);
                 }
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const float2 nw = load_once(xs + 1024 * (8 + r));
+                float2 nw = load_once(xs + 1024 * (8 + r));
+                if (PILOT) nw = csub(nw, pv);
                 v[r] = keep[r];
                 v[8 + r] = nw;
                 keep[r] = nw;
@@ -807,19 +812,20 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
     for (int k2 = 0; k2 < 16; ++k2) dst[1024 * k2] = acc[k2];
 }
 
-template <int DET> static hipError_t launch1x_half(const WelchArgs &a, hipStream_t s) {
+template <int DET, bool PILOT = false> static hipError_t launch1x_half(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
     constexpr size_t lds = x1h_lds_bytes();
-    const void *fn = reinterpret_cast<const void *>(welch16k1x_half_kernel<DET>);
+    const void *fn = reinterpret_cast<const void *>(welch16k1x_half_kernel<DET, PILOT>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((welch16k1x_half_kernel<DET>), grid, dim3(1024), lds, s, a);
+    hipLaunchKernelGGL((welch16k1x_half_kernel<DET, PILOT>), grid, dim3(1024), lds, s, a);
     return hipGetLastError();
 }
 
 // step = N / 2; detrend none, or constant through the frequency-domain form (a.fd = the table described above)
 hipError_t launch_welch_tuned16k1x_half(const WelchArgs &a, hipStream_t s) {
-    return (a.detrend && a.fd) ? launch1x_half<2>(a, s) : launch1x_half<0>(a, s);
+    if (a.detrend && a.fd) return a.pilot ? launch1x_half<2, true>(a, s) : launch1x_half<2>(a, s);
+    return launch1x_half<0>(a, s);
 }
 
 template <bool WINDOW> static hipError_t launch1x(const WelchArgs &a, hipStream_t s) {

@@ -74,8 +74,9 @@ namespace {
 
 // NA = nperseg / 256: rows a < NA of a segment hold samples, the rest is the zero padding up to 4096
 // (NA = 16: nperseg = nfft; NA = 4: the sweeper's nperseg = nfft / 4, spectrum_sweeper.py:263).
-template <bool DETREND, int NA>
+template <bool DETREND, int NA, bool PILOT = false>
 __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(WelchArgs p) {
+    static_assert(DETREND || !PILOT, "the pilot belongs to the detrend");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lx = reinterpret_cast<float2 *>(smem);
     float2 *red = lx + LDS_X;
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
     float acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot comes off every sample as it arrives
+    const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, stream);
 
     // LDS addresses (in float2): exchange-1 write/read, exchange-2 write/read
     const int w1 = hi * 17 + lo;            // + k0 * RS      (thread is (b,c))
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
       {   // chunk prologue: both halves of its first segment (half-block h = samples [2048 h, 2048 h + 2048))
           const float2 *xs = xb + sb * 2048 + t;
 #pragma unroll
-          for (int a = 0; a < 8; ++a) keep[a] = xs[256 * a];
+          for (int a = 0; a < 8; ++a) keep[a] = PILOT ? csub(xs[256 * a], pv) : xs[256 * a];
 #pragma unroll
           for (int a = 0; a < 8; ++a) nxt[a] = xs[2048 + 256 * a];
       }
@@ -149,8 +152,8 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             v[a] = keep[a];
-            v[8 + a] = nxt[a];
-            keep[a] = nxt[a];
+            v[8 + a] = PILOT ? csub(nxt[a], pv) : nxt[a];
+            keep[a] = v[8 + a];
         }
         if (s + 1 < se) {   // the half the NEXT segment adds; lands while this segment is transformed
             const float2 *xn = xb + (s + 2) * 2048 + t;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 #else
         const float2 *xs = xb + s * p.step + t;
 #pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = (a < NA) ? xs[256 * a] : make_float2(0.f, 0.f);
+        for (int a = 0; a < 16; ++a) v[a] = (a < NA) ? (PILOT ? csub(xs[256 * a], pv) : xs[256 * a]) : make_float2(0.f, 0.f);
 #endif
 
         float2 mean = make_float2(0.f, 0.f);
@@ -305,7 +308,9 @@ hipError_t OTH_CAT(launch_welch_tuned4096_, OTH_W4096_TAG)(const WelchArgs &a, h
     const dim3 grid(a.wg_per_stream, a.nstreams);
 #define OTH_W4096_LAUNCH(NA)                                                                         \
     case 256 * NA:                                                                                   \
-        if (a.detrend)                                                                               \
+        if (a.detrend && a.pilot)                                                                    \
+            hipLaunchKernelGGL((welch4096_kernel<true, NA, true>), grid, dim3(T4), LDS_BYTES, s, a); \
+        else if (a.detrend)                                                                          \
             hipLaunchKernelGGL((welch4096_kernel<true, NA>), grid, dim3(T4), LDS_BYTES, s, a);      \
         else                                                                                         \
             hipLaunchKernelGGL((welch4096_kernel<false, NA>), grid, dim3(T4), LDS_BYTES, s, a);     \

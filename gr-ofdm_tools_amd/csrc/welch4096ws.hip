@@ -95,8 +95,9 @@ constexpr size_t WS_LDS_BYTES = (2 * LDS_X + WS_RED) * sizeof(float2) + WS_CTRL 
 
 enum { ITEM_STOP = 0, ITEM_DATA = 1, ITEM_BUBBLE = 2 };
 
-template <bool DETREND>
+template <bool DETREND, bool PILOT = false>
 __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
+    static_assert(DETREND || !PILOT, "the pilot belongs to the detrend");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *img = reinterpret_cast<float2 *>(smem);             // two images of LDS_X float2
     float2 *red = img + 2 * LDS_X;                              // [2][8]
@@ -140,6 +141,9 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
 #endif
         float2 kw[8], nxt[8];
         float2 prev_new = make_float2(0.f, 0.f);     // this wave's sum of the previous segment's new half
+        // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot comes off every sample as it arrives, so the transform and
+        // the sums see x - pilot (two scalar registers, two subtractions per sample: +1 % on the launch)
+        const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, stream);
         int it = 0;
         unsigned ticket = 0;
         using std::false_type;
@@ -197,13 +201,14 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             if (FIRST) {
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {      // kw still holds the raw first half of the chunk's first segment
+                    if (PILOT) kw[a] = csub(kw[a], pv);
                     sumf = cadd(sumf, kw[a]);
                     kw[a] = make_float2(kw[a].x * win[a], kw[a].y * win[a]);
                 }
             }
 #pragma unroll
             for (int a = 0; a < 8; ++a) {      // the new half is windowed for both of its roles as it arrives
-                const float2 r = nxt[a];
+                const float2 r = PILOT ? csub(nxt[a], pv) : nxt[a];
                 v[a] = kw[a];
                 v[8 + a] = make_float2(r.x * wh[a], r.y * wh[a]);
                 if (MODE == 0) kw[a] = make_float2(r.x * win[a], r.y * win[a]);      // (else kw is reloaded below)
@@ -404,7 +409,7 @@ int OTH_CAT(tuned4096_blocks_per_cu_, OTH_WS_TAG)() {
     static int cached = 0;
     if (cached) return cached;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, welch4096ws_kernel<true>, TWS, WS_LDS_BYTES) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, welch4096ws_kernel<true, false>, TWS, WS_LDS_BYTES) != hipSuccess || n < 1)
         n = 1;
     return cached = n;
 }
@@ -416,18 +421,20 @@ hipError_t OTH_CAT(launch_welch_tuned4096_, OTH_WS_TAG)(const WelchArgs &a, hipS
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63, armed[63] = false;
     bool &big_lds = armed[dev];
     if (!big_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(welch4096ws_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(welch4096ws_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
+        hipError_t e = hipSuccess;
+        for (const void *fn : {reinterpret_cast<const void *>(welch4096ws_kernel<true, true>),
+                               reinterpret_cast<const void *>(welch4096ws_kernel<true, false>),
+                               reinterpret_cast<const void *>(welch4096ws_kernel<false, false>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
         if (e != hipSuccess) return e;
         big_lds = true;
     }
-    if (a.detrend)
-        hipLaunchKernelGGL((welch4096ws_kernel<true>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
+    if (a.detrend && a.pilot)
+        hipLaunchKernelGGL((welch4096ws_kernel<true, true>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
+    else if (a.detrend)
+        hipLaunchKernelGGL((welch4096ws_kernel<true, false>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
     else
-        hipLaunchKernelGGL((welch4096ws_kernel<false>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
+        hipLaunchKernelGGL((welch4096ws_kernel<false, false>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
     return hipGetLastError();
 }
 

@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 OK = 0
-DETREND_NONE, DETREND_CONSTANT, DETREND_CONSTANT_EXACT = 0, 1, 2
+DETREND_NONE, DETREND_CONSTANT, DETREND_CONSTANT_EXACT, DETREND_CONSTANT_FAST = 0, 1, 2, 3
 SCALE_RAW, SCALE_DENSITY, SCALE_OVER_N2, SCALE_SPECTRUM = 0, 1, 2, 3
 EPI_MAG, EPI_MAG2, EPI_MAG2_OVER_N2 = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TUNED = 0, 1, 2

@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 #define OTH_ABI_VERSION 4      /* 3 = 2 + oth_chain_ticket_rows, oth_scan_decide_dev_out; 4 = 3 + OTH_ERR_INTERNAL,
-                                  OTH_DETREND_CONSTANT_EXACT (additions only) */
+                                  OTH_DETREND_CONSTANT_EXACT, OTH_DETREND_CONSTANT_FAST (additions only) */
 
 #define OTH_OK               0
 #define OTH_ERR_INVALID     -1   /* bad argument */
@@ -57,16 +57,27 @@ extern "C" {
 
 /* detrend (scipy.signal.welch detrend=...) */
 #define OTH_DETREND_NONE     0
-#define OTH_DETREND_CONSTANT 1   /* per-segment mean removal, SciPy default.  The library picks the form: in the time
-                                   domain, (x - m) w, or - on the fastest 2048 / 4096 / 8192 / 16384-point builds at
-                                   50 % overlap, for launches of 8 or more segments per stream - after the transform,
-                                   FFT(x w) - m FFT(w).  The second form leaves, in bins 0 and +-1 only, a relative error
-                                   of about 1e-7 sqrt(nfft / nseg) |m| / sigma of the detrended power (m = segment mean,
-                                   sigma = rms of the rest; measured on MI355X at 2047 segments of 4096 points: 2e-6 at
-                                   |m| = 30 sigma, 6e-5 at 300 sigma, 6e-4 at 3000 sigma - DESIGN.md section 2): inside
-                                   the 1e-4 parity gate up to a DC line ~50 dB above the signal's total power. */
-#define OTH_DETREND_CONSTANT_EXACT 2 /* the same operation, always in the time domain: no DC-dependent error at any
-                                   offset (the transform never sees the DC line); 7-25 % slower on those builds */
+#define OTH_DETREND_CONSTANT 1   /* per-segment mean removal, SciPy default - computed on x - pilot: before anything else
+                                   every kernel takes a pilot value per stream (the mean of the stream's first nperseg
+                                   samples, one 2 us launch) off each sample as it is loaded, so no float32 arithmetic
+                                   ever handles the DC line - neither the transform (the fastest 2048 / 4096 / 8192 /
+                                   16384-point builds at 50 % overlap remove the mean after it, FFT(x w) - m FFT(w)) nor
+                                   the segment mean, which becomes a small residual.  Mathematically the same result;
+                                   measured against float64: every bin inside 1e-4 at 1 ... 9
+                                   segments and |m| = 35 sigma, every bin at 2e-7 with 2047 segments and a DC line of
+                                   3000 sigma (70 dB above the signal), bins 0, +-1 at 1e-6 where SciPy on complex64
+                                   input reads 1e-4 ... 5e-3. */
+#define OTH_DETREND_CONSTANT_EXACT 2 /* = OTH_DETREND_CONSTANT (the name under which the offset-proof detrend was first
+                                   asked for; accepted, same builds) */
+#define OTH_DETREND_CONSTANT_FAST 3 /* the same operation on the raw samples, -1 ... +2 % of the launch (no pilot launch, no
+                                   subtractions).  Launches of fewer than 8 segments per stream detrend before the
+                                   window; the fast builds above detrend after the transform, which then carries the
+                                   rounding of the DC line m sum(w): about 1e-7 sqrt(nfft / nseg) |m| / sigma of the
+                                   detrended power in every bin (measured on MI355X at 2047 segments of 4096 points:
+                                   1e-6 at |m| = 30 sigma, 4e-5 at 300 sigma, 1.5e-4 at 3000 sigma), and bins 0, +-1
+                                   stand where any float32 mean of the raw samples leaves them, SciPy's included
+                                   (2 * 2^-23 |m| |W[k]| / |X[k]|) - inside the 1e-4 parity gate up to a DC line
+                                   ~50 dB above the signal's total power. */
 
 /* scaling of the averaged |X|^2 */
 #define OTH_SCALE_RAW        0   /* mean over segments of |X|^2 */
@@ -157,7 +168,7 @@ int oth_plan_out_len(oth_plan *plan, int *n);
 /* Launch tuning for A/B tools and the parity suite: which build of the 4096-point kernel ("dpp", "pipe", "ws") or
  * of the 256 ... 2048-point kernels ("seg3", "seg4": registers held to 3 / 4 waves per SIMD; NULL or "" = the
  * library's choice), or only the detrend form of the size's default kernel ("fd": after the transform even below 8
- * segments per stream; "td": before it at any length - what OTH_DETREND_CONSTANT_EXACT plans always do), a schedule override (-1 = the plan's), segments per chunk and per tail chunk
+ * segments per stream of an OTH_DETREND_CONSTANT_FAST plan; "td": before it at any length), a schedule override (-1 = the plan's), segments per chunk and per tail chunk
  * (0 = default).  The OTH_W4096_VARIANT / _SCHED / _CHUNK / _TAIL environment variables give the initial values
  * and are read once, in oth_welch_plan(). */
 int oth_plan_set_tuning(oth_plan *plan, const char *variant, int sched, int chunk, int tail_chunk);

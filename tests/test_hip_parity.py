@@ -877,27 +877,33 @@ def _dc_bins_gate(got, ref64, ref32, N, m_abs):
 
 @pytest.mark.parametrize('N', [2048, 4096, 8192, 16384])
 def test_detrend_forms_few_segments_and_large_dc(ctx, hip, N):
-    """SciPy's default detrend='constant' (ofdm_cr_tools.py:214,322,342) where the frequency-domain form of the fast
-    builds is weakest: 1-9 segments and a DC line far above the noise.  Compared with the float64 oracle on ALL bins:
-      * every bin but k = 0, +-1: 1e-4, always;
-      * k = 0, +-1: 1e-4 - or, where no float32 detrend can hold that, the float32-mean bound (_f32_mean_bound).  The
-        reference's own arithmetic (SciPy on GNU Radio's complex64 = float32 throughout, oracle.welch_c64) is measured
-        beside it: at one segment and |m| = 35 sigma it loses 1e-4 ... 5e-3 there itself;
-      * the plan's own choice (fewer than 8 segments per stream: time-domain builds) and OTH_DETREND_CONSTANT_EXACT
-        both meet this at every segment count; the FORCED frequency-domain form is only recorded below 8 segments
-        (there it spreads the DC line's rounding over all bins - why the plan does not pick it);
-      * with many segments: auto holds 1e-4 on all bins up to |m| = 300 sigma; EXACT keeps every bin but k = 0, +-1
-        at 1e-6 for any offset tried (3000 sigma) and those three inside the float32-mean bound."""
+    """SciPy's default detrend='constant' (ofdm_cr_tools.py:214,322,342) where single precision is weakest: 1-9 segments
+    and a DC line far above the noise, then many segments at 30 / 300 / 3000 sigma.  Compared with the float64 oracle
+    on ALL bins, for the two detrend modes of the ABI and the forced forms:
+      * OTH_DETREND_CONSTANT ('auto', the default): the PILOT builds - every kernel takes the mean of the stream's first
+        nperseg samples off each sample as it is loaded, so neither detrend form handles the DC line in float32.  Flat
+        1e-4 on ALL bins at every segment count and offset; with many segments every bin at the rounding of the average
+        (2e-6) where the reference's own arithmetic (SciPy on GNU Radio's complex64 = float32 throughout,
+        oracle.welch_c64, measured beside every case) stands at 3e-4 ... 2.6e-3 in k = 0, +-1.  'td' forces the
+        time-domain pilot builds, same gates;
+      * OTH_DETREND_CONSTANT_FAST ('fast'): the raw-sample builds.  Every bin but k = 0, +-1 at 1e-4; k = 0, +-1 at
+        1e-4 - or, where no float32 detrend of the raw samples can hold that, the float32-mean bound (_f32_mean_bound):
+        at one segment and |m| = 35 sigma the reference loses 1e-4 ... 5e-3 there itself.  Fewer than 8 segments per
+        stream take the time-domain builds; the FORCED frequency-domain form ('fast-fd') is only recorded below 8
+        segments (there it spreads the DC line's rounding over all bins - why the plan does not pick it).  With many
+        segments: 1e-4 on all bins up to |m| = 300 sigma, < 1e-3 at 3000 sigma (the bound include/ofdm_tools_hip.h
+        states)."""
     step = N // 2
     lines = []
-    fmt = 'N=%d |m|=%g sigma nseg=%d %-5s: k=0,+-1 %.2e (reference float32: %.2e), other bins %.2e'
+    fmt = 'N=%d |m|=%g sigma nseg=%d %-8s: k=0,+-1 %.2e (reference float32: %.2e), other bins %.2e'
+    forms = (('auto', hip.DETREND_CONSTANT, None), ('td', hip.DETREND_CONSTANT, 'td'),
+             ('fast', hip.DETREND_CONSTANT_FAST, None), ('fast-fd', hip.DETREND_CONSTANT_FAST, 'fd'))
     for ratio in (3.6, 35.0):
         for nseg in (1, 2, 3, 7, 8, 9):
             x = _dc_stream(N + step * (nseg - 1) + 5, ratio, 1000 * nseg + N)
             _, ref = R.welch_np(x, nperseg=N, nfft=N)
             ref32 = R.welch_c64(x, nperseg=N, nfft=N)
-            for name, det, force in (('auto', hip.DETREND_CONSTANT, None), ('exact', hip.DETREND_CONSTANT_EXACT, None),
-                                     ('fd', hip.DETREND_CONSTANT, 'fd')):
+            for name, det, force in forms:
                 plan = ctx.welch_plan(N, window=hann(N), detrend=det, kernel=hip.KERNEL_TUNED)
                 plan.set_tuning(force)
                 got = plan.exec(x)
@@ -905,7 +911,9 @@ def test_detrend_forms_few_segments_and_large_dc(ctx, hip, N):
                 plan.close()
                 rest, dc, dc32, ok = _dc_bins_gate(got, ref, ref32, N, ratio)
                 lines.append(fmt % (N, ratio, nseg, name, dc, dc32, rest))
-                if name != 'fd' or nseg >= 8:
+                if not name.startswith('fast'):
+                    assert rest < RTOL and dc < RTOL, lines[-1]
+                elif name != 'fast-fd' or nseg >= 8:
                     assert rest < RTOL and ok, lines[-1]
     nseg = 2047 if N <= 4096 else 511
     measured = {}
@@ -913,29 +921,33 @@ def test_detrend_forms_few_segments_and_large_dc(ctx, hip, N):
         x = _dc_stream(N + step * (nseg - 1), ratio, 7 + N)
         _, ref = R.welch_np(x, nperseg=N, nfft=N)
         ref32 = R.welch_c64(x, nperseg=N, nfft=N)
-        for name, det in (('auto', hip.DETREND_CONSTANT), ('exact', hip.DETREND_CONSTANT_EXACT)):
+        for name, det, force in forms[:3]:
             plan = ctx.welch_plan(N, window=hann(N), detrend=det, kernel=hip.KERNEL_TUNED)
+            plan.set_tuning(force)
             got = plan.exec(x)
             plan.close()
             measured[(name, ratio)] = m = _dc_bins_gate(got, ref, ref32, N, ratio)
             lines.append(fmt % (N, ratio, nseg, name, m[1], m[2], m[0]))
     print('\n'.join(['', 'detrend forms, N = %d' % N] + lines))
     for ratio in (30.0, 300.0, 3000.0):
-        # EXACT: every other bin clean at any offset; k = 0, +-1 inside the float32-mean bound (at 3000 sigma the
-        # reference's own float32 arithmetic loses 3e-4 ... 1.4e-3 there, printed above)
-        rest, dc, dc32, ok = measured[('exact', ratio)]
-        assert rest < 2e-5 and ok, (N, ratio, measured[('exact', ratio)])
-        assert measured[('auto', ratio)][3], (N, ratio, measured[('auto', ratio)])
-    # the fast (frequency-domain) form: all bins inside 1e-4 up to |m| = 300 sigma; at 3000 sigma the DC line's rounding
-    # reaches the other bins (1.5e-4 ... 3.3e-4 measured) - the bound the header states, and what EXACT is for
-    assert measured[('auto', 30.0)][0] < RTOL and measured[('auto', 30.0)][1] < 3e-5
-    assert measured[('auto', 300.0)][0] < RTOL             # (k = 0, +-1: inside the float32-mean bound, asserted above)
-    assert measured[('auto', 3000.0)][0] < 1e-3
+        for name in ('auto', 'td'):
+            # a DC line 70 dB above the signal's total power leaves no trace: every bin at the rounding of the average
+            rest, dc, dc32, ok = measured[(name, ratio)]
+            assert rest < 2e-6 and dc < 2e-5, (N, ratio, name, measured[(name, ratio)])
+        assert measured[('fast', ratio)][3], (N, ratio, measured[('fast', ratio)])
+    # the fast form on raw samples: all bins inside 1e-4 up to |m| = 300 sigma; at 3000 sigma the DC line's rounding
+    # reaches the other bins (1.5e-4 ... 3.8e-4 measured) - the bound the header states
+    assert measured[('fast', 30.0)][0] < RTOL and measured[('fast', 30.0)][1] < 3e-5
+    assert measured[('fast', 300.0)][0] < RTOL             # (k = 0, +-1: inside the float32-mean bound, asserted above)
+    assert measured[('fast', 3000.0)][0] < 1e-3
 
 
-def test_csd_few_segments_with_dc_take_the_time_domain_build(ctx, hip):
-    """The two-channel kernel's role-split build detrends in the frequency domain too: 1-7 segment pairs with a DC line
-    go to the one-role kernel.  Pxx, Pyy, Pxy and Cxy against the float64 oracle, bins k = 0, +-1 judged as above."""
+def test_csd_few_segments_with_dc(ctx, hip):
+    """The two-channel kernels with 1-9 segment pairs under DC lines of 35 / 12 sigma, Pxx, Pyy, Pxy and Cxy against
+    the float64 oracle.  OTH_DETREND_CONSTANT (the PILOT builds of the role-split kernel and, forced with 'csd1', of the
+    one-role kernel): flat 1e-4 on all bins.  OTH_DETREND_CONSTANT_FAST: the role-split build detrends after the
+    transform on raw samples, so 1-7 segment pairs go to the one-role kernel; bins k = 0, +-1 judged by the
+    float32-mean bound as in test_detrend_forms_few_segments_and_large_dc."""
     N = 4096
     dc = DC_BINS(N)
     for nseg in (1, 2, 3, 7, 9):
@@ -944,18 +956,85 @@ def test_csd_few_segments_with_dc_take_the_time_domain_build(ctx, hip):
         y = (0.7 * np.roll(x, 5) + _dc_stream(n, 10.0, 90 + nseg) * 0.5).astype(np.complex64)
         my = abs(0.7 * 35.0 + 0.5 * 10.0)
         _, cxy, pxx, pyy, pxy = R.coherence_np(x, y, nperseg=N, nfft=N)
-        plan = ctx.welch_plan(N, window=hann(N), kernel=hip.KERNEL_TUNED)
+        norm = np.sqrt(pxx * pyy)
+        for force in (None, 'csd1'):
+            plan = ctx.welch_plan(N, window=hann(N), kernel=hip.KERNEL_TUNED)
+            plan.set_tuning(force)
+            gxx, gyy, gxy, gc = plan.csd(x, y)
+            plan.close()
+            assert relerr(gxx, pxx) < RTOL and relerr(gyy, pyy) < RTOL, (force, nseg, relerr(gxx, pxx), relerr(gyy, pyy))
+            assert (np.abs(gxy - pxy) / norm).max() < RTOL, (force, nseg)
+            if nseg > 1:                                   # one segment: Cxy = 1 identically
+                assert np.max(np.abs(gc - cxy)) < RTOL, (force, nseg)
+        plan = ctx.welch_plan(N, window=hann(N), detrend=hip.DETREND_CONSTANT_FAST, kernel=hip.KERNEL_TUNED)
         gxx, gyy, gxy, gc = plan.csd(x, y)
         plan.close()
         for got, ref, sig, m_abs in ((gxx, pxx, x, 35.0), (gyy, pyy, y, my)):
             rest, e_dc, e32, ok = _dc_bins_gate(got, ref, R.welch_c64(sig, nperseg=N, nfft=N), N, m_abs)
             assert rest < RTOL and ok, (nseg, rest, e_dc, e32)
-        norm = np.sqrt(pxx * pyy)
         e = np.abs(gxy - pxy) / norm
         bound = np.maximum(RTOL, _f32_mean_bound(pxx, 35.0, N) + _f32_mean_bound(pyy, my, N))
         assert np.delete(e, dc).max() < RTOL and np.all(e[dc] <= bound), (nseg, e.max(), e[dc], bound)
-        if nseg > 1:                                   # one segment: Cxy = 1 identically, 0 / 0 under the DC line
+        if nseg > 1:                                   # (0 / 0 under the DC line)
             assert np.max(np.abs(np.delete(gc - cxy, dc))) < RTOL
+
+
+def test_detrend_pilot_and_fast_build_of_every_kernel(ctx, hip):
+    """OTH_DETREND_CONSTANT (the pilot builds; OTH_DETREND_CONSTANT_EXACT is the same mode) over every kernel family that detrends (sizes 64 ... 16384; 50 % overlap with a window
+    whose spectrum is confined / is not; other steps; zero-padded segments; the coverage kernel): three device-resident
+    streams in one launch with DC lines of 40 sigma, none, and 8 sigma - the pilot is per stream - against the float64
+    oracle, flat 1e-4 on ALL bins, and streamed in ragged chunks through accumulate().  Then the same launch with
+    OTH_DETREND_CONSTANT_FAST (the builds without the pilot): every bin outside the main lobe of the removed line at
+    1e-4 on the 8-sigma and the offset-free stream."""
+    import scipy.signal as sg
+    ham = lambda n: sg.windows.hamming(n, sym=True).astype(np.float32)      # noqa: E731  1/k sidelobes: time-domain builds
+    cases = [(64, 64, 32, hann), (128, 128, 64, hann), (256, 256, 128, hann), (256, 256, 0, hann), (512, 512, 256, ham),
+             (1024, 1024, 512, hann), (1024, 1024, 100, hann), (1024, 256, 128, flattop), (1024, 512, 256, hann),
+             (2048, 2048, 1024, hann), (2048, 2048, 1024, ham), (2048, 512, 256, flattop), (2048, 1024, 512, hann),
+             (4096, 4096, 2048, hann), (4096, 4096, 2048, ham), (4096, 4096, 1000, hann), (4096, 1024, 512, flattop),
+             (4096, 512, 256, hann), (4096, 256, 0, hann), (8192, 8192, 4096, hann), (8192, 8192, 4096, ham),
+             (8192, 8192, 1000, hann), (8192, 2048, 1024, flattop), (16384, 16384, 8192, hann), (16384, 16384, 8192, ham),
+             (16384, 16384, 3000, hann), (16384, 4096, 2048, flattop)]
+    ratios = (40.0, 0.0, 8.0)
+    for nfft, nperseg, nov, wf in cases:
+        w = wf(nperseg)
+        step = nperseg - nov
+        nseg = 37 if nfft >= 4096 else 150
+        n = nperseg + step * (nseg - 1) + 7
+        xs = np.stack([_dc_stream(n, r, 31 * nfft + i) for i, r in enumerate(ratios)])
+        refs = [R.welch_np(x, window=w.astype(np.float64), nperseg=nperseg, noverlap=nov, nfft=nfft)[1] for x in xs]
+        d_in, d_out = ctx.alloc(xs.nbytes), ctx.alloc(3 * nfft * 4)
+        try:
+            ctx.h2d(d_in, xs)
+            for kern in (hip.KERNEL_TUNED, hip.KERNEL_GENERIC):
+                kern_eff = hip.KERNEL_AUTO if kern == hip.KERNEL_TUNED and nfft < 256 else kern
+                plan = ctx.welch_plan(nfft, nperseg=nperseg, noverlap=nov, window=w, kernel=kern_eff,
+                                      detrend=hip.DETREND_CONSTANT_EXACT if nfft == 512 else hip.DETREND_CONSTANT)
+                assert plan.exec_dev(d_in, n, d_out, nstreams=3, stream_stride=n) == nseg
+                got = ctx.d2h(d_out, (3, nfft), np.float32)
+                for i in range(3):
+                    assert relerr(got[i], refs[i]) < RTOL, (nfft, nperseg, nov, wf.__name__, kern, i, relerr(got[i], refs[i]))
+                fast = ctx.welch_plan(nfft, nperseg=nperseg, noverlap=nov, window=w, kernel=kern_eff,
+                                      detrend=hip.DETREND_CONSTANT_FAST)
+                assert fast.exec_dev(d_in, n, d_out, nstreams=3, stream_stride=n) == nseg
+                got = ctx.d2h(d_out, (3, nfft), np.float32)
+                fast.close()
+                hw = 5 * nfft // nperseg                 # the removed line's main lobe (a flat-top's: +-5 bins of nperseg)
+                lobe = np.r_[0:hw + 1, nfft - hw:nfft]
+                for i in (1, 2):
+                    e = np.abs(got[i] - refs[i]) / refs[i]
+                    assert np.delete(e, lobe).max() < RTOL, (nfft, nperseg, nov, 'fast', kern, i, e.max())
+                if kern == hip.KERNEL_TUNED:      # the same stream in ragged chunks: every launch takes its own pilot
+                    plan.reset()
+                    pos = 0
+                    for ln in (nperseg + 3, 5, 3 * step + 1, n):
+                        plan.accumulate(xs[0][pos:pos + ln])
+                        pos += ln
+                    assert relerr(plan.finalize(), refs[0]) < RTOL, (nfft, nperseg, nov, 'chunks')
+                plan.close()
+        finally:
+            ctx.free(d_in)
+            ctx.free(d_out)
 
 
 def test_welch4096_window_with_wide_spectrum_takes_the_time_domain_detrend(ctx, hip):

@@ -23,10 +23,18 @@ from ofdm_tools import _hip, windows  # noqa: E402
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'C2'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 TONES = ((0.5, 0.1234), (0.05, -0.31), (2.0, 0.4071))
-DC = 0.1 + 0.05j
+DC = complex(os.environ.get('PROF_DC', '0.1+0.05j'))      # PROF_DC=70+35j: a DC line far above the signal (the pilot's slow path)
 ctx = _hip.Context(0)
 hann = lambda n: windows.get_window('hann', n)      # noqa: E731
 bufs = []
+# PROF_DETREND=fast: OTH_DETREND_CONSTANT_FAST (the builds without the pilot) wherever a configuration detrends
+DETMODE = _hip.DETREND_CONSTANT_FAST if os.environ.get('PROF_DETREND') == 'fast' else _hip.DETREND_CONSTANT
+
+
+def welch_plan(*a, **k):
+    k.setdefault('detrend', DETMODE)
+    return ctx.welch_plan(*a, **k)
+
 
 
 def dev(nbytes):
@@ -43,7 +51,7 @@ if cfg == 'C2':
     n = (1 << (log2n or 28)) - (2048 if os.environ.get('PROF_EVEN') else 0)      # PROF_EVEN: an even segment count (variant ws2)
     d, o = dev(n * 8), dev(4096 * 4)
     ctx.synth_iq(d, n, 1002, TONES, DC)
-    plan = ctx.welch_plan(4096, window=hann(4096), fs=1.0)
+    plan = welch_plan(4096, window=hann(4096), fs=1.0)
     run = lambda: plan.exec_dev(d, n, o)      # noqa: E731
     nbytes = 8 * n
 elif cfg == 'C3':
@@ -51,7 +59,7 @@ elif cfg == 'C3':
     dx, dy = dev(n * 8), dev(n * 8)
     ctx.synth_iq(dx, n, 1003, TONES, DC)
     ctx.synth_iq(dy, n, 1004, TONES, DC)
-    plan = ctx.welch_plan(4096, window=hann(4096), fs=1.0)
+    plan = welch_plan(4096, window=hann(4096), fs=1.0)
     run = lambda: plan.csd_device_src(dx, dy, n)      # noqa: E731
     nbytes = 16 * n
 elif cfg in ('C4', 'C4ref'):
@@ -60,7 +68,7 @@ elif cfg in ('C4', 'C4ref'):
     for i in range(nrf):
         ctx.synth_iq(d + i * S * 8, S, 2000 + i, TONES, DC)
     kw = dict(window=hann(4096)) if cfg == 'C4' else dict(nperseg=1024, window=windows.get_window('flattop', 1024))
-    plan = ctx.welch_plan(4096, fs=2.0e6, fftshift=True, trim_bins=256, db=True, **kw)
+    plan = welch_plan(4096, fs=2.0e6, fftshift=True, trim_bins=256, db=True, **kw)
     run = lambda: plan.exec_dev(d, S, o, nstreams=nrf, stream_stride=S)      # noqa: E731
     nbytes = 8 * nrf * S
 elif cfg == 'C5':
@@ -69,7 +77,7 @@ elif cfg == 'C5':
     d, o = dev(nch * stride * 8), dev(nch * N * 4)
     for i in range(nch):
         ctx.synth_iq(d + i * stride * 8, S, 3000 + i, TONES, DC)
-    plan = ctx.welch_plan(N, noverlap=0, window=None, detrend=_hip.DETREND_NONE, scaling=_hip.SCALE_OVER_N2,
+    plan = welch_plan(N, noverlap=0, window=None, detrend=_hip.DETREND_NONE, scaling=_hip.SCALE_OVER_N2,
                           fftshift=True)
     run = lambda: plan.exec_dev(d, S, o, nstreams=nch, stream_stride=stride)      # noqa: E731
     nbytes = 8 * nch * S
@@ -92,7 +100,7 @@ elif cfg in ('w1024', 'w2048', 'w512', 'w256', 'w8192', 'w16384'):
     n = 1 << (log2n or 27)
     d, o = dev(n * 8), dev(N * 4)
     ctx.synth_iq(d, n, 1002, TONES, DC)
-    plan = ctx.welch_plan(N, window=hann(N), fs=1.0)
+    plan = welch_plan(N, window=hann(N), fs=1.0)
     run = lambda: plan.exec_dev(d, n, o)      # noqa: E731
     nbytes = 8 * n
 elif cfg in ('p1024', 'p2048', 'p8192', 'p16384'):      # the sweeper's call at these sizes: flattop, nperseg = nfft / 4 zero-padded, 50 % overlap
@@ -100,7 +108,7 @@ elif cfg in ('p1024', 'p2048', 'p8192', 'p16384'):      # the sweeper's call at 
     n = 1 << (log2n or 27)
     d, o = dev(n * 8), dev(N * 4)
     ctx.synth_iq(d, n, 1002, TONES, DC)
-    plan = ctx.welch_plan(N, nperseg=N // 4, window=windows.get_window('flattop', N // 4), fs=2.0e6, fftshift=True, db=True)
+    plan = welch_plan(N, nperseg=N // 4, window=windows.get_window('flattop', N // 4), fs=2.0e6, fftshift=True, db=True)
     run = lambda: plan.exec_dev(d, n, o)      # noqa: E731
     nbytes = 8 * n
 elif cfg.startswith('chain'):
