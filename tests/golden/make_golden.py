@@ -23,9 +23,11 @@ Rows tagged ``reference`` (files ``ref_*.npz``) are different: ``reference_fixtu
 reference's OWN function bodies - cut out of /root/reference/python/{ofdm_cr_tools,spectrum_sweeper}.py at
 generation time by ``ref_extract.py`` and exec'd against the real numpy / scipy.signal - on inputs for which
 Python-2 and Python-3 ``/`` agree (float or even-int Sf).  They pin rows a4, a6, a7 and a14 to the reference
-itself.  Not run that way (they do not execute unmodified under Python 3 / SciPy 1.15): ``xcorr`` / ``fac``
-(a12, ``len(h)/2`` index) and ``src_power_fft`` (``sg.flattop``), which stay NumPy-pinned; the GNU Radio
-chains a1-a3 stay unpinned.  Only numbers are written; no reference text is stored in any form.
+itself.  ``xcorr`` / ``fac`` (a12, ``len(h)/2`` index), ``src_power_fft`` (``sg.flattop``) and ``make_plot`` run
+unmodified in the namespace of the reference's day (ref_extract.py); the thread bodies and packers that hold
+Python-2 print statements (a5, a8 in full, a10, a15, f1) run after lib2to3's print fixer and nothing else
+(``reference_thread_fixtures`` -> ref_threads.npz); the GNU Radio chains a1-a3 stay unpinned.  Only numbers are
+written; no reference text is stored in any form.
 
 Run from the repo root:  python tests/golden/make_golden.py            (everything)
                          python tests/golden/make_golden.py --reference  (only the ref_*.npz files)
@@ -231,6 +233,197 @@ def reference_fixtures():
         out['text_%d' % i] = np.frombuffer(text.encode('ascii'), np.uint8)
         out['case_%d' % i] = np.array([W, H, N, Sf, tf], np.float64)
     save('ref_ascii_plot.npz', source=np.array('reference'), n=len(cases), **out)
+    reference_thread_fixtures(E, T, S)
+
+
+def reference_thread_fixtures(E, T, S):
+    """ref_threads.npz: the reference's own thread bodies and packers, run on stand-in queues / receivers / ports
+    (ref_extract.load_method(..., py2_print=True): the only change to their text is lib2to3's print fixer).
+      a8   stats_watcher.spectrum_scanner (spectrum_sensor_v2.py:445-479): EMA, cumulative / periodic max, noise
+           estimate, threshold, occupied channels - over the 16 committed PSD rows;
+      a10  psd_watcher.run (:336-354) and waterfall_watcher.run (:304-322): last vector of a message wins, running peak,
+           waterfall rows;
+      a15  main_thread.run (local_worker.py:126-139) and data_colector.run (spectrum_sweeper.py:161-172): the same
+           last-vector rule in front of the packer / the sample store;
+      a5   spectrum_stitcher.run (spectrum_sweeper.py:207-231): retune order, tune delay, concatenation, blend, pack;
+      f1   packet_source.send_packet of local_worker.py:147-172 (float32 and int8) and spectrum_sweeper.py:240-258."""
+    import io
+    import math
+    import struct
+    from contextlib import redirect_stdout
+    from types import SimpleNamespace as NS
+    npd = E.NumpyOfItsDay()
+    out = {}
+    g = np.load(os.path.join(HERE, 'scanner_state_seq.npz'))
+    rows = g['rows'].astype(np.float32)
+
+    # ---- a8: the stats watcher's scanner over the committed rows, constructor values as in make_golden.main()
+    fft_len, Sf, cs, sbw, tune, trunc_band = 1024, 1000000, 25e3, 12.5e3, 100000000, 800000
+    Fr = float(Sf) / fft_len
+    trunc = Sf - trunc_band
+    trunc_ch = int(trunc / cs) // 2
+    ax_ch = T['frange'](tune - Sf // 2, tune + Sf // 2, cs)[trunc_ch:-trunc_ch]
+    sent = []
+
+    class Logger(object):      # ofdm_cr_tools.py:1878-1894 initial values, :1932-1938 setters
+        cumulative_max_power = None
+        periodic_max_power = None
+
+        def set_cumulative_max_power(self, v):
+            self.cumulative_max_power = v
+
+        def set_periodic_max_power(self, v):
+            self.periodic_max_power = v
+
+    me = NS(fft_len=fft_len, Fr=Fr, sample_rate=Sf, bb_freqs=T['frange'](-Sf // 2, Sf // 2, cs), srch_bins=sbw / Fr,
+            trunc=trunc, trunc_ch=trunc_ch, plc=np.array([0.0] * len(ax_ch)), ax_ch=ax_ch, noise_estimate=1e-11,
+            alpha_avg=0.5, thr_leveler=4, verbose=True, logger=Logger(),
+            data_queue=NS(put=lambda v: sent.append(np.array(v))))
+    scan = E.load_method('spectrum_sensor_v2.py', 'stats_watcher', 'spectrum_scanner',
+                         {'np': npd, 'src_power': T['src_power']}, py2_print=True)
+    occ, noise, said = [], [], io.StringIO()
+    with redirect_stdout(said):
+        for r in rows:
+            hz = scan(me, r)
+            occ.append(np.array([1.0 if a in hz else 0.0 for a in ax_ch]))
+            noise.append(me.noise_estimate)
+    assert said.getvalue().count('noise_estimate dB (channel)') == len(rows)
+    out.update(stats_plc_seq=np.array(sent), stats_occupied_seq=np.array(occ), stats_noise_seq=np.array(noise),
+               stats_cumulative_max=np.array(me.logger.cumulative_max_power),
+               stats_periodic_max=np.array(me.logger.periodic_max_power))
+
+    # ---- a10 / a15: messages of 1, 3, 1, 2, 1, 4, 1, 3 vectors; the queue ends the loop with its last message
+    counts = (1, 3, 1, 2, 1, 4, 1, 3)
+    assert sum(counts) == len(rows)
+
+    def messages(vectors, dtype):
+        msgs, k = [], 0
+        for c in counts:
+            body = np.ascontiguousarray(vectors[k:k + c], dtype).tobytes()
+            itemsize = len(body) // c
+            msgs.append(NS(arg1=lambda i=itemsize: float(i), arg2=lambda c=c: float(c), to_string=lambda b=body: b))
+            k += c
+        return msgs
+
+    def queue_for(owner, msgs):
+        pending = list(msgs)
+
+        def delete_head():
+            m = pending.pop(0)
+            if not pending:
+                owner.keep_running = False
+            return m
+        return NS(delete_head=delete_head)
+
+    class PsdLogger(object):      # ofdm_cr_tools.py:1878-1906 initial values and setters
+        cumulative_psd = None
+        periodic_psd_peaks = None
+        cumulative_waterfall = None
+
+        def set_cumulative_psd(self, v):
+            self.cumulative_psd = v
+
+        def set_periodic_psd_peaks(self, v):
+            self.periodic_psd_peaks = v
+
+        def set_cumulative_waterfall(self, v):
+            self.cumulative_waterfall = v
+
+    lg = PsdLogger()
+    lg.cumulative_waterfall = []
+    w = NS(keep_running=True, logger=lg)
+    w.rcvd_data = queue_for(w, messages(rows, np.float32))
+    E.load_method('spectrum_sensor_v2.py', 'psd_watcher', 'run', {'np': npd}, py2_print=True)(w)
+    w = NS(keep_running=True, logger=lg)
+    w.rcvd_data = queue_for(w, messages(rows, np.float32))
+    E.load_method('spectrum_sensor_v2.py', 'waterfall_watcher', 'run', {'np': npd}, py2_print=True)(w)
+    out.update(msg_counts=np.array(counts), psd_cumulative=np.array(lg.cumulative_psd),
+               psd_periodic_peaks=np.array(lg.periodic_psd_peaks), waterfall=np.array(lg.cumulative_waterfall))
+
+    handed = []
+    w = NS(keep_running=True, max_tu=1470, fft_len=fft_len, data_precision=True,
+           packet_source=NS(send_packet=lambda data, max_tu, n, prec: handed.append(np.frombuffer(data, np.float32).copy())))
+    w.rcvd_data = queue_for(w, messages(rows, np.float32))
+    with redirect_stdout(io.StringIO()):
+        E.load_method('local_worker.py', 'main_thread', 'run', {'np': npd}, py2_print=True)(w)
+    out['worker_vectors'] = np.array(handed)
+    iq = g['x'].astype(np.complex64).reshape(len(rows), -1)
+    stored = []
+    w = NS(keep_running=True, set_samples=lambda v: stored.append(np.array(v)))
+    w.rcvd_data = queue_for(w, messages(iq, np.complex64))
+    with redirect_stdout(io.StringIO()):
+        E.load_method('spectrum_sweeper.py', 'data_colector', 'run', {'np': npd}, py2_print=True)(w)
+    out['collector_vectors'] = np.array(stored)
+
+    # ---- f1: both packers on the vector of fragments.bin; a stand-in port collects the frames
+    class Port(object):
+        def __init__(self):
+            self.frames = []
+
+        def message_port_pub(self, port, pdu):
+            assert port == 'out' and pdu[0] is None
+            self.frames.append(bytes(pdu[1]))
+
+    pmt = NS(make_u8vector=lambda n, fill: bytearray([fill]) * n, PMT_NIL=None, intern=lambda s: s,
+             u8vector_set=lambda v, i, val: v.__setitem__(i, val), cons=lambda a, b: (a, b))
+    ns = {'np': npd, 'pmt': pmt, 'struct': struct, 'math': math, 'ord': E.py2_ord, 'len': lambda v: E.Py2Int(len(v))}
+    worker_send = E.load_method('local_worker.py', 'packet_source', 'send_packet', ns)
+    sweeper_send = E.load_method('spectrum_sweeper.py', 'packet_source', 'send_packet', ns)
+    db = (np.arange(4096, dtype=np.float32) * 0.01 - 90).astype('<f4')
+    groups = []
+    for prec in (True, False):
+        port = Port()
+        worker_send(port, db.tobytes(), 1472 - 2, 4096, prec)
+        groups.append(port.frames)
+    port = Port()
+    sweeper_send(port, db.tobytes(), 1472 - 2)
+    groups.append(port.frames)
+    blob = b''
+    for group in groups:
+        blob += np.uint32(len(group)).tobytes()
+        for fr in group:
+            blob += np.uint32(len(fr)).tobytes() + fr
+    with open(os.path.join(HERE, 'fragments.bin'), 'rb') as fh:
+        assert fh.read() == blob, 'fragments.bin (restated) differs from the reference packers'
+    out['fragments_bin'] = np.frombuffer(blob, np.uint8)
+    # lengths around the fragment boundaries: the worker's ceil and the sweeper's floor + 1 (one empty frame at multiples)
+    for n in (1, 367, 368, 735, 736, 1104):
+        v = (np.arange(n, dtype=np.float32) * 0.5 - 70).astype('<f4')
+        port = Port()
+        worker_send(port, v.tobytes(), 1472, n, True)
+        out['worker_frames_%d' % n] = np.frombuffer(b''.join(np.uint32(len(f)).tobytes() + f for f in port.frames), np.uint8)
+        port = Port()
+        sweeper_send(port, v.tobytes(), 1472)
+        out['sweeper_frames_%d' % n] = np.frombuffer(b''.join(np.uint32(len(f)).tobytes() + f for f in port.frames), np.uint8)
+    out['frame_lengths'] = np.array([1, 367, 368, 735, 736, 1104])
+
+    # ---- a5: one pass of the stitcher's loop over three tuned captures of the committed flattop input
+    gq = np.load(os.path.join(HERE, 'welch_flattop_nperseg_quarter.npz'))
+    xq = gq['x'].astype(np.complex64)
+    nfft_s, fs_s, excess = int(gq['nfft']), float(gq['fs']), 96
+    third = len(xq) // 3
+    captures = [xq[i * third:(i + 1) * third] for i in range(3)]
+    freqs = [100.0e6, 101.5e6, 103.0e6]
+    tuned, slept, packed = [], [], []
+    pending = list(captures)
+    st = NS(keep_running=True, tune_frequencies=freqs, fft_len=nfft_s, sample_rate=fs_s, excess_bins=excess,
+            tune_delay=0.125, average=0.25, max_tu=1472, get_samples=lambda: pending.pop(0),
+            rf_receiver=NS(set_center_freq=lambda f, ch: tuned.append((f, ch))))
+
+    def stitcher_send(data, max_tu):
+        packed.append((data, max_tu))
+        st.keep_running = False
+    st.packet_source = NS(send_packet=stitcher_send)
+    run = E.load_method('spectrum_sweeper.py', 'spectrum_stitcher', 'run',
+                        {'np': npd, 'struct': struct, 'time': NS(sleep=slept.append), '_src_power': S['_src_power']},
+                        py2_print=True)
+    with redirect_stdout(io.StringIO()):
+        run(st)
+    assert len(packed) == 1 and packed[0][1] == 1472 and not pending
+    out.update(stitch_captures=np.array(captures), stitch_nfft=nfft_s, stitch_fs=fs_s, stitch_excess=excess,
+               stitch_average=0.25, stitch_freqs=np.array(freqs), stitch_tuned=np.array(tuned, np.float64),
+               stitch_sleeps=np.array(slept), stitch_packed=np.frombuffer(packed[0][0], np.uint8))
+    save('ref_threads.npz', source=np.array('reference'), input_from=np.array('scanner_state_seq.npz'), **out)
 
 
 def consumer_fixture():

@@ -16,6 +16,18 @@ unmodified as well; only the namespace they run in is the older one (``py2_names
     ``scipy.signal.windows`` second - the same function object either way.
   * ``xcorr`` / ``fac`` slice with ``h[len(h)/2:]``: under Python 2 ``int / int`` floors.  The ``len`` handed to them
     returns an ``int`` subclass whose ``/`` by an int floors (``Py2Int``, also used for ``ascii_plotter.make_plot``).
+
+Methods that contain a Python-2 ``print`` STATEMENT do not parse under Python 3 at all.  ``load_method(...,
+py2_print=True)`` passes the cut text through ``lib2to3``'s ``fix_print`` - the standard library's own Python-2 to
+Python-3 translator, restricted to that one fixer - before compiling it: ``print a, b`` becomes ``print(a, b)`` and
+nothing else changes (no arithmetic, no control flow).  The thread bodies and packers pinned that way
+(``stats_watcher.spectrum_scanner``, ``psd_watcher.run``, ``waterfall_watcher.run``, ``main_thread.run``,
+``data_colector.run``, ``spectrum_stitcher.run``, both ``packet_source.send_packet``) run against stand-in queues,
+receivers and ports, and against two more pieces of the environment of their day:
+  * ``np.maximum(x, None)``: the logger starts its peak arrays at ``None`` and Python 2 ordered ``None`` below every
+    number, so the first ``np.maximum`` returned the data (``NumpyOfItsDay.maximum``);
+  * ``ord(frame[i])`` over a byte string: indexing a Python-2 ``str`` gives a 1-character ``str``, indexing Python-3
+    ``bytes`` gives the ``int`` already (``py2_ord``).
 """
 import ast
 import math
@@ -41,6 +53,37 @@ class _SignalOfItsDay(object):
         if hasattr(sg, name):
             return getattr(sg, name)
         return getattr(sg.windows, name)
+
+
+class NumpyOfItsDay(object):
+    """numpy as the reference's threads used it under Python 2: ``maximum`` with a ``None`` operand returns the other
+    operand (``None`` ordered below every number there); everything else is numpy's own."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def maximum(a, b):
+        if a is None:
+            return b
+        if b is None:
+            return a
+        return np.maximum(a, b)
+
+
+def py2_ord(c):
+    """``ord`` over the elements of a byte string: Python-3 ``bytes`` index to ints already."""
+    return c if isinstance(c, int) else ord(c)
+
+
+def _fix_py2_print(text):
+    """The cut text with Python-2 print statements rewritten as calls - lib2to3's fix_print and nothing else."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        from lib2to3 import refactor
+        tool = refactor.RefactoringTool(['lib2to3.fixes.fix_print'])
+        return str(tool.refactor_string(text if text.endswith('\n') else text + '\n', '<reference>'))
 
 
 def py2_namespace():
@@ -90,9 +133,10 @@ def load(module, names, namespace=None):
     return out
 
 
-def load_method(module, cls, name, namespace=None):
+def load_method(module, cls, name, namespace=None, py2_print=False):
     """A method of a reference class as a plain function taking ``self`` (the caller passes a stand-in object
-    carrying the attributes the method reads): the ``def`` is cut by its indentation inside ``class cls``."""
+    carrying the attributes the method reads): the ``def`` is cut by its indentation inside ``class cls``.
+    py2_print: the method holds Python-2 print statements - see the module docstring."""
     path = os.path.join(REF_PY, module)
     with open(path) as fh:
         lines = fh.readlines()
@@ -118,6 +162,8 @@ def load_method(module, cls, name, namespace=None):
             end = j
             break
     text = ''.join(ln[len(indent):] if ln.startswith(indent) else ln.lstrip() for ln in lines[start:end])
+    if py2_print:
+        text = _fix_py2_print(text)
     tree = ast.parse(text)
     assert len(tree.body) == 1 and isinstance(tree.body[0], ast.FunctionDef) and tree.body[0].name == name
     ns = {'np': np, 'sg': sg, 'math': math, '__builtins__': __builtins__}

@@ -191,6 +191,64 @@ def test_spectrum_sweeper_sweep_and_wire_format(ctx):
     assert np.array_equal(blk2.get_samples(), x[pts:2 * pts])
 
 
+def test_ref_stitcher_pass_through_the_block(ctx, golden):
+    """a5 against the reference's OWN spectrum_stitcher.run (spectrum_sweeper.py:207-231, ref_threads.npz): the same
+    three captures through the block - retune order on channel 0, the tune delay after every retune, concatenation,
+    the blend with the 1e-10 floor, little-endian float32 payload, the sweeper's framing."""
+    import ofdm_tools
+    from ofdm_tools import packets
+    g = golden('ref_threads.npz')
+    nfft, fs, ex = int(g['stitch_nfft']), int(g['stitch_fs']), int(g['stitch_excess'])
+    freqs = [float(f) for f in g['stitch_freqs']]
+    tSf = fs - 2 * ex * fs // nfft                       # excess_bins = floor((Sf - tSf) / 2 / (Sf / fft_len)) = 96
+    rx = FakeReceiver()
+    tuned = []
+    rx.set_center_freq = lambda f, chan: tuned.append([f, float(chan)])
+    blk = ofdm_tools.spectrum_sweeper(rx, 'rtl', nfft, fs, tSf, freqs[0] - tSf / 2, freqs[-1] + tSf / 2, 15,
+                                      float(g['stitch_average']), 8, 125, 1472, ctx=ctx, threaded=False)
+    assert blk.excess_bins == ex and blk.get_tune_delay() == 0.125
+    blk.tune_frequencies = freqs
+    it = iter(list(g['stitch_captures']))
+    blk.get_samples = lambda: next(it)
+    frames, sleeps = [], []
+    blk.msg_connect('pdus', lambda m: frames.append(m[1]))
+    psd = blk.sweep_once(sleep=sleeps.append)
+    assert tuned == g['stitch_tuned'].tolist() and sleeps == g['stitch_sleeps'].tolist()[1:]
+    want = np.frombuffer(bytes(g['stitch_packed']), '<f4').astype(np.float64)
+    got = np.frombuffer(packets.reassemble(frames), '<f4').astype(np.float64)
+    assert got.shape == want.shape == psd.shape
+    # the reference's Welch ran in SciPy's single precision (complex64 in), 2e-5 off the float64 oracle itself
+    assert relerr(10 ** (got / 10), 10 ** (want / 10)) < RTOL + 2e-5
+    assert [f[:2] for f in frames] == [f[:2] for f in R.sweeper_fragments(bytes(g['stitch_packed']), 1470)]
+    assert [len(f) for f in frames] == [len(f) for f in R.sweeper_fragments(bytes(g['stitch_packed']), 1470)]
+
+
+def test_ref_watchers_through_the_blocks(ctx, golden, tmp_path):
+    """a10 / a15 against the reference's OWN watcher bodies (psd_watcher.run, waterfall_watcher.run,
+    spectrum_sensor_v2.py:304-354; main_thread.run, local_worker.py:126-139): work() calls of 1, 3, 1, 2, 1, 4, 1, 3
+    vectors stand for the messages - the last vector of each is the one that counts; the PSD peak is the running
+    maximum of those, the waterfall their sequence, local_worker's PDUs carry them."""
+    import ofdm_tools
+    from ofdm_tools import packets
+    from test_hip_parity import check_single_rows
+    g = golden('ref_threads.npz')
+    c = golden(str(g['input_from']))
+    N = 1024
+    x = c['x'].astype(np.complex64)
+    edges = np.concatenate(([0], np.cumsum(g['msg_counts']))) * N
+    blk = ofdm_tools.spectrum_sensor_v2(N, 1, N, psd=True, waterfall=True, ctx=ctx, threaded=False,
+                                        log_directory=str(tmp_path))
+    assert blk.decimation == 1
+    for a, b in zip(edges[:-1], edges[1:]):
+        assert blk.work([x[a:b]], []) == b - a
+    rows = np.array(blk._logger.cumulative_waterfall)
+    assert rows.shape == g['waterfall'].shape
+    check_single_rows(rows, g['waterfall'].astype(np.float64))
+    check_single_rows(blk._logger.cumulative_psd[None, :], g['psd_cumulative'][None, :].astype(np.float64))
+    check_single_rows(blk._logger.periodic_psd_peaks[None, :], g['psd_periodic_peaks'][None, :].astype(np.float64))
+    blk.stop()
+
+
 def test_spectrum_sweeper_stitcher_thread_sweeps_by_itself(ctx):
     """spectrum_sweeper.py:99-105,207-231: constructing the block starts the stitcher; a flowgraph only feeds work().
     Nothing here calls sweep_once."""

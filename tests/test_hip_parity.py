@@ -1181,6 +1181,18 @@ def test_ref_a8_a9_a11_host_state_machines(ctx, golden):
     subj = [float(v) for v in c['subject_channels']]
     pwr, top = S.top4(st.plc, st.subject_index(subj), subj)
     assert np.allclose(pwr, g['subject_pwr'], atol=1e-4) and top == list(g['top4'])
+    # a8 in full against the reference's own stats_watcher.spectrum_scanner (:445-479, ref_threads.npz): EMA, max
+    # hold, noise estimate, threshold decision per row
+    t = golden('ref_threads.npz')
+    st = S.ChannelScanner(1024, 1000000, 25e3, 12.5e3, tune_freq=100000000, trunc_band=800000, thr_leveler=4,
+                          alpha_avg=0.5, ctx=ctx)
+    for i, r in enumerate(c['rows']):
+        occ = st.scan(r.astype(np.float32))
+        assert np.allclose(st.plc, t['stats_plc_seq'][i], rtol=1e-5)
+        assert np.isclose(st.noise_estimate, t['stats_noise_seq'][i], rtol=1e-5)
+        assert [1.0 if a in occ else 0.0 for a in st.ax_ch] == list(t['stats_occupied_seq'][i])
+    assert np.allclose(st.cumulative_max_power, t['stats_cumulative_max'], rtol=1e-5)
+    assert np.allclose(st.periodic_max_power, t['stats_periodic_max'], rtol=1e-5)
 
 
 # ------------------------------------------- device / partial forms added in ABI 2 ----

@@ -41,6 +41,32 @@ def test_packet_framing_matches_golden_and_oracle():
     assert len(fr) == 3 and fr[2][2:] == b'' and fr == R.sweeper_fragments(b'x' * 2940, 1470)
 
 
+def test_packers_match_the_reference_packers_around_fragment_boundaries():
+    """f1 against the reference's OWN packet_source.send_packet bodies (tests/golden/ref_threads.npz, made by
+    make_golden.reference_thread_fixtures): local_worker.py:147-172 and spectrum_sweeper.py:240-258 at payload lengths on
+    and around multiples of max_tu - the worker's ceil() and the sweeper's floor() + 1 with its empty closing frame."""
+    from ofdm_tools import packets
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'ref_threads.npz'))
+    assert str(g['source']) == 'reference'
+
+    def frames_of(blob):
+        raw, pos, frames = bytes(blob), 0, []
+        while pos < len(raw):
+            ln = struct.unpack_from('<I', raw, pos)[0]
+            frames.append(raw[pos + 4:pos + 4 + ln])
+            pos += 4 + ln
+        return frames
+    for n in g['frame_lengths']:
+        v = (np.arange(n, dtype=np.float32) * 0.5 - 70).astype('<f4')
+        want_w, want_s = frames_of(g['worker_frames_%d' % n]), frames_of(g['sweeper_frames_%d' % n])
+        assert packets.worker_fragments(v, 1472, int(n), True) == want_w, n
+        assert packets.sweeper_fragments(v.tobytes(), 1472) == want_s, n
+        assert packets.sweeper_fragment_count(4 * int(n), 1472) == len(want_s)
+        assert packets.reassemble(want_w) == v.tobytes() and packets.reassemble(want_s) == v.tobytes()
+    raw = open(os.path.join(ROOT, 'tests', 'golden', 'fragments.bin'), 'rb').read()
+    assert raw == bytes(g['fragments_bin'])          # the byte fixture used above IS what the reference packers emit
+
+
 def read_consumer_fixture():
     raw = open(os.path.join(ROOT, 'tests', 'golden', 'fragments_consumer.bin'), 'rb').read()
     pos = [0]

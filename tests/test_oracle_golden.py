@@ -203,7 +203,7 @@ def test_reference_fixtures_are_tagged(golden):
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'ref_*.npz')))
     assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_scanner_seq.npz', 'ref_src_power_cases.npz',
                      'ref_src_power_fft.npz', 'ref_src_power_welch_2048.npz', 'ref_sweeper_src_power.npz',
-                     'ref_welch_hann_4096.npz', 'ref_xcorr_fac.npz']
+                     'ref_threads.npz', 'ref_welch_hann_4096.npz', 'ref_xcorr_fac.npz']
     for n in names:
         g = golden(n)
         assert str(g['source']) == 'reference'
@@ -346,3 +346,81 @@ def test_ref_src_power_fft_and_fft_scan(golden):
     assert np.allclose(plc, g['scan_plc'], rtol=1e-12)
     ax_ch = R.frange(float(g['scan_fc']) - Sf / 2, float(g['scan_fc']) + Sf / 2, cs)
     assert [1.0 if a in occ else 0.0 for a in ax_ch] == list(g['scan_occupied'])
+
+
+def _frames_of(blob):
+    """u32 length + bytes records -> list of frames."""
+    raw, pos, frames = bytes(blob), 0, []
+    while pos < len(raw):
+        ln = struct.unpack_from('<I', raw, pos)[0]
+        frames.append(raw[pos + 4:pos + 4 + ln])
+        pos += 4 + ln
+    return frames
+
+
+def test_ref_stats_scanner_noise_threshold_and_max_hold(golden):
+    """a8 in full - EMA, cumulative / periodic max, noise estimate, threshold, occupied channels: the reference's own
+    stats_watcher.spectrum_scanner (spectrum_sensor_v2.py:445-479) over the committed rows, against the restatement
+    AND against the fixture the restatement wrote (scanner_state_seq.npz, tagged 'restated' - now pinned)."""
+    g = golden('ref_threads.npz')
+    c = golden(str(g['input_from']))
+    st = R.ScannerState(1024, 1000000, 25e3, 12.5e3, tune_freq=100000000, trunc_band=800000,
+                        thr_leveler=4, alpha_avg=0.5)
+    for i, r in enumerate(c['rows']):
+        _, occ = st.scan(r.astype(np.float32))
+        assert np.allclose(st.plc, g['stats_plc_seq'][i], rtol=1e-12, atol=0)
+        assert np.isclose(st.noise_estimate, g['stats_noise_seq'][i], rtol=1e-12, atol=0)
+        assert [1.0 if a in occ else 0.0 for a in st.ax_ch] == list(g['stats_occupied_seq'][i])
+    assert np.allclose(st.cumulative_max_power, g['stats_cumulative_max'], rtol=1e-12, atol=0)
+    assert np.array_equal(g['stats_cumulative_max'], g['stats_periodic_max'])
+    assert 0 < g['stats_occupied_seq'].sum() < g['stats_occupied_seq'].size          # the threshold decides something
+    for ref_key, restated_key in (('stats_plc_seq', 'plc_seq'), ('stats_noise_seq', 'noise_seq'),
+                                  ('stats_occupied_seq', 'occupied_seq'), ('stats_cumulative_max', 'cumulative_max')):
+        assert np.allclose(g[ref_key], c[restated_key], rtol=1e-12, atol=0), ref_key
+
+
+def test_ref_watchers_last_vector_peak_hold_and_waterfall(golden):
+    """a10 / a15: psd_watcher.run, waterfall_watcher.run (spectrum_sensor_v2.py:304-354), main_thread.run
+    (local_worker.py:126-139) and data_colector.run (spectrum_sweeper.py:161-172) on messages of 1-4 vectors - only the
+    LAST vector of a message is used, the peak is a running bin-wise maximum that starts from the first vector."""
+    g = golden('ref_threads.npz')
+    c = golden(str(g['input_from']))
+    rows = c['rows'].astype(np.float32)
+    last = np.cumsum(g['msg_counts']) - 1
+    assert np.array_equal(g['waterfall'], rows[last])
+    assert np.array_equal(g['worker_vectors'], rows[last])
+    assert np.array_equal(g['collector_vectors'], c['x'].astype(np.complex64).reshape(len(rows), -1)[last])
+    peak = R.peak_hold(rows[last])[-1]
+    assert np.array_equal(g['psd_cumulative'], peak) and np.array_equal(g['psd_periodic_peaks'], peak)
+    # the row the GNU Radio chain hands over: keep_one_in_n in front of the sink keeps the LAST of n as well
+    assert R.gr_kept_vectors(np.arange(12), 2, 3).tolist() == [[4, 5], [10, 11]]
+
+
+def test_ref_packers_worker_and_sweeper(golden):
+    """f1: the reference's own packet_source.send_packet (local_worker.py:147-172, float32 and int8;
+    spectrum_sweeper.py:240-258) - the byte fixture fragments.bin, which the restatement wrote, is what they emit; and
+    lengths around the fragment boundary (the worker's ceil, the sweeper's floor + 1 with its empty last frame)."""
+    g = golden('ref_threads.npz')
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'fragments.bin')
+    assert open(path, 'rb').read() == bytes(g['fragments_bin'])
+    for n in g['frame_lengths']:
+        v = (np.arange(n, dtype=np.float32) * 0.5 - 70).astype('<f4')
+        assert R.worker_fragments(v, 1472, int(n), True) == _frames_of(g['worker_frames_%d' % n]), n
+        assert R.sweeper_fragments(v.tobytes(), 1472) == _frames_of(g['sweeper_frames_%d' % n]), n
+    assert len(_frames_of(g['sweeper_frames_368'])) == 2 and _frames_of(g['sweeper_frames_368'])[1][2:] == b''
+    assert len(_frames_of(g['worker_frames_368'])) == 1
+
+
+def test_ref_stitcher_run(golden):
+    """a5: one pass of spectrum_stitcher.run (spectrum_sweeper.py:207-231) - 2 s start delay, retune in list order on
+    channel 0 with the tune delay after each, concatenate, blend with the 1e-10 floor it re-creates every sweep, pack
+    little-endian float32.  The reference's Welch runs on complex64 here (SciPy keeps single precision), the
+    restatement in float64: the packed floats agree to float32 rounding."""
+    g = golden('ref_threads.npz')
+    assert g['stitch_sleeps'].tolist() == [2.0, 0.125, 0.125, 0.125]
+    assert g['stitch_tuned'].tolist() == [[f, 0.0] for f in g['stitch_freqs']]
+    nfft, fs, ex = int(g['stitch_nfft']), float(g['stitch_fs']), int(g['stitch_excess'])
+    got = np.frombuffer(bytes(g['stitch_packed']), '<f4')
+    assert len(got) == 3 * (nfft - 2 * ex)
+    want = R.sweeper_stitch(list(g['stitch_captures']), nfft, fs, ex, float(g['stitch_average']))
+    assert np.max(np.abs(got - want) / np.abs(want)) < 2e-5
