@@ -74,7 +74,9 @@ class spectrum_sensor(sync_block):
             import pmt
             data = str(pmt.cdr(msg))
         else:
-            data = str(msg[1]) if isinstance(msg, tuple) else str(msg)
+            if not (isinstance(msg, tuple) and len(msg) == 2):      # "Message is not a valid PDU" (:76-81): no reply
+                return
+            data = str(msg[1])
         if data == 'PAPR':
             self.set_papr(self.get_vector_sample())
             self.send_msg('papr', self.get_papr())
@@ -134,8 +136,14 @@ class spectrum_sensor(sync_block):
     def get_tune_freq(self):
         return self.tune_freq
 
+    def _log_setter(self, field, value):
+        """The setters the reference logs (:172-201): ``Time,<HHMMSS>,<field>,<value>``."""
+        if self.log:
+            self.log_file.row(field, value)
+
     def set_tune_freq(self, tune_freq):
         self.tune_freq = tune_freq
+        self._log_setter('set_tune_freq', tune_freq)
 
     def set_block_length(self, block_length):
         self.block_length = block_length
@@ -145,24 +153,28 @@ class spectrum_sensor(sync_block):
 
     def set_sample_rate(self, sample_rate):
         self.sample_rate = sample_rate
+        self._log_setter('set_samp_rate', sample_rate)
 
     def set_fft_len(self, fft_len):
         self.fft_len = fft_len
 
     def set_channel_space(self, channel_space):
         self.channel_space = channel_space
+        self._log_setter('set_channel_space', channel_space)
 
     def get_channel_space(self):
         return self.channel_space
 
     def set_search_bw(self, search_bw):
         self.search_bw = search_bw
+        self._log_setter('set_search_bw', search_bw)
 
     def get_search_bw(self):
         return self.search_bw
 
     def set_thr_leveler(self, thr_leveler):
         self.thr_leveler = thr_leveler
+        self._log_setter('set_thr_leveler', thr_leveler)
 
     def get_thr_leveler(self):
         return self.thr_leveler

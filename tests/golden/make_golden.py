@@ -234,6 +234,8 @@ def reference_fixtures():
         out['case_%d' % i] = np.array([W, H, N, Sf, tf], np.float64)
     save('ref_ascii_plot.npz', source=np.array('reference'), n=len(cases), **out)
     reference_thread_fixtures(E, T, S)
+    reference_legacy_sensor_fixture(E, T, scan)
+    reference_flank_fixture(E, T)
 
 
 def reference_thread_fixtures(E, T, S):
@@ -424,6 +426,123 @@ def reference_thread_fixtures(E, T, S):
                stitch_average=0.25, stitch_freqs=np.array(freqs), stitch_tuned=np.array(tuned, np.float64),
                stitch_sleeps=np.array(slept), stitch_packed=np.frombuffer(packed[0][0], np.uint8))
     save('ref_threads.npz', source=np.array('reference'), input_from=np.array('scanner_state_seq.npz'), **out)
+
+
+def reference_legacy_sensor_fixture(E, T, scan):
+    """ref_legacy_sensor.npz (f3): the reference's own spectrum_sensor methods (spectrum_sensor.py:73-206: work,
+    cogeng_rx, send_msg, set_papr, set_spectrum_constraint_hz, the logging setters) bound to a class without its
+    GNU Radio base, driven through one scripted session with a fixed clock; `pmt` is a stand-in where a PDU is a
+    (meta, data) tuple.  Recorded: every PDU the block publishes and the text of its request log."""
+    import io
+    from contextlib import redirect_stdout
+    from types import SimpleNamespace as NS
+    names = ['work', 'cogeng_rx', 'send_msg', 'set_spectrum_constraint_hz', 'get_spectrum_constraint_hz',
+             'get_threshold', 'get_noise_estimate', 'get_power_level_ch', 'set_papr', 'get_papr', 'set_vector_sample',
+             'get_vector_sample', 'set_sample_rate', 'set_tune_freq', 'get_tune_freq', 'set_channel_space',
+             'set_search_bw', 'set_thr_leveler', 'get_alpha_avg']
+    pmt = NS(car=lambda m: m[0], cdr=lambda m: m[1], to_python=lambda v: v, to_pmt=lambda v: v,
+             cons=lambda a, b: (a, b), intern=lambda s: s)
+    clock = NS(strftime=lambda fmt: {'%H%M%S': '120000', '%y%m%d': '140101'}[fmt])
+    Ref = E.load_methods('spectrum_sensor.py', 'spectrum_sensor', names,
+                         {'np': np, 'pmt': pmt, 'time': clock, 'fast_spectrum_scan': scan}, py2_print=True)
+    x = np.load(os.path.join(HERE, 'welch_flattop_2048.npz'))['x']
+    out = {}
+    for method in ('welch', 'fft'):
+        pdus = []
+        me = Ref()
+        me.block_length, me.sample_rate, me.fft_len = (8192 if method == 'welch' else 2048), 1000000, 2048
+        me.channel_space, me.search_bw, me.method, me.thr_leveler = 50e3, 25e3, method, 4
+        me.tune_freq, me.vector_sample, me.papr, me.spectrum_constraint_hz = 100.0e6, [0, 0], 1e-10, []
+        me.threshold, me.power_level_ch, me.noise_estimate, me.alpha_avg = 0, [], 1e-11, 0.5
+        me.log, me.log_file = True, io.StringIO()
+        me.message_port_pub = lambda port, pdu, pdus=pdus: pdus.append((port,) + tuple(pdu))
+        with redirect_stdout(io.StringIO()):
+            assert me.work([x.astype(np.complex128)], []) == me.block_length
+            me.cogeng_rx(({}, 'SC'))
+            me.cogeng_rx(({}, 'PAPR'))
+            me.cogeng_rx(({}, 'bogus'))
+            me.set_tune_freq(101.0e6)
+            me.set_thr_leveler(6)
+            assert me.work([x[5000:].astype(np.complex128)], []) == me.block_length
+            me.cogeng_rx(({}, 'SC'))                     # the noise estimate carries over (alpha_avg = 0.5)
+            me.cogeng_rx('not a pdu'[:0])                # pmt.car of a non-PDU: "Message is not a valid PDU", no reply
+        assert all(p[0] == 'PDU spect_msg' for p in pdus)
+        metas = [p[1] for p in pdus]
+        assert metas == ['thre', 'nois', 'cons', 'papr', 'unkn', 'thre', 'nois', 'cons']
+        ax_ch = T['frange'](100.0e6 - 1000000 / 2, 100.0e6 + 1000000 / 2, 50e3)
+        ax_ch2 = T['frange'](101.0e6 - 1000000 / 2, 101.0e6 + 1000000 / 2, 50e3)
+        out[method + '_metas'] = np.array(metas)
+        out[method + '_thre'] = np.array([pdus[0][2], pdus[5][2]])
+        out[method + '_nois'] = np.array([pdus[1][2], pdus[6][2]])
+        out[method + '_cons0'] = np.array([1.0 if a in pdus[2][2] else 0.0 for a in ax_ch])
+        out[method + '_cons1'] = np.array([1.0 if a in pdus[7][2] else 0.0 for a in ax_ch2])
+        assert len(pdus[2][2]) == int(out[method + '_cons0'].sum()) and len(pdus[7][2]) == int(out[method + '_cons1'].sum())
+        out[method + '_papr'] = np.array(pdus[3][2])
+        out[method + '_unkn'] = np.array(pdus[4][2])
+        out[method + '_log'] = np.frombuffer(me.log_file.getvalue().encode('ascii'), np.uint8)
+        out[method + '_block_length'] = np.array(me.block_length)
+    save('ref_legacy_sensor.npz', source=np.array('reference'), input_from=np.array('welch_flattop_2048.npz'),
+         second_offset=5000, sample_rate=1000000, fft_len=2048, channel_space=50e3, search_bw=25e3, thr_leveler=4,
+         thr_leveler2=6, tune_freq=100.0e6, tune_freq2=101.0e6, alpha_avg=0.5, **out)
+
+
+def reference_flank_fixture(E, T):
+    """ref_flank.npz (f4): the reference's own _queue0_watcher.flank_detector (flanck_detector.py:345-399) over 30 PSD
+    rows in which a tone switches on in one subject channel for ten rows - peak-tracking power, flags, alpha, noise
+    estimate per row and the edge counts.  The rows are the rectangular |FFT|^2 / N^2 chain of the committed IQ."""
+    import io
+    from contextlib import redirect_stdout
+    from types import SimpleNamespace as NS
+    N, Sf, cs, sbw = 1024, 1024000, 32000.0, 16e3
+    nvec = 30
+    x = R.synth_iq(N * nvec, 71, tones=(), dc=0)
+    t = np.arange(N * nvec)
+    Fr = float(Sf) / N
+    ax_ch = T['frange'](0 - Sf // 2, 0 + Sf // 2, cs)               # trunc_band = Sf: no truncation
+    subj = [ax_ch[10], ax_ch[20]]
+    gate = ((t // N >= 8) & (t // N < 18)).astype(np.float64)
+    x = (x + 3.0 * gate * np.exp(2j * np.pi * (ax_ch[20] / Sf) * t)).astype(np.complex64)
+    rows = R.chain_sensor_v2(x, N).astype(np.float32)
+
+    class Logger(object):      # flanck_detector.py:38-128: the dictionaries and their setters
+        def __init__(self):
+            self.cumulative_statistics, self.periodic_statistic, self.settings = {}, {}, {'n_measurements': 0}
+            self.n_measurements_period = 0
+
+        def set_settings(self, v):
+            self.settings = v
+
+        def set_n_measurements_period(self, v):
+            self.n_measurements_period = v
+
+        def set_cumulative_statistics(self, v):
+            self.cumulative_statistics = v
+
+        def set_periodic_statistic(self, v):
+            self.periodic_statistic = v
+
+    n = len(subj)
+    me = NS(fft_len=N, Fr=Fr, sample_rate=Sf, bb_freqs=T['frange'](-Sf // 2, Sf // 2, cs), srch_bins=sbw / Fr, trunc=0,
+            trunc_ch=0, noise_estimate=1e-11, alpha_avg=0.2, thr_leveler=4, verbose=True, ax_ch=ax_ch,
+            subject_channels=subj, idx_subject_channels=[ax_ch.index(c) for c in subj],
+            prev_power=np.array([1.0] * n), curr_power=np.array([1.0] * n), flag=[True] * n,
+            peak_alpha=np.array([0.0] * n), peak_alpha_original=0.5, logger=Logger())
+    detect = E.load_method('flanck_detector.py', '_queue0_watcher', 'flank_detector',
+                           {'np': np, 'src_power': T['src_power']}, py2_print=True)
+    curr, flags, alphas, noise = [], [], [], []
+    with redirect_stdout(io.StringIO()):
+        for r in rows:
+            detect(me, r)
+            curr.append(me.curr_power.copy())
+            flags.append([1.0 if f else 0.0 for f in me.flag])
+            alphas.append(me.peak_alpha.copy())
+            noise.append(me.noise_estimate)
+    stats = me.logger.cumulative_statistics
+    assert stats == me.logger.periodic_statistic and stats.get(subj[1], 0) >= 1
+    save('ref_flank.npz', source=np.array('reference'), x=x, rows=rows, fft_len=N, sample_rate=Sf, channel_space=cs,
+         search_bw=sbw, thr_leveler=4, alpha_avg=0.2, peak_alpha=0.5, subject_channels=np.array(subj),
+         curr_power_seq=np.array(curr), flag_seq=np.array(flags), peak_alpha_seq=np.array(alphas),
+         noise_seq=np.array(noise), stat_channels=np.array(sorted(stats)), stat_counts=np.array([stats[k] for k in sorted(stats)]))
 
 
 def consumer_fixture():

@@ -184,3 +184,10 @@ def cr_tools():
 
 def sweeper():
     return load('spectrum_sweeper.py', SWEEPER)
+
+
+def load_methods(module, cls, names, namespace=None, py2_print=False):
+    """-> a fresh class whose methods ARE the reference's (``load_method`` each): instantiate it without the
+    reference's ``__init__`` and set the attributes that constructor would have set."""
+    return type('Ref_' + cls, (object,),
+                {n: load_method(module, cls, n, namespace, py2_print) for n in names})

@@ -373,6 +373,49 @@ def test_legacy_spectrum_sensor_request_response(ctx, tmp_path):
         assert np.isclose(float(rows[2][3]), 10 * np.log10(thr + 1e-20), atol=1e-3) and rows[4][3] == str(cons)
 
 
+def test_ref_legacy_spectrum_sensor_session(ctx, golden, tmp_path):
+    """f3 against the reference's OWN spectrum_sensor methods (spectrum_sensor.py:73-206, ref_legacy_sensor.npz): one
+    scripted session - SC, PAPR, an unknown request, two logged setters, a second SC whose noise estimate carries
+    over, a message that is not a PDU - must publish the same PDUs in the same order and write the same log rows
+    (field names and order exact, lists exact, dB values to 1e-3: the reference computed in float64)."""
+    import ofdm_tools
+    g = golden('ref_legacy_sensor.npz')
+    x = golden(str(g['input_from']))['x']
+    Sf, N = int(g['sample_rate']), int(g['fft_len'])
+    for method in ('welch', 'fft'):
+        os.makedirs(str(tmp_path / method))
+        blk = ofdm_tools.spectrum_sensor(int(g[method + '_block_length']), sample_rate=Sf, fft_len=N,
+                                         channel_space=float(g['channel_space']), search_bw=float(g['search_bw']),
+                                         method=method, thr_leveler=int(g['thr_leveler']), tune_freq=float(g['tune_freq']),
+                                         alpha_avg=float(g['alpha_avg']), ctx=ctx, log=True, log_dir=str(tmp_path / method))
+        out = []
+        blk.msg_connect('PDU spect_msg', out.append)
+        assert blk.work([x], []) == blk.block_length
+        blk.post('PDU from_cogeng', ({}, 'SC'))
+        blk.post('PDU from_cogeng', ({}, 'PAPR'))
+        blk.post('PDU from_cogeng', ({}, 'bogus'))
+        blk.set_tune_freq(float(g['tune_freq2']))
+        blk.set_thr_leveler(int(g['thr_leveler2']))
+        assert blk.work([x[int(g['second_offset']):]], []) == blk.block_length
+        blk.post('PDU from_cogeng', ({}, 'SC'))
+        blk.post('PDU from_cogeng', '')
+        assert [m[0] for m in out] == list(g[method + '_metas'])
+        assert np.allclose([out[0][1], out[5][1]], g[method + '_thre'], rtol=1e-4)
+        assert np.allclose([out[1][1], out[6][1]], g[method + '_nois'], rtol=1e-4)
+        for k, (pdu, tune) in enumerate(((out[2], float(g['tune_freq'])), (out[7], float(g['tune_freq2'])))):
+            ax = R.frange(tune - Sf / 2, tune + Sf / 2, float(g['channel_space']))
+            assert [1.0 if a in pdu[1] else 0.0 for a in ax] == list(g[method + '_cons%d' % k])
+        assert np.isclose(out[3][1], float(g[method + '_papr']), atol=1e-4) and out[4][1] == str(g[method + '_unkn'])
+        want = [ln.split(',', 3) for ln in bytes(g[method + '_log']).decode('ascii').splitlines()]
+        got = [ln.split(',', 3) for ln in open(blk.log_file.path).read().splitlines()][1:]      # [0]: the ctor's header row
+        assert [r[2] for r in got] == [r[2] for r in want] and all(r[0] == 'Time' and len(r[1]) == 6 for r in got)
+        for a, b in zip(got, want):
+            if a[2] in ('threshold[dB]', 'noise[dB]', 'papr'):
+                assert abs(float(a[3]) - float(b[3])) < 1e-3, (a, b)
+            else:
+                assert a[3:] == b[3:], (a, b)
+
+
 def test_helper_functions_match_oracle(ctx):
     from ofdm_tools import ofdm_cr_tools as T
     x = R.synth_iq(40000, 9)
@@ -507,6 +550,27 @@ def test_flanck_detector_edges(ctx, tmp_path):
     ch20 = [e for e in blk.events if e[0] == subj[1]]
     assert (subj[1], +1) in ch20 and ch20[-1] == (subj[1], -1)
     assert blk._logger.cumulative_statistics == ref.cumulative_statistics
+
+
+def test_ref_flank_detector_through_the_block(ctx, golden, tmp_path):
+    """f4 against the reference's OWN flank_detector (flanck_detector.py:345-399, ref_flank.npz): the committed IQ
+    through the block, one vector per work() call - peak-tracking power, flags and edge counts row by row."""
+    import ofdm_tools
+    g = golden('ref_flank.npz')
+    N, Sf = int(g['fft_len']), int(g['sample_rate'])
+    subj = [float(c) for c in g['subject_channels']]
+    blk = ofdm_tools.flanck_detector(N, Sf / N, Sf, subject_channels=subj, ctx=ctx, threaded=False,
+                                     log_directory=str(tmp_path), channel_space=float(g['channel_space']),
+                                     search_bw=float(g['search_bw']), thr_leveler=int(g['thr_leveler']),
+                                     alpha_avg=float(g['alpha_avg']), trunc_band=Sf, peak_alpha=float(g['peak_alpha']))
+    x = g['x']
+    for i in range(len(g['rows'])):
+        blk.work([x[i * N:(i + 1) * N]], [])
+        assert np.allclose(blk.curr_power, g['curr_power_seq'][i], rtol=1e-4), i
+        assert [1.0 if f else 0.0 for f in blk.flag] == list(g['flag_seq'][i]), i
+    stats = blk._logger.cumulative_statistics
+    assert sorted(stats) == list(g['stat_channels']) and [stats[k] for k in sorted(stats)] == list(g['stat_counts'])
+    blk.stop()
 
 
 def test_two_threads_share_one_context():

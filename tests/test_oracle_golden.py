@@ -201,13 +201,15 @@ def test_known_answers():
 def test_reference_fixtures_are_tagged(golden):
     import glob
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'ref_*.npz')))
-    assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_scanner_seq.npz', 'ref_src_power_cases.npz',
+    assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_flank.npz', 'ref_legacy_sensor.npz',
+                     'ref_scanner_seq.npz',
+                     'ref_src_power_cases.npz',
                      'ref_src_power_fft.npz', 'ref_src_power_welch_2048.npz', 'ref_sweeper_src_power.npz',
                      'ref_threads.npz', 'ref_welch_hann_4096.npz', 'ref_xcorr_fac.npz']
     for n in names:
         g = golden(n)
         assert str(g['source']) == 'reference'
-        if n != 'ref_ascii_plot.npz':      # (carries its own input rows)
+        if n not in ('ref_ascii_plot.npz', 'ref_flank.npz'):      # (carry their own input rows)
             assert os.path.exists(os.path.join(os.path.dirname(__file__), 'golden', str(g['input_from'])))
 
 
@@ -424,3 +426,48 @@ def test_ref_stitcher_run(golden):
     assert len(got) == 3 * (nfft - 2 * ex)
     want = R.sweeper_stitch(list(g['stitch_captures']), nfft, fs, ex, float(g['stitch_average']))
     assert np.max(np.abs(got - want) / np.abs(want)) < 2e-5
+
+
+def test_ref_legacy_sensor_session(golden):
+    """f3: the reference's own spectrum_sensor methods through a scripted session (spectrum_sensor.py:73-206) - the
+    restated fast_spectrum_scan and PAPR give the PDUs it published; the second scan starts from the first one's
+    noise estimate."""
+    g = golden('ref_legacy_sensor.npz')
+    x = golden(str(g['input_from']))['x'].astype(np.complex128)
+    Sf, N, cs, sbw = int(g['sample_rate']), int(g['fft_len']), float(g['channel_space']), float(g['search_bw'])
+    for method in ('welch', 'fft'):
+        L = int(g[method + '_block_length'])
+        ne = 1e-11
+        for k, (off, tune, lev) in enumerate(((0, float(g['tune_freq']), int(g['thr_leveler'])),
+                                              (int(g['second_offset']), float(g['tune_freq2']), int(g['thr_leveler2'])))):
+            thr, plc, ne, cons = R.fast_spectrum_scan(x[off:off + L], tune, cs, sbw, N, Sf, method, lev, ne,
+                                                      float(g['alpha_avg']))
+            assert np.isclose(thr, g[method + '_thre'][k], rtol=1e-9) and np.isclose(ne, g[method + '_nois'][k], rtol=1e-9)
+            ax = R.frange(tune - Sf / 2, tune + Sf / 2, cs)
+            assert [1.0 if a in cons else 0.0 for a in ax] == list(g[method + '_cons%d' % k])
+        v = x[:L]
+        papr = 10 * np.log10((max(v * np.conjugate(v)) / (np.vdot(v, v) / len(v))).real + 1e-20)
+        assert np.isclose(papr, float(g[method + '_papr']), rtol=1e-12)
+        log = bytes(g[method + '_log']).decode('ascii').splitlines()
+        assert [ln.split(',')[2] for ln in log] == ['tune_freq[Hz]', 'threshold[dB]', 'noise[dB]', 'spectrum_constraint[Hz]',
+                                                    'tune_freq', 'papr', 'received unknown request', 'set_tune_freq',
+                                                    'set_thr_leveler', 'tune_freq[Hz]', 'threshold[dB]', 'noise[dB]',
+                                                    'spectrum_constraint[Hz]']
+
+
+def test_ref_flank_detector(golden):
+    """f4: the reference's own _queue0_watcher.flank_detector (flanck_detector.py:345-399) row by row - clipped
+    peak-tracking power, the AGC step to thr2, rising / falling edge flags, alpha reset, noise estimate, edge counts."""
+    g = golden('ref_flank.npz')
+    st = R.FlankState(int(g['fft_len']), int(g['sample_rate']), float(g['channel_space']), float(g['search_bw']),
+                      [float(c) for c in g['subject_channels']], trunc_band=int(g['sample_rate']),
+                      thr_leveler=int(g['thr_leveler']), alpha_avg=float(g['alpha_avg']), peak_alpha=float(g['peak_alpha']))
+    for i, r in enumerate(g['rows']):
+        st.detect(r)
+        assert np.allclose(st.curr_power, g['curr_power_seq'][i], rtol=1e-12, atol=0)
+        assert [1.0 if f else 0.0 for f in st.flag] == list(g['flag_seq'][i])
+        assert np.array_equal(st.peak_alpha, g['peak_alpha_seq'][i])
+        assert np.isclose(st.noise_estimate, g['noise_seq'][i], rtol=1e-12, atol=0)
+    assert sorted(st.cumulative_statistics) == list(g['stat_channels'])
+    assert [st.cumulative_statistics[k] for k in sorted(st.cumulative_statistics)] == list(g['stat_counts'])
+    assert np.allclose(R.chain_sensor_v2(g['x'], int(g['fft_len'])), g['rows'], rtol=1e-6)
