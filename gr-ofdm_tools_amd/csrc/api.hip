@@ -696,7 +696,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         if (tuned_16k && p->nfft == 8192 && p->step * 2 == p->nfft && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC &&
             nseg_run / (W > 0 ? W : 1) >= 16)
             a.sched = OTH_SCHED_CONTIGUOUS;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? (p->step * 2 == p->nfft ? 16 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : ((p->nfft == 1024 && !seg_ws) || (p->nfft == 2048 && seg_ws) ? 32 : 16)) : 8)));
+        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? ((p->step * 2 == p->nfft || (p->nperseg * 4 == p->nfft && p->step * 2 == p->nperseg)) ? 16 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : ((p->nfft == 1024 && !seg_ws) || (p->nfft == 2048 && seg_ws) ? 32 : 16)) : 8)));
         if (a.chunk < 1) a.chunk = 1;
         if ((tuned_16k1x) && a.chunk < 2) a.chunk = 2;      // its ticket for the NEXT chunk is published with a chunk's first
                                                           // segment and read at its last: chunks of at least two segments
