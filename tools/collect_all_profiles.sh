@@ -7,7 +7,7 @@
 set -u
 TAG=$1; shift
 ONLY=" $* "
-for spec in "C2:welch4096ws" "C3:csd4096ws" "C4:welch4096ws" "C4ref:welch4096_kernel" "C5:welch16k1x_pipe" "C5old:welch16k_kernel" \
+for spec in "C2:welch4096ws" "C2fast:welch4096ws" "C3:csd4096ws" "C4:welch4096ws" "C4ref:welch4096_kernel" "C5:welch16k1x_pipe" "C5old:welch16k_kernel" \
             "w256:seg_kernel" "w512:seg_kernel" "w1024:segws_kernel" "w2048:segws_kernel" "w8192:welch16k" \
             "w16384:welch16k1x_half" "p1024:seg_kernel" "p2048:seg_kernel" "p8192:welch16k" "p16384:welch16k" \
             "chain256:seg_kernel" "chain512:seg_kernel" "chain1024:seg_kernel" "chain2048:seg_kernel" "chain4096:seg_kernel" \
@@ -16,6 +16,8 @@ for spec in "C2:welch4096ws" "C3:csd4096ws" "C4:welch4096ws" "C4ref:welch4096_ke
     if [ "$ONLY" != "  " ] && [[ "$ONLY" != *" $cfg "* ]]; then continue; fi
     drv=$cfg; var=
     if [ "$cfg" = "C5old" ]; then drv=C5; var=16k4; fi
+    unset PROF_DETREND
+    if [ "$cfg" = "C2fast" ]; then drv=C2; export PROF_DETREND=fast; fi      # OTH_DETREND_CONSTANT_FAST: the build without the pilot
     OTH_W4096_VARIANT=$var tools/pmc_passes.sh prof_${TAG}_${cfg} $drv 5 $pat > /dev/null 2>&1
     echo "== $cfg"; grep -E "GB/s" $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${cfg}/trace.log | tail -1
 done

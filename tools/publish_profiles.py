@@ -23,6 +23,7 @@ CONFIGS = {
     'C2': ('welch4096ws', 8 * 2 ** 28, 'C2: 4096-pt Hann Welch, 50 % overlap, one 2^28-sample stream'),
     'C3': ('csd4096ws', 16 * 2 ** 26, 'C3: two-channel csd / coherence, 2 x 2^26 samples (16 B per sample pair)'),
     'C4': ('welch4096ws', 8 * 8 * 2 ** 25, 'C4: sweep of 8 x 2^25 samples on one GPU, Hann 4096, shift + trim + dB'),
+    'C2fast': ('welch4096ws', 8 * 2 ** 28, 'C2 with OTH_DETREND_CONSTANT_FAST: the same launch on the build without the pilot (welch4096ws_kernel<true, false>), same box and passes'),
     'C4ref': ('welch4096_kernel', 8 * 8 * 2 ** 25, 'C4 reference-faithful: flattop, nperseg 1024 zero-padded to 4096 '
               '(spectrum_sweeper.py:263): 4 transforms per 2048 new samples'),
     'C5': ('welch16k1x_pipe', 8 * 64 * 2 ** 22, 'C5: 64 channel streams x 2^22 samples, 16384-pt rect |X|^2/N^2 mean (welch16k1x_pipe_kernel: '
