@@ -788,18 +788,22 @@ __global__ void iq_power_kernel(const float2 *iq, size_t n, double *acc4) {
     }
 }
 
-// Pilot of the constant detrend (WelchArgs.pilot): the mean of a stream's first n samples, one block per stream
-// (and per channel of a pair), double accumulation; ~2 us.  Its value only has to be NEAR the stream's mean.
-__global__ __launch_bounds__(256) void pilot_mean_kernel(const float2 *x, const float2 *y, size_t stream_stride, int n,
-                                                         int nstreams, float2 *out) {
-    __shared__ double red[2][4];
+// Pilot of the constant detrend (WelchArgs.pilot): the mean of a stream's first n samples, one 1024-thread block per
+// stream (and per channel of a pair), double accumulation.  Its value only has to be NEAR the stream's mean.  Four
+// independent loads per thread and trip: at nperseg = 4096 every load of the block is in flight at once (a 256-thread
+// loop of dependent loads took 5.7 us per launch, this takes ~2).
+__global__ __launch_bounds__(1024) void pilot_mean_kernel(const float2 *x, const float2 *y, size_t stream_stride, int n,
+                                                          int nstreams, float2 *out) {
+    __shared__ double red[2][16];
     const int stream = blockIdx.x % nstreams, ch = blockIdx.x / nstreams;
     const float2 *src = (ch ? y : x) + (size_t)stream * stream_stride;
     double sr = 0.0, si = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float2 v = src[i];
-        sr += v.x;
-        si += v.y;
+    for (int i = threadIdx.x; i < n; i += 4096) {
+        float2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (i + 1024 * k < n) ? src[i + 1024 * k] : make_float2(0.f, 0.f);
+        sr += ((double)v[0].x + v[1].x) + ((double)v[2].x + v[3].x);
+        si += ((double)v[0].y + v[1].y) + ((double)v[2].y + v[3].y);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -811,16 +815,21 @@ __global__ __launch_bounds__(256) void pilot_mean_kernel(const float2 *x, const 
         red[1][threadIdx.x >> 6] = si;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const double inv = 1.0 / n;
-        out[blockIdx.x] = make_float2((float)((red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv),
-                                      (float)((red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv));
+    if (threadIdx.x < 64) {
+        sr = threadIdx.x < 16 ? red[0][threadIdx.x] : 0.0;
+        si = threadIdx.x < 16 ? red[1][threadIdx.x] : 0.0;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            sr += __shfl_xor(sr, off, 64);
+            si += __shfl_xor(si, off, 64);
+        }
+        if (threadIdx.x == 0) out[blockIdx.x] = make_float2((float)(sr / n), (float)(si / n));
     }
 }
 
 hipError_t launch_pilot_mean(const float2 *x, const float2 *y, size_t stream_stride, int n, int nstreams, float2 *out,
                              hipStream_t s) {
-    hipLaunchKernelGGL(pilot_mean_kernel, dim3(nstreams * (y ? 2 : 1)), dim3(256), 0, s, x, y, stream_stride, n, nstreams, out);
+    hipLaunchKernelGGL(pilot_mean_kernel, dim3(nstreams * (y ? 2 : 1)), dim3(1024), 0, s, x, y, stream_stride, n, nstreams, out);
     return hipGetLastError();
 }
 
