@@ -66,7 +66,10 @@ extern "C" {
                                    measured against float64: every bin inside 1e-4 at 1 ... 9
                                    segments and |m| = 35 sigma, every bin at 2e-7 with 2047 segments and a DC line of
                                    3000 sigma (70 dB above the signal), bins 0, +-1 at 1e-6 where SciPy on complex64
-                                   input reads 1e-4 ... 5e-3. */
+                                   input reads 1e-4 ... 5e-3.  The pilot is taken once per launch, per stream: an offset
+                                   that DRIFTS by D within one launch leaves the OTH_DETREND_CONSTANT_FAST bound below
+                                   with |m| = D (a drift of 10 % of a 3000-sigma line: 4e-5); chunked streaming
+                                   (oth_welch_accumulate) takes a fresh pilot per chunk. */
 #define OTH_DETREND_CONSTANT_EXACT 2 /* = OTH_DETREND_CONSTANT (the name under which the offset-proof detrend was first
                                    asked for; accepted, same builds) */
 #define OTH_DETREND_CONSTANT_FAST 3 /* the same operation on the raw samples, -1 ... +2 % of the launch (no pilot launch, no
