@@ -649,9 +649,9 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     // the pilot of every stream, then the PILOT build of whichever kernel runs (OTH_DETREND_CONSTANT_FAST: without)
     a.pilot = nullptr;
     if (p->detrend != OTH_DETREND_NONE && !p->fast_detrend) {
-        rc = ensure(c, &p->d_pilot, &p->pilot_cap, sizeof(float2) * 2 * (size_t)nstreams);
+        rc = ensure(c, &p->d_pilot, &p->pilot_cap, sizeof(float2) * 2 * kPilotProbes * (size_t)nstreams);
         if (rc) return rc;
-        HIPCHK(c, launch_pilot_mean(x, csd ? y : nullptr, stride, p->nperseg, nstreams, p->d_pilot, c->stream));
+        HIPCHK(c, launch_pilot_mean(x, csd ? y : nullptr, stride, p->nperseg, p->step, nseg, nstreams, p->d_pilot, c->stream));
         a.pilot = p->d_pilot;
     }
     if (tuned || tuned_csd || tuned_16k || tuned_seg) {

@@ -5,6 +5,8 @@
 #include "fft_lds.hip.h"
 #include "oth_internal.h"
 
+static_assert(oth::kPilotProbes == 8, "load_pilot() (fft_lds.hip.h) adds eight probe means");
+
 namespace oth {
 namespace {
 

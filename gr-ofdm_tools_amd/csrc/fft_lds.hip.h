@@ -20,10 +20,16 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// WelchArgs.pilot / SegArgs.pilot of one stream as a wave-uniform value (two scalar registers; zero without a table)
+// WelchArgs.pilot / SegArgs.pilot of one stream as a wave-uniform value (two scalar registers; zero without a table):
+// the average of the stream's eight probe means (oth_internal.h: kPilotProbes), added in one fixed order so that every
+// wave of the launch holds the same bits.
 __device__ __forceinline__ float2 load_pilot(const float2 *pilot, int idx) {
     float2 pv = make_float2(0.f, 0.f);
-    if (pilot) pv = pilot[idx];
+    if (pilot) {
+        const float2 *q = pilot + 8 * idx;
+        const float2 a = cadd(cadd(q[0], q[1]), cadd(q[2], q[3])), b = cadd(cadd(q[4], q[5]), cadd(q[6], q[7]));
+        pv = make_float2((a.x + b.x) * 0.125f, (a.y + b.y) * 0.125f);
+    }
     pv.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pv.x)));
     pv.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pv.y)));
     return pv;

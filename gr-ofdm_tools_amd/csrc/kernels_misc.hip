@@ -788,15 +788,17 @@ __global__ void iq_power_kernel(const float2 *iq, size_t n, double *acc4) {
     }
 }
 
-// Pilot of the constant detrend (WelchArgs.pilot): the mean of a stream's first n samples, one 1024-thread block per
-// stream (and per channel of a pair), double accumulation.  Its value only has to be NEAR the stream's mean.  Four
-// independent loads per thread and trip: at nperseg = 4096 every load of the block is in flight at once (a 256-thread
-// loop of dependent loads took 5.7 us per launch, this takes ~2).
+// Pilot of the constant detrend (WelchArgs.pilot): per stream (and per channel of a pair) the means of kPilotProbes
+// segments spread evenly over the launch - segment (nseg - 1) k / 7 for probe k; load_pilot() averages them, so the pilot
+// is near the stream's mean also when the stream opens with a transient or its offset drifts.  One 1024-thread block
+// per probe, double accumulation, four independent loads per thread and trip (at nperseg = 4096 every load of the block
+// is in flight at once).  Its value only has to be NEAR the mean: any constant comes off exactly.
 __global__ __launch_bounds__(1024) void pilot_mean_kernel(const float2 *x, const float2 *y, size_t stream_stride, int n,
-                                                          int nstreams, float2 *out) {
+                                                          long long step, long long nseg, int nstreams, float2 *out) {
     __shared__ double red[2][16];
-    const int stream = blockIdx.x % nstreams, ch = blockIdx.x / nstreams;
-    const float2 *src = (ch ? y : x) + (size_t)stream * stream_stride;
+    const int probe = blockIdx.x % kPilotProbes, sc = blockIdx.x / kPilotProbes;
+    const int stream = sc % nstreams, ch = sc / nstreams;
+    const float2 *src = (ch ? y : x) + (size_t)stream * stream_stride + (size_t)(((nseg - 1) * probe) / (kPilotProbes - 1)) * step;
     double sr = 0.0, si = 0.0;
     for (int i = threadIdx.x; i < n; i += 4096) {
         float2 v[4];
@@ -827,9 +829,10 @@ __global__ __launch_bounds__(1024) void pilot_mean_kernel(const float2 *x, const
     }
 }
 
-hipError_t launch_pilot_mean(const float2 *x, const float2 *y, size_t stream_stride, int n, int nstreams, float2 *out,
-                             hipStream_t s) {
-    hipLaunchKernelGGL(pilot_mean_kernel, dim3(nstreams * (y ? 2 : 1)), dim3(1024), 0, s, x, y, stream_stride, n, nstreams, out);
+hipError_t launch_pilot_mean(const float2 *x, const float2 *y, size_t stream_stride, int n, long long step, long long nseg,
+                             int nstreams, float2 *out, hipStream_t s) {
+    hipLaunchKernelGGL(pilot_mean_kernel, dim3(nstreams * (y ? 2 : 1) * kPilotProbes), dim3(1024), 0, s, x, y, stream_stride,
+                       n, step, nseg, nstreams, out);
     return hipGetLastError();
 }
 

@@ -7,6 +7,8 @@
 namespace oth {
 
 // Launch description of the segment-averaging (Welch / CSD) kernels.
+constexpr int kPilotProbes = 8;      // segment means per stream behind WelchArgs.pilot / SegArgs.pilot
+
 struct WelchArgs {
     const float2 *x;        // device IQ, stream 0
     const float2 *y;        // second channel (CSD) or nullptr
@@ -29,13 +31,14 @@ struct WelchArgs {
     // welch4096ws frequency-domain detrend: per consumer thread t = 16 k0 + k1 the window spectrum at bins
     // k0 + 16 k1 and k0 + 16 k1 + 3840 (re, im, re, im); nullptr when the window's spectrum is not confined
     const float4 *fd;
-    // Pilot of the constant detrend (round 4; every plan but OTH_DETREND_CONSTANT_FAST): one complex value per stream (x streams, then y streams) NEAR the
-    // stream's mean - the mean of its first nperseg samples (launch_pilot_mean).  The PILOT build of every detrending
-    // kernel subtracts it from each sample as it is loaded, so the sums, the window products and (in the builds that
-    // detrend after the transform) the transform itself see x - pilot: no DC line whose float32 rounding would stay
-    // behind, and the segment mean that is removed afterwards is a small residual known to its own rounding.  The
-    // result is mathematically unchanged (a constant detrend removes any constant); numerically bins 0, +-1 go from
-    // the float32 mean's 1e-4 ... 5e-3 (SciPy on complex64 included) to 1e-6.  nullptr: the builds without.
+    // Pilot of the constant detrend (round 4; every plan but OTH_DETREND_CONSTANT_FAST): per stream (x streams, then y
+    // streams) kPilotProbes segment means spread over the launch (launch_pilot_mean); load_pilot() averages them into one
+    // complex value NEAR the stream's mean.  The PILOT build of every detrending kernel subtracts it from each sample
+    // as it is loaded, so the sums, the window products and (in the builds that detrend after the transform) the
+    // transform itself see x - pilot: no DC line whose float32 rounding would stay behind, and the segment mean that is
+    // removed afterwards is a small residual known to its own rounding.  The result is mathematically unchanged (a
+    // constant detrend removes any constant); numerically bins 0, +-1 go from the float32 mean's 1e-4 ... 5e-3 (SciPy
+    // on complex64 included) to 1e-6.  nullptr: the builds without.
     const float2 *pilot;
 };
 
@@ -197,9 +200,10 @@ hipError_t launch_synth(float2 *iq, size_t n, uint64_t seed, int ntones, const f
 hipError_t launch_read_probe(const void *p, size_t bytes, float *sink, hipStream_t s);
 hipError_t launch_read_probe8(const void *p, size_t bytes, float *sink, hipStream_t s);
 hipError_t launch_iq_power(const float2 *iq, size_t n, double *acc4, hipStream_t s);
-// out[stream] = mean of the first n samples of stream `stream` of x (and out[nstreams + stream] of y when y != nullptr)
-hipError_t launch_pilot_mean(const float2 *x, const float2 *y, size_t stream_stride, int n, int nstreams, float2 *out,
-                             hipStream_t s);
+// out[(channel * nstreams + stream) * kPilotProbes + k] = mean of the n samples of segment (nseg - 1) k / (kPilotProbes - 1)
+// of stream `stream` of x (channel 0) and, when y != nullptr, of y (channel 1)
+hipError_t launch_pilot_mean(const float2 *x, const float2 *y, size_t stream_stride, int n, long long step, long long nseg,
+                             int nstreams, float2 *out, hipStream_t s);
 
 bool generic_supported(int nfft);
 size_t generic_lds_bytes(int nfft);

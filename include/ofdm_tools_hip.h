@@ -58,18 +58,19 @@ extern "C" {
 /* detrend (scipy.signal.welch detrend=...) */
 #define OTH_DETREND_NONE     0
 #define OTH_DETREND_CONSTANT 1   /* per-segment mean removal, SciPy default - computed on x - pilot: before anything else
-                                   every kernel takes a pilot value per stream (the mean of the stream's first nperseg
-                                   samples, one 2 us launch) off each sample as it is loaded, so no float32 arithmetic
-                                   ever handles the DC line - neither the transform (the fastest 2048 / 4096 / 8192 /
-                                   16384-point builds at 50 % overlap remove the mean after it, FFT(x w) - m FFT(w)) nor
-                                   the segment mean, which becomes a small residual.  Mathematically the same result;
-                                   measured against float64: every bin inside 1e-4 at 1 ... 9
-                                   segments and |m| = 35 sigma, every bin at 2e-7 with 2047 segments and a DC line of
-                                   3000 sigma (70 dB above the signal), bins 0, +-1 at 1e-6 where SciPy on complex64
-                                   input reads 1e-4 ... 5e-3.  The pilot is taken once per launch, per stream: an offset
-                                   that DRIFTS by D within one launch leaves the OTH_DETREND_CONSTANT_FAST bound below
-                                   with |m| = D (a drift of 10 % of a 3000-sigma line: 4e-5); chunked streaming
-                                   (oth_welch_accumulate) takes a fresh pilot per chunk. */
+                                   every kernel takes a pilot value per stream (the average of eight segment means
+                                   spread over the launch, one small launch in front) off each sample as it is loaded,
+                                   so no float32 arithmetic ever handles the DC line - neither the transform (the fastest
+                                   2048 / 4096 / 8192 / 16384-point builds at 50 % overlap remove the mean after it,
+                                   FFT(x w) - m FFT(w)) nor the segment mean, which becomes a small residual.
+                                   Mathematically the same result; measured against float64: every
+                                   bin inside 1e-4 at 1 ... 9 segments and |m| = 35 sigma, every bin at 2e-7 with 2047
+                                   segments and a DC line of 3000 sigma (70 dB above the signal), bins 0, +-1 at 1e-6
+                                   where SciPy on complex64 input reads 1e-4 ... 5e-3.  The pilot is one value per
+                                   launch and stream: an offset that moves by D around it within one launch leaves the
+                                   OTH_DETREND_CONSTANT_FAST bound below with |m| = D / 2 (a drift from 0 to 1200 sigma
+                                   over 2047 segments: 2e-5); chunked streaming (oth_welch_accumulate) takes a fresh
+                                   pilot per chunk. */
 #define OTH_DETREND_CONSTANT_EXACT 2 /* = OTH_DETREND_CONSTANT (the name under which the offset-proof detrend was first
                                    asked for; accepted, same builds) */
 #define OTH_DETREND_CONSTANT_FAST 3 /* the same operation on the raw samples, -1 ... +2 % of the launch (no pilot launch, no
