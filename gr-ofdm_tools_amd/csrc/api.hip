@@ -2171,14 +2171,15 @@ int oth_scan_decide_dev(oth_ctx *c, const float *psd_rows_dev, int nrows, int nf
     if (use_device(c)) return OTH_ERR_HIP;
     const size_t nb = (size_t)nrows * nfft;
     const size_t o_ma = 0, o_mask = up16(o_ma + sizeof(double) * nb), o_noise = up16(o_mask + nb),
-                 o_pw = up16(o_noise + sizeof(float) * nrows), bytes = up16(o_pw + sizeof(float) * nrows * (nch + 1));
+                 o_pw = up16(o_noise + sizeof(float) * nrows), o_tm = up16(o_pw + sizeof(float) * nrows * (nch + 1)),
+                 bytes = up16(o_tm + sizeof(float) * nrows * scan_decide_tiles(nfft));
     int rc = ensure(c, &c->scratch, &c->scratch_cap, bytes);
     if (rc) return rc;
     unsigned char *d = c->scratch;
     const int *dlo = nullptr, *dhi = nullptr;
     if ((rc = channel_bounds_dev(c, nch, lo, hi, &dlo, &dhi))) return rc;
     HIPCHK(c, launch_scan_decide(psd_rows_dev, nrows, nfft, srch_bins, thr_leveler, nch, dlo,
-                                 dhi, (double *)(d + o_ma), mask_out ? d + o_mask : nullptr,
+                                 dhi, (double *)(d + o_ma), (float *)(d + o_tm), mask_out ? d + o_mask : nullptr,
                                  (float *)(d + o_noise), nch ? (float *)(d + o_pw) : nullptr, c->stream));
     if (mask_out) HIPCHK(c, hipMemcpyAsync(mask_out, d + o_mask, nb, hipMemcpyDeviceToHost, c->stream));
     if (noise_out)
@@ -2202,13 +2203,14 @@ int oth_scan_decide_dev_out(oth_ctx *c, const float *psd_rows_dev, int nrows, in
         if (lo[i] < 0 || hi[i] > nfft) return fail(c, OTH_ERR_INVALID, "channel slice outside [0, nfft]");
     if (use_device(c)) return OTH_ERR_HIP;
     const size_t nb = (size_t)nrows * nfft;
-    const size_t bytes = up16(sizeof(double) * nb);
+    const size_t o_tm = up16(sizeof(double) * nb), bytes = up16(o_tm + sizeof(float) * nrows * scan_decide_tiles(nfft));
     int rc = ensure(c, &c->scratch, &c->scratch_cap, bytes);
     if (rc) return rc;
     unsigned char *d = c->scratch;
     const int *dlo = nullptr, *dhi = nullptr;      // cached on the device: no host copy on the steady-state path
     if ((rc = channel_bounds_dev(c, nch, lo, hi, &dlo, &dhi))) return rc;
-    HIPCHK(c, launch_scan_decide(psd_rows_dev, nrows, nfft, srch_bins, thr_leveler, nch, dlo, dhi, (double *)d, mask_dev,
+    HIPCHK(c, launch_scan_decide(psd_rows_dev, nrows, nfft, srch_bins, thr_leveler, nch, dlo, dhi, (double *)d,
+                                 (float *)(d + o_tm), mask_dev,
                                  noise_dev, nch ? power_dev : nullptr, c->stream));
     return OTH_OK;
     OTH_CATCH(c)

@@ -563,15 +563,16 @@ __global__ __launch_bounds__(256) void bin_threshold_ma_kernel(const float *psd,
 // and moves on by + x[in] - x[out] for the other 15.  Sums of a few hundred float32 values in double are exact
 // (24-bit mantissas, 53-bit accumulator), so the sliding sum IS the direct one, not an approximation of it; 12 adds
 // per output instead of M = 163 at config 5's search bandwidth.  The row minimum (the noise floor of
-// spectrum_sensor_v2.py:465-467, per row) is taken on the way: non-negative floats order like their bit patterns, so
-// one atomicMin per block on the row's word, which the launcher presets to 0x7F7F7F7F (3.39e38).
+// spectrum_sensor_v2.py:465-467, per row) is taken on the way: every block leaves the minimum of its tile in
+// tile_min[row][tile], and scan_post_kernel takes the minimum of a row's few tiles (round 4: an atomicMin on a word the
+// launcher had to preset cost a fill launch per call).
 // The 4096 + M - 1 inputs of a block's 4096 outputs are staged in LDS first (coalesced; one pad word per 16 so that
 // the per-thread runs, 16 apart, fall into different banks): the taps then cost LDS reads, not dependent global loads
 // (35 us -> 5 us for 64 rows of 16384 at M = 163).
 constexpr int kMaTile = 4096, kMaRun = 16, kMaMaxM = 1024;
 __device__ __forceinline__ int ma_pad(int k) { return k + (k >> 4); }
 __global__ __launch_bounds__(256) void movavg_run_kernel(const float *psd, int nfft, double srch_bins, double *movavg,
-                                                         unsigned *noise_bits) {
+                                                         float *tile_min) {
     __shared__ float xs[(kMaTile + kMaMaxM) + (kMaTile + kMaMaxM) / 16 + 1];
     __shared__ double ys[kMaTile + kMaTile / 16];      // the outputs, written back coalesced (a thread's own run of 16
                                                        // doubles is 64 different cache lines per store instruction)
@@ -610,42 +611,58 @@ __global__ __launch_bounds__(256) void movavg_run_kernel(const float *psd, int n
     for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMin(noise_bits + blockIdx.y, __float_as_uint(fminf(fminf(red[0], red[1]), fminf(red[2], red[3]))));
+    if (threadIdx.x == 0) tile_min[blockIdx.y * gridDim.x + blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
 }
 
-// mask[k] = psd[k] > thr * noise[row]: 1024 bins per block (the one-workgroup-per-row form left 192 of 256 CUs idle at
-// 64 rows)
-__global__ __launch_bounds__(256) void row_mask_kernel(const float *psd, const float *noise, int nfft, float thr,
-                                                       unsigned char *mask) {
-    const size_t row = (size_t)blockIdx.y * nfft;
-    const float level = noise[blockIdx.y] * thr;
-    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i + 3 < nfft) {
-        const float4 v = *reinterpret_cast<const float4 *>(psd + row + i);
-        uchar4 m;
-        m.x = v.x > level ? 1 : 0;
-        m.y = v.y > level ? 1 : 0;
-        m.z = v.z > level ? 1 : 0;
-        m.w = v.w > level ? 1 : 0;
-        *reinterpret_cast<uchar4 *>(mask + row + i) = m;
-    } else {
-        for (int k = i; k < nfft; ++k) mask[row + k] = psd[row + k] > level ? 1 : 0;
+// What follows the moving average, one launch (round 4: mask and channel sums were two, behind a fill): the row's noise
+// floor = the minimum of its tile minima; blocks [0, nmb) write mask[k] = psd[k] > thr * noise for 1024 bins each (the
+// one-workgroup-per-row form left 192 of 256 CUs idle at 64 rows), blocks behind them take four channel slices each,
+// one wave per slice (ofdm_cr_tools.py:232-249: sums of the moving average over [lo, hi)).
+__global__ __launch_bounds__(256) void scan_post_kernel(const float *psd, const double *movavg, const float *tile_min,
+                                                        int ntiles, int nfft, float thr, int nmb, int nch, const int *lo,
+                                                        const int *hi, unsigned char *mask, float *noise, float *power) {
+    float floor_ = tile_min[blockIdx.y * ntiles];
+    for (int k = 1; k < ntiles; ++k) floor_ = fminf(floor_, tile_min[blockIdx.y * ntiles + k]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) noise[blockIdx.y] = floor_;
+    if ((int)blockIdx.x < nmb) {
+        if (!mask) return;
+        const size_t row = (size_t)blockIdx.y * nfft;
+        const float level = floor_ * thr;
+        const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (i + 3 < nfft) {
+            const float4 v = *reinterpret_cast<const float4 *>(psd + row + i);
+            uchar4 m;
+            m.x = v.x > level ? 1 : 0;
+            m.y = v.y > level ? 1 : 0;
+            m.z = v.z > level ? 1 : 0;
+            m.w = v.w > level ? 1 : 0;
+            *reinterpret_cast<uchar4 *>(mask + row + i) = m;
+        } else {
+            for (int k = i; k < nfft; ++k) mask[row + k] = psd[row + k] > level ? 1 : 0;
+        }
+        return;
     }
+    const int c = ((int)blockIdx.x - nmb) * 4 + (threadIdx.x >> 6);
+    if (c >= nch) return;
+    const double *row = movavg + (size_t)blockIdx.y * nfft;
+    double s = 0.0;
+    for (int i = lo[c] + (threadIdx.x & 63); i < hi[c]; i += 64) s += row[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) power[(size_t)blockIdx.y * nch + c] = (float)s;
 }
+
+int scan_decide_tiles(int nfft) { return (nfft + kMaTile - 1) / kMaTile; }
 
 hipError_t launch_scan_decide(const float *psd, int nrows, int nfft, double srch_bins, float thr, int nch, const int *lo,
-                              const int *hi, double *movavg, unsigned char *mask, float *noise, float *power,
+                              const int *hi, double *movavg, float *tile_min, unsigned char *mask, float *noise, float *power,
                               hipStream_t s) {
     if ((nfft & 3) == 0 && (reinterpret_cast<uintptr_t>(psd) & 15) == 0 && (!mask || (reinterpret_cast<uintptr_t>(mask) & 3) == 0) &&
         (int)srch_bins <= kMaMaxM) {
-        hipError_t e = hipMemsetAsync(noise, 0x7F, sizeof(float) * (size_t)nrows, s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(movavg_run_kernel, dim3((nfft + kMaTile - 1) / kMaTile, nrows), dim3(256), 0, s, psd, nfft, srch_bins,
-                           movavg, reinterpret_cast<unsigned *>(noise));
-        if (nch > 0 && power)
-            hipLaunchKernelGGL(channel_sum_kernel, dim3(nch, nrows), dim3(64), 0, s, movavg, nfft, nch, lo, hi, power);
-        if (mask)
-            hipLaunchKernelGGL(row_mask_kernel, dim3((nfft + 1023) / 1024, nrows), dim3(256), 0, s, psd, noise, nfft, thr, mask);
+        const int ntiles = scan_decide_tiles(nfft), nmb = (nfft + 1023) / 1024, ncb = (nch > 0 && power) ? (nch + 3) / 4 : 0;
+        hipLaunchKernelGGL(movavg_run_kernel, dim3(ntiles, nrows), dim3(256), 0, s, psd, nfft, srch_bins, movavg, tile_min);
+        hipLaunchKernelGGL(scan_post_kernel, dim3(nmb + ncb, nrows), dim3(256), 0, s, psd, movavg, tile_min, ntiles, nfft, thr,
+                           nmb, ncb ? nch : 0, lo, hi, mask, noise, power);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(movavg_kernel, dim3((nfft + 255) / 256, nrows), dim3(256), 0, s, psd, nfft, srch_bins, movavg,

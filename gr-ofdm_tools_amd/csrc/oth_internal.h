@@ -188,8 +188,10 @@ hipError_t launch_rows_epilogue(float *rows, long long nrows, int nfft, float al
 hipError_t launch_group_mean(const float *rows, long long ngroups, int nfft, int group, float *out, hipStream_t s);
 hipError_t launch_channel_power(const float *psd, int nrows, int nfft, double srch_bins, int nch, const int *lo,
                                 const int *hi, double *movavg, float *power, float *movavg_f, hipStream_t s);
+// tile_min: nrows x scan_decide_tiles(nfft) floats of scratch (the per-tile minima of the moving average)
+int scan_decide_tiles(int nfft);
 hipError_t launch_scan_decide(const float *psd, int nrows, int nfft, double srch_bins, float thr, int nch, const int *lo,
-                              const int *hi, double *movavg, unsigned char *mask, float *noise, float *power,
+                              const int *hi, double *movavg, float *tile_min, unsigned char *mask, float *noise, float *power,
                               hipStream_t s);
 hipError_t launch_bin_threshold(const float *psd, int nrows, int nfft, double srch_bins, float thr,
                                 unsigned char *mask, float *noise, hipStream_t s);
