@@ -569,30 +569,47 @@ __global__ __launch_bounds__(256) void bin_threshold_ma_kernel(const float *psd,
 // The 4096 + M - 1 inputs of a block's 4096 outputs are staged in LDS first (coalesced; one pad word per 16 so that
 // the per-thread runs, 16 apart, fall into different banks): the taps then cost LDS reads, not dependent global loads
 // (35 us -> 5 us for 64 rows of 16384 at M = 163).
-constexpr int kMaTile = 4096, kMaRun = 16, kMaMaxM = 1024;
-__device__ __forceinline__ int ma_pad(int k) { return k + (k >> 4); }
-__global__ __launch_bounds__(256) void movavg_run_kernel(const float *psd, int nfft, double srch_bins, double *movavg,
+#ifndef OTH_MA_RUN
+#define OTH_MA_RUN 16
+#endif
+constexpr int kMaTile = 4096, kMaRun = OTH_MA_RUN, kMaMaxM = 1024, kMaThreads = kMaTile / kMaRun;
+__device__ __forceinline__ int ma_pad(int k) { return k + k / kMaRun; }      // one pad word per run: a thread stride of kMaRun + 1 words
+__global__ __launch_bounds__(kMaThreads) void movavg_run_kernel(const float *psd, int nfft, double srch_bins, double *movavg,
                                                          float *tile_min) {
-    __shared__ float xs[(kMaTile + kMaMaxM) + (kMaTile + kMaMaxM) / 16 + 1];
-    __shared__ double ys[kMaTile + kMaTile / 16];      // the outputs, written back coalesced (a thread's own run of 16
+    __shared__ float xs[(kMaTile + kMaMaxM) + (kMaTile + kMaMaxM) / kMaRun + 1];
+    __shared__ double ys[kMaTile + kMaTile / kMaRun];      // the outputs, written back coalesced (a thread's own run of 16
                                                        // doubles is 64 different cache lines per store instruction)
-    __shared__ float red[4];
+    __shared__ float red[kMaThreads / 64];
     const float *x = psd + (size_t)blockIdx.y * nfft;
     double *out = movavg + (size_t)blockIdx.y * nfft;
     const int M = (int)srch_bins, half = (M - 1) / 2;
     const double inv = 1.0 / srch_bins;      // np.convolve(x, ones(M) / sb): the taps are 1 / sb there too; 16 double divisions less
     const int base = blockIdx.x * kMaTile;
     const int lo = base + half - M + 1, count = kMaTile + M - 1;      // inputs n = lo + k, k in [0, count)
-    for (int k = threadIdx.x; k < count; k += 256) {
-        const int n = lo + k;
-        xs[ma_pad(k)] = (n >= 0 && n < nfft) ? x[n] : 0.f;            // out-of-range taps are skipped = add 0
+    for (int k0 = threadIdx.x; k0 < count; k0 += 8 * kMaThreads) {          // eight independent loads per thread and trip
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = lo + k0 + kMaThreads * u;
+            a[u] = (k0 + kMaThreads * u < count && n >= 0 && n < nfft) ? x[n] : 0.f;      // out-of-range taps are skipped = add 0
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + kMaThreads * u < count) xs[ma_pad(k0 + kMaThreads * u)] = a[u];
     }
     __syncthreads();
     const int t0 = threadIdx.x * kMaRun, i0 = base + t0;              // output i0 + r takes xs[t0 + r .. t0 + r + M - 1]
     float mn = 3.4e38f;
     if (i0 < nfft) {
         double s = 0.0;
-        for (int j = 0; j < M; ++j) s += (double)xs[ma_pad(t0 + j)];
+        int j = 0;
+        for (; j + 8 <= M; j += 8) {      // eight independent LDS reads per trip (one read per trip waited ~100 cycles each)
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = xs[ma_pad(t0 + j + u)];
+            s += (((double)a[0] + a[1]) + ((double)a[2] + a[3])) + (((double)a[4] + a[5]) + ((double)a[6] + a[7]));
+        }
+        for (; j < M; ++j) s += (double)xs[ma_pad(t0 + j)];
         double v = fabs(s * inv);
         ys[ma_pad(t0)] = v;
         mn = (float)v;
@@ -606,12 +623,17 @@ __global__ __launch_bounds__(256) void movavg_run_kernel(const float *psd, int n
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < kMaTile && base + k < nfft; k += 256) out[base + k] = ys[ma_pad(k)];
+    for (int k = threadIdx.x; k < kMaTile && base + k < nfft; k += kMaThreads) out[base + k] = ys[ma_pad(k)];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
     __syncthreads();
-    if (threadIdx.x == 0) tile_min[blockIdx.y * gridDim.x + blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    if (threadIdx.x == 0) {
+        float m = red[0];
+#pragma unroll
+        for (int w = 1; w < kMaThreads / 64; ++w) m = fminf(m, red[w]);
+        tile_min[blockIdx.y * gridDim.x + blockIdx.x] = m;
+    }
 }
 
 // What follows the moving average, one launch (round 4: mask and channel sums were two, behind a fill): the row's noise
@@ -660,7 +682,7 @@ hipError_t launch_scan_decide(const float *psd, int nrows, int nfft, double srch
     if ((nfft & 3) == 0 && (reinterpret_cast<uintptr_t>(psd) & 15) == 0 && (!mask || (reinterpret_cast<uintptr_t>(mask) & 3) == 0) &&
         (int)srch_bins <= kMaMaxM) {
         const int ntiles = scan_decide_tiles(nfft), nmb = (nfft + 1023) / 1024, ncb = (nch > 0 && power) ? (nch + 3) / 4 : 0;
-        hipLaunchKernelGGL(movavg_run_kernel, dim3(ntiles, nrows), dim3(256), 0, s, psd, nfft, srch_bins, movavg, tile_min);
+        hipLaunchKernelGGL(movavg_run_kernel, dim3(ntiles, nrows), dim3(kMaThreads), 0, s, psd, nfft, srch_bins, movavg, tile_min);
         hipLaunchKernelGGL(scan_post_kernel, dim3(nmb + ncb, nrows), dim3(256), 0, s, psd, movavg, tile_min, ntiles, nfft, thr,
                            nmb, ncb ? nch : 0, lo, hi, mask, noise, power);
         return hipGetLastError();
