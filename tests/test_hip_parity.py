@@ -719,6 +719,100 @@ def test_full_size_256M_properties(ctx, hip):
         ctx.free(d_in)
 
 
+def test_full_size_config3_csd_properties(ctx, hip):
+    """BASELINE config 3 at its full size (2 x 2^26 samples on the device; the oracle cannot run there): y is x delayed by
+    five samples (the same buffer, five samples in), so the truth is known in closed form -
+      (1) the role-split kernel against the independent coverage kernel on Pxx, Pyy, Pxy;
+      (2) Pxx of the pair equals the one-channel Welch PSD of x;
+      (3) magnitude-squared coherence = 1 and the phase of Pxy = conj(X) Y is that of a five-sample delay,
+          -2 pi 5 f0, at the bin of every tone f0;
+      (4) csd(y, x) = conj(csd(x, y));
+      (5) a 2^20-sample prefix against the float64 oracle."""
+    n, N, delay = 1 << 26, 4096, 5
+    d_in = ctx.alloc((n + delay) * 8)
+    try:
+        ctx.synth_iq(d_in, n + delay, 1003, R.TONES, R.DC)
+        dx, dy = d_in + 8 * delay, d_in                      # y[i] = x[i - delay]
+        tuned = ctx.welch_plan(N, window=hann(N), fs=1.0, kernel=hip.KERNEL_TUNED)
+        pxx, pyy, pxy, cxy = tuned.csd_device_src(dx, dy, n)
+        assert tuned.last_nseg == (n - 2048) // 2048
+        gen = ctx.welch_plan(N, window=hann(N), fs=1.0, kernel=hip.KERNEL_GENERIC)
+        gxx, gyy, gxy, gc = gen.csd_device_src(dx, dy, n)
+        assert relerr(pxx, gxx) < 2e-5 and relerr(pyy, gyy) < 2e-5
+        assert np.max(np.abs(pxy - gxy) / np.sqrt(gxx.astype(np.float64) * gyy)) < 2e-5
+        assert relerr(pxx, tuned.exec_device_src(dx, n)) < 2e-5
+        # a pure delay: |Pxy|^2 = Pxx Pyy up to the segment edges (5 of 4096 samples differ per segment)
+        assert np.all(cxy < 1.0 + 1e-5) and cxy.min() > 0.99
+        for amp, f0 in R.TONES:                              # at a tone's bin Pxy = conj(X) Y has the phase -2 pi d f0
+            kc = int(round(f0 * N)) % N
+            dphi = np.angle(pxy[kc] * np.exp(2j * np.pi * delay * f0))
+            assert abs(dphi) < 1e-3, (f0, dphi)
+        qxx, qyy, qxy, _ = tuned.csd_device_src(dy, dx, n)
+        assert relerr(qxx, pyy) < 2e-6 and relerr(qyy, pxx) < 2e-6
+        assert np.max(np.abs(qxy - np.conj(pxy)) / np.sqrt(pxx.astype(np.float64) * pyy)) < 2e-6
+        m = 1 << 20
+        buf = ctx.d2h(d_in, (m + delay,), np.complex64)
+        _, rc, rxx, ryy, rxy = R.coherence_np(buf[delay:], buf[:m], nperseg=N, nfft=N)
+        hxx, hyy, hxy, hc = tuned.csd(buf[delay:], buf[:m])
+        assert relerr(hxx, rxx) < RTOL and relerr(hyy, ryy) < RTOL
+        assert np.max(np.abs(hxy - rxy) / np.sqrt(rxx * ryy)) < RTOL and np.max(np.abs(hc - rc)) < RTOL
+    finally:
+        ctx.free(d_in)
+
+
+def test_full_size_config5_scanner_properties(ctx, hip):
+    """BASELINE config 5 at its full size (64 channel streams x 2^22 samples, 16384-point rectangular |X|^2 / N^2 mean
+    + the device decision stage): (1) the pipelined one-exchange kernel against the coverage kernel on all 64 rows;
+    (2) Parseval per row - with a rectangular window and no overlap the row sums to the stream's mean power exactly
+    (here: to float32 summation); (3) identical streams give identical rows, a stream scaled by 2 a row scaled by 4 and
+    the same mask; (4) the decision stage's noise floor / mask / channel sums against the restatement on the rows;
+    (5) a prefix of one stream against the float64 oracle."""
+    from ofdm_tools.scan_batch import BatchScanPlan
+    N, ns, per = 16384, 64, 1 << 22
+    d_in, d_out, d_gen = ctx.alloc(ns * per * 8), ctx.alloc(ns * N * 4), ctx.alloc(ns * N * 4)
+    try:
+        for i in range(ns):                                  # streams 0 and 1 identical
+            ctx.synth_iq(d_in + i * per * 8, per, 4000 + max(i, 1), R.TONES, R.DC)
+        bp = BatchScanPlan(ctx, N, 1000000, 15625.0, 10e3, thr_leveler=3)
+        assert bp.psd_rows_dev(d_in, per, ns, per, d_out) == per // N
+        rows = ctx.d2h(d_out, (ns, N), np.float32)
+        gen = ctx.welch_plan(N, noverlap=0, window=None, detrend=hip.DETREND_NONE, scaling=hip.SCALE_OVER_N2,
+                             fftshift=True, kernel=hip.KERNEL_GENERIC)
+        assert gen.exec_dev(d_in, per, d_gen, nstreams=ns, stream_stride=per) == per // N
+        assert relerr(rows, ctx.d2h(d_gen, (ns, N), np.float32)) < 2e-5
+        assert np.array_equal(rows[0], rows[1])
+        for i in (1, 17, 63):
+            mean, var = ctx.iq_power(d_in + i * per * 8, per)
+            power = var + abs(mean) ** 2                     # mean |x|^2
+            assert abs(rows[i].astype(np.float64).sum() - power) / power < 1e-5, i
+        mask, noise, plc = bp.decide_dev(d_out, ns)
+        st = R.ScannerState(N, 1000000, 15625.0, 10e3, trunc_band=1000000)
+        for i in (0, 1, 40):
+            ref = rows[i].astype(np.float64)
+            ma = R.movingaverage(ref, st.srch_bins)
+            assert np.isclose(noise[i], ma.min(), rtol=1e-5)
+            want = rows[i] > np.float32(3) * noise[i]
+            assert np.array_equal(mask[i].astype(bool), want)
+            assert np.allclose(plc[i], R.src_power(ref, N, st.Fr, 1000000, st.bb_freqs, st.srch_bins), rtol=1e-5)
+        assert np.array_equal(mask[0], mask[1]) and 0 < mask[0].sum() < N
+        x = ctx.d2h(d_in + 5 * per * 8, (N * 6,), np.complex64)
+        x2 = (2 * x).astype(np.complex64)
+        d_s = ctx.alloc(2 * x.nbytes)
+        try:
+            ctx.h2d(d_s, np.concatenate((x, x2)))
+            assert bp.psd_rows_dev(d_s, len(x), 2, len(x), d_out) == 6
+            pair = ctx.d2h(d_out, (2, N), np.float32)
+            assert np.array_equal(pair[1], 4 * pair[0])      # powers of two scale exactly in float32
+            m2, n2, _ = bp.decide_dev(d_out, 2)
+            assert np.array_equal(m2[0], m2[1]) and np.isclose(n2[1], 4 * n2[0], rtol=1e-6)
+        finally:
+            ctx.free(d_s)
+        assert relerr(pair[0], R.chain_sensor_v2(x, N).mean(axis=0)) < RTOL
+    finally:
+        for ptr in (d_in, d_out, d_gen):
+            ctx.free(ptr)
+
+
 def test_beyond_4GiB_offsets(ctx, hip):
     """2^29 + 5000 samples (4 GiB + a ragged tail): byte offsets pass 2^32.  The PSD of the whole stream equals
     the segment-weighted mean of the PSDs of its two halves cut with a 2048-sample halo (integer/pointer
