@@ -23,10 +23,10 @@ while time.time() - t0 < secs:
     kind = rng.choice(['welch', 'welch', 'csd', 'chain'])
     if kind == 'welch':
         nfft = int(rng.choice([256, 512, 1024, 2048, 8192, 16384]))
-        # zero-padded segments (the sweeper's nperseg = nfft / 4, and nfft / 2) at 1024 / 2048
-        nps = nfft // int(rng.choice([1, 1, 2, 4])) if nfft in (1024, 2048) else nfft
+        # zero-padded segments (the sweeper's nperseg = nfft / 4, and nfft / 2) at 1024 / 2048, nfft / 4 at 8192 / 16384
+        nps = nfft // int(rng.choice([1, 1, 2, 4])) if nfft in (1024, 2048) else (nfft // int(rng.choice([1, 1, 4])) if nfft >= 8192 else nfft)
         nov = int(rng.choice([nps // 2, nps // 2, nps // 2, 0, nps // 4, nps - 1]))
-        det = _hip.DETREND_CONSTANT if rng.random() < 0.7 else _hip.DETREND_NONE
+        det = int(rng.choice([_hip.DETREND_CONSTANT, _hip.DETREND_CONSTANT, _hip.DETREND_CONSTANT_FAST, _hip.DETREND_NONE]))
         step = nps - nov
         nseg = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(1, 3000)), int(rng.integers(3000, 30000))]))
         ns = int(rng.integers(1, 5))
@@ -49,7 +49,7 @@ while time.time() - t0 < secs:
         tuned.close()
         gen.close()
     elif kind == 'csd':
-        det = _hip.DETREND_CONSTANT if rng.random() < 0.7 else _hip.DETREND_NONE
+        det = int(rng.choice([_hip.DETREND_CONSTANT, _hip.DETREND_CONSTANT, _hip.DETREND_CONSTANT_FAST, _hip.DETREND_NONE]))
         nseg = int(rng.choice([int(rng.integers(1, 20)), int(rng.integers(1, 3000)), int(rng.integers(3000, 8000))]))
         n = 4096 + 2048 * (nseg - 1) + int(rng.integers(0, 2048))
         w = windows.get_window('hann', 4096)

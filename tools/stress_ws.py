@@ -21,14 +21,14 @@ ctx.synth_iq(d_in, 4 * nmax, 3, ((0.5, 0.1234), (2.0, 0.4071)), 0.3 - 0.2j)
 w = windows.get_window('hann', 4096)
 plans = {d: (ctx.welch_plan(4096, window=w, detrend=d, kernel=_hip.KERNEL_TUNED),
              ctx.welch_plan(4096, window=w, detrend=d, kernel=_hip.KERNEL_GENERIC))
-         for d in (_hip.DETREND_CONSTANT, _hip.DETREND_NONE)}
+         for d in (_hip.DETREND_CONSTANT, _hip.DETREND_CONSTANT_FAST, _hip.DETREND_NONE)}
 t0, n_cases, worst = time.time(), 0, 0.0
 while time.time() - t0 < secs:
     nseg = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(1, 3000)), int(rng.integers(3000, 20000))]))
     n = 4096 + 2048 * (nseg - 1) + int(rng.integers(0, 2048))
     ns = int(rng.integers(1, 5))
-    det = _hip.DETREND_CONSTANT if rng.random() < 0.7 else _hip.DETREND_NONE
-    variant = str(rng.choice(['ws', 'ws', 'ws2', 'pipe', 'dpp']))
+    det = int(rng.choice([_hip.DETREND_CONSTANT, _hip.DETREND_CONSTANT, _hip.DETREND_CONSTANT_FAST, _hip.DETREND_NONE]))      # pilot builds, raw-sample builds, none
+    variant = str(rng.choice(['ws', 'ws', 'pipe', 'dpp']))
     chunk = int(rng.choice([0, 1, 2, 3, 4, 7, 20, 33]))
     tuned, gen = plans[det]
     tuned.set_tuning(variant, chunk=chunk)
