@@ -70,29 +70,37 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     }
 }
 
-// One-launch form for the one-channel case with many partial rows (the headline Welch path): 256 threads = POS / 4
-// float4 columns (POS consecutive positions) x 1024 / POS row slices; slice sums in double, combined in a fixed
-// order.  POS = 16 gives nfft / 16 blocks (one per CU at nfft = 4096).
-template <int POS>
+// One-launch form for many partial rows (the headline Welch path; NCH = 4: the two-channel path, round 4 - it went
+// through reduce_partials_kernel + finalize_kernel, two launches): 256 threads = POS / 4 float4 columns (POS consecutive
+// positions) x 1024 / POS row slices; slice sums in double, combined in a fixed order.  POS = 16 gives nfft / 16 blocks
+// (one per CU at nfft = 4096).  Rows are [w][channel][nfft].
+template <int POS, int NCH>
 __global__ __launch_bounds__(256) void finalize_wide_kernel(FinalizeArgs a) {
     constexpr int COLS = POS / 4, SLICES = 256 / COLS;
-    __shared__ double red[SLICES][POS + 1];
+    __shared__ double red[NCH][SLICES][POS + 1];
     if (a.queue_reset && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < a.queue_n) a.queue_reset[threadIdx.x] = 0u;
     const int col = threadIdx.x % COLS, slice = threadIdx.x / COLS;
     const int stream = blockIdx.y;
-    const float *base = a.partial + (size_t)stream * a.W * a.nfft + blockIdx.x * POS + col * 4;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const float *base = a.partial + (size_t)stream * a.W * NCH * a.nfft + blockIdx.x * POS + col * 4;
+    double s[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) s[c][0] = s[c][1] = s[c][2] = s[c][3] = 0.0;
     for (int w = slice; w < a.W; w += SLICES) {
-        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)w * a.nfft);
-        s0 += v.x;
-        s1 += v.y;
-        s2 += v.z;
-        s3 += v.w;
+        float4 v[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[c] = *reinterpret_cast<const float4 *>(base + ((size_t)w * NCH + c) * a.nfft);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            s[c][0] += v[c].x;
+            s[c][1] += v[c].y;
+            s[c][2] += v[c].z;
+            s[c][3] += v[c].w;
+        }
     }
-    red[slice][col * 4] = s0;
-    red[slice][col * 4 + 1] = s1;
-    red[slice][col * 4 + 2] = s2;
-    red[slice][col * 4 + 3] = s3;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[c][slice][col * 4 + e] = s[c][e];
     __syncthreads();
     if (threadIdx.x >= POS) return;
     const int pos = blockIdx.x * POS + threadIdx.x;
@@ -100,14 +108,28 @@ __global__ __launch_bounds__(256) void finalize_wide_kernel(FinalizeArgs a) {
     const int ks = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;
     const int i = ks - a.trim;
     if (i < 0 || i >= a.nout) return;
-    double t = 0.0;
-    for (int q = 0; q < SLICES; ++q) t += red[q][threadIdx.x];
+    double t[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        t[c] = 0.0;
+        for (int q = 0; q < SLICES; ++q) t[c] += red[c][q][threadIdx.x];
+    }
     const size_t o = (size_t)stream * a.nout + i;
-    if (a.accumulate) {
-        a.out0[o] += (float)t;
-    } else {
-        const double v = t * a.scale;
-        a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
+    if constexpr (NCH == 1) {
+        if (a.accumulate) {
+            a.out0[o] += (float)t[0];
+        } else {
+            const double v = t[0] * a.scale;
+            a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
+        }
+    } else {      // as finalize_kernel: Pxx, Pyy, Pxy, Cxy
+        if (a.out0) a.out0[o] = (float)(t[0] * a.scale);
+        if (a.out1) a.out1[o] = (float)(t[1] * a.scale);
+        if (a.out2) {
+            a.out2[2 * o] = (float)(t[2] * a.scale);
+            a.out2[2 * o + 1] = (float)(t[3] * a.scale);
+        }
+        if (a.out3) a.out3[o] = (float)((t[2] * t[2] + t[3] * t[3]) / (t[0] * t[1]));
     }
 }
 
@@ -195,7 +217,11 @@ hipError_t launch_finalize(const FinalizeArgs &a_in, int nstreams, hipStream_t s
     }
     if (a.nch == 1 && a.W >= 64 && (a.nfft % 16) == 0) {
         // 16 positions per block: 5.2 us for 512 rows of 4096 against 6.8 us with 32 (half as many blocks)
-        hipLaunchKernelGGL(finalize_wide_kernel<16>, dim3(a.nfft / 16, nstreams), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((finalize_wide_kernel<16, 1>), dim3(a.nfft / 16, nstreams), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.nch == 4 && a.W >= 64 && (a.nfft % 16) == 0 && !a.accumulate && !a.db) {
+        hipLaunchKernelGGL((finalize_wide_kernel<16, 4>), dim3(a.nfft / 16, nstreams), dim3(256), 0, s, a);
         return hipGetLastError();
     }
     if (a.W > 2 * kReduceGroups && a.scratch && (a.nfft % 256) == 0) {
