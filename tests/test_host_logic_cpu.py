@@ -1,5 +1,5 @@
 """CPU tests of the host logic around the HIP path: wire format, decision stage, block API
-surface, and the multi-rank sweep sharding over gloo (world_size 2)."""
+surface, and the multi-rank sweep sharding over gloo (world_size 2, and 8 for BASELINE config 4's own shape)."""
 import inspect
 import os
 import struct
@@ -519,6 +519,21 @@ def test_sweep_sharding_world_size_2_gloo(nseg, tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert 'ok %d' % ((nseg + 1) // 2) in outs[0] and 'ok %d' % (nseg // 2) in outs[1]
+
+
+def test_sweep_sharding_world_size_8_gloo_one_segment_per_rank(tmp_path):
+    """BASELINE config 4's own shape - 8 RF segments, 8 ranks, one segment each, ONE all-gather, wideband PSD in tune
+    order on every rank - rehearsed over gloo on the CPU (the oracle stands in for the HIP plan): the 8-GPU run is the
+    driver's to launch, the partition and the reorder are checked here."""
+    script = tmp_path / 'worker8.py'
+    script.write_text(GLOO_WORKER % {'root': ROOT, 'nseg': 8})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29618', WORLD_SIZE='8', OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert 'rank %d ok 1' % r in o, o            # every rank computed exactly its own segment
 
 
 def test_sweep_shard_assignment():
