@@ -669,6 +669,24 @@ def test_long_stream_and_channel_sharding_world_size_2_gloo(nsamples, nch, tmp_p
     assert 'ok %d %d' % (nseg, min(per, nseg)) in outs[0] and 'ok %d %d' % (nseg, nseg - min(per, nseg)) in outs[1]
 
 
+def test_long_stream_and_64_channel_sharding_world_size_8_gloo(tmp_path):
+    """BASELINE config 5's shape over 8 ranks - 64 channel rows, channel c on rank c mod 8, gathered back into channel
+    order - and a long stream cut into 8 time runs with halos (Welch and coherence partial sums all-gathered and summed
+    in rank order, the same bits on every rank), rehearsed over gloo on the CPU."""
+    nsamples = 512 * 83 + 512 + 77
+    script = tmp_path / 'worker8.py'
+    script.write_text(GLOO_LONG_STREAM % {'root': ROOT, 'nsamples': nsamples, 'nch': 64})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29664', WORLD_SIZE='8', OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    nseg = (nsamples - 512) // 512
+    per = -(-nseg // 8)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert 'rank %d ok %d %d' % (r, nseg, max(0, min(per, nseg - r * per))) in o, o
+
+
 def test_time_shard_covers_every_segment_once():
     from ofdm_tools import sweep
     for n, nper, step, world in [(2 ** 20, 4096, 2048, 8), (100000, 4096, 2048, 3), (4096, 4096, 2048, 4),
