@@ -148,6 +148,9 @@ class spectrum_sensor(sync_block):
     def set_block_length(self, block_length):
         self.block_length = block_length
 
+    def set_time_observation(self, time_observation):                                    # :166-167
+        self.time_observation = time_observation
+
     def get_sample_rate(self):
         return self.sample_rate
 
