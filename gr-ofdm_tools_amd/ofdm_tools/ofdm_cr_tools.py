@@ -98,14 +98,50 @@ def src_power_fft(vector, npts, nFFT, Fr, Sf, bb_freqs, srch_bins, ctx=None):
 
 def clc_power_freq(vector, nFFT, Sf, ctx=None):
     """ofdm_cr_tools.py:149-153."""
-    ctx = ctx or _hip.default_context()
     n = len(vector)                       # normalisation uses the full length even when fft() truncates
+    return float((_raw_periodogram(vector, nFFT, ctx or _hip.default_context(), False) / n / Sf).sum())
+
+
+def _raw_periodogram(vector, nFFT, ctx, fftshift):
+    """|FFT(vector, nFFT)|^2 on the device - np.fft.fft(v, n) truncates a longer vector and zero-pads a shorter one."""
     vector = np.asarray(vector)[:nFFT]
     plan = ctx.welch_plan(nFFT, nperseg=len(vector), noverlap=0, window=None, detrend=_hip.DETREND_NONE,
-                          scaling=_hip.SCALE_RAW)
-    psd = plan.exec(vector).astype(np.float64) / n / Sf
+                          scaling=_hip.SCALE_RAW, fftshift=fftshift)
+    psd = plan.exec(vector).astype(np.float64)
     plan.close()
-    return float(psd.sum())
+    return psd
+
+
+def clc_power_time(vector, ctx=None):
+    """ofdm_cr_tools.py:144-146: mean |x|^2 (one reduction on the device)."""
+    ctx = ctx or _hip.default_context()
+    v = np.ascontiguousarray(vector, np.complex64)
+    d = ctx.alloc(v.nbytes)
+    try:
+        ctx.h2d(d, v)
+        mean, var = ctx.iq_power(d, len(v))
+    finally:
+        ctx.free(d)
+    return float(var + abs(mean) ** 2)
+
+
+def td_power_estimate(vector, Sf, ctx=None):
+    """ofdm_cr_tools.py:337-339: sum |x|^2 / Sf."""
+    return clc_power_time(vector, ctx) * len(vector) / Sf
+
+
+def fft_plot_dB(data, Sf, fc, nfft, ctx=None):
+    """ofdm_cr_tools.py:312-319: one rectangular periodogram / (npts Sf), shifted, in dB over the shifted axis."""
+    psd = _raw_periodogram(data, nfft, ctx or _hip.default_context(), True) / (len(data) * Sf)
+    fft_axis = _py2div(Sf, 2) * np.linspace(-1, 1, nfft)
+    return [item + fc for item in fft_axis], [10 * math.log10(item + 1e-20) for item in psd]
+
+
+def fft_plot_lin(data, Sf, fc, nfft, ctx=None):
+    """ofdm_cr_tools.py:328-335: the same periodogram, linear."""
+    psd = _raw_periodogram(data, nfft, ctx or _hip.default_context(), True) / len(data) / Sf
+    fft_axis = _py2div(Sf, 2) * np.linspace(-1, 1, nfft)
+    return [item + fc for item in fft_axis], psd
 
 
 def xcorr(a, b, length, ctx=None):
@@ -162,3 +198,7 @@ def fast_spectrum_scan(vct_sample, fc, channel_rate, srch_bw, n_fft, samp_rate, 
         if item > thr:
             spectrum_constraint_hz.append(ax_ch[i])
     return thr, power_level_ch, noise_estimate, spectrum_constraint_hz
+
+
+# the reference keeps its file logger next to the numeric helpers (ofdm_cr_tools.py:1850-2107): same import path here
+from .sensing_log import logger  # noqa: E402,F401

@@ -86,6 +86,30 @@ def clc_power_freq(vector, nFFT, Sf):
     return float(sum(psd_fft))
 
 
+def clc_power_time(vector):
+    """ofdm_cr_tools.py:144-146."""
+    return float(np.sum(np.absolute(np.asarray(vector, np.complex128)) ** 2)) / len(vector)
+
+
+def td_power_estimate(vector, Sf):
+    """ofdm_cr_tools.py:337-339."""
+    return float(np.sum(np.absolute(np.asarray(vector, np.complex128)) ** 2)) / Sf
+
+
+def fft_plot_lin(data, Sf, fc, nfft):
+    """ofdm_cr_tools.py:328-335: fftshift(|fft(data, nfft)|^2 / npts) / Sf over Sf/2 * linspace(-1, 1, nfft) + fc."""
+    npts = len(data)
+    psd = np.fft.fftshift(np.absolute(np.fft.fft(np.asarray(data, np.complex128), nfft)) ** 2 / npts) / Sf
+    axis = _py2div(Sf, 2) * np.linspace(-1, 1, nfft)
+    return [a + fc for a in axis], psd
+
+
+def fft_plot_dB(data, Sf, fc, nfft):
+    """ofdm_cr_tools.py:312-319: the same periodogram / (npts Sf) in dB (+1e-20 inside the log)."""
+    axis, psd = fft_plot_lin(data, Sf, fc, nfft)
+    return axis, [10 * math.log10(v + 1e-20) for v in psd]
+
+
 def xcorr(a, b, length):
     """ofdm_cr_tools.py:155-161 (``len(h)/2`` is Python-2 integer division)."""
     e = np.fft.fft(a, length)

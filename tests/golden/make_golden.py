@@ -236,6 +236,7 @@ def reference_fixtures():
     reference_thread_fixtures(E, T, S)
     reference_legacy_sensor_fixture(E, T, scan)
     reference_flank_fixture(E, T)
+    reference_fft_plot_fixture(E)
 
 
 def reference_thread_fixtures(E, T, S):
@@ -543,6 +544,29 @@ def reference_flank_fixture(E, T):
          search_bw=sbw, thr_leveler=4, alpha_avg=0.2, peak_alpha=0.5, subject_channels=np.array(subj),
          curr_power_seq=np.array(curr), flag_seq=np.array(flags), peak_alpha_seq=np.array(alphas),
          noise_seq=np.array(noise), stat_channels=np.array(sorted(stats)), stat_counts=np.array([stats[k] for k in sorted(stats)]))
+
+
+def reference_fft_plot_fixture(E):
+    """ref_fft_plot.npz: clc_power_time (ofdm_cr_tools.py:144-146), td_power_estimate (:337-339), fft_plot_dB (:312-319)
+    and fft_plot_lin (:328-335) - the reference's own bodies on the committed flattop input: a vector of exactly nfft
+    samples, a shorter one (fft() zero-pads) and a longer one (fft() truncates, the normalisation keeps the full length)."""
+    F = E.load('ofdm_cr_tools.py', ['clc_power_time', 'td_power_estimate', 'fft_plot_dB', 'fft_plot_lin'])
+    x = np.load(os.path.join(HERE, 'welch_flattop_2048.npz'))['x']
+    Sf, fc, nfft = 1000000, 100.0e6, 2048
+    out = {}
+    for tag, lo, hi in (('exact', 0, 2048), ('short', 3000, 4500), ('long', 0, 5000)):
+        v = x[lo:hi].astype(np.complex128)
+        ax, db = F['fft_plot_dB'](v, Sf, fc, nfft)
+        ax2, lin = F['fft_plot_lin'](v, Sf, fc, nfft)
+        assert ax == ax2
+        out[tag + '_range'] = np.array([lo, hi])
+        out[tag + '_axis'] = np.array(ax)
+        out[tag + '_db'] = np.array(db)
+        out[tag + '_lin'] = np.array(lin)
+        out[tag + '_power_time'] = np.array(F['clc_power_time'](v))
+        out[tag + '_td_power'] = np.array(F['td_power_estimate'](v, Sf))
+    save('ref_fft_plot.npz', source=np.array('reference'), input_from=np.array('welch_flattop_2048.npz'), Sf=Sf, fc=fc,
+         nfft=nfft, **out)
 
 
 def consumer_fixture():

@@ -435,6 +435,29 @@ def test_helper_functions_match_oracle(ctx):
         assert relerr(psd, psd2) < RTOL and np.allclose(plc, plc2, rtol=1e-4) and np.allclose(axis, axis2)
 
 
+def test_ref_fft_plot_and_time_domain_power_on_the_gpu(ctx, golden):
+    """The product helpers of the same names (HIP periodogram, device reduction) against the reference's own
+    fft_plot_dB / fft_plot_lin / clc_power_time / td_power_estimate (ref_fft_plot.npz)."""
+    from ofdm_tools import ofdm_cr_tools as T
+    g = golden('ref_fft_plot.npz')
+    x = golden(str(g['input_from']))['x']
+    Sf, fc, nfft = int(g['Sf']), float(g['fc']), int(g['nfft'])
+    for tag in ('exact', 'short', 'long'):
+        lo, hi = g[tag + '_range']
+        v = x[lo:hi]
+        ax, lin = T.fft_plot_lin(v, Sf, fc, nfft, ctx)
+        ax2, db = T.fft_plot_dB(v, Sf, fc, nfft, ctx)
+        assert np.array_equal(ax, g[tag + '_axis']) and ax == ax2
+        # a single rectangular periodogram: its deepest bins sit 1e-7 of the peak, so rows are judged by ulps of the peak
+        from test_hip_parity import check_single_rows
+        check_single_rows(np.asarray(lin)[None, :], g[tag + '_lin'][None, :])
+        strong = g[tag + '_lin'] > 1e-4 * g[tag + '_lin'].max()
+        assert np.max(np.abs(np.array(db) - g[tag + '_db'])[strong]) < 1e-3
+        assert np.isclose(T.clc_power_time(v, ctx), float(g[tag + '_power_time']), rtol=1e-5)
+        assert np.isclose(T.td_power_estimate(v, Sf, ctx), float(g[tag + '_td_power']), rtol=1e-5)
+    assert T.logger is __import__('ofdm_tools.sensing_log', fromlist=['logger']).logger      # the reference's import path
+
+
 def test_ref_src_power_fft_and_fft_scan_on_the_gpu(ctx, golden):
     """a14 through the product helpers (HIP periodogram + device channel sums) against the reference's own
     `src_power_fft` / `fast_spectrum_scan(method='fft')` output (ref_src_power_fft.npz)."""

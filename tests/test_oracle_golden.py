@@ -201,7 +201,8 @@ def test_known_answers():
 def test_reference_fixtures_are_tagged(golden):
     import glob
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'ref_*.npz')))
-    assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_flank.npz', 'ref_legacy_sensor.npz',
+    assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_fft_plot.npz', 'ref_flank.npz',
+                     'ref_legacy_sensor.npz',
                      'ref_scanner_seq.npz',
                      'ref_src_power_cases.npz',
                      'ref_src_power_fft.npz', 'ref_src_power_welch_2048.npz', 'ref_sweeper_src_power.npz',
@@ -471,3 +472,21 @@ def test_ref_flank_detector(golden):
     assert sorted(st.cumulative_statistics) == list(g['stat_channels'])
     assert [st.cumulative_statistics[k] for k in sorted(st.cumulative_statistics)] == list(g['stat_counts'])
     assert np.allclose(R.chain_sensor_v2(g['x'], int(g['fft_len'])), g['rows'], rtol=1e-6)
+
+
+def test_ref_fft_plot_and_time_domain_power(golden):
+    """clc_power_time (ofdm_cr_tools.py:144-146), td_power_estimate (:337-339), fft_plot_dB (:312-319), fft_plot_lin
+    (:328-335): the reference's own bodies on a vector of nfft samples, a shorter one (zero-padded by fft()) and a longer
+    one (truncated by fft(), normalised by its full length)."""
+    g = golden('ref_fft_plot.npz')
+    x = golden(str(g['input_from']))['x']
+    Sf, fc, nfft = int(g['Sf']), float(g['fc']), int(g['nfft'])
+    for tag in ('exact', 'short', 'long'):
+        lo, hi = g[tag + '_range']
+        v = x[lo:hi]
+        ax, lin = R.fft_plot_lin(v, Sf, fc, nfft)
+        ax2, db = R.fft_plot_dB(v, Sf, fc, nfft)
+        assert ax == ax2 and np.array_equal(ax, g[tag + '_axis'])
+        assert relerr(lin, g[tag + '_lin']) < RTOL and np.max(np.abs(np.array(db) - g[tag + '_db'])) < 1e-8
+        assert np.isclose(R.clc_power_time(v), float(g[tag + '_power_time']), rtol=1e-12)
+        assert np.isclose(R.td_power_estimate(v, Sf), float(g[tag + '_td_power']), rtol=1e-12)
