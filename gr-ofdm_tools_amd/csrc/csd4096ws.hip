@@ -91,25 +91,27 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
     const int tid = threadIdx.x;
     const bool producer = tid < 512;
     const int cidx = tid - 512;                                   // consumers: x in lanes 0..31, y in lanes 32..63
-    // producers: one stream per team, wave-uniform (scalar base addresses); consumers: per lane half
-    const int pair = producer ? __builtin_amdgcn_readfirstlane(tid >> 8) : ((cidx >> 5) & 1);
-    unsigned char *base = smem + pair * CS_PAIR_BYTES;
-    float2 *img = reinterpret_cast<float2 *>(base);             // two images of LDS_X float2
-    float2 *red = img + 2 * LDS_X;
-    int *ctrl = reinterpret_cast<int *>(red + CS_RED);
     int *ctrl0 = reinterpret_cast<int *>(reinterpret_cast<float2 *>(smem) + 2 * LDS_X + CS_RED);   // pair 0's: the ticket
 
-    const int t = producer ? (tid & 255) : (((cidx >> 6) << 5) | (cidx & 31));
-    const int hi = t >> 4, lo = t & 15;
-    const int wave = t >> 6;
     const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
-    const float2 *xb = (pair ? p.y : p.x) + (size_t)stream * p.stream_stride;
     const int sched = p.sched;
     const long long nchunks = sched ? chunk_count(p) : 1;
-    const int w1 = hi * 17 + lo, r1 = hi * RS + lo, w2 = hi * RS + lo, r2 = hi * RS + lo * 17;
 
     if (producer) {
         // ------------------------------------------------------------------ producer (welch4096ws.hip)
+        // One stream per team: the team index is wave-uniform and is taken INSIDE this branch, so that the stream's base
+        // address and the team's LDS addresses are scalars (round 5: formed in front of the branch as a select between
+        // the producers' uniform value and the consumers' per-lane one they were vector registers - every sample load
+        // carried a 64-bit VGPR address and a v_lshl_add_u64, 450 of them in the file, and the PILOT build spilled).
+        // (the thread index likewise: as a select with the consumers' index its range was unknown, and a lane offset that is
+        // not provably below 2^32 bytes rules out the scalar-base + 32-bit-offset form of global_load)
+        const int pair = __builtin_amdgcn_readfirstlane(tid >> 8);
+        const int t = tid & 255, hi = t >> 4, lo = t & 15, wave = t >> 6;
+        const int w1 = hi * 17 + lo;
+        float2 *img = reinterpret_cast<float2 *>(smem + pair * CS_PAIR_BYTES);      // two images of LDS_X float2
+        float2 *red = img + 2 * LDS_X;
+        int *ctrl = reinterpret_cast<int *>(red + CS_RED);
+        const float2 *xb = (pair ? p.y : p.x) + (size_t)stream * p.stream_stride;
         float win[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) win[a] = p.win[256 * a + t];
@@ -267,6 +269,11 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
         step_end(CS_STOP);
     } else {
         // ------------------------------------------------------------------ consumer
+        const int pair = (cidx >> 5) & 1;      // per lane half: x in lanes 0..31, y in lanes 32..63
+        const int t = ((cidx >> 6) << 5) | (cidx & 31), hi = t >> 4, lo = t & 15;
+        const int r1 = hi * RS + lo, w2 = hi * RS + lo, r2 = hi * RS + lo * 17;
+        float2 *img = reinterpret_cast<float2 *>(smem + pair * CS_PAIR_BYTES);
+        float2 *red = img + 2 * LDS_X;
         // W256^c, W256^(4c): the fifteen pass-2 twiddles are multiplied out per item (32 accumulators leave no room
         // for the thirty registers the headline kernel's consumer spends on them)
 #if OTH_CSDWS_TW == 1

@@ -13,7 +13,7 @@ detector's axis ``range(-N/2, N/2) * Fr + tune_freq`` (:188).
 import numpy as np
 
 from . import _hip, windows
-from .gr_compat import sync_block
+from .gr_compat import sync_block, to_msg
 
 
 def find_nearest_index(array, value):
@@ -110,5 +110,5 @@ class coherence_estimator(sync_block):
                                                                     self._y[:self.block_len])
             self._x = self._x[self.block_len:]
             self._y = self._y[self.block_len:]
-            self.message_port_pub('coherence', self.cxy)
+            self.message_port_pub('coherence', to_msg('coherence', self.cxy))      # (key . f32vector) pair
         return n

@@ -20,7 +20,7 @@ import threading
 
 import numpy as np
 
-try:                                            # pragma: no cover - not available in this image
+try:                                            # GNU Radio is not in this image: tests/gr_standin.py stands in for it
     from gnuradio import gr as _gr
     import pmt as _pmt
     HAVE_GNURADIO = True
@@ -64,18 +64,46 @@ class LossyQueue(object):
             return len(self._q)
 
 
+def _plain(value):
+    """Python scalars / lists for pmt.to_pmt: it converts None, bool, str, int, float, complex, dict, list, tuple and
+    numpy ARRAYS (gnuradio/pmt/pmt_to_python.py) but not numpy scalars - and the sensing results are numpy scalars
+    (np.float32 thresholds, lists of np.float64 channel frequencies)."""
+    if isinstance(value, np.generic):
+        return value.item()
+    if isinstance(value, (list, tuple)):
+        return [_plain(v) for v in value]
+    return value
+
+
 def to_msg(key, value):
-    """("freq", value) pair: a PMT cons under GNU Radio, a tuple otherwise."""
-    if HAVE_GNURADIO:                           # pragma: no cover
-        return _pmt.cons(_pmt.to_pmt(key), _pmt.to_pmt(value))
+    """(key, value) pair: pmt.cons(to_pmt(key), to_pmt(value)) under GNU Radio (python/spectrum_sensor.py:122-128), a
+    tuple otherwise."""
+    if HAVE_GNURADIO:
+        return _pmt.cons(_pmt.to_pmt(key), _pmt.to_pmt(_plain(value)))
     return (key, value)
 
 
 def pdu(payload):
     """PDU with nil metadata and a u8vector body (python/local_worker.py:168-171)."""
-    if HAVE_GNURADIO:                           # pragma: no cover
+    if HAVE_GNURADIO:
         return _pmt.cons(_pmt.PMT_NIL, _pmt.init_u8vector(len(payload), list(bytearray(payload))))
     return (None, bytes(payload))
+
+
+def pdu_parts(msg):
+    """(metadata dict, body) of a PDU, or None for a message that is not a pair - "Message is not a valid PDU", which
+    the reference answers with nothing (python/spectrum_sensor.py:77-86).  Under GNU Radio the body stays a PMT: the
+    legacy sensor compares ``str(body)`` with its request names."""
+    if HAVE_GNURADIO:
+        try:
+            meta, body = _pmt.car(msg), _pmt.cdr(msg)
+        except Exception:
+            return None
+        meta = _pmt.to_python(meta)
+        return (meta if isinstance(meta, dict) else {}), body
+    if isinstance(msg, tuple) and len(msg) == 2:
+        return (msg[0] if isinstance(msg[0], dict) else {}), msg[1]
+    return None
 
 
 class _LocalSyncBlock(object):
@@ -135,7 +163,7 @@ class _LocalSyncBlock(object):
         return pos
 
 
-if HAVE_GNURADIO:                               # pragma: no cover
+if HAVE_GNURADIO:
     class sync_block(_gr.sync_block):
         def __init__(self, name, in_sig, out_sig):
             _gr.sync_block.__init__(self, name=name, in_sig=in_sig, out_sig=out_sig)

@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 from . import _hip
-from .gr_compat import HAVE_GNURADIO, sync_block, to_msg
+from .gr_compat import pdu_parts, sync_block, to_msg
 from .ofdm_cr_tools import fast_spectrum_scan
 
 
@@ -69,34 +69,37 @@ class spectrum_sensor(sync_block):
         self.set_vector_sample(np.array(in0, np.complex64))      # the caller's buffer dies after the call
         return len(in0)
 
+    # request name (the PDU's body as text) -> method that answers it (python/spectrum_sensor.py:88-120)
+    _REQUESTS = {'PAPR': '_answer_papr', 'SC': '_answer_spectrum_constraint'}
+
     def cogeng_rx(self, msg):
-        if HAVE_GNURADIO:                                       # pragma: no cover
-            import pmt
-            data = str(pmt.cdr(msg))
-        else:
-            if not (isinstance(msg, tuple) and len(msg) == 2):      # "Message is not a valid PDU" (:76-81): no reply
-                return
-            data = str(msg[1])
-        if data == 'PAPR':
-            self.set_papr(self.get_vector_sample())
-            self.send_msg('papr', self.get_papr())
-            if self.log:                                                                # :96-98
-                self.log_file.row('tune_freq', self.get_tune_freq())
-                self.log_file.row('papr', self.get_papr())
-        elif data == 'SC':
-            self.set_spectrum_constraint_hz(self.get_vector_sample())
-            self.send_msg('thre', self.get_threshold())
-            self.send_msg('nois', self.get_noise_estimate())
-            self.send_msg('cons', self.get_spectrum_constraint_hz())
-            if self.log:                                                                # :113-117
-                self.log_file.row('tune_freq[Hz]', self.get_tune_freq())
-                self.log_file.row('threshold[dB]', 10 * np.log10(self.get_threshold() + 1e-20))
-                self.log_file.row('noise[dB]', 10 * np.log10(self.get_noise_estimate() + 1e-20))
-                self.log_file.row('spectrum_constraint[Hz]', self.get_spectrum_constraint_hz())
-        else:
-            self.send_msg('unkn', 'received unknown request')
-            if self.log:                                                                # :120
-                self.log_file.row('received unknown request')
+        parts = pdu_parts(msg)
+        if parts is None:               # "Message is not a valid PDU" (:77-83): no reply
+            return
+        getattr(self, self._REQUESTS.get(str(parts[1]), '_answer_unknown'))()
+
+    def _answer_papr(self):
+        self.set_papr(self.get_vector_sample())
+        self.send_msg('papr', self.get_papr())
+        if self.log:                                                                    # :96-98
+            self.log_file.row('tune_freq', self.get_tune_freq())
+            self.log_file.row('papr', self.get_papr())
+
+    def _answer_spectrum_constraint(self):
+        self.set_spectrum_constraint_hz(self.get_vector_sample())
+        for field, value in (('thre', self.get_threshold()), ('nois', self.get_noise_estimate()),
+                             ('cons', self.get_spectrum_constraint_hz())):
+            self.send_msg(field, value)
+        if self.log:                                                                    # :113-117
+            self.log_file.row('tune_freq[Hz]', self.get_tune_freq())
+            self.log_file.row('threshold[dB]', 10 * np.log10(self.get_threshold() + 1e-20))
+            self.log_file.row('noise[dB]', 10 * np.log10(self.get_noise_estimate() + 1e-20))
+            self.log_file.row('spectrum_constraint[Hz]', self.get_spectrum_constraint_hz())
+
+    def _answer_unknown(self):
+        self.send_msg('unkn', 'received unknown request')
+        if self.log:                                                                    # :120
+            self.log_file.row('received unknown request')
 
     def send_msg(self, meta, data):
         self.message_port_pub('PDU spect_msg', to_msg(meta, data))
