@@ -5,6 +5,9 @@
 #include "../../include/ofdm_tools_hip.h"
 #include "oth_internal.h"
 
+#include <sched.h>
+#include <time.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +37,7 @@ struct oth_ctx {
     float *sink = nullptr;
     double *acc4 = nullptr;
     unsigned *queue = nullptr;         // 64 chunk tickets for the dynamic segment schedule
+    unsigned *done_count = nullptr;    // arrival counter of a finalize launch that signals a polling host (FinalizeArgs)
     std::recursive_mutex mu;           // every entry point that takes this context (or a plan / chain of it) holds it
     bool queue_clean = false;          // all zero on the stream's timeline (finalize_kernel re-zeroes what a launch used)
     int queue_used = 0;                // counters the last averaging launch drew from
@@ -70,8 +74,16 @@ struct oth_plan {
     size_t reduce_cap = 0;
     float *d_out = nullptr;            // [4][nfft] + pxy extra
     size_t out_cap = 0;
-    float *h_out = nullptr;            // pinned, device-visible [nfft]: oth_welch_exec's finalize launch writes the PSD straight
-                                       // into host memory (no copy-engine hop between the last kernel and the synchronisation)
+    // Host-output ring of oth_welch_exec / _exec_async (round 5).  The finalize launch writes the PSD straight into a
+    // pinned, device-visible row (no copy-engine hop) and then a completion word next to it (FinalizeArgs.host_seq);
+    // the host polls that word instead of sleeping in hipStreamSynchronize.  A slot is reused kOutRing launches later.
+    static constexpr int kOutRing = 4;
+    float *h_out = nullptr;            // pinned [kOutRing][nfft]
+    unsigned *h_seq = nullptr;         // pinned [kOutRing]: low 32 bits of the ticket whose row is complete
+    uint64_t out_ticket[kOutRing] = {0, 0, 0, 0};
+    uint64_t out_nseg[kOutRing] = {0, 0, 0, 0};
+    uint64_t next_out_ticket = 1;
+    bool pilot_launch = false;         // A/B + parity: the pilot from pilot_mean_kernel also where the kernel could form it
     float2 *d_stage = nullptr;         // host-input staging (x then y)
     size_t stage_cap = 0;
     // streaming state
@@ -140,7 +152,7 @@ constexpr size_t kPinnedRingMax = 64u << 20;
 
 thread_local std::string g_err = "no error";
 
-// fewest segments per stream for which OTH_DETREND_CONSTANT_FAST picks the frequency-domain detrend builds (run_average)
+// fewest segments per stream for which a detrending plan picks the frequency-domain detrend builds (run_average)
 constexpr long long kFdMinSegments = 8;
 
 // A host buffer the runtime can DMA from directly (hipHostMalloc / hipHostRegister'd, e.g. a torch pinned tensor or a
@@ -321,11 +333,12 @@ struct W4096Variant {
     int chunk;      // default segments per chunk of the dynamic schedule (same-box A/B, tools/ab_variants.py)
     int rows;       // rows of partial sums each workgroup writes
     bool fd;        // detrends in the frequency domain: needs WelchArgs.fd (a window with a confined spectrum)
+    bool inline_pilot = false;      // forms the pilot of the constant detrend in its own prologue (WelchArgs.pilot_inline)
 };
 const W4096Variant kVariants[] = {
     {"dpp", launch_welch_tuned4096_dpp, tuned4096_blocks_per_cu_dpp, 8, 1, false},            // any step
     {"pipe", launch_welch_tuned4096_pipe, tuned4096_blocks_per_cu_pipe, 16, 1, false},        // step 2048 (50 % overlap)
-    {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 20, 1, true},     // step 2048, confined window spectrum
+    {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 20, 1, true, true},     // step 2048, confined window spectrum
 #ifdef OTH_EXPERIMENTS
     {"ws2", launch_welch_tuned4096_ws2, tuned4096_blocks_per_cu_ws2, 20, 2, true},  // the same in one 1024-thread workgroup per CU (A/B, +7 %)
     {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16, 1, false},      // stamped build (tools/diag_stamps.py)
@@ -333,10 +346,10 @@ const W4096Variant kVariants[] = {
     {"exp2", launch_welch_tuned4096_exp2, tuned4096_blocks_per_cu_exp2, 16, 1, false},
     {"exp3", launch_welch_tuned4096_exp3, tuned4096_blocks_per_cu_exp3, 16, 1, false},
     {"exp4", launch_welch_tuned4096_exp4, tuned4096_blocks_per_cu_exp4, 16, 1, false},
-    {"wsx1", launch_welch_tuned4096_wsx1, tuned4096_blocks_per_cu_wsx1, 32, 1, true},
-    {"wsx2", launch_welch_tuned4096_wsx2, tuned4096_blocks_per_cu_wsx2, 32, 1, true},
-    {"wsx3", launch_welch_tuned4096_wsx3, tuned4096_blocks_per_cu_wsx3, 32, 1, true},
-    {"wsx4", launch_welch_tuned4096_wsx4, tuned4096_blocks_per_cu_wsx4, 32, 1, true},
+    {"wsx1", launch_welch_tuned4096_wsx1, tuned4096_blocks_per_cu_wsx1, 32, 1, true, true},
+    {"wsx2", launch_welch_tuned4096_wsx2, tuned4096_blocks_per_cu_wsx2, 32, 1, true, true},
+    {"wsx3", launch_welch_tuned4096_wsx3, tuned4096_blocks_per_cu_wsx3, 32, 1, true, true},
+    {"wsx4", launch_welch_tuned4096_wsx4, tuned4096_blocks_per_cu_wsx4, 32, 1, true, true},
 #endif
 };
 // the three shipped builds are looked up by tag, never by position: the table is edited between rounds
@@ -553,17 +566,20 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     const bool csd = (y != nullptr);
     // Which detrend form.  The role-split / half-keeping builds remove the segment mean AFTER the transform,
     // FFT((x - m) w) = FFT(x w) - m FFT(w).  OTH_DETREND_CONSTANT plans run the PILOT builds of whichever form
-    // (WelchArgs.pilot): they transform x - pilot, there is no DC line, and the form after the transform is then the most
-    // accurate one at any segment count - so it is chosen whenever the window's spectrum is confined.
-    // OTH_DETREND_CONSTANT_FAST plans work on the raw samples: the fp32 transform then carries the rounding of the DC
-    // line m sum(w) into every bin - per segment about 1e-7 sqrt(nfft) |m| / sigma of the detrended power (measured:
-    // tests/test_hip_parity.py::test_detrend_forms_few_segments_and_large_dc).  Averaging takes it down by
-    // sqrt(nseg), so their launches of fewer than kFdMinSegments segments per stream - which do not need those builds'
-    // throughput either - take the time-domain builds.  A variant forced through oth_plan_set_tuning (parity suite,
-    // A/B tools) is honoured; "td" forces the time-domain builds at any length.
-    const bool fd_forced = !p->tune_variant.empty() && p->tune_variant != "td";
-    const float4 *fd_tab = (p->d_fd && p->tune_variant != "td" && (fd_forced || !p->fast_detrend || nseg >= kFdMinSegments))
-                               ? p->d_fd : nullptr;
+    // (WelchArgs.pilot): they transform x - pilot, so for a CONSTANT offset there is no DC line and the form after the
+    // transform is as accurate as the one before it at any segment count.  OTH_DETREND_CONSTANT_FAST plans
+    // work on the raw samples: the fp32 transform then carries the rounding of the DC line m sum(w) into every bin - per
+    // segment about 1e-7 sqrt(nfft) |m| / sigma of the detrended power (tests/test_hip_parity.py::
+    // test_detrend_forms_few_segments_and_large_dc), averaged down by sqrt(nseg).
+    // Launches of fewer than kFdMinSegments segments per stream take the time-domain builds in BOTH modes (round 5;
+    // round 4: FAST plans only): the pilot is one value per launch, so an offset that MOVES by D within the launch
+    // leaves a line of about D / 2 in every segment, and with one or two segments nothing averages its rounding down
+    // (advisor, round 4: D = 100 sigma at nfft >= 4096 is past 1e-4).  The time-domain pilot builds remove each
+    // segment's own mean before the transform, are as accurate on a constant offset (8.5e-7 against 1.1e-6 at one
+    // segment and 35 sigma) and such launches do not need the role-split kernels' throughput.  A variant forced through
+    // oth_plan_set_tuning (parity suite, A/B tools) is honoured; "td" forces the time-domain builds at any length.
+    const bool fd_forced = !p->tune_variant.empty() && p->tune_variant != "td" && p->tune_variant != "plaunch";
+    const float4 *fd_tab = (p->d_fd && p->tune_variant != "td" && (fd_forced || nseg >= kFdMinSegments)) ? p->d_fd : nullptr;
     // welch4096 covers nperseg = 256, 512, ..., 4096 (zero-padded to 4096)
     bool tuned = p->nfft == 4096 && p->nperseg >= 256 && (p->nperseg & (p->nperseg - 1)) == 0 && !csd;
     const bool tuned_csd = csd && p->nfft == 4096 && p->nperseg == 4096 && p->kernel != OTH_KERNEL_GENERIC;
@@ -647,12 +663,20 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     a.queue = nullptr;
     a.fd = tuned_16k1x_half ? fd1x : fd_tab;
     // the pilot of every stream, then the PILOT build of whichever kernel runs (OTH_DETREND_CONSTANT_FAST: without)
+    // (the role-split 4096-point kernels form it in their own prologue - WelchArgs.pilot_inline, round 5: one launch
+    // less in front of the transform; "plaunch" / OTH_PILOT_LAUNCH=1 keep the separate launch for A/B and parity)
     a.pilot = nullptr;
+    a.pilot_inline = 0;
     if (p->detrend != OTH_DETREND_NONE && !p->fast_detrend) {
-        rc = ensure(c, &p->d_pilot, &p->pilot_cap, sizeof(float2) * 2 * kPilotProbes * (size_t)nstreams);
-        if (rc) return rc;
-        HIPCHK(c, launch_pilot_mean(x, csd ? y : nullptr, stride, p->nperseg, p->step, nseg, nstreams, p->d_pilot, c->stream));
-        a.pilot = p->d_pilot;
+        const bool can_inline = ((tuned && var->inline_pilot) || csd_ws) && !p->pilot_launch && p->tune_variant != "plaunch";
+        if (can_inline) {
+            a.pilot_inline = 1;
+        } else {
+            rc = ensure(c, &p->d_pilot, &p->pilot_cap, sizeof(float2) * 2 * kPilotProbes * (size_t)nstreams);
+            if (rc) return rc;
+            HIPCHK(c, launch_pilot_mean(x, csd ? y : nullptr, stride, p->nperseg, p->step, nseg, nstreams, p->d_pilot, c->stream));
+            a.pilot = p->d_pilot;
+        }
     }
     if (tuned || tuned_csd || tuned_16k || tuned_seg) {
         a.sched = p->tune_sched >= 0 ? p->tune_sched : p->sched;
@@ -838,10 +862,14 @@ static int ctx_create(int device_id, void *stream, bool adopt, oth_ctx **out) {
         c->own_stream = true;
     }
     if (hipMalloc(&c->sink, 256) != hipSuccess || hipMalloc(&c->acc4, 4 * sizeof(double)) != hipSuccess ||
-        hipMalloc(&c->queue, 64 * sizeof(unsigned)) != hipSuccess) {
+        hipMalloc(&c->queue, 65 * sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(c->queue, 0, 65 * sizeof(unsigned), c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
         delete c;
         return fail(nullptr, OTH_ERR_NOMEM, "hipMalloc failed for context scratch");
     }
+    c->queue_clean = true;
+    c->done_count = c->queue + 64;     // zero now; every signalling finalize launch leaves it at zero again
     *out = c;
     return OTH_OK;
 }
@@ -1071,6 +1099,7 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     if (const char *e = getenv("OTH_W4096_SCHED")) p->tune_sched = atoi(e);
     if (const char *e = getenv("OTH_W4096_CHUNK")) p->tune_chunk = atoi(e);
     if (const char *e = getenv("OTH_W4096_TAIL")) p->tune_tail = atoi(e);
+    if (const char *e = getenv("OTH_PILOT_LAUNCH")) p->pilot_launch = atoi(e) != 0;
     std::vector<float> w(nfft, 0.f);   // zero-extended so that kernels may index [0, nfft)
     double s1 = 0.0, s2 = 0.0;
     p->rect_window = true;
@@ -1136,6 +1165,7 @@ int oth_plan_destroy(oth_plan *p) {
     if (p->d_reduce) hipFree(p->d_reduce);
     if (p->d_out) hipFree(p->d_out);
     if (p->h_out) hipHostFree(p->h_out);
+    if (p->h_seq) hipHostFree(p->h_seq);
     if (p->d_stage) hipFree(p->d_stage);
     if (p->d_sum) hipFree(p->d_sum);
     if (p->d_stream) hipFree(p->d_stream);
@@ -1187,6 +1217,7 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
         bool known = !strcmp(variant, "seg3") || !strcmp(variant, "seg4") || !strcmp(variant, "segws") ||   // 1024 / 2048
                      !strcmp(variant, "csd1") ||                                // the one-role two-channel kernel
                      !strcmp(variant, "fd") || !strcmp(variant, "td") ||        // detrend form only (run_average)
+                     !strcmp(variant, "plaunch") ||                             // pilot from its own launch (run_average)
                      !strcmp(variant, "16k4") || !strcmp(variant, "16kplain");  // 16384 points: the 4 x 4096 build / the
                                                                                 // un-pipelined one-exchange build
         for (const auto &v : kVariants) known = known || !strcmp(variant, v.tag);
@@ -1209,11 +1240,10 @@ int oth_plan_out_len(oth_plan *p, int *n) {
     OTH_CATCH((p ? p->ctx : nullptr))
 }
 
-int oth_welch_exec_dev(oth_plan *p, const void *iq_dev, size_t nsamples, int nstreams, size_t stream_stride,
-                       float *psd_out_dev, uint64_t *nseg_out) {
-    OTH_TRY
-    CtxGuard guard_(p ? p->ctx : nullptr);
-    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+// averaging launch + finalize into psd_out (device memory, or a pinned host row when host_seq is given: the finalize
+// launch then also publishes seq_value there once the row is complete)
+static int welch_exec_dev_impl(oth_plan *p, const void *iq_dev, size_t nsamples, int nstreams, size_t stream_stride,
+                               float *psd_out_dev, uint64_t *nseg_out, unsigned *host_seq, unsigned seq_value) {
     oth_ctx *c = p->ctx;
     if (!iq_dev || !psd_out_dev || nstreams < 1) return fail(c, OTH_ERR_INVALID, "bad argument");
     if (nstreams > 1 && stream_stride < nsamples) return fail(c, OTH_ERR_INVALID, "stream_stride < nsamples");
@@ -1235,9 +1265,22 @@ int oth_welch_exec_dev(oth_plan *p, const void *iq_dev, size_t nsamples, int nst
     f.trim = p->trim;
     f.db = p->db;
     f.nout = p->nfft - 2 * p->trim;
+    if (host_seq) {
+        f.done_count = c->done_count;
+        f.host_seq = host_seq;
+        f.seq_value = seq_value;
+    }
     if (int frc = finalize_and_rearm(c, f, nstreams)) return frc;
     if (nseg_out) *nseg_out = (uint64_t)nseg;
     return OTH_OK;
+}
+
+int oth_welch_exec_dev(oth_plan *p, const void *iq_dev, size_t nsamples, int nstreams, size_t stream_stride,
+                       float *psd_out_dev, uint64_t *nseg_out) {
+    OTH_TRY
+    CtxGuard guard_(p ? p->ctx : nullptr);
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    return welch_exec_dev_impl(p, iq_dev, nsamples, nstreams, stream_stride, psd_out_dev, nseg_out, nullptr, 0u);
     OTH_CATCH((p ? p->ctx : nullptr))
 }
 
@@ -1255,38 +1298,190 @@ static int stage_host(oth_plan *p, const void *x, const void *y, size_t nsamples
     return OTH_OK;
 }
 
-int oth_welch_exec(oth_plan *p, const void *iq, size_t nsamples, int src_is_device, float *psd_out,
-                   uint64_t *nseg_out) {
+// ---- host-output forms: oth_welch_exec (blocking), oth_welch_exec_async / _poll / _wait (tickets) --------------------
+// SURVEY 8d ends the metric at "PSD available on host".  Round 4: three launches, then hipStreamSynchronize - an
+// interrupt wake-up whose latency differs by 100 us between hosts of the same pool.  Now the finalize launch writes the
+// row into pinned host memory and a completion word behind it (kernels_misc.hip finalize_signal), and the host polls
+// that word: first in a tight loop, then yielding the CPU between looks, and only after kPollFallbackMs through
+// hipStreamSynchronize (which also turns a faulted launch into an error code instead of an endless wait).
+// OTH_HOSTWAIT=sync restores the wait of round 4 for the A/B.
+namespace {
+constexpr double kPollSpinUs = 200.0;          // tight polling (pause instructions only)
+constexpr double kPollFallbackMs = 200.0;      // then yield between looks; past this, hipStreamSynchronize
+
+inline double now_us() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+
+inline bool seq_reached(const unsigned *word, unsigned want) {
+    return __atomic_load_n(word, __ATOMIC_ACQUIRE) == want;
+}
+
+// -> true when the word shows `want` (the row behind it is then visible to this thread)
+bool poll_seq(const unsigned *word, unsigned want, double budget_ms) {
+    if (seq_reached(word, want)) return true;
+    const double t0 = now_us();
+    for (;;) {
+        for (int i = 0; i < 32; ++i) {
+            if (seq_reached(word, want)) return true;
+            __builtin_ia32_pause();
+        }
+        const double dt = now_us() - t0;
+        if (dt > budget_ms * 1e3) return false;
+        if (dt > kPollSpinUs) sched_yield();
+    }
+}
+
+int out_ring_init(oth_plan *p) {
+    oth_ctx *c = p->ctx;
+    if (p->h_out) return OTH_OK;
+    void *rows = nullptr, *seq = nullptr;
+    if (hipHostMalloc(&rows, sizeof(float) * p->nfft * oth_plan::kOutRing, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&seq, sizeof(unsigned) * 16 * oth_plan::kOutRing, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (rows) hipHostFree(rows);
+        return fail(c, OTH_ERR_NOMEM, "pinned host allocation failed");
+    }
+    memset(seq, 0, sizeof(unsigned) * 16 * oth_plan::kOutRing);      // one word per 64-byte line
+    p->h_out = (float *)rows;
+    p->h_seq = (unsigned *)seq;
+    return OTH_OK;
+}
+
+// Enqueue one host-output launch; the caller holds the context lock.
+int welch_enqueue(oth_plan *p, const void *iq, size_t nsamples, int src_is_device, bool caller_blocks, uint64_t *ticket_out) {
+    oth_ctx *c = p->ctx;
+    if (!iq) return fail(c, OTH_ERR_INVALID, "iq is NULL");
+    if (nsamples < (size_t)p->nperseg) return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
+    if (use_device(c)) return OTH_ERR_HIP;
+    int rc = out_ring_init(p);
+    if (rc) return rc;
+    const uint64_t ticket = p->next_out_ticket;
+    const int slot = (int)(ticket % oth_plan::kOutRing);
+    unsigned *word = p->h_seq + 16 * slot;
+    // the slot's previous launch (kOutRing tickets ago) must have delivered before its row is written again
+    if (p->out_ticket[slot] && !seq_reached(word, (unsigned)p->out_ticket[slot])) {
+        if (!poll_seq(word, (unsigned)p->out_ticket[slot], kPollFallbackMs)) HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    const float2 *dx = (const float2 *)iq, *dy = nullptr;
+    if (!src_is_device) {
+        // the caller's buffer is valid during the call only (sync_block.work()): pageable memory is staged by the
+        // runtime before hipMemcpyAsync returns; a pinned / registered source would be read asynchronously, so that
+        // copy is awaited (the one case in which the asynchronous form waits for the stream)
+        const size_t bytes = nsamples * sizeof(float2);
+        if (!caller_blocks && bytes <= kPinnedStageMax) {
+            // work()-sized buffers: through a pinned slot (as oth_welch_accumulate), so that the call returns at once -
+            // from pageable memory hipMemcpyAsync may hold the host until the stream has drained
+            if ((rc = ensure(c, &p->d_stage, &p->stage_cap, bytes))) return rc;
+            const unsigned rs = p->h_ring_next++ & 3u;
+            if (!p->h_ring_ev[rs]) HIPCHK(c, hipEventCreateWithFlags(&p->h_ring_ev[rs], hipEventDisableTiming));
+            else HIPCHK(c, hipEventSynchronize(p->h_ring_ev[rs]));
+            if (p->h_ring_cap[rs] < bytes) {
+                if (p->h_ring[rs]) HIPCHK(c, hipHostFree(p->h_ring[rs]));
+                p->h_ring[rs] = nullptr;
+                p->h_ring_cap[rs] = 0;
+                HIPCHK(c, hipHostMalloc(&p->h_ring[rs], bytes + bytes / 2 + 4096, hipHostMallocDefault));
+                p->h_ring_cap[rs] = bytes + bytes / 2 + 4096;
+            }
+            memcpy(p->h_ring[rs], iq, bytes);
+            HIPCHK(c, hipMemcpyAsync(p->d_stage, p->h_ring[rs], bytes, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipEventRecord(p->h_ring_ev[rs], c->stream));
+            dx = p->d_stage;
+        } else if (!caller_blocks && host_ptr_is_pinned(iq)) {
+            if ((rc = ensure(c, &p->d_stage, &p->stage_cap, bytes))) return rc;
+            if ((rc = copy_in_and_wait(c, p->d_stage, iq, bytes))) return rc;
+            dx = p->d_stage;
+        } else if ((rc = stage_host(p, iq, nullptr, nsamples, &dx, &dy))) {
+            return rc;
+        }
+    }
+    uint64_t nseg = 0;
+    if ((rc = welch_exec_dev_impl(p, dx, nsamples, 1, nsamples, p->h_out + (size_t)slot * p->nfft, &nseg, word,
+                                  (unsigned)ticket)))
+        return rc;
+    p->out_ticket[slot] = ticket;
+    p->out_nseg[slot] = nseg;
+    p->next_out_ticket = ticket + 1;
+    *ticket_out = ticket;
+    return OTH_OK;
+}
+
+// Collect a ticket: wait == 0 looks once, wait == 1 polls (outside the context lock) and falls back to the stream.
+int welch_collect(oth_plan *p, uint64_t ticket, float *psd_out, uint64_t *nseg_out, int *ready, bool wait) {
+    oth_ctx *c = p->ctx;
+    const int slot = (int)(ticket % oth_plan::kOutRing);
+    const unsigned *word;
+    uint64_t nseg;
+    {
+        CtxGuard guard_(c);
+        if (!ticket || !p->h_out || p->out_ticket[slot] != ticket)
+            return fail(c, OTH_ERR_STATE, "ticket unknown or overwritten (the ring keeps the last 4 launches)");
+        word = p->h_seq + 16 * slot;
+        nseg = p->out_nseg[slot];
+    }
+    static const char *hostwait = getenv("OTH_HOSTWAIT");
+    bool done = seq_reached(word, (unsigned)ticket);
+    if (!done && wait) {
+        if (!(hostwait && !strcmp(hostwait, "sync"))) done = poll_seq(word, (unsigned)ticket, kPollFallbackMs);
+        if (!done) {
+            CtxGuard guard_(c);
+            if (use_device(c)) return OTH_ERR_HIP;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            done = seq_reached(word, (unsigned)ticket);
+            if (!done) return fail(c, OTH_ERR_INTERNAL, "stream idle but the completion word was never written");
+        }
+    }
+    if (ready) *ready = done ? 1 : 0;
+    if (!done) return OTH_OK;
+    {
+        CtxGuard guard_(c);      // (a newer launch may have taken the slot while this thread was polling)
+        if (p->out_ticket[slot] != ticket)
+            return fail(c, OTH_ERR_STATE, "ticket overwritten while waiting (the ring keeps the last 4 launches)");
+        if (psd_out) memcpy(psd_out, p->h_out + (size_t)slot * p->nfft, sizeof(float) * (p->nfft - 2 * p->trim));
+    }
+    if (nseg_out) *nseg_out = nseg;
+    return OTH_OK;
+}
+}  // namespace
+
+int oth_welch_exec_async(oth_plan *p, const void *iq, size_t nsamples, int src_is_device, uint64_t *ticket_out) {
     OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
-    oth_ctx *c = p->ctx;
-    if (!iq || !psd_out) return fail(c, OTH_ERR_INVALID, "bad argument");
-    if (nsamples < (size_t)p->nperseg) return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
-    if (use_device(c)) return OTH_ERR_HIP;
-    const float2 *dx = (const float2 *)iq, *dy = nullptr;
-    int rc;
-    if (!src_is_device && (rc = stage_host(p, iq, nullptr, nsamples, &dx, &dy))) return rc;
-    const int nout = p->nfft - 2 * p->trim;
-    if (!p->h_out) {
-        if (hipHostMalloc((void **)&p->h_out, sizeof(float) * p->nfft, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            p->h_out = nullptr;
-            return fail(c, OTH_ERR_NOMEM, "pinned host allocation failed");
-        }
+    if (!ticket_out) return fail(p->ctx, OTH_ERR_INVALID, "ticket_out is NULL");
+    *ticket_out = 0;
+    return welch_enqueue(p, iq, nsamples, src_is_device, false, ticket_out);
+    OTH_CATCH((p ? p->ctx : nullptr))
+}
+
+int oth_welch_poll(oth_plan *p, uint64_t ticket, float *psd_out, uint64_t *nseg_out, int *ready) {
+    OTH_TRY
+    if (!p || !ready) return fail(p ? p->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
+    *ready = 0;
+    return welch_collect(p, ticket, psd_out, nseg_out, ready, false);
+    OTH_CATCH((p ? p->ctx : nullptr))
+}
+
+int oth_welch_wait(oth_plan *p, uint64_t ticket, float *psd_out, uint64_t *nseg_out) {
+    OTH_TRY
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    return welch_collect(p, ticket, psd_out, nseg_out, nullptr, true);
+    OTH_CATCH((p ? p->ctx : nullptr))
+}
+
+int oth_welch_exec(oth_plan *p, const void *iq, size_t nsamples, int src_is_device, float *psd_out,
+                   uint64_t *nseg_out) {
+    OTH_TRY
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    if (!iq || !psd_out) return fail(p->ctx, OTH_ERR_INVALID, "bad argument");
+    uint64_t ticket = 0;
+    {
+        CtxGuard guard_(p->ctx);
+        if (int rc = welch_enqueue(p, iq, nsamples, src_is_device, true, &ticket)) return rc;
     }
-    static const char *hostout = getenv("OTH_HOSTOUT");      // A/B: "copy" = device row + hipMemcpyAsync (rounds 1-3)
-    if (hostout && !strcmp(hostout, "copy")) {
-        if ((rc = ensure(c, &p->d_out, &p->out_cap, sizeof(float) * 5 * p->nfft))) return rc;
-        if ((rc = oth_welch_exec_dev(p, dx, nsamples, 1, nsamples, p->d_out, nseg_out))) return rc;
-        HIPCHK(c, hipMemcpyAsync(psd_out, p->d_out, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        return OTH_OK;
-    }
-    if ((rc = oth_welch_exec_dev(p, dx, nsamples, 1, nsamples, p->h_out, nseg_out))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    memcpy(psd_out, p->h_out, sizeof(float) * nout);
-    return OTH_OK;
+    return welch_collect(p, ticket, psd_out, nseg_out, nullptr, true);      // polls outside the context lock
     OTH_CATCH((p ? p->ctx : nullptr))
 }
 

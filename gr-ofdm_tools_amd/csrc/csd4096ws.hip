@@ -119,7 +119,8 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
         float2 kw[8], nxt[8];
         float2 prev_new = make_float2(0.f, 0.f);
         // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot of this team's channel comes off every sample as it arrives
-        const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, pair * p.nstreams + stream);
+        float2 pv = make_float2(0.f, 0.f);      // pilot_inline: formed below, behind the first sample loads (welch4096ws.hip)
+        if (PILOT && !p.pilot_inline) pv = load_pilot(p.pilot, pair * p.nstreams + stream);
         int it = 0;
         unsigned ticket = 0;
         using std::false_type;
@@ -229,6 +230,12 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
         };
         bool have = open_chunk(sched ? wg : 0);
         if (have) load_chunk_head(sb);
+        if (PILOT && p.pilot_inline) {      // this team's stream; per-wave totals into its image 1 (welch4096ws.hip)
+            const PilotProbes probes = inline_pilot_load(xb, p.nseg, 2048, t);
+            inline_pilot_store(probes, t, img + LDS_X);
+            lds_barrier();
+            pv = inline_pilot_value(img + LDS_X);
+        }
         while (have) {
             const int n = se - sb;
             int ncur = 0;
@@ -337,6 +344,7 @@ __global__ __launch_bounds__(TCS, 4) void csd4096ws_kernel(WelchArgs p) {
 #if !OTH_CSDWS_SWAP
         const int partner = ((tid & 63) ^ 32) << 2;      // ds_bpermute address of the lane that holds the other stream's bin
 #endif
+        if (PILOT && p.pilot_inline) lds_barrier();      // the producers' pilot barrier
         int item = next_item();
         for (;;) {
             while (item == CS_BUBBLE) item = next_item();
@@ -486,7 +494,7 @@ hipError_t launch_csd_tuned4096ws(const WelchArgs &a, hipStream_t s) {
         if (e != hipSuccess) return e;
         big_lds = true;
     }
-    if (a.detrend && a.pilot)
+    if (a.detrend && (a.pilot || a.pilot_inline))
         hipLaunchKernelGGL((csd4096ws_kernel<true, true>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
     else if (a.detrend)
         hipLaunchKernelGGL((csd4096ws_kernel<true, false>), grid, dim3(TCS), CS_LDS_BYTES, s, a);

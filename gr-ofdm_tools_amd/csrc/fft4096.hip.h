@@ -293,5 +293,43 @@ __device__ __forceinline__ float wave_total_lane63(float v) {
     return v;
 }
 
+// WelchArgs.pilot_inline: a 256-thread producer team's share of forming the pilot inside the launch.  Probe k (of
+// kPilotProbes = 8) is 256 consecutive samples - thread t takes sample t - out of segment (nseg - 1) k / 7, the k-th
+// eighth of it, so the probes cover the launch in time like pilot_mean_kernel's and each is one coalesced 2 KiB read
+// (all eight in flight at once; after the first workgroup of an XCD they are L2 hits).  inline_pilot_load() only issues
+// the loads (the caller puts its first sample loads in front of them: one round trip for both); inline_pilot_store()
+// leaves every probe's per-wave total in slot[4 k + wave] (lane 63); the CALLER places a workgroup barrier behind it
+// and then reads inline_pilot_value() = the average of the eight probe means, as load_pilot().
+struct PilotProbes {
+    float2 v[kPilotProbes];
+};
+__device__ __forceinline__ PilotProbes inline_pilot_load(const float2 *xb, long long nseg, int step, int t) {
+    PilotProbes r;
+#pragma unroll
+    for (int k = 0; k < kPilotProbes; ++k) {
+        const long long seg = ((nseg - 1) * k) / (kPilotProbes - 1);
+        const float2 *src = xb + (size_t)__builtin_amdgcn_readfirstlane((int)seg) * (size_t)step + 512 * k;
+        r.v[k] = src[(unsigned)t];
+    }
+    return r;
+}
+__device__ __forceinline__ void inline_pilot_store(const PilotProbes &r, int t, float2 *slot) {
+#pragma unroll
+    for (int k = 0; k < kPilotProbes; ++k) {
+        const float2 s = make_float2(wave_total_lane63(r.v[k].x), wave_total_lane63(r.v[k].y));
+        if ((t & 63) == 63) slot[4 * k + (t >> 6)] = s;
+    }
+}
+__device__ __forceinline__ float2 inline_pilot_value(const float2 *slot) {
+    float2 q[kPilotProbes];
+#pragma unroll
+    for (int k = 0; k < kPilotProbes; ++k) {
+        const float2 a = cadd(slot[4 * k], slot[4 * k + 1]), b = cadd(slot[4 * k + 2], slot[4 * k + 3]);
+        q[k] = make_float2((a.x + b.x) * (1.0f / 256.0f), (a.y + b.y) * (1.0f / 256.0f));
+    }
+    return pilot_of_probes(q);
+}
+
+
 }  // namespace
 }  // namespace oth

@@ -20,19 +20,25 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// WelchArgs.pilot / SegArgs.pilot of one stream as a wave-uniform value (two scalar registers; zero without a table):
-// the average of the stream's eight probe means (oth_internal.h: kPilotProbes), added in one fixed order so that every
-// wave of the launch holds the same bits.
-__device__ __forceinline__ float2 load_pilot(const float2 *pilot, int idx) {
-    float2 pv = make_float2(0.f, 0.f);
-    if (pilot) {
-        const float2 *q = pilot + 8 * idx;
-        const float2 a = cadd(cadd(q[0], q[1]), cadd(q[2], q[3])), b = cadd(cadd(q[4], q[5]), cadd(q[6], q[7]));
-        pv = make_float2((a.x + b.x) * 0.125f, (a.y + b.y) * 0.125f);
-    }
+// WelchArgs.pilot / SegArgs.pilot of one stream as a wave-uniform value (two scalar registers; zero without a table).
+// The pilot of a stream: the average of its eight probe means (oth_internal.h: kPilotProbes), added in one fixed order so
+// that every wave of the launch holds the same bits.  (Round 5 tried the MEDIAN of the probe means, so that one probe
+// inside a transient would not pull the pilot away from the other segments: over four seeds of
+// test_pilot_under_a_transient_and_a_drifting_offset the mean read 4.7-6.3e-5 on the 3000-sigma opening transient and the
+// median 4.8e-5 ... 1.3e-4 - what decides there is the float32 rounding of the one or two segments that hold the step,
+// which no constant removes; the exact time-domain builds read 3.9e-5 ... 1.1e-4 on the same inputs.)
+__device__ __forceinline__ float2 pilot_of_probes(const float2 (&q)[8]) {
+    const float2 a = cadd(cadd(q[0], q[1]), cadd(q[2], q[3])), b = cadd(cadd(q[4], q[5]), cadd(q[6], q[7]));
+    float2 pv = make_float2((a.x + b.x) * 0.125f, (a.y + b.y) * 0.125f);
     pv.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pv.x)));
     pv.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pv.y)));
     return pv;
+}
+__device__ __forceinline__ float2 load_pilot(const float2 *pilot, int idx) {
+    if (!pilot) return make_float2(0.f, 0.f);
+    const float2 *src = pilot + 8 * idx;
+    const float2 q[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+    return pilot_of_probes(q);
 }
 // multiply by -i (forward) / +i (inverse)
 template <bool INV> __device__ __forceinline__ float2 rot90(float2 a) {

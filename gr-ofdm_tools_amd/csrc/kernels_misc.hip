@@ -23,6 +23,26 @@ __device__ __forceinline__ int bin_pos(int pos, int layout) {
     return layout == 1 ? q : (pos >> 12) + (layout == 2 ? 4 : 2) * q;
 }
 
+// Completion word for a polling host (FinalizeArgs.host_seq; round 5).  Called by EVERY thread of the block after its
+// last output store: the fence holds each wave until its own stores have been performed at system scope (the outputs of
+// such a launch are pinned host memory), the block barrier collects the waves, and thread 0 arrives on the device
+// counter.  Whoever arrives last has, through that counter, all other blocks' fences before it: it re-arms the counter
+// for the next launch and publishes the sequence value with a system-scope release store.  The host (oth_welch_exec /
+// _poll / _wait in api.hip) reads the word with acquire semantics and then the rows.
+__device__ __forceinline__ void finalize_signal(const FinalizeArgs &a) {
+    if (!a.host_seq) return;      // launch-uniform
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned nblocks = gridDim.x * gridDim.y;
+        const unsigned prev = __hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == nblocks - 1) {
+            __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.host_seq, a.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // 256 threads = 32 consecutive bins x 8 slices of the workgroup axis; the 8 slice sums are
 // combined in a fixed order, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
@@ -44,30 +64,32 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     }
     for (int c = 0; c < a.nch; ++c) red[c][slice][lane] = s[c];
     __syncthreads();
-    if (slice != 0 || !live) return;
-    for (int c = 0; c < a.nch; ++c) {
-        double t = 0.0;
-        for (int q = 0; q < 8; ++q) t += red[c][q][lane];
-        s[c] = t;
-    }
-    const size_t o = (size_t)stream * a.nout + i;
-    if (a.nch == 1) {
-        if (a.accumulate) {
-            a.out0[o] += (float)s[0];
+    if (slice == 0 && live) {
+        for (int c = 0; c < a.nch; ++c) {
+            double t = 0.0;
+            for (int q = 0; q < 8; ++q) t += red[c][q][lane];
+            s[c] = t;
+        }
+        const size_t o = (size_t)stream * a.nout + i;
+        if (a.nch == 1) {
+            if (a.accumulate) {
+                a.out0[o] += (float)s[0];
+            } else {
+                const double v = s[0] * a.scale;
+                a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
+            }
         } else {
-            const double v = s[0] * a.scale;
-            a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
+            const double pxx = s[0] * a.scale, pyy = s[1] * a.scale, re = s[2] * a.scale, im = s[3] * a.scale;
+            if (a.out0) a.out0[o] = (float)pxx;
+            if (a.out1) a.out1[o] = (float)pyy;
+            if (a.out2) {
+                a.out2[2 * o] = (float)re;
+                a.out2[2 * o + 1] = (float)im;
+            }
+            if (a.out3) a.out3[o] = (float)((s[2] * s[2] + s[3] * s[3]) / (s[0] * s[1]));
         }
-    } else {
-        const double pxx = s[0] * a.scale, pyy = s[1] * a.scale, re = s[2] * a.scale, im = s[3] * a.scale;
-        if (a.out0) a.out0[o] = (float)pxx;
-        if (a.out1) a.out1[o] = (float)pyy;
-        if (a.out2) {
-            a.out2[2 * o] = (float)re;
-            a.out2[2 * o + 1] = (float)im;
-        }
-        if (a.out3) a.out3[o] = (float)((s[2] * s[2] + s[3] * s[3]) / (s[0] * s[1]));
     }
+    finalize_signal(a);
 }
 
 // One-launch form for many partial rows (the headline Welch path; NCH = 4: the two-channel path, round 4 - it went
@@ -102,35 +124,36 @@ __global__ __launch_bounds__(256) void finalize_wide_kernel(FinalizeArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[c][slice][col * 4 + e] = s[c][e];
     __syncthreads();
-    if (threadIdx.x >= POS) return;
     const int pos = blockIdx.x * POS + threadIdx.x;
     const int k = bin_pos(pos, a.layout);
     const int ks = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;
     const int i = ks - a.trim;
-    if (i < 0 || i >= a.nout) return;
-    double t[NCH];
+    if (threadIdx.x < POS && i >= 0 && i < a.nout) {
+        double t[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        t[c] = 0.0;
-        for (int q = 0; q < SLICES; ++q) t[c] += red[c][q][threadIdx.x];
-    }
-    const size_t o = (size_t)stream * a.nout + i;
-    if constexpr (NCH == 1) {
-        if (a.accumulate) {
-            a.out0[o] += (float)t[0];
-        } else {
-            const double v = t[0] * a.scale;
-            a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
+        for (int c = 0; c < NCH; ++c) {
+            t[c] = 0.0;
+            for (int q = 0; q < SLICES; ++q) t[c] += red[c][q][threadIdx.x];
         }
-    } else {      // as finalize_kernel: Pxx, Pyy, Pxy, Cxy
-        if (a.out0) a.out0[o] = (float)(t[0] * a.scale);
-        if (a.out1) a.out1[o] = (float)(t[1] * a.scale);
-        if (a.out2) {
-            a.out2[2 * o] = (float)(t[2] * a.scale);
-            a.out2[2 * o + 1] = (float)(t[3] * a.scale);
+        const size_t o = (size_t)stream * a.nout + i;
+        if constexpr (NCH == 1) {
+            if (a.accumulate) {
+                a.out0[o] += (float)t[0];
+            } else {
+                const double v = t[0] * a.scale;
+                a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
+            }
+        } else {      // as finalize_kernel: Pxx, Pyy, Pxy, Cxy
+            if (a.out0) a.out0[o] = (float)(t[0] * a.scale);
+            if (a.out1) a.out1[o] = (float)(t[1] * a.scale);
+            if (a.out2) {
+                a.out2[2 * o] = (float)(t[2] * a.scale);
+                a.out2[2 * o + 1] = (float)(t[3] * a.scale);
+            }
+            if (a.out3) a.out3[o] = (float)((t[2] * t[2] + t[3] * t[3]) / (t[0] * t[1]));
         }
-        if (a.out3) a.out3[o] = (float)((t[2] * t[2] + t[3] * t[3]) / (t[0] * t[1]));
     }
+    finalize_signal(a);
 }
 
 // Stage 1 of the cross-workgroup reduction when there are many partial rows: row group g of
@@ -207,6 +230,7 @@ __global__ __launch_bounds__(256) void finalize_l4_kernel(FinalizeArgs a) {
             a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
         }
     }
+    finalize_signal(a);
 }
 
 hipError_t launch_finalize(const FinalizeArgs &a_in, int nstreams, hipStream_t s) {

@@ -40,6 +40,12 @@ struct WelchArgs {
     // constant detrend removes any constant); numerically bins 0, +-1 go from the float32 mean's 1e-4 ... 5e-3 (SciPy
     // on complex64 included) to 1e-6.  nullptr: the builds without.
     const float2 *pilot;
+    // 1 (round 5; the role-split 4096-point kernels, one- and two-channel): the PILOT build forms its pilot itself in
+    // the launch's prologue - every producer team adds eight probes of 256 consecutive samples spread over its stream
+    // (inline_pilot() in fft4096.hip.h) - instead of reading WelchArgs.pilot: no pilot_mean_kernel launch in front of the
+    // transform (5.9 us + a dependent-launch gap per step).  The pilot only has to be NEAR the mean; every workgroup reads
+    // the same samples in the same order, so all hold the same bits.
+    int pilot_inline;
 };
 
 // Launch description of segfft.hip: segment transforms of 1024 / 2048 / 4096 points by teams of nfft / 16
@@ -111,6 +117,13 @@ struct FinalizeArgs {
     int accumulate;         // out0 += (raw sums; streaming form)
     unsigned *queue_reset;  // chunk-ticket counters of the averaging kernel, zeroed here for the next launch (or null)
     int queue_n;
+    // Completion word for a host that polls instead of sleeping in hipStreamSynchronize (oth_welch_exec / _poll / _wait,
+    // round 5): the outputs go straight to pinned host memory; every block makes its stores visible at system scope and
+    // arrives on done_count (device; the last block re-arms it to 0), and the last one to arrive then stores seq_value
+    // into *host_seq (pinned).  nullptr: none of this runs.
+    unsigned *done_count;
+    unsigned *host_seq;
+    unsigned seq_value;
 };
 
 // Every launcher returns hipSuccess / error of the launch only (asynchronous).

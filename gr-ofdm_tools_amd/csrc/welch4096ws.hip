@@ -143,7 +143,10 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
         float2 prev_new = make_float2(0.f, 0.f);     // this wave's sum of the previous segment's new half
         // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot comes off every sample as it arrives, so the transform and
         // the sums see x - pilot (two scalar registers, two subtractions per sample: +1 % on the launch)
-        const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, stream);
+        // pilot_inline (round 5): formed in the launch from eight 2 KiB probes (below, behind the first sample loads)
+        // instead of by a launch in front of this one
+        float2 pv = make_float2(0.f, 0.f);
+        if (PILOT && !p.pilot_inline) pv = load_pilot(p.pilot, stream);
         int it = 0;
         unsigned ticket = 0;
         using std::false_type;
@@ -276,6 +279,15 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
         };
         bool have = open_chunk(sched ? wg : 0);
         if (have) load_chunk_head(sb);
+        if (PILOT && p.pilot_inline) {
+            // the probe loads go out behind the chunk head's (one memory round trip for both); per-wave totals into
+            // image 1, which no step writes before the barrier of step 0; one extra workgroup barrier (the consumers
+            // take it in front of their loop)
+            const PilotProbes probes = inline_pilot_load(xb, p.nseg, 2048, t);
+            inline_pilot_store(probes, t, img + LDS_X);
+            lds_barrier();
+            pv = inline_pilot_value(img + LDS_X);
+        }
         while (have) {
             const int n = se - sb;
             int ncur = 0;
@@ -350,6 +362,7 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             ++it;
             return kind;
         };
+        if (PILOT && p.pilot_inline) lds_barrier();      // the producers' pilot barrier
         int item = next_item();           // nothing to consume in step 0
         for (;;) {
             // idle steps stay out of the path that updates the accumulators (with both in one conditional the
@@ -429,7 +442,7 @@ hipError_t OTH_CAT(launch_welch_tuned4096_, OTH_WS_TAG)(const WelchArgs &a, hipS
         if (e != hipSuccess) return e;
         big_lds = true;
     }
-    if (a.detrend && a.pilot)
+    if (a.detrend && (a.pilot || a.pilot_inline))
         hipLaunchKernelGGL((welch4096ws_kernel<true, true>), grid, dim3(TWS), WS_LDS_BYTES, s, a);
     else if (a.detrend)
         hipLaunchKernelGGL((welch4096ws_kernel<true, false>), grid, dim3(TWS), WS_LDS_BYTES, s, a);

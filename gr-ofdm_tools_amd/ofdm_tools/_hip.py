@@ -67,6 +67,9 @@ SIGNATURES = {
     'oth_plan_out_len': (C.c_int, [_p, C.POINTER(C.c_int)]),
     'oth_plan_set_tuning': (C.c_int, [_p, C.c_char_p, C.c_int, C.c_int, C.c_int]),
     'oth_welch_exec': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f, _u64p]),
+    'oth_welch_exec_async': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _u64p]),
+    'oth_welch_poll': (C.c_int, [_p, C.c_uint64, _f, _u64p, C.POINTER(C.c_int)]),
+    'oth_welch_wait': (C.c_int, [_p, C.c_uint64, _f, _u64p]),
     'oth_welch_exec_dev': (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_size_t, _p, _u64p]),
     'oth_welch_partial_dev': (C.c_int, [_p, _p, C.c_size_t, _p, _u64p]),
     'oth_welch_scale_dev': (C.c_int, [_p, _p, C.c_uint64, _p]),
@@ -397,6 +400,36 @@ class WelchPlan(object):
         n = C.c_uint64()
         self.ctx.check(self.ctx.lib.oth_welch_exec(self.h, C.c_void_p(dptr), nsamples, 1, _fptr(out), C.byref(n)),
                        'oth_welch_exec')
+        self.last_nseg = n.value
+        return out
+
+    def exec_async(self, x, nsamples=None):
+        """work() form: enqueue one Welch scan and return a ticket at once.  x: host complex64 array (may be reused as
+        soon as the call returns), or a device pointer when nsamples is given."""
+        t = C.c_uint64()
+        if nsamples is None:
+            x = _c64(x)
+            rc = self.ctx.lib.oth_welch_exec_async(self.h, x.ctypes.data_as(_p), len(x), 0, C.byref(t))
+        else:
+            rc = self.ctx.lib.oth_welch_exec_async(self.h, C.c_void_p(x), int(nsamples), 1, C.byref(t))
+        self.ctx.check(rc, 'oth_welch_exec_async')
+        return int(t.value)
+
+    def poll(self, ticket):
+        """-> None while the GPU is still working, else the float32 PSD (last_nseg is set)."""
+        out = np.empty(self.out_len, np.float32)
+        n, ready = C.c_uint64(), C.c_int()
+        self.ctx.check(self.ctx.lib.oth_welch_poll(self.h, int(ticket), _fptr(out), C.byref(n), C.byref(ready)),
+                       'oth_welch_poll')
+        if not ready.value:
+            return None
+        self.last_nseg = n.value
+        return out
+
+    def wait(self, ticket):
+        out = np.empty(self.out_len, np.float32)
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_welch_wait(self.h, int(ticket), _fptr(out), C.byref(n)), 'oth_welch_wait')
         self.last_nseg = n.value
         return out
 

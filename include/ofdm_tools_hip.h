@@ -44,8 +44,9 @@
 extern "C" {
 #endif
 
-#define OTH_ABI_VERSION 4      /* 3 = 2 + oth_chain_ticket_rows, oth_scan_decide_dev_out; 4 = 3 + OTH_ERR_INTERNAL,
-                                  OTH_DETREND_CONSTANT_EXACT, OTH_DETREND_CONSTANT_FAST (additions only) */
+#define OTH_ABI_VERSION 5      /* 3 = 2 + oth_chain_ticket_rows, oth_scan_decide_dev_out; 4 = 3 + OTH_ERR_INTERNAL,
+                                  OTH_DETREND_CONSTANT_EXACT, OTH_DETREND_CONSTANT_FAST; 5 = 4 + oth_welch_exec_async /
+                                  _poll / _wait (additions only) */
 
 #define OTH_OK               0
 #define OTH_ERR_INVALID     -1   /* bad argument */
@@ -58,24 +59,33 @@ extern "C" {
 /* detrend (scipy.signal.welch detrend=...) */
 #define OTH_DETREND_NONE     0
 #define OTH_DETREND_CONSTANT 1   /* per-segment mean removal, SciPy default - computed on x - pilot: before anything else
-                                   every kernel takes a pilot value per stream (the average of eight segment means
-                                   spread over the launch, one small launch in front) off each sample as it is loaded,
+                                   every kernel takes a pilot value per stream (the average of eight probe means
+                                   spread over the launch: formed in the prologue of the role-split 4096-point kernels,
+                                   by one small launch in front of the others) off each sample as it is loaded,
                                    so no float32 arithmetic ever handles the DC line - neither the transform (the fastest
                                    2048 / 4096 / 8192 / 16384-point builds at 50 % overlap remove the mean after it,
                                    FFT(x w) - m FFT(w)) nor the segment mean, which becomes a small residual.
                                    Mathematically the same result; measured against float64: every
                                    bin inside 1e-4 at 1 ... 9 segments and |m| = 35 sigma, every bin at 2e-7 with 2047
                                    segments and a DC line of 3000 sigma (70 dB above the signal), bins 0, +-1 at 1e-6
-                                   where SciPy on complex64 input reads 1e-4 ... 5e-3.  The pilot is one value per
-                                   launch and stream: an offset that moves by D around it within one launch leaves the
-                                   OTH_DETREND_CONSTANT_FAST bound below with |m| = D / 2 (a drift from 0 to 1200 sigma
-                                   over 2047 segments: 2e-5); chunked streaming (oth_welch_accumulate) takes a fresh
-                                   pilot per chunk. */
+                                   where SciPy on complex64 input reads 1e-4 ... 5e-3.  That is for a CONSTANT
+                                   offset.  The pilot is one value per launch and stream: an offset that MOVES by D
+                                   within one launch leaves a line of about D / 2 (a step: of D, in the one or two
+                                   segments that hold it) to the float32 transform - which holds for the exact
+                                   time-domain form as well, the line then being real signal.  Measured over four
+                                   noise seeds at 2047 segments of 4096 points: every bin inside 1e-4 for offsets
+                                   moving by up to 1000 sigma, inside 2e-4 for a 3000-sigma opening transient and a
+                                   drift of 1200 sigma (default 4.7e-5 ... 1.05e-4, time-domain builds 5e-6 ... 1.1e-4).
+                                   Launches of fewer than 8 segments per stream detrend before the window (their own
+                                   mean per segment); with 1-3 segments and an offset moving by 100 sigma every bin
+                                   stays within 4 ulp of the row's peak amplitude (what a single float32 transform of a
+                                   strong ramp leaves: 1e-4 ... 3e-4 of the weakest bins; SciPy on complex64: up to
+                                   7e-4).  Chunked streaming (oth_welch_accumulate) takes a fresh pilot per chunk. */
 #define OTH_DETREND_CONSTANT_EXACT 2 /* = OTH_DETREND_CONSTANT (the name under which the offset-proof detrend was first
                                    asked for; accepted, same builds) */
-#define OTH_DETREND_CONSTANT_FAST 3 /* the same operation on the raw samples, -1 ... +2 % of the launch (no pilot launch, no
+#define OTH_DETREND_CONSTANT_FAST 3 /* the same operation on the raw samples, -1 ... +2 % of the launch (no pilot, no
                                    subtractions).  Launches of fewer than 8 segments per stream detrend before the
-                                   window; the fast builds above detrend after the transform, which then carries the
+                                   window (as above); the fast builds detrend after the transform, which then carries the
                                    rounding of the DC line m sum(w): about 1e-7 sqrt(nfft / nseg) |m| / sigma of the
                                    detrended power in every bin (measured on MI355X at 2047 segments of 4096 points:
                                    1e-6 at |m| = 30 sigma, 4e-5 at 300 sigma, 1.5e-4 at 3000 sigma), and bins 0, +-1
@@ -177,9 +187,22 @@ int oth_plan_out_len(oth_plan *plan, int *n);
  * and are read once, in oth_welch_plan(). */
 int oth_plan_set_tuning(oth_plan *plan, const char *variant, int sched, int chunk, int tail_chunk);
 
-/* one-shot: nsamples complex64 -> psd_out[nfft - 2*trim] (host) */
+/* one-shot: nsamples complex64 -> psd_out[nfft - 2*trim] (host).  Blocking: returns when the PSD is in psd_out.  The
+ * last launch writes the row and a completion word into pinned host memory and the call polls that word (no interrupt
+ * wake-up; after 200 ms it falls back to a stream synchronisation, which also reports a failed launch). */
 int oth_welch_exec(oth_plan *plan, const void *iq, size_t nsamples, int src_is_device,
                    float *psd_out, uint64_t *nseg_out);
+/* The same step without blocking (ABI 5) - what a gr.sync_block's work() or message handler needs for a Welch scan
+ * (reference: python/spectrum_sensor.py:71-75,105-117 -> ofdm_cr_tools.py:471-537; the chain has oth_chain_push_async):
+ * _exec_async enqueues copy + kernels and returns a ticket (> 0) at once - the caller's host buffer may be reused when
+ * it returns (buffers up to 1 MiB go through a pinned ring and never wait; a larger pageable buffer is staged by the HIP
+ * runtime, which may hold the call until earlier work on the stream has finished); _poll looks once (*ready = 0: still running; 1: psd_out / nseg_out are filled); _wait polls until the
+ * row is there.  Neither holds the context while it waits.  The plan keeps the last 4 launches: an older ticket
+ * reports OTH_ERR_STATE, and _exec_async itself waits only when the GPU is 4 launches behind.  psd_out may be NULL
+ * (completion only). */
+int oth_welch_exec_async(oth_plan *plan, const void *iq, size_t nsamples, int src_is_device, uint64_t *ticket_out);
+int oth_welch_poll(oth_plan *plan, uint64_t ticket, float *psd_out, uint64_t *nseg_out, int *ready);
+int oth_welch_wait(oth_plan *plan, uint64_t ticket, float *psd_out, uint64_t *nseg_out);
 /* nstreams independent streams laid out every stream_stride samples; device in,
  * device out [nstreams][out_len]; asynchronous. */
 int oth_welch_exec_dev(oth_plan *plan, const void *iq_dev, size_t nsamples, int nstreams,

@@ -47,7 +47,7 @@ def test_no_cpu_fallback_without_gpu():
     from ofdm_tools import _hip
     if not os.path.exists(_hip.LIB_PATH):
         pytest.skip('library not built yet')
-    assert _hip.load().oth_abi_version() == 4
+    assert _hip.load().oth_abi_version() == 5
     with pytest.raises(_hip.HipError) as ei:
         _hip.Context(0)
     assert ei.value.code == -2 and 'no CPU fallback' in str(ei.value)
