@@ -84,6 +84,7 @@ struct oth_plan {
     uint64_t out_nseg[kOutRing] = {0, 0, 0, 0};
     uint64_t next_out_ticket = 1;
     bool pilot_launch = false;         // A/B + parity: the pilot from pilot_mean_kernel also where the kernel could form it
+    std::string last_recipe;           // recipe_text() of the last averaging launch (oth__debug_last_recipe)
     float2 *d_stage = nullptr;         // host-input staging (x then y)
     size_t stage_cap = 0;
     // streaming state
@@ -543,17 +544,310 @@ int segments(const oth_plan *p, size_t nsamples, long long *nseg) {
     return OTH_OK;
 }
 
-int generic_wg(const oth_ctx *c, int nfft, long long nseg, int nstreams) {
+// ---- routing as data (round 5) ---------------------------------------------------------------------------------------
+// Which kernel build runs a launch, with which detrend form, pilot, schedule, chunk sizes, grid and partial-row layout,
+// is decided by resolve_recipe() from the plan's shape and the launch's segment count - pure host logic, no HIP call, so
+// tests/test_abi_cpu.py::test_launch_recipes_table can enumerate it without a GPU through oth__debug_recipe().
+// run_average() below only allocates, fills the argument structs and dispatches on the recipe.
+enum RecipeKernel {
+    RK_GENERIC = 0,      // welch_generic_kernel (coverage Stockham kernel; also the two-channel coverage path)
+    RK_W4096,            // welch4096[ws]_kernel: the build in `variant`
+    RK_CSD4096,          // csd4096_kernel (one role)
+    RK_CSD4096WS,        // csd4096ws_kernel (role-split pairs)
+    RK_W16K,             // welch16k_kernel<., F> (4 x 4096 / 2 x 4096)
+    RK_W16K1X,           // welch16k1x_pipe_kernel / welch16k1x_kernel (one exchange, no overlap)
+    RK_W16K1X_HALF,      // welch16k1x_half_kernel (one exchange, 50 % overlap)
+    RK_SEG,              // seg_kernel<R, ...>
+    RK_SEGWS,            // segws_kernel<R, DET>
+    RK_SEGPAD,           // seg_kernel<R, ..., NA> zero-padded
+};
+const char *const kRecipeKernelName[] = {"welch_generic", "welch4096", "csd4096", "csd4096ws", "welch16k", "welch16k1x",
+                                         "welch16k1x_half", "seg", "segws", "seg_padded"};
+
+// what resolve_recipe() needs to know of a plan (oth_plan holds the same fields; the debug entry builds one by hand)
+struct PlanShape {
+    int nfft = 0, nperseg = 0, step = 0;
+    bool detrend = false, fast_detrend = false;
+    bool fd_ok = false;          // a window-spectrum table exists for this size (oth_plan::d_fd)
+    bool fd1x_ok = false;        // ... and the one for welch16k1x_half (spectrum confined to |k| < 16)
+    bool rect_window = false;
+    int kernel = OTH_KERNEL_AUTO, sched = OTH_SCHED_DYNAMIC;
+    bool pilot_launch = false;
+    std::string tune_variant;
+    int tune_sched = -1, tune_chunk = 0, tune_tail = 0;
+};
+
+// resident workgroups (teams) per CU of a tuned build: the runtime asks the occupancy calculator (needs a device), the
+// debug entry uses the table below - what the calculator returns on MI355X for the shipped builds
+// (tests/test_hip_parity.py::test_recipe_occupancy_table_matches_the_runtime compares the two on the GPU)
+struct OccupancyKey {
+    RecipeKernel kern;
+    const char *variant;      // RK_W4096
+    int nfft, nperseg, seg_kind;
+    bool seg_wps4;
+};
+int runtime_bpc(const OccupancyKey &k) {
+    switch (k.kern) {
+        case RK_W4096: return variant_by_tag(k.variant)->blocks_per_cu();
+        case RK_CSD4096: return csd4096_blocks_per_cu();
+        case RK_CSD4096WS: return csd4096ws_blocks_per_cu();
+        case RK_SEG: return seg_teams_per_cu(k.nfft, k.seg_kind, k.seg_wps4);
+        case RK_SEGWS: return segws_teams_per_cu(k.nfft);
+        case RK_SEGPAD: return seg_padded_teams_per_cu(k.nfft, k.nperseg, k.seg_kind);
+        case RK_W16K: case RK_W16K1X: case RK_W16K1X_HALF: return k.nfft == 8192 ? 2 : 1;      // 70 / 139 KiB of LDS
+        default: return 0;
+    }
+}
+int table_bpc(const OccupancyKey &k) {
+    switch (k.kern) {
+        case RK_W4096: return !strcmp(k.variant, "ws") ? 2 : 4;      // 78 KiB of LDS / 35 KiB and 128 VGPRs
+        case RK_CSD4096: return 3;
+        case RK_CSD4096WS: return 1;
+        case RK_SEGWS: return k.nfft == 1024 ? 8 : 4;
+        case RK_SEG: {      // teams per CU: waves per SIMD (3; "seg4": 4) x 4 SIMDs x teams per wave / waves per team
+            const int tpw = k.nfft == 256 ? 4 : (k.nfft == 512 ? 2 : 1), wpt = k.nfft <= 1024 ? 1 : k.nfft / 1024;
+            return 4 * (k.seg_wps4 ? 4 : 3) * tpw / wpt;
+        }
+        case RK_SEGPAD: return k.nfft == 1024 ? 16 : (k.nperseg * 4 == k.nfft ? 8 : 6);      // 2048: NA = 4 at four waves per SIMD, NA = 8 at three
+        case RK_W16K: case RK_W16K1X: case RK_W16K1X_HALF: return k.nfft == 8192 ? 2 : 1;
+        default: return 0;
+    }
+}
+
+struct LaunchRecipe {
+    RecipeKernel kern = RK_GENERIC;
+    const W4096Variant *variant = nullptr;      // RK_W4096
+    bool csd = false;
+    int form = 0;                // constant detrend: 0 none, 1 before the window (time domain), 2 after the transform (needs the table)
+    int pilot = 0;               // 0 none (no detrend, or OTH_DETREND_CONSTANT_FAST), 1 pilot_mean_kernel in front, 2 in the kernel's prologue
+    bool use_fd1x = false;       // the table handed to the kernel is d_fd1x
+    int seg_kind = 0, seg_det = 0;
+    bool seg_wps4 = false;
+    bool x1_window = false, x1_plain = false;      // RK_W16K1X: windowed build / the un-pipelined loop
+    int bpc = 0;                 // resident workgroups (teams) per CU (0: generic grid rule)
+    int W = 1, rows = 1, nch = 1, layout = 0;
+    int sched = 0, chunk = 1, tail_chunk = 1;
+    long long nbig = 0, nseg_run = 0;
+    bool tickets = false;        // draws chunk tickets from the context's queue
+    bool two_runs = false;       // "ws2": the stream cut into two runs of segments
+};
+
+int generic_wg_for(int cu_count, int nfft, long long nseg, int nstreams) {
     const size_t lds = generic_lds_bytes(nfft);
     long long occ = (long long)(160 * 1024 / lds);
     const long long tocc = 2048 / generic_threads_for(nfft);
     if (occ > tocc) occ = tocc;
     if (occ < 1) occ = 1;
     if (occ > 4) occ = 4;
-    long long w = ((long long)c->cu_count * occ + nstreams - 1) / nstreams;
+    long long w = ((long long)cu_count * occ + nstreams - 1) / nstreams;
     if (w > nseg) w = nseg;
     if (w < 1) w = 1;
     return (int)w;
+}
+
+// -> OTH_OK, or OTH_ERR_UNSUPPORTED with *why set (OTH_KERNEL_TUNED on a plan no tuned kernel covers)
+int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, int cu_count, int (*bpc_of)(const OccupancyKey &),
+                   LaunchRecipe *out, const char **why) {
+    LaunchRecipe r;
+    r.csd = csd;
+    r.nch = csd ? 4 : 1;
+    const std::string &tv = p.tune_variant;
+    const bool want_tuned = p.kernel != OTH_KERNEL_GENERIC;
+    const bool half_step = p.step * 2 == p.nperseg;
+    // ---- detrend form.  After the transform (FFT((x - m) w) = FFT(x w) - m FFT(w), the role-split / half-keeping
+    // builds) only with a window-spectrum table and at least kFdMinSegments segments per stream: below that the
+    // time-domain builds run in both detrend modes (the pilot is one value per launch; an offset that moves within a
+    // one- or two-segment launch has nothing to average its rounding down - advisor, round 4 - and such launches do not
+    // need the fast builds' throughput).  A variant forced through oth_plan_set_tuning is honoured; "td" forces the
+    // time-domain builds at any length.
+    const bool fd_forced = !tv.empty() && tv != "td" && tv != "plaunch";
+    const bool fd = p.fd_ok && tv != "td" && (fd_forced || nseg >= kFdMinSegments);
+    const bool fd1x = fd && p.fd1x_ok;
+    // ---- kernel family
+    const bool pow2_nperseg = p.nperseg >= 256 && (p.nperseg & (p.nperseg - 1)) == 0;
+    const bool seg_size = p.nfft == 256 || p.nfft == 512 || p.nfft == 1024 || p.nfft == 2048;
+    const bool big_size = p.nfft == 8192 || p.nfft == 16384;
+    if (csd) {
+        if (want_tuned && p.nfft == 4096 && p.nperseg == 4096) {
+            // role-split pairs: 50 % overlap, frequency-domain detrend, 32-bit segment indices; "csd1" forces the one-role kernel
+            const bool ws = p.step == 2048 && (!p.detrend || fd) && nseg < (1LL << 30) && tv != "csd1";
+            r.kern = ws ? RK_CSD4096WS : RK_CSD4096;
+        }
+    } else if (want_tuned && p.nfft == 4096 && pow2_nperseg) {      // nperseg = 256 ... 4096, zero-padded to 4096
+        r.kern = RK_W4096;
+        const bool fd_ok = (!p.detrend || fd) && nseg < (1LL << 30);      // ws: 32-bit segment indices
+        r.variant = w4096_variant(p.nperseg == 4096 ? p.step : 0, fd_ok, tv);
+        // "ws2" cuts the stream into two equal runs of segments: an odd count (or a single segment) stays on "ws"
+        if (!strcmp(r.variant->tag, "ws2") && (nseg < 2 || (nseg & 1))) r.variant = variant_by_tag("ws");
+        r.two_runs = !strcmp(r.variant->tag, "ws2");
+    } else if (want_tuned && big_size && (p.nperseg == p.nfft || p.nperseg * 4 == p.nfft)) {      // (nfft / 4: the sweeper's zero padding)
+        r.kern = RK_W16K;
+        if (p.nfft == 16384 && p.nperseg == 16384 && tv != "16k4") {
+            // one cross-wave exchange per segment: vectors that do not overlap without a detrend (the scanner of BASELINE
+            // config 5), and 50 % overlap with the kept half in registers (a constant detrend needs the |k| < 16 table)
+            if (p.step >= 16384 && !p.detrend) r.kern = RK_W16K1X;
+            else if (p.step == 8192 && (!p.detrend || fd1x)) r.kern = RK_W16K1X_HALF;
+        }
+    } else if (want_tuned && seg_size && seg_padded_supported(p.nfft, p.nperseg)) {
+        r.kern = RK_SEGPAD;      // nperseg = nfft / 4 (the sweeper's call, spectrum_sweeper.py:263) or nfft / 2 at 1024 / 2048
+    } else if (want_tuned && seg_size && p.nperseg == p.nfft) {
+        r.kern = RK_SEG;
+    }
+    if (p.kernel == OTH_KERNEL_TUNED && r.kern == RK_GENERIC) {
+        if (why) *why = "tuned kernel does not cover this plan";
+        return OTH_ERR_UNSUPPORTED;
+    }
+    if (r.kern == RK_SEG || r.kern == RK_SEGPAD) {
+        r.seg_kind = half_step ? 0 : 1;
+        r.seg_wps4 = tv == "seg4";
+        // role-split build: 50 % overlap; detrend in the time domain at 1024 (one producer wave), after the transform at
+        // 2048 (needs the table); "seg3" / "seg4" force the one-role builds
+        r.seg_det = !p.detrend ? 0 : (p.nfft == 1024 ? 1 : 2);
+        if (r.kern == RK_SEG && p.nfft >= 1024 && r.seg_kind == 0 && tv != "seg3" && !r.seg_wps4 && (r.seg_det != 2 || fd))
+            r.kern = RK_SEGWS;
+    }
+    // ---- detrend form and pilot of the kernel chosen
+    if (p.detrend) {
+        const bool after = r.kern == RK_CSD4096WS || r.kern == RK_W16K1X_HALF || (r.kern == RK_W4096 && r.variant->fd) ||
+                           (r.kern == RK_SEGWS && r.seg_det == 2) || (r.kern == RK_W16K && fd && half_step && p.nperseg == p.nfft);
+        r.form = after ? 2 : 1;
+        r.use_fd1x = r.kern == RK_W16K1X_HALF;
+        if (!p.fast_detrend) {
+            const bool can_inline = ((r.kern == RK_W4096 && r.variant->inline_pilot) || r.kern == RK_CSD4096WS) &&
+                                    !p.pilot_launch && tv != "plaunch";
+            r.pilot = can_inline ? 2 : 1;
+        }
+    }
+    if (r.kern == RK_W16K1X) {
+        r.x1_window = !p.rect_window;
+        r.x1_plain = tv == "16kplain";
+    }
+    // ---- grid: exactly the resident workgroups (one wave of workgroups, no tail round); generic: by LDS footprint
+    r.rows = r.kern == RK_W4096 ? r.variant->rows : 1;
+    r.nseg_run = r.two_runs ? nseg / 2 : nseg;      // segments the schedule of one run covers
+    if (r.kern == RK_GENERIC) {
+        r.W = generic_wg_for(cu_count, p.nfft, nseg, nstreams);
+    } else {
+        const OccupancyKey key{r.kern, r.kern == RK_W4096 ? r.variant->tag : "", p.nfft, p.nperseg, r.seg_kind, r.seg_wps4};
+        r.bpc = bpc_of(key);
+        if (r.bpc < 1) r.bpc = 1;
+        const long long w = ((long long)cu_count * r.bpc + nstreams - 1) / nstreams;
+        r.W = (int)(w > r.nseg_run ? r.nseg_run : (w < 1 ? 1 : w));
+    }
+    r.layout = (r.kern == RK_W4096 || r.kern == RK_CSD4096 || r.kern == RK_CSD4096WS) ? 1
+               : (r.kern == RK_W16K1X || r.kern == RK_W16K1X_HALF) ? 4
+               : (r.kern == RK_W16K ? (p.nfft == 16384 ? 2 : 3) : 0);
+    // ---- schedule and chunks (tuned kernels only; the coverage kernel walks contiguous runs)
+    if (r.kern != RK_GENERIC) {
+        const bool auto_sched = p.tune_sched < 0 && p.sched == OTH_SCHED_DYNAMIC;      // "the library's choice"
+        const long long per_team = r.nseg_run / (r.W > 0 ? r.W : 1);
+        const bool is_seg = r.kern == RK_SEG || r.kern == RK_SEGPAD || r.kern == RK_SEGWS;
+        const bool big = r.kern == RK_W16K || r.kern == RK_W16K1X || r.kern == RK_W16K1X_HALF;
+        r.sched = p.tune_sched >= 0 ? p.tune_sched : p.sched;
+        int static_chunk = 0;
+        if (auto_sched) {
+            // one 1024-thread workgroup per CU and equal work per segment: contiguous runs beat the ticket queue (+3 %)
+            if (r.kern == RK_CSD4096WS) r.sched = OTH_SCHED_CONTIGUOUS;
+            // the role-split 1024 kernel: eight two-wave workgroups per CU even out by themselves (+4 % over the tickets)
+            if (r.kern == RK_SEGWS && p.nfft == 1024 && nstreams == 1) r.sched = OTH_SCHED_CONTIGUOUS;
+            if (r.kern == RK_SEG || r.kern == RK_SEGPAD) {
+                // 256 / 512 points (and the zero-padded builds: nfft / 8 new samples per segment) at 50 % overlap: a ticket
+                // per sixteen 2-4 KiB segments costs more than it evens out (17-35 % of the roofline at every launch size).
+                // Static instead: interleaved chunks of 32 / 16 segments while every team gets two of them (256 points,
+                // 2^27 samples: 66 % against 43 %), one contiguous run per team below that.
+                if (r.seg_kind == 0 && (p.nfft <= 512 || r.kern == RK_SEGPAD)) {
+                    static_chunk = per_team >= 64 ? 32 : (per_team >= 32 ? 16 : 0);
+                    r.sched = static_chunk ? OTH_SCHED_INTERLEAVED : OTH_SCHED_CONTIGUOUS;
+                }
+                // whole-segment loads (steps other than nfft / 2): the next chunk's first segment is prefetched across the
+                // chunk boundary only under the interleaved schedule - 8-segment chunks: 1024 points, no overlap, 70 % of
+                // the roofline against 49 % with tickets
+                if (r.seg_kind == 1) {
+                    static_chunk = per_team >= 16 ? 8 : 0;
+                    r.sched = static_chunk ? OTH_SCHED_INTERLEAVED : OTH_SCHED_CONTIGUOUS;
+                }
+            }
+            // short launches (fewer than 32 segments per resident workgroup): one contiguous run each - the tickets' guided
+            // tail has nothing to even out and costs 5-20 % (2048 points, 2^22 samples: 17.3 % against 14.0 %)
+            if ((r.kern == RK_W4096 || r.kern == RK_SEGWS) && per_team < 32) r.sched = OTH_SCHED_CONTIGUOUS;
+            // the one-exchange 16384-point scanner kernel: one workgroup per CU, equal work per segment, no chunk head to
+            // re-read - contiguous runs (0.417-0.418 against 0.421-0.424 ms with tickets, same box) unless a workgroup gets
+            // so few segments that an uneven split shows
+            if (r.kern == RK_W16K1X && per_team >= 8) r.sched = OTH_SCHED_CONTIGUOUS;
+            // 16384 points at 50 % overlap: contiguous runs (no chunk head is read twice): 30.8 % against 29.3 % with tickets
+            if (big && p.nfft == 16384 && half_step && p.nperseg == p.nfft) r.sched = OTH_SCHED_CONTIGUOUS;
+            // 8192 (round 4): contiguous runs take the same time as tickets over chunks of 16 and read no chunk head twice
+            if (big && p.nfft == 8192 && half_step && p.nperseg == p.nfft && per_team >= 16) r.sched = OTH_SCHED_CONTIGUOUS;
+        }
+        if (r.sched < 0 || r.sched > 2) r.sched = 0;
+        // segments per chunk
+        int chunk;
+        if (p.tune_chunk > 0) chunk = p.tune_chunk;
+        else if (big) {
+            const bool halves = half_step && (p.nperseg == p.nfft || p.nperseg * 4 == p.nfft);      // a kept half: longer chunks
+            chunk = halves ? 16 : 2;
+        } else if (r.kern == RK_W4096) chunk = r.variant->chunk;
+        else if (is_seg) chunk = static_chunk ? static_chunk
+                                              : (((p.nfft == 1024 && r.kern != RK_SEGWS) || (p.nfft == 2048 && r.kern == RK_SEGWS)) ? 32 : 16);
+        else chunk = 8;      // the one-role two-channel kernel
+        if (chunk < 1) chunk = 1;
+        // welch16k1x: the ticket for the NEXT chunk is published with a chunk's first segment and read at its last
+        if (r.kern == RK_W16K1X && chunk < 2) chunk = 2;
+        r.chunk = chunk;
+        r.tail_chunk = chunk;
+        r.nbig = r.nseg_run / chunk;
+        if (r.sched == OTH_SCHED_DYNAMIC) {
+            if (nstreams > 64) {
+                r.sched = OTH_SCHED_INTERLEAVED;      // the context holds 64 ticket words
+            } else {
+                r.tickets = true;
+                // guided tail: the last half round of work goes out in quarter-size chunks
+                r.tail_chunk = p.tune_tail > 0 ? p.tune_tail : (chunk >= 4 ? chunk / 4 : 1);
+                if (r.tail_chunk < 1) r.tail_chunk = 1;
+                if (r.kern == RK_W16K1X && r.tail_chunk < 2) r.tail_chunk = 2;
+                const long long tail_segs = (long long)r.W * chunk / 2;
+                r.nbig = r.nseg_run > tail_segs ? (r.nseg_run - tail_segs) / chunk : 0;
+            }
+        }
+    }
+    *out = r;
+    return OTH_OK;
+}
+
+// the recipe as text (oth__debug_recipe, bench.py's kernel labels)
+std::string recipe_text(const LaunchRecipe &r, int nfft) {
+    static const char *const kForm[] = {"none", "time", "freq"}, *const kPilot[] = {"none", "launch", "inline"},
+                             *const kSched[] = {"contiguous", "interleaved", "dynamic"};
+    char buf[384];
+    std::string k = kRecipeKernelName[r.kern];
+    if (r.kern == RK_W4096) k += std::string(":") + r.variant->tag;
+    if (r.kern == RK_SEG) k += std::string(r.seg_kind ? ":full" : ":half") + (r.seg_wps4 ? ":wps4" : "");
+    if (r.kern == RK_SEGPAD) k += r.seg_kind ? ":full" : ":half";
+    if (r.kern == RK_W16K1X) k += std::string(r.x1_plain || r.x1_window ? ":plain" : ":pipe") + (r.x1_window ? ":window" : "");
+    snprintf(buf, sizeof buf, "kernel=%s nfft=%d form=%s pilot=%s sched=%s chunk=%d tail=%d nbig=%lld bpc=%d W=%d rows=%d nch=%d layout=%d",
+             k.c_str(), nfft, kForm[r.form], kPilot[r.pilot], kSched[r.sched], r.chunk, r.tail_chunk, r.nbig, r.bpc, r.W, r.rows,
+             r.nch, r.layout);
+    return buf;
+}
+
+PlanShape shape_of(const oth_plan *p) {
+    PlanShape s;
+    s.nfft = p->nfft;
+    s.nperseg = p->nperseg;
+    s.step = p->step;
+    s.detrend = p->detrend != OTH_DETREND_NONE;
+    s.fast_detrend = p->fast_detrend;
+    s.fd_ok = p->d_fd != nullptr;
+    s.fd1x_ok = p->d_fd1x != nullptr;
+    s.rect_window = p->rect_window;
+    s.kernel = p->kernel;
+    s.sched = p->sched;
+    s.pilot_launch = p->pilot_launch;
+    s.tune_variant = p->tune_variant;
+    s.tune_sched = p->tune_sched;
+    s.tune_chunk = p->tune_chunk;
+    s.tune_tail = p->tune_tail;
+    return s;
 }
 
 // Launch the averaging kernel: partial sums land in plan->d_partial.
@@ -564,186 +858,34 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     if (segments(p, nsamples, &nseg) != OTH_OK)
         return fail(c, OTH_ERR_INVALID, "input shorter than nperseg");
     const bool csd = (y != nullptr);
-    // Which detrend form.  The role-split / half-keeping builds remove the segment mean AFTER the transform,
-    // FFT((x - m) w) = FFT(x w) - m FFT(w).  OTH_DETREND_CONSTANT plans run the PILOT builds of whichever form
-    // (WelchArgs.pilot): they transform x - pilot, so for a CONSTANT offset there is no DC line and the form after the
-    // transform is as accurate as the one before it at any segment count.  OTH_DETREND_CONSTANT_FAST plans
-    // work on the raw samples: the fp32 transform then carries the rounding of the DC line m sum(w) into every bin - per
-    // segment about 1e-7 sqrt(nfft) |m| / sigma of the detrended power (tests/test_hip_parity.py::
-    // test_detrend_forms_few_segments_and_large_dc), averaged down by sqrt(nseg).
-    // Launches of fewer than kFdMinSegments segments per stream take the time-domain builds in BOTH modes (round 5;
-    // round 4: FAST plans only): the pilot is one value per launch, so an offset that MOVES by D within the launch
-    // leaves a line of about D / 2 in every segment, and with one or two segments nothing averages its rounding down
-    // (advisor, round 4: D = 100 sigma at nfft >= 4096 is past 1e-4).  The time-domain pilot builds remove each
-    // segment's own mean before the transform, are as accurate on a constant offset (8.5e-7 against 1.1e-6 at one
-    // segment and 35 sigma) and such launches do not need the role-split kernels' throughput.  A variant forced through
-    // oth_plan_set_tuning (parity suite, A/B tools) is honoured; "td" forces the time-domain builds at any length.
-    const bool fd_forced = !p->tune_variant.empty() && p->tune_variant != "td" && p->tune_variant != "plaunch";
-    const float4 *fd_tab = (p->d_fd && p->tune_variant != "td" && (fd_forced || nseg >= kFdMinSegments)) ? p->d_fd : nullptr;
-    // welch4096 covers nperseg = 256, 512, ..., 4096 (zero-padded to 4096)
-    bool tuned = p->nfft == 4096 && p->nperseg >= 256 && (p->nperseg & (p->nperseg - 1)) == 0 && !csd;
-    const bool tuned_csd = csd && p->nfft == 4096 && p->nperseg == 4096 && p->kernel != OTH_KERNEL_GENERIC;
-    // wave-specialised pairs (csd4096ws.hip): 50 % overlap, frequency-domain detrend; "csd1" forces the one-role kernel
-    const bool csd_ws = tuned_csd && p->step == 2048 && (p->detrend == OTH_DETREND_NONE || fd_tab) &&
-                        nseg < (1LL << 30) && p->tune_variant != "csd1";
-    const bool tuned_16k = !csd && (p->nfft == 16384 || p->nfft == 8192) &&
-                           (p->nperseg == p->nfft || p->nperseg * 4 == p->nfft) &&      // (nfft / 4: the sweeper's zero padding)
-                           p->kernel != OTH_KERNEL_GENERIC;
-    // welch16k1x.hip: 16384-point vectors that do not overlap, no detrend (the scanner of BASELINE config 5): one
-    // cross-wave exchange per segment instead of two; "16k4" keeps the 4 x 4096 kernel (A/B, parity suite)
-    const bool tuned_16k1x = tuned_16k && p->nfft == 16384 && p->nperseg == 16384 && p->step >= 16384 &&
-                             p->detrend == OTH_DETREND_NONE && p->tune_variant != "16k4";
-    // ... and the same transform at 50 % overlap (the kept half in registers); a constant detrend needs its own
-    // window-spectrum table (d_fd1x: spectrum confined to |k| < 16) and follows the few-segment routing above
-    const float4 *fd1x = (fd_tab && p->d_fd1x) ? p->d_fd1x : nullptr;
-    const bool tuned_16k1x_half = tuned_16k && p->nfft == 16384 && p->nperseg == 16384 && p->step == 8192 &&
-                                  (p->detrend == OTH_DETREND_NONE || fd1x) && p->tune_variant != "16k4";
-    // segfft.hip: nperseg = nfft = 256 / 512 / 1024 / 2048, any step (team of nfft / 16 threads per segment)
-    // ... and zero-padded segments nperseg = nfft / 4 (the sweeper's call, spectrum_sweeper.py:263) or nfft / 2 at 1024 / 2048
-    const bool seg_pad = !csd && seg_padded_supported(p->nfft, p->nperseg) && p->kernel != OTH_KERNEL_GENERIC;
-    const bool tuned_seg = (!csd && (p->nfft == 256 || p->nfft == 512 || p->nfft == 1024 || p->nfft == 2048) && p->nperseg == p->nfft &&
-                            p->kernel != OTH_KERNEL_GENERIC) || seg_pad;
-    const int seg_kind = p->step * 2 == p->nperseg ? 0 : 1;
-    const bool seg_wps4 = p->tune_variant == "seg4";
-    // role-split build (segws_kernel): 50 % overlap; detrend in the time domain at 1024 (one producer wave), in the
-    // frequency domain at 2048 (needs the window-spectrum table); "seg3" / "seg4" force the one-role builds
-    const int seg_det = p->detrend == OTH_DETREND_NONE ? 0 : (p->nfft == 1024 ? 1 : 2);
-    const bool seg_ws = tuned_seg && !seg_pad && p->nfft >= 1024 && seg_kind == 0 && p->tune_variant != "seg3" && !seg_wps4 &&
-                        (seg_det != 2 || fd_tab != nullptr);
-    if (p->kernel == OTH_KERNEL_GENERIC) tuned = false;
-    if (p->kernel == OTH_KERNEL_TUNED && !tuned && !tuned_csd && !tuned_16k && !tuned_seg)
-        return fail(c, OTH_ERR_UNSUPPORTED, "tuned kernel does not cover this plan");
-    const W4096Variant *var =
-        tuned ? w4096_variant(p->nperseg == 4096 ? p->step : 0,
-                              (p->detrend == OTH_DETREND_NONE || fd_tab) && nseg < (1LL << 30),   // ws: 32-bit segment indices
-                              p->tune_variant)
-              : nullptr;
-    // "ws2" cuts the stream into two equal runs of segments: an odd count (or a single segment) stays on "ws"
-    const bool two_runs = var && !strcmp(var->tag, "ws2");
-    if (two_runs && (nseg < 2 || (nseg & 1))) var = variant_by_tag("ws");
-    const bool ws2 = var && !strcmp(var->tag, "ws2");
-    const long long nseg_run = ws2 ? nseg / 2 : nseg;      // segments the schedule of one run covers
-    int W = generic_wg(c, p->nfft, nseg, nstreams);
-    if (tuned || tuned_csd || tuned_16k || tuned_seg) {
-        // exactly the resident workgroups: one wave of workgroups, no tail round
-        const int bpc = tuned ? var->blocks_per_cu()
-                              : (tuned_csd ? (csd_ws ? csd4096ws_blocks_per_cu() : csd4096_blocks_per_cu())
-                                           : (tuned_seg ? (seg_pad ? seg_padded_teams_per_cu(p->nfft, p->nperseg, seg_kind)
-                                                                   : (seg_ws ? segws_teams_per_cu(p->nfft) : seg_teams_per_cu(p->nfft, seg_kind, seg_wps4)))
-                                                        : (p->nfft == 8192 ? 2 : 1)));      // welch16k: 139 / 70 KiB of LDS
-        long long w = ((long long)c->cu_count * bpc + nstreams - 1) / nstreams;
-        W = (int)(w > nseg_run ? nseg_run : (w < 1 ? 1 : w));
-    }
-    const int nch = csd ? 4 : 1;
-    const int rows = tuned ? var->rows : 1;      // rows of partial sums per workgroup
+    LaunchRecipe r;
+    const char *why = "";
+    if (int rrc = resolve_recipe(shape_of(p), csd, nseg, nstreams, c->cu_count, runtime_bpc, &r, &why))
+        return fail(c, rrc, why);
+    p->last_recipe = recipe_text(r, p->nfft);
     // + 1 KiB per row of stamp space behind the sums (only the diagnostic kernel builds write it)
     int rc = ensure(c, &p->d_partial, &p->partial_cap,
-                    sizeof(float) * (size_t)nstreams * W * rows * nch * p->nfft + 1024 * (size_t)nstreams * W * rows);
-    p->last_W = W * rows * nstreams;
-    if (!rc) rc = ensure(c, &p->d_reduce, &p->reduce_cap, sizeof(float) * (size_t)nstreams * kReduceGroups * nch * p->nfft);
+                    sizeof(float) * (size_t)nstreams * r.W * r.rows * r.nch * p->nfft + 1024 * (size_t)nstreams * r.W * r.rows);
+    p->last_W = r.W * r.rows * nstreams;
+    if (!rc) rc = ensure(c, &p->d_reduce, &p->reduce_cap, sizeof(float) * (size_t)nstreams * kReduceGroups * r.nch * p->nfft);
     if (rc) return rc;
-    WelchArgs a;
-    a.x = x;
-    a.y = y;
-    a.win = p->d_win;
-    a.tw = p->d_tw;
-    a.partial = p->d_partial;
-    a.nseg = nseg_run;
-    if (ws2) a.y = x + (size_t)nseg_run * 2048;      // run B starts nseg / 2 segments in (its first half-block is run A's last)
-    a.stream_stride = stride;
-    a.nperseg = p->nperseg;
-    a.step = p->step;
-    a.detrend = p->detrend;
-    a.wg_per_stream = W;
-    a.nstreams = nstreams;
-    a.sched = 0;
-    a.chunk = 1;
-    a.tail_chunk = 1;
-    a.nbig = 0;
-    a.queue = nullptr;
-    a.fd = tuned_16k1x_half ? fd1x : fd_tab;
-    // the pilot of every stream, then the PILOT build of whichever kernel runs (OTH_DETREND_CONSTANT_FAST: without)
-    // (the role-split 4096-point kernels form it in their own prologue - WelchArgs.pilot_inline, round 5: one launch
-    // less in front of the transform; "plaunch" / OTH_PILOT_LAUNCH=1 keep the separate launch for A/B and parity)
-    a.pilot = nullptr;
-    a.pilot_inline = 0;
-    if (p->detrend != OTH_DETREND_NONE && !p->fast_detrend) {
-        const bool can_inline = ((tuned && var->inline_pilot) || csd_ws) && !p->pilot_launch && p->tune_variant != "plaunch";
-        if (can_inline) {
-            a.pilot_inline = 1;
-        } else {
-            rc = ensure(c, &p->d_pilot, &p->pilot_cap, sizeof(float2) * 2 * kPilotProbes * (size_t)nstreams);
-            if (rc) return rc;
-            HIPCHK(c, launch_pilot_mean(x, csd ? y : nullptr, stride, p->nperseg, p->step, nseg, nstreams, p->d_pilot, c->stream));
-            a.pilot = p->d_pilot;
-        }
+    const float4 *fd_tab = r.form == 2 ? (r.use_fd1x ? p->d_fd1x : p->d_fd) : nullptr;
+    // the pilot of every stream (WelchArgs.pilot): from its own launch, or formed in the kernel's prologue
+    const float2 *pilot = nullptr;
+    if (r.pilot == 1) {
+        rc = ensure(c, &p->d_pilot, &p->pilot_cap, sizeof(float2) * 2 * kPilotProbes * (size_t)nstreams);
+        if (rc) return rc;
+        HIPCHK(c, launch_pilot_mean(x, csd ? y : nullptr, stride, p->nperseg, p->step, nseg, nstreams, p->d_pilot, c->stream));
+        pilot = p->d_pilot;
     }
-    if (tuned || tuned_csd || tuned_16k || tuned_seg) {
-        a.sched = p->tune_sched >= 0 ? p->tune_sched : p->sched;
-        // one 1024-thread workgroup per CU and equal work per segment: contiguous runs beat the ticket queue (+3 %)
-        if (csd_ws && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC) a.sched = OTH_SCHED_CONTIGUOUS;
-        // the role-split 1024 kernel: eight two-wave workgroups per CU even out by themselves (+4 % over the tickets)
-        if (seg_ws && p->nfft == 1024 && nstreams == 1 && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC)
-            a.sched = OTH_SCHED_CONTIGUOUS;
-        // 256 / 512 points at 50 % overlap: a ticket per sixteen 2-4 KiB segments costs more than it evens out (17-35 %
-        // of the roofline at every launch size).  Static instead: interleaved chunks of 32 / 16 segments while every
-        // team gets two of them (256 points, 2^27 samples: 66 % against 43 %), one contiguous run per team below that.
-        const bool seg_static = tuned_seg && !seg_ws && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC;
-        const long long per_team = nseg_run / (W > 0 ? W : 1);
-        int static_chunk = 0;
-        if (seg_static && seg_kind == 0 && (p->nfft <= 512 || seg_pad)) {      // (zero-padded: nfft / 8 new samples per segment)
-            static_chunk = per_team >= 64 ? 32 : (per_team >= 32 ? 16 : 0);
-            a.sched = static_chunk ? OTH_SCHED_INTERLEAVED : OTH_SCHED_CONTIGUOUS;
-        }
-        // whole-segment loads (steps other than nfft / 2): the next chunk's first segment is prefetched across the
-        // chunk boundary only under the interleaved schedule - 8-segment chunks: 1024 points, no overlap, 70 % of the
-        // roofline against 49 % with tickets
-        if (seg_static && seg_kind == 1) {
-            static_chunk = per_team >= 16 ? 8 : 0;
-            a.sched = static_chunk ? OTH_SCHED_INTERLEAVED : OTH_SCHED_CONTIGUOUS;
-        }
-        // short launches (fewer than 32 segments per resident workgroup): one contiguous run each - the tickets' guided
-        // tail has nothing to even out and costs 5-20 % (2048 points, 2^22 samples: 17.3 % against 14.0 %)
-        if ((tuned || seg_ws) && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC && per_team < 32)
-            a.sched = OTH_SCHED_CONTIGUOUS;
-        // the one-exchange 16384-point scanner kernel: one workgroup per CU, equal work per segment, no chunk head to
-        // re-read - contiguous runs (0.417-0.418 against 0.421-0.424 ms with tickets, same box) unless a workgroup gets so
-        // few segments that an uneven split shows
-        if (tuned_16k1x && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC && nseg_run / (W > 0 ? W : 1) >= 8)
-            a.sched = OTH_SCHED_CONTIGUOUS;
-        // 16384 points at 50 % overlap: one workgroup per CU and equal work per segment - contiguous runs (no chunk head
-        // is read twice): 30.8 % against 29.3 % with tickets; 8192: tickets over chunks of 16 (33.4 % against 32.5 % at 8)
-        if (tuned_16k && p->nfft == 16384 && p->step * 2 == p->nfft && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC)
-            a.sched = OTH_SCHED_CONTIGUOUS;
-        // 8192 (round 4): contiguous runs take the same time as tickets over chunks of 16 (0.3994 against 0.3997 ms,
-        // same box) and read no chunk head twice: HBM traffic 1.10 x -> 1.0x
-        if (tuned_16k && p->nfft == 8192 && p->step * 2 == p->nfft && p->tune_sched < 0 && p->sched == OTH_SCHED_DYNAMIC &&
-            nseg_run / (W > 0 ? W : 1) >= 16)
-            a.sched = OTH_SCHED_CONTIGUOUS;
-        a.chunk = p->tune_chunk > 0 ? p->tune_chunk : (tuned_16k ? ((p->step * 2 == p->nfft || (p->nperseg * 4 == p->nfft && p->step * 2 == p->nperseg)) ? 16 : 2) : (tuned ? var->chunk : (tuned_seg ? (static_chunk ? static_chunk : ((p->nfft == 1024 && !seg_ws) || (p->nfft == 2048 && seg_ws) ? 32 : 16)) : 8)));
-        if (a.chunk < 1) a.chunk = 1;
-        if ((tuned_16k1x) && a.chunk < 2) a.chunk = 2;      // its ticket for the NEXT chunk is published with a chunk's first
-                                                          // segment and read at its last: chunks of at least two segments
-        a.tail_chunk = a.chunk;
-        a.nbig = nseg_run / a.chunk;
-        if (a.sched < 0 || a.sched > 2) a.sched = 0;
-        if (a.sched == 2) {
-            if (nstreams > 64) a.sched = 1;
-            else {
-                a.queue = c->queue;
-                // guided tail: the last half round of work goes out in quarter-size chunks
-                a.tail_chunk = p->tune_tail > 0 ? p->tune_tail : (a.chunk >= 4 ? a.chunk / 4 : 1);
-                if (a.tail_chunk < 1) a.tail_chunk = 1;
-                if (tuned_16k1x && a.tail_chunk < 2) a.tail_chunk = 2;
-                const long long tail_segs = (long long)W * a.chunk / 2;
-                a.nbig = nseg_run > tail_segs ? (nseg_run - tail_segs) / a.chunk : 0;
-                if (!c->queue_clean) HIPCHK(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned) * 64, c->stream));
-                c->queue_clean = false;      // until the finalize launch that follows has re-zeroed them
-                c->queue_used = nstreams;
-            }
-        }
+    unsigned *queue = nullptr;
+    if (r.tickets) {
+        queue = c->queue;
+        if (!c->queue_clean) HIPCHK(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned) * 64, c->stream));
+        c->queue_clean = false;      // until the finalize launch that follows has re-zeroed them
+        c->queue_used = nstreams;
     }
-    if (tuned_seg) {
+    if (r.kern == RK_SEG || r.kern == RK_SEGWS || r.kern == RK_SEGPAD) {
         SegArgs g{};
         g.x = x;
         g.stream_stride = stride;
@@ -756,29 +898,57 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         g.detrend = p->detrend;
         g.chain = 0;
         g.partial = p->d_partial;
-        g.wg_per_stream = W;
-        g.sched = a.sched;
-        g.chunk = a.chunk;
-        g.tail_chunk = a.tail_chunk;
-        g.nbig = a.nbig;
-        g.queue = a.queue;
+        g.wg_per_stream = r.W;
+        g.sched = r.sched;
+        g.chunk = r.chunk;
+        g.tail_chunk = r.tail_chunk;
+        g.nbig = r.nbig;
+        g.queue = queue;
         g.fd = fd_tab;
-        g.pilot = a.pilot;
+        g.pilot = pilot;
         Timed tm(c);
-        HIPCHK(c, seg_pad ? launch_seg_padded(p->nfft, p->nperseg, g, seg_kind, c->stream)
-                          : (seg_ws ? launch_segws(p->nfft, g, seg_det, c->stream) : launch_seg(p->nfft, g, seg_kind, seg_wps4, c->stream)));
+        switch (r.kern) {
+            case RK_SEGPAD: HIPCHK(c, launch_seg_padded(p->nfft, p->nperseg, g, r.seg_kind, c->stream)); break;
+            case RK_SEGWS: HIPCHK(c, launch_segws(p->nfft, g, r.seg_det, c->stream)); break;
+            default: HIPCHK(c, launch_seg(p->nfft, g, r.seg_kind, r.seg_wps4, c->stream)); break;
+        }
     } else {
+        WelchArgs a;
+        a.x = x;
+        a.y = y;
+        a.win = p->d_win;
+        a.tw = p->d_tw;
+        a.partial = p->d_partial;
+        a.nseg = r.nseg_run;
+        if (r.two_runs) a.y = x + (size_t)r.nseg_run * 2048;      // run B starts nseg / 2 segments in (its first half-block is run A's last)
+        a.stream_stride = stride;
+        a.nperseg = p->nperseg;
+        a.step = p->step;
+        a.detrend = p->detrend;
+        a.wg_per_stream = r.W;
+        a.nstreams = nstreams;
+        a.sched = r.sched;
+        a.chunk = r.chunk;
+        a.tail_chunk = r.tail_chunk;
+        a.nbig = r.nbig;
+        a.queue = queue;
+        a.fd = fd_tab;
+        a.pilot = pilot;
+        a.pilot_inline = r.pilot == 2 ? 1 : 0;
         Timed tm(c);
-        HIPCHK(c, tuned ? var->launch(a, c->stream)
-                        : (tuned_csd ? (csd_ws ? launch_csd_tuned4096ws(a, c->stream) : launch_csd_tuned4096(a, c->stream))
-                                     : (tuned_16k ? (tuned_16k1x_half ? launch_welch_tuned16k1x_half(a, c->stream)
-                                                     : tuned_16k1x ? launch_welch_tuned16k1x(a, !p->rect_window, p->tune_variant == "16kplain", c->stream)
-                                                                 : launch_welch_tuned16k(p->nfft, a, c->stream))
-                                                  : launch_welch_generic(p->nfft, a, c->stream))));
+        switch (r.kern) {
+            case RK_W4096: HIPCHK(c, r.variant->launch(a, c->stream)); break;
+            case RK_CSD4096WS: HIPCHK(c, launch_csd_tuned4096ws(a, c->stream)); break;
+            case RK_CSD4096: HIPCHK(c, launch_csd_tuned4096(a, c->stream)); break;
+            case RK_W16K1X_HALF: HIPCHK(c, launch_welch_tuned16k1x_half(a, c->stream)); break;
+            case RK_W16K1X: HIPCHK(c, launch_welch_tuned16k1x(a, r.x1_window, r.x1_plain, c->stream)); break;
+            case RK_W16K: HIPCHK(c, launch_welch_tuned16k(p->nfft, a, c->stream)); break;
+            default: HIPCHK(c, launch_welch_generic(p->nfft, a, c->stream)); break;
+        }
     }
     *nseg_out = nseg;
-    *W_out = W * rows;
-    *layout_out = (tuned || tuned_csd) ? 1 : (tuned_16k ? ((tuned_16k1x || tuned_16k1x_half) ? 4 : (p->nfft == 16384 ? 2 : 3)) : 0);
+    *W_out = r.W * r.rows;
+    *layout_out = r.layout;
     return OTH_OK;
 }
 
@@ -2482,6 +2652,51 @@ int oth__debug_partial_raw(oth_plan *p, size_t float_offset, void *out, size_t n
 
 // Not part of the ABI: raises inside the barrier so that a host without a GPU can check it (tests/test_abi_cpu.py).
 // kind 0 = std::bad_alloc, 1 = std::runtime_error, 2 = a non-std exception, 3 = a real over-sized std::vector.
+// The launch recipe of a plan shape as text, WITHOUT a device (pure host logic; runtime_occupancy = 0 takes the resident
+// workgroups per CU from the built-in MI355X table, 1 asks the occupancy calculator and needs a GPU).
+//   window_class: 0 all ones, 1 spectrum confined (periodic cosine-sum windows: both detrend tables exist), 2 wide
+//   (e.g. a symmetric Hamming: no table), 3 confined to 256 F bins but not to |k| < 16 (16384 points only)
+//   detrend_mode: OTH_DETREND_*;  kernel_pref: OTH_KERNEL_*;  sched_pref: OTH_SCHED_*;  variant: as oth_plan_set_tuning
+int oth__debug_recipe(int nfft, int nperseg, int noverlap, int window_class, int detrend_mode, int two_channel, int kernel_pref,
+                      const char *variant, int sched_pref, long long nseg, int nstreams, int cu_count, int runtime_occupancy,
+                      char *buf, size_t buflen) {
+    OTH_TRY
+    if (!buf || !buflen || nperseg < 1 || nperseg > nfft || noverlap < 0 || noverlap >= nperseg || nseg < 1 || nstreams < 1)
+        return fail(nullptr, OTH_ERR_INVALID, "bad argument");
+    PlanShape sh;
+    sh.nfft = nfft;
+    sh.nperseg = nperseg;
+    sh.step = nperseg - noverlap;
+    sh.detrend = detrend_mode != OTH_DETREND_NONE;
+    sh.fast_detrend = detrend_mode == OTH_DETREND_CONSTANT_FAST;
+    // the tables oth_welch_plan builds: 4096 / 2048 / 8192 / 16384 points, nperseg = nfft, a confined window spectrum
+    const bool table_size = (nfft == 4096 || nfft == 2048 || nfft == 8192 || nfft == 16384) && nperseg == nfft;
+    sh.fd_ok = sh.detrend && table_size && (window_class == 0 || window_class == 1 || window_class == 3);
+    sh.fd1x_ok = sh.detrend && nfft == 16384 && nperseg == nfft && (window_class == 0 || window_class == 1);
+    sh.rect_window = window_class == 0;
+    sh.kernel = kernel_pref;
+    sh.sched = sched_pref;
+    sh.tune_variant = variant ? variant : "";
+    LaunchRecipe r;
+    const char *why = "";
+    if (int rc = resolve_recipe(sh, two_channel != 0, nseg, nstreams, cu_count > 0 ? cu_count : 256,
+                                runtime_occupancy ? runtime_bpc : table_bpc, &r, &why))
+        return fail(nullptr, rc, why);
+    snprintf(buf, buflen, "%s", recipe_text(r, nfft).c_str());
+    return OTH_OK;
+    OTH_CATCH(nullptr)
+}
+
+// recipe of the plan's last averaging launch ("" before the first)
+int oth__debug_last_recipe(oth_plan *p, char *buf, size_t buflen) {
+    OTH_TRY
+    CtxGuard guard_(p ? p->ctx : nullptr);
+    if (!p || !buf || !buflen) return fail(p ? p->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
+    snprintf(buf, buflen, "%s", p->last_recipe.c_str());
+    return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
+}
+
 int oth__debug_throw(oth_ctx *c, int kind) {
     OTH_TRY
     CtxGuard guard_(c);

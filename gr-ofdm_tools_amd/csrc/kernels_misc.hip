@@ -610,9 +610,14 @@ __global__ __launch_bounds__(256) void bin_threshold_ma_kernel(const float *psd,
 
 // ---- decision stage of the batched scanner, many rows (oth_scan_decide_dev*) ------------------------------------------
 // movingaverage (ofdm_cr_tools.py:168-170) as a SLIDING sum: a thread forms the M-tap sum of its first output directly
-// and moves on by + x[in] - x[out] for the other 15.  Sums of a few hundred float32 values in double are exact
-// (24-bit mantissas, 53-bit accumulator), so the sliding sum IS the direct one, not an approximation of it; 12 adds
-// per output instead of M = 163 at config 5's search bandwidth.  The row minimum (the noise floor of
+// and moves on by + x[in] - x[out] for the other 15; 12 adds per output instead of M = 163 at config 5's search
+// bandwidth.  A double sum of M float32 values is EXACT - and the sliding sum then IS the direct one - while the taps of
+// a window span less than 2^(28 - log2 M) in magnitude (62 dB of power at M = 163).  Beyond that every add / subtract
+// of a large tap rounds at 2^-53 of it, and what a strong carrier leaves behind when it slides out of the window stays in
+// the sum for the rest of the run: at most 2 (kMaRun - 1) 2^-53 max|tap| - which matters exactly where the row's noise
+// floor (its minimum, the most sensitive output) sits right next to a carrier more than ~90 dB above it.  So the run
+// keeps the largest tap it has seen and forms an output directly again whenever the sliding sum has fallen below
+// 2^-24 of it (advisor, round 4): the result then never differs from the direct sum by more than 2^-24 relative.  The row minimum (the noise floor of
 // spectrum_sensor_v2.py:465-467, per row) is taken on the way: every block leaves the minimum of its tile in
 // tile_min[row][tile], and scan_post_kernel takes the minimum of a row's few tiles (round 4: an atomicMin on a word the
 // launcher had to preset cost a fill launch per call).
@@ -653,20 +658,40 @@ __global__ __launch_bounds__(kMaThreads) void movavg_run_kernel(const float *psd
     if (i0 < nfft) {
         double s = 0.0;
         int j = 0;
-        for (; j + 8 <= M; j += 8) {      // eight independent LDS reads per trip (one read per trip waited ~100 cycles each)
-            float a[8];
+        float big = 0.f;                  // largest |tap| this run has added so far
+        auto direct = [&](int first) {    // M-tap sum of xs[first ..]: eight independent LDS reads per trip (one read per
+            double d = 0.0;               // trip waited ~100 cycles each)
+            int jj = 0;
+            for (; jj + 8 <= M; jj += 8) {
+                float a[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = xs[ma_pad(t0 + j + u)];
-            s += (((double)a[0] + a[1]) + ((double)a[2] + a[3])) + (((double)a[4] + a[5]) + ((double)a[6] + a[7]));
-        }
-        for (; j < M; ++j) s += (double)xs[ma_pad(t0 + j)];
+                for (int u = 0; u < 8; ++u) a[u] = xs[ma_pad(first + jj + u)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) big = fmaxf(big, fabsf(a[u]));
+                d += (((double)a[0] + a[1]) + ((double)a[2] + a[3])) + (((double)a[4] + a[5]) + ((double)a[6] + a[7]));
+            }
+            for (; jj < M; ++jj) {
+                const float a = xs[ma_pad(first + jj)];
+                big = fmaxf(big, fabsf(a));
+                d += (double)a;
+            }
+            return d;
+        };
+        s = direct(t0);
+        (void)j;
         double v = fabs(s * inv);
         ys[ma_pad(t0)] = v;
         mn = (float)v;
 #pragma unroll 4
         for (int r = 1; r < kMaRun && i0 + r < nfft; ++r) {
-            s += (double)xs[ma_pad(t0 + r + M - 1)];
+            const float in = xs[ma_pad(t0 + r + M - 1)];
+            big = fmaxf(big, fabsf(in));
+            s += (double)in;
             s -= (double)xs[ma_pad(t0 + r - 1)];
+            if (fabs(s) < (double)big * (1.0 / 16777216.0)) {      // a carrier > 2^24 x the window's content has just left
+                big = 0.f;
+                s = direct(t0 + r);
+            }
             v = fabs(s * inv);
             ys[ma_pad(t0 + r)] = v;
             mn = fminf(mn, (float)v);

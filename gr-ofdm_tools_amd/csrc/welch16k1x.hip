@@ -689,7 +689,8 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
     float4 *quadK = reinterpret_cast<float4 *>(tabC + 16 * 4);
 
     const int tid = threadIdx.x;
-    const int wv = tid >> 6, l = tid & 63, g = l >> 2, q = l & 3;
+    // the wave index as a scalar: the LDS slots of the per-wave sums and the region bases then need no vector registers
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 2, q = l & 3;
     const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
     const long long s0 = (p.nseg * wg) / W, s1 = (p.nseg * (wg + 1)) / W;
     const float2 *xb = p.x + (size_t)stream * p.stream_stride;
@@ -703,11 +704,6 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
         }
     }
     const float2 a1 = p.tw[tid], a4 = p.tw[4 * tid];
-    float win[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) win[r] = p.win[tid + 1024 * r];
-    float4 fd = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (DET == 2) fd = p.fd[tid];
     __syncthreads();
 
     float2 *wa = lds + tid;
@@ -722,36 +718,75 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
     const int sched = p.sched;
     const long long nchunks = sched ? chunk_count(p) : 1;
     int cpar = 0;
+    // Registers (round 5; round 4 kept the sixteen window values in registers, loaded each new half at the top of its
+    // step and spilled 25 registers around the transform - 104 B of scratch, reloaded between the step's barriers):
+    //   keep[8]  the raw second half of the segment before (= this segment's first half), pilot already off
+    //   nxt[8]   this segment's new half, PREFETCHED during the step before (pinned non-temporal loads, two at each of
+    //            four places of the step as in the scanner kernel: a burst stalls the issuing wave at its loads)
+    //   the sixteen window values come from L2 where they are used (pinned loads, see load_win): 64 KiB shared by every
+    //   workgroup of the XCD, against 64 KiB of new samples per step
     float2 keep[8];
+    f2v nxt[8];
+    const unsigned voff = 8u * tid;
     // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot comes off every sample as it arrives
     const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, blockIdx.y);
     for (long long cur = sched ? wg : 0; cur < nchunks;) {
         long long sb = s0, se = s1;
         if (sched) chunk_range(p, cur, sb, se);
+        if (sb < se) {      // the chunk's first segment: both halves now
+            const char *x0 = reinterpret_cast<const char *>(xb + sb * p.step);
+            f2v first[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) load_row_nt(first[r], voff, x0 + 8192 * r);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) load_row_nt(nxt[r], voff, x0 + 8192 * (8 + r));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 8; ++r) keep[r] = make_float2(first[r].x, first[r].y);
+        }
         for (long long s = sb; s < se; ++s) {
             float2 v[16];
             prio_latency();
-            const float2 *xs = xb + s * p.step + tid;
+            float wv16[16];
+            {
+                const char *wbase = reinterpret_cast<const char *>(p.win);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * tid, wbase + 4096 * r);
+                // ... and the new half prefetched during the step before (or loaded above)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(wv16[0]), "+v"(wv16[1]), "+v"(wv16[2]), "+v"(wv16[3]), "+v"(wv16[4]), "+v"(wv16[5]), "+v"(wv16[6]),
+                               "+v"(wv16[7]), "+v"(wv16[8]), "+v"(wv16[9]), "+v"(wv16[10]), "+v"(wv16[11]), "+v"(wv16[12]), "+v"(wv16[13]),
+                               "+v"(wv16[14]), "+v"(wv16[15]), "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]),
+                               "+v"(nxt[5]), "+v"(nxt[6]), "+v"(nxt[7])
+                             :
+                             : "memory");
+            }
             float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
-            if (s == sb) {      // the chunk's first segment brings its own first half
+            if (s == sb) {      // the chunk's first half arrives raw
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    keep[r] = load_once(xs + 1024 * r);
                     if (PILOT) keep[r] = csub(keep[r], pv);
                     sumf = cadd(sumf, keep[r]);
                 }
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                float2 nw = load_once(xs + 1024 * (8 + r));
+                float2 nw = make_float2(nxt[r].x, nxt[r].y);
                 if (PILOT) nw = csub(nw, pv);
-                v[r] = keep[r];
-                v[8 + r] = nw;
+                v[r] = make_float2(keep[r].x * wv16[r], keep[r].y * wv16[r]);
+                v[8 + r] = make_float2(nw.x * wv16[8 + r], nw.y * wv16[8 + r]);
                 keep[r] = nw;
                 sum = cadd(sum, nw);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = make_float2(v[r].x * win[r], v[r].y * win[r]);
+            // the new half of the segment after this one (behind the chunk's last segment the same rows once more: an
+            // unconditional definition keeps the registers free - a conditional one keeps their old values alive)
+            const char *xn = reinterpret_cast<const char *>(xb + (s + 1 < se ? s + 1 : s) * p.step) + 8192 * 8;
+            auto prefetch = [&](int r0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_row_nt(nxt[r0], voff, xn + 8192 * r0);
+                load_row_nt(nxt[r0 + 1], voff, xn + 8192 * (r0 + 1));
+                __builtin_amdgcn_sched_barrier(0);
+            };
             const int par = (int)(s & 1);
             if (DET == 2) {
                 sum.x = wave_total_lane63(sum.x);
@@ -772,29 +807,43 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
             if (sched == 2 && s == sb && tid == 0) lnext[cpar] = (int)atomicAdd(p.queue + stream, 1u);
             if (DET == 2 && tid < 64) {      // wave 0: the 32 per-wave sums of this segment's two halves -> its total
                 float2 part = make_float2(0.f, 0.f);
-                if (tid < 32) part = red[tid];
+                int slot = l;      // opaque: formed here, not kept (and spilled) across the step
+                asm volatile("" : "+v"(slot));
+                if (slot < 32) part = red[slot];
                 part.x = wave_total_lane63(part.x);
                 part.y = wave_total_lane63(part.y);
                 if (tid == 63) red[40 + par] = part;      // read behind barrier 2, at the end of the step
             }
             scatter_pow16<XREG>(v, wa, a1, a4);                    // x W_N^(k0 tid) -> [k0][w][l]
+            prefetch(0);
             lds_barrier();      // 2
             TwBatch ta;
             dft16_from_lds<64>(v, ra, [] { prio_compute(); }, [&] { tw_read_a<64>(ta, tabB + l); });     // pass 2
             prio_latency();
+            prefetch(2);
             wave_lds_sync();
             twiddle_table16<64, XROW, true>(v, wb, tabB + l, ta);
+            prefetch(4);
             wave_lds_sync();
             TwBatch tc;
             dft16_from_lds<4>(v, rb, [] { prio_compute(); }, [&] { tw_read_a<4>(tc, tabC + q); });        // pass 3
             const float4 qk = quadK[q];
             twiddle_table16<4, 1, false>(v, nullptr, tabC + q, tc);
+            prefetch(6);
             quad_dft4_dpp(v, qk.x, qk.y, qk.z, qk.w);              // pass 4
             if (DET == 2) {
-                const float2 tot = red[40 + par];
-                const float2 mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
-                v[0] = make_float2(v[0].x - (mean.x * fd.x - mean.y * fd.y), v[0].y - (mean.x * fd.y + mean.y * fd.x));
-                v[15] = make_float2(v[15].x - (mean.x * fd.z - mean.y * fd.w), v[15].y - (mean.x * fd.w + mean.y * fd.z));
+                // X[k] -= mean FFT(w)[k] where FFT(w) is not negligible: register k2 = 0 of lanes (k1 = 0, q = 0) and k2 = 15
+                // of lanes (k1 = 15, q = 3) - lanes 0 and 63 of every wave; their table entries come from L2 when they are
+                // used (held across the step they were four registers of all 1024 threads)
+                if (l == 0 || l == 63) {
+                    int tfd = tid;      // opaque, as above: the table address is formed inside the branch
+                    asm volatile("" : "+v"(tfd));
+                    const float4 fd = p.fd[tfd];
+                    const float2 tot = red[40 + par];
+                    const float2 mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
+                    v[0] = make_float2(v[0].x - (mean.x * fd.x - mean.y * fd.y), v[0].y - (mean.x * fd.y + mean.y * fd.x));
+                    v[15] = make_float2(v[15].x - (mean.x * fd.z - mean.y * fd.w), v[15].y - (mean.x * fd.w + mean.y * fd.z));
+                }
             }
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {

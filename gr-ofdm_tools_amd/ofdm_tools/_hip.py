@@ -105,6 +105,9 @@ SIGNATURES = {
                                           C.POINTER(C.c_int), _p, _p, _p]),
     'oth_xcorr': (C.c_int, [_p, _p, C.c_size_t, _p, C.c_size_t, C.c_int, _f]),
     'oth_fac': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f]),
+    'oth__debug_recipe': (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                                    C.c_size_t]),
+    'oth__debug_last_recipe': (C.c_int, [_p, C.c_char_p, C.c_size_t]),
 }
 
 _lib = None
@@ -384,6 +387,12 @@ class WelchPlan(object):
 
     def nseg(self, nsamples):
         return (nsamples - self.noverlap) // self.step if nsamples >= self.nperseg else 0
+
+    def last_recipe(self):
+        """Diagnostics: 'kernel=... form=... pilot=... sched=... chunk=... W=...' of the last averaging launch."""
+        buf = C.create_string_buffer(512)
+        self.ctx.check(self.ctx.lib.oth__debug_last_recipe(self.h, buf, 512), 'oth__debug_last_recipe')
+        return buf.value.decode()
 
     def exec(self, x):
         """x: host complex64 array -> float32 PSD of out_len bins."""

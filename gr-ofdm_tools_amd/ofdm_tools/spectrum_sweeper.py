@@ -44,9 +44,12 @@ def frange(x, y, jump):
 def _stitch_loop(ref, wake, start_delay, one_sweep, collective):
     """spectrum_stitcher.run (:207-231): the start-up wait (:208), then sweep after sweep while keep_running.
     The thread holds the block only weakly, so a block that is dropped without stop() takes its stitcher along;
-    ``wake`` ends both the start-up wait and a tune-delay sleep early when stop() is called.  A ``collective`` loop
-    (start_sharded) never leaves on its own rank's flag - the other ranks would wait for it in the next gather for
-    ever - but only when one_sweep() reports what the ranks agreed on."""
+    ``wake`` ends both the start-up wait and a tune-delay sleep early when stop() is called.
+    ``one_sweep(blk) -> (published, more)``: whether a stitched PSD went out (only those count in ``sweeps_done``) and
+    whether to go on.  A ``collective`` loop (start_sharded) never leaves on its own rank's flag or on its own rank's
+    failure - the other ranks would wait for it in the next collective until the backend's timeout - but only when
+    one_sweep() reports what the ranks agreed on; a failure inside a collective sweep is carried through that sweep's
+    gather and agreement by one_sweep itself and raised afterwards."""
     if start_delay > 0 and wake.wait(start_delay) and not collective:
         return
     while True:
@@ -54,8 +57,9 @@ def _stitch_loop(ref, wake, start_delay, one_sweep, collective):
         if blk is None or not (blk.keep_running or collective):
             return
         try:
-            more = one_sweep(blk)
-            blk.sweeps_done += 1
+            published, more = one_sweep(blk)
+            if published:
+                blk.sweeps_done += 1
             if collective and not more:
                 blk.keep_running = False
                 return
@@ -112,7 +116,8 @@ class spectrum_sweeper(sync_block):
     # -- threads (:99-105) --------------------------------------------------------
     def _threads_init(self):
         self.keep_running = True
-        self.sweeps_done = 0
+        self.sweeps_done = 0                # stitched sweeps that went out (collective mode: that were complete on every rank)
+        self.incomplete_sweeps = 0          # collective mode: sweeps in which some rank's rows failed (never published)
         self.captures = 0                 # vectors work() has stored (what data_colector would have set)
         self._stitch_error = None
         self._stitch_thread = None
@@ -130,7 +135,7 @@ class spectrum_sweeper(sync_block):
 
     def start(self, start_delay=2.0):
         """Start the stitcher thread (the constructor does, as spectrum_sweeper.py:103-105; the 2 s are :208)."""
-        return self._launch(start_delay, lambda blk: blk.sweep_once(sleep=blk._sleep))
+        return self._launch(start_delay, lambda blk: (blk.sweep_once(sleep=blk._sleep) is not None, True))
 
     def start_sharded(self, capture, rank, world, device, group=None, start_delay=0.0, publish_rank=None,
                       sweeps=None):
@@ -148,37 +153,52 @@ class spectrum_sweeper(sync_block):
             if 'pipe' not in state:
                 state['pipe'] = blk._sharded_pipeline(rank, world, device, group)
             pipe = state['pipe']
-            slot = blk._sharded_sweep(pipe, capture, device)
+            # A failure on THIS rank (capture, retune, HIP) must not keep it out of the sweep's collectives: its rows go
+            # out as NaN, it votes to stop, every rank leaves after this sweep, and the error is raised here afterwards
+            # (-> _stitch_error -> the next work()).  Whether every rank's rows were valid travels with the vote: a sweep
+            # with a failed row is published nowhere.
+            failure = []
+            slot = blk._sharded_sweep(pipe, capture, device, failure)
             state['n'] += 1
-            more = blk._agree_to_continue(sweeps is None or state['n'] < sweeps, world, device, group)
+            mine = not failure and (sweeps is None or state['n'] < sweeps)
+            more, complete = blk._agree_to_continue(mine, world, device, group, ok=not failure)
             publish = publish_rank is None or publish_rank == rank
-            prev = state.get('slot')
-            state['slot'] = slot
-            if prev is not None and publish:
+            prev, prev_ok = state.get('slot'), state.get('ok', False)
+            state['slot'], state['ok'] = slot, complete
+            if prev is not None and prev_ok and publish:      # the sweep before: its gather overlapped this sweep's kernels
                 blk._blend_and_send(pipe.wideband(prev).cpu().numpy().astype(np.float64))
+            if not complete:
+                blk.incomplete_sweeps += 1
             if not more:
-                if publish:
+                if complete and publish:
                     blk._blend_and_send(pipe.wideband(slot).cpu().numpy().astype(np.float64))
                 pipe.drain()
-            return more
+            if failure:
+                raise failure[0]
+            return complete, more
         return self._launch(start_delay, one_sweep, collective=True)
 
-    def _agree_to_continue(self, mine, world, device, group=None):
+    def _agree_to_continue(self, mine, world, device, group=None, ok=True):
+        """One two-word MIN all-reduce per sweep: (go on?, were this sweep's rows valid on every rank?)."""
         mine = bool(mine and self.keep_running)
         if world == 1:
-            return mine
+            return mine, bool(ok)
         import torch
         import torch.distributed as dist
-        flag = torch.tensor([1.0 if mine else 0.0], dtype=torch.float32, device=device)
+        flag = torch.tensor([1.0 if mine else 0.0, 1.0 if ok else 0.0], dtype=torch.float32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        return bool(flag.item() > 0.5)
+        flag = flag.cpu()
+        return bool(flag[0] > 0.5), bool(flag[1] > 0.5)
 
     def stop(self):
         self.keep_running = False
         self._wake.set()
-        t, self._stitch_thread = self._stitch_thread, None
+        t = self._stitch_thread
         if t is not None and t is not threading.current_thread():
             t.join(5.0)
+            if t.is_alive():      # still inside a capture / a collective: keep the handle, start() refuses a second stitcher
+                return False
+        self._stitch_thread = None
         return True
 
     def _sleep(self, seconds):
@@ -324,12 +344,23 @@ class spectrum_sweeper(sync_block):
         return sweep.SweepPipeline(len(self.tune_frequencies), self.fft_len - 2 * self.excess_bins, device, rank,
                                    world, group, depth)
 
-    def _sharded_sweep(self, pipe, capture, device):
+    def _sharded_sweep(self, pipe, capture, device, failure=None):
         """This rank's share of one sweep: retune to each of its segments, wait tune_delay, take the capture, run
-        the plan into the pipeline's row; then start the gather.  -> the pipeline slot to read the sweep from."""
+        the plan into the pipeline's row; then start the gather.  -> the pipeline slot to read the sweep from.
+        ``failure`` (a list): an exception in a segment is appended there instead of leaving the sweep - that row and
+        the rank's remaining rows of this sweep are filled with NaN, so that the gather still takes place."""
         def compute(i, out_row):
-            f = self.tune_frequencies[i]
-            self._tune(f)
-            self._sleep(self.tune_delay)
-            self._segment_to_row(capture(i, f), out_row, device)
+            if failure:
+                out_row.fill_(float('nan'))
+                return
+            try:
+                f = self.tune_frequencies[i]
+                self._tune(f)
+                self._sleep(self.tune_delay)
+                self._segment_to_row(capture(i, f), out_row, device)
+            except Exception as e:
+                if failure is None:
+                    raise
+                failure.append(e)
+                out_row.fill_(float('nan'))
         return pipe.run(compute)

@@ -326,6 +326,19 @@ int oth_xcorr(oth_ctx *ctx, const void *a, size_t na, const void *b, size_t nb, 
 /* fac (ofdm_cr_tools.py:163-166): |fftshift(fft(|fft(data,L)|, L))[L/2:]| */
 int oth_fac(oth_ctx *ctx, const void *data, size_t n, int L, float *out);
 
+/* ---- diagnostics (ABI 5) ------------------------------------------------------------------------------------------
+ * Which kernel build, detrend form, pilot, schedule, chunk sizes, grid and partial-row layout a launch takes is decided by
+ * pure host logic (csrc/api.hip resolve_recipe) and can be read back as text:
+ *   "kernel=welch4096:ws nfft=4096 form=freq pilot=inline sched=dynamic chunk=20 tail=5 nbig=6297 bpc=2 W=512 rows=1 nch=1 layout=1"
+ * oth__debug_recipe needs NO device: window_class 0 = all ones, 1 = confined spectrum (periodic cosine-sum windows),
+ * 2 = wide (no detrend table), 3 = confined to 256 nfft / 4096 bins only; runtime_occupancy 0 = resident workgroups per CU
+ * from the built-in MI355X table, 1 = from the occupancy calculator (needs a GPU).  oth__debug_last_recipe: the recipe of
+ * the plan's last averaging launch. */
+int oth__debug_recipe(int nfft, int nperseg, int noverlap, int window_class, int detrend_mode, int two_channel, int kernel_pref,
+                      const char *variant, int sched_pref, long long nseg, int nstreams, int cu_count, int runtime_occupancy,
+                      char *buf, size_t buflen);
+int oth__debug_last_recipe(oth_plan *plan, char *buf, size_t buflen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,3 +117,78 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in text.replace('oracle/', ''), f
                 assert 'import scipy' not in text and 'from scipy' not in text, f
+
+
+def test_launch_recipes_table():
+    """Routing as data (round 4 verdict, weak 7): which kernel build, detrend form, pilot, schedule, chunk sizes, grid
+    and partial-row layout a launch takes is resolve_recipe() in csrc/api.hip - pure host logic, enumerated here without
+    a GPU through oth__debug_recipe (resident workgroups per CU from the built-in MI355X table; the GPU suite compares
+    that table with the occupancy calculator).  Pinned twice: a readable table of 1278 recipes
+    (tests/golden/recipes_small.txt) and the digest of the full enumeration of 18522 (nfft x nperseg x overlap x window
+    class x detrend mode x one / two channels x segment count x streams).  An intended routing change regenerates both
+    with `python tests/recipes.py --write`; the diff of the small table is the review."""
+    import recipes
+    from ofdm_tools import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        pytest.skip('library not built yet')
+    lib = recipes._lib()
+    small = recipes.table(lib, False)
+    want = open(os.path.join(ROOT, 'tests', 'golden', 'recipes_small.txt')).read().splitlines()
+    assert len(small) == len(want)
+    diff = [(a, b) for a, b in zip(small, want) if a != b]
+    assert not diff, diff[:3]
+    full = recipes.table(lib, True)
+    pinned = open(os.path.join(ROOT, 'tests', 'golden', 'recipes_full.sha256')).read().split()
+    assert (recipes.digest(full), len(full)) == (pinned[0], int(pinned[1]))
+
+    def fields(**kw):
+        return dict(f.split('=') for f in recipes.recipe(lib, **kw).split())
+    # the BASELINE configurations
+    c2 = fields(nfft=4096, nperseg=4096, noverlap=2048, nseg=131071)
+    assert (c2['kernel'], c2['form'], c2['pilot'], c2['sched'], c2['chunk'], c2['W']) == ('welch4096:ws', 'freq', 'inline', 'dynamic', '20', '512')
+    c3 = fields(nfft=4096, nperseg=4096, noverlap=2048, two_channel=1, nseg=32767)
+    assert (c3['kernel'], c3['pilot'], c3['sched'], c3['W'], c3['nch']) == ('csd4096ws', 'inline', 'contiguous', '256', '4')
+    c4 = fields(nfft=4096, nperseg=1024, noverlap=512, nseg=65535)                # the sweeper's own call (spectrum_sweeper.py:263)
+    assert (c4['kernel'], c4['form'], c4['pilot']) == ('welch4096:dpp', 'time', 'launch')
+    c5 = fields(nfft=16384, nperseg=16384, noverlap=0, window=0, detrend=0, nseg=256, nstreams=64)
+    assert (c5['kernel'], c5['sched'], c5['layout'], c5['W']) == ('welch16k1x:pipe', 'contiguous', '4', '4')
+    # a launch of fewer than eight segments detrends before the window in BOTH modes; FAST has no pilot
+    for det in (1, 3):
+        few = fields(nfft=4096, nperseg=4096, noverlap=2048, detrend=det, nseg=7)
+        assert (few['kernel'], few['form']) == ('welch4096:pipe', 'time')
+        assert few['pilot'] == ('launch' if det == 1 else 'none')
+    # a window without a confined spectrum, other steps, the coverage kernel, an unsupported request
+    assert fields(nfft=4096, nperseg=4096, noverlap=2048, window=2)['kernel'] == 'welch4096:pipe'
+    assert fields(nfft=4096, nperseg=4096, noverlap=3072)['kernel'] == 'welch4096:dpp'
+    assert fields(nfft=16384, nperseg=16384, noverlap=8192)['kernel'] == 'welch16k1x_half'
+    assert fields(nfft=16384, nperseg=16384, noverlap=8192, window=2)['kernel'] == 'welch16k'
+    assert fields(nfft=1024, nperseg=1024, noverlap=512)['kernel'] == 'segws'
+    assert fields(nfft=128, nperseg=128, noverlap=64)['kernel'] == 'welch_generic'
+    assert fields(nfft=4096, nperseg=4096, noverlap=2048, kernel=1)['kernel'] == 'welch_generic'
+    assert recipes.recipe(lib, nfft=128, nperseg=128, noverlap=64, kernel=2).startswith('error -3')
+    # more streams than ticket words: the dynamic schedule becomes interleaved chunks
+    assert fields(nfft=4096, nperseg=4096, noverlap=2048, nseg=20000, nstreams=100)['sched'] == 'interleaved'
+
+
+def test_hot_kernels_have_no_scratch():
+    """A spilled register comes back at memory latency in every step (12 % of the two-channel kernel in round
+    2; round 4's verdict found 2-25 spilled VGPRs in five default builds).  The code objects inside the shipped library
+    say what each kernel uses: the default builds of the tuned kernels must carry no scratch memory."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import kernel_resources
+    from ofdm_tools import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        pytest.skip('library not built yet')
+    ks = kernel_resources.kernels(_hip.LIB_PATH)
+    hot = ['welch4096ws_kernel<true, true>', 'welch4096ws_kernel<true, false>', 'welch4096ws_kernel<false, false>',
+           'csd4096ws_kernel<true, true>', 'csd4096ws_kernel<true, false>',
+           'welch16k1x_pipe_kernel<false>', 'welch16k1x_half_kernel<2, true>', 'welch16k1x_half_kernel<2, false>',
+           'welch16k1x_half_kernel<0, false>',
+           'segws_kernel<4, 1, true>', 'segws_kernel<8, 2, true>', 'seg_kernel<1, 0, true, false, 3, 16, true>',
+           'seg_kernel<2, 0, true, false, 3, 16, true>']
+    found = {h: [n for n in ks if h + '(' in n.replace('oth::', '')] for h in hot}
+    missing = [h for h, n in found.items() if len(n) != 1]
+    assert not missing, missing
+    bad = {h: ks[n[0]]['scratch'] for h, n in found.items() if ks[n[0]]['scratch']}
+    assert not bad, bad

@@ -239,14 +239,8 @@ def test_welch16k1x_scanner_kernels_schedules_and_counts(ctx, hip):
                 a = ctx.d2h(d_a, (ns, N), np.float32).astype(np.float64)
                 err = np.max(np.abs(a - b) / np.maximum(b, 0.1 * np.median(b)))
                 assert err < (5e-5 if nseg >= 8 else 2e-4), (nseg, ns, variant, sched, chunk, err)
-        # vectors further apart than their length (keep_one_in_n > 1 on the stream)
-        plan = ctx.welch_plan(N, nperseg=N, noverlap=0, window=None, detrend=hip.DETREND_NONE, scaling=hip.SCALE_OVER_N2,
-                              kernel=hip.KERNEL_TUNED)
-        n = N * 40
-        assert plan.exec_dev(d_in, n, d_a) == 40 and gen.exec_dev(d_in, n, d_b) == 40
         tuned.close()
         gen.close()
-        plan.close()
     finally:
         for ptr in (d_in, d_a, d_b):
             ctx.free(ptr)
@@ -314,14 +308,20 @@ def test_welch16k_hann_overlap_detrend_many_segments(ctx, hip, N):
     import scipy.signal as sg
     for wname, w in (('flattop', flattop(N)), ('hamming_sym', sg.windows.hamming(N, sym=True).astype(np.float32))):
         _, ref = R.welch_np(xdc, window=w.astype(np.float64), nperseg=N, nfft=N)
+        # |m| = 35 sigma over 23 segments.  The default plan (OTH_DETREND_CONSTANT: computed on x - pilot) is held to the
+        # flat 1e-4 on EVERY bin, the bins under the removed DC line included (round 4 still allowed them the float32-mean
+        # bound here); that bound belongs to OTH_DETREND_CONSTANT_FAST alone, which works on the raw samples.
         plan = ctx.welch_plan(N, window=w, kernel=hip.KERNEL_TUNED)
-        # |m| = 35 sigma over 23 segments: the bins under the removed DC line (the window's main lobe, |k| <= 4 for a
-        # flat-top) are held to the float32-mean bound, every other bin to 1e-4 (see _f32_mean_bound)
         e = np.abs(plan.exec(xdc) - ref) / ref
-        lobe = [0, 1, 2, 3, 4, N - 4, N - 3, N - 2, N - 1]
+        assert e.max() < RTOL, (wname, e.max(), int(np.argmax(e)))
+        plan.close()
+        fast = ctx.welch_plan(N, window=w, kernel=hip.KERNEL_TUNED, detrend=hip.DETREND_CONSTANT_FAST)
+        e = np.abs(fast.exec(xdc) - ref) / ref
+        fast.close()
+        lobe = [0, 1, 2, 3, 4, N - 4, N - 3, N - 2, N - 1]      # the window's main lobe: |k| <= 4 for a flat-top
         Wk = np.abs(np.fft.fft(w.astype(np.float64)))[lobe]
         bound = 2 * (2 * 2.0 ** -23 * abs(30.0 - 18.0j)) * Wk / np.sqrt(ref[lobe] * float(np.sum(w.astype(np.float64) ** 2)))
-        assert np.delete(e, lobe).max() < RTOL and np.all(e[lobe] <= np.maximum(RTOL, bound)), (wname, e.max())
+        assert np.delete(e, lobe).max() < RTOL and np.all(e[lobe] <= np.maximum(RTOL, bound)), (wname, 'fast', e.max())
     # many segments, device-resident, against the coverage kernel: counts around chunk and grid multiples, 1-3 streams
     step = N // 2
     nmax = N + step * 2100
@@ -1445,6 +1445,23 @@ def test_scan_decide_dev_on_device_rows(ctx, hip):
     # host-row convenience form goes through the same entry point
     m3, n3, p3 = bp.decide(rows)
     assert np.array_equal(m3, mask) and np.array_equal(p3, plc)
+    # rows with carriers 100 / 130 / 150 dB above a floor that sits right next to them (a float32 PSD row spans up to
+    # ~140 dB): the sliding sum of the moving average must not carry the carrier's rounding into the floor's minimum
+    # (advisor, round 4) - noise floor and channel sums against the oracle's direct np.convolve
+    rng = np.random.default_rng(9)
+    hard = np.empty((3, N), np.float32)
+    for i, db in enumerate((100.0, 130.0, 150.0)):
+        row = (1e-12 * (1.0 + 0.1 * rng.random(N))).astype(np.float32)
+        for k in (700, 701, 702, 5000, 9000, 9163, 16000):      # single bins and a pair exactly one window apart
+            row[k] = np.float32(1e-12 * 10.0 ** (db / 10.0))
+        hard[i] = row
+    m4, n4, p4 = bp.decide(hard)
+    for i in range(3):
+        ma = R.movingaverage(hard[i], st.srch_bins)
+        assert np.isclose(n4[i], ma.min(), rtol=2e-6), (i, n4[i], ma.min())
+        want = R.src_power(hard[i], N, st.Fr, Sf, st.bb_freqs, st.srch_bins)
+        assert np.allclose(p4[i], want, rtol=1e-5)
+        assert np.array_equal(m4[i], (hard[i] > np.float32(3.0) * n4[i]).astype(np.uint8))
 
 
 # ------------------------------------------- segfft.hip: 1024 / 2048 Welch, fused chain ----
@@ -1788,3 +1805,47 @@ def test_pilot_formed_inside_the_launch_equals_the_pilot_launch(ctx, hip, dc):
         assert np.max(np.abs(gxy - rxy) / np.sqrt(rxx * ryy)) < RTOL and np.max(np.abs(gc - rc)) < RTOL
     inl.close()
     lau.close()
+
+
+def test_recipe_occupancy_table_matches_the_runtime(ctx, hip):
+    """tests/test_abi_cpu.py::test_launch_recipes_table enumerates the launch recipes without a GPU, with the resident
+    workgroups per CU taken from a built-in table.  Here, on the device: that table equals what the occupancy calculator
+    says for every tuned build, and the recipe a real launch recorded equals the table's recipe for the same shape."""
+    import recipes
+    lib = hip.load()
+    from ofdm_tools import windows
+    shapes = [dict(nfft=4096, nperseg=4096, noverlap=2048), dict(nfft=4096, nperseg=4096, noverlap=2048, window=2),
+              dict(nfft=4096, nperseg=4096, noverlap=1024), dict(nfft=4096, nperseg=1024, noverlap=512),
+              dict(nfft=4096, nperseg=4096, noverlap=2048, two_channel=1),
+              dict(nfft=4096, nperseg=4096, noverlap=2048, two_channel=1, variant='csd1'),
+              dict(nfft=16384, nperseg=16384, noverlap=0, window=0, detrend=0), dict(nfft=16384, nperseg=16384, noverlap=8192),
+              dict(nfft=8192, nperseg=8192, noverlap=4096), dict(nfft=8192, nperseg=8192, noverlap=0, window=0, detrend=0)]
+    for nfft in (256, 512, 1024, 2048):
+        shapes += [dict(nfft=nfft, nperseg=nfft, noverlap=nfft // 2), dict(nfft=nfft, nperseg=nfft, noverlap=0),
+                   dict(nfft=nfft, nperseg=nfft, noverlap=nfft // 2, variant='seg3'),
+                   dict(nfft=nfft, nperseg=nfft, noverlap=nfft // 2, variant='seg4')]
+    for nfft in (1024, 2048):
+        shapes += [dict(nfft=nfft, nperseg=nfft // f, noverlap=nov) for f in (4, 2) for nov in (nfft // f // 2, 0)]
+    wrong = []
+    for sh in shapes:
+        a = recipes.recipe(lib, nseg=20000, runtime=0, **sh)
+        b = recipes.recipe(lib, nseg=20000, runtime=1, **sh)
+        if a != b:
+            wrong.append((sh, a.split('nbig')[1], b.split('nbig')[1]))
+    assert not wrong, wrong
+    # a real launch records the recipe it ran
+    n = 4096 + 2048 * 599
+    d, o = ctx.alloc(n * 8), ctx.alloc(4096 * 4)
+    try:
+        ctx.synth_iq(d, n, 5, (), 0.1 + 0.05j)
+        plan = ctx.welch_plan(4096, window=windows.get_window('hann', 4096))
+        assert plan.last_recipe() == ''
+        assert plan.exec_dev(d, n, o) == 600
+        assert plan.last_recipe() == recipes.recipe(lib, nfft=4096, nperseg=4096, noverlap=2048, nseg=600)
+        plan.set_tuning('plaunch')
+        plan.exec_dev(d, n, o)
+        assert 'pilot=launch' in plan.last_recipe() and 'kernel=welch4096:ws' in plan.last_recipe()
+        plan.close()
+    finally:
+        ctx.free(d)
+        ctx.free(o)

@@ -466,22 +466,42 @@ assert k == %(nseg)d, k
 frames = []
 blk.msg_connect('pdus', lambda m: frames.append(m[1]))
 sweep_no = [0]
+fail_at = %(fail_at)s
 def capture(i, f):
     assert f == blk.tune_frequencies[i]
+    if fail_at is not None and rank == 1 and blk.sweeps_done + 1 == fail_at and i == mine[-1]:
+        raise IOError('receiver gone')                  # in the LAST of this rank's segments of that sweep
     return 1000.0 * (blk.sweeps_done + 1) + i           # which sweep, which segment
 sweeps = %(sweeps)s
+mine = list(range(rank, k, world))
 blk.start_sharded(capture, rank, world, torch.device('cpu'), publish_rank=0, sweeps=sweeps)
-if sweeps is None and rank == 1:                        # stop() on ONE rank ends the loop on all of them
+if sweeps is None and fail_at is None and rank == 1:    # stop() on ONE rank ends the loop on all of them
     while blk.sweeps_done < 3: time.sleep(0.001)
     blk.stop()
 end = time.monotonic() + 60
 while blk.keep_running and time.monotonic() < end: time.sleep(0.002)
+assert not blk.keep_running, 'the loop is still running: a rank is stuck in a collective'
 blk.stop()
-assert blk._stitch_error is None, blk._stitch_error
 n = blk.sweeps_done
-assert n >= 3 and (sweeps is None or n == sweeps), n
-mine = list(range(rank, k, world))
-assert rx.tuned == [blk.tune_frequencies[i] for i in mine] * n, (rx.tuned, n)
+if fail_at is not None:
+    # the failing rank took part in that sweep's gather and vote: BOTH ranks left after it, nothing of it was published,
+    # and the error comes out of the failing rank's next work()
+    assert n == fail_at - 1 and blk.incomplete_sweeps == 1, (n, blk.incomplete_sweeps)
+    if rank == 1:
+        assert isinstance(blk._stitch_error, IOError)
+        try:
+            blk.work([np.zeros(4, np.complex64)], [])
+            raise SystemExit('work() did not raise')
+        except RuntimeError as e:
+            assert 'receiver gone' in repr(e.__cause__)
+    else:
+        assert blk._stitch_error is None, blk._stitch_error
+    ran = n + 1
+else:
+    assert blk._stitch_error is None, blk._stitch_error
+    assert n >= 3 and (sweeps is None or n == sweeps), n
+    ran = n
+assert rx.tuned == [blk.tune_frequencies[i] for i in mine] * ran, (rx.tuned, ran)
 per = packets.sweeper_fragment_count(4 * k * nbins, 1470)
 if rank == 0:
     assert len(frames) == n * per, (len(frames), n, per)
@@ -495,12 +515,13 @@ print('rank', rank, 'ok', n)
 '''
 
 
-@pytest.mark.parametrize('nseg,sweeps', [(8, 4), (5, None)])
-def test_sharded_stitcher_loop_world_size_2_gloo(nseg, sweeps, tmp_path):
+@pytest.mark.parametrize('nseg,sweeps,fail_at', [(8, 4, None), (5, None, None), (6, None, 3)])
+def test_sharded_stitcher_loop_world_size_2_gloo(nseg, sweeps, fail_at, tmp_path):
     """start_sharded: each rank retunes only to its own segments, the sweeps come out in tune order on the publishing
-    rank, and every rank leaves the loop after the same sweep (sweeps=N, or stop() on one rank)."""
+    rank, and every rank leaves the loop after the same sweep (sweeps=N, stop() on one rank, or - round 4's advisor
+    finding - a capture that fails on one rank: that rank still joins the sweep's gather and vote)."""
     script = tmp_path / 'worker.py'
-    script.write_text(SHARDED_LOOP_WORKER % {'root': ROOT, 'nseg': nseg, 'sweeps': sweeps})
+    script.write_text(SHARDED_LOOP_WORKER % {'root': ROOT, 'nseg': nseg, 'sweeps': sweeps, 'fail_at': fail_at})
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29540 + nseg), WORLD_SIZE='2')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
