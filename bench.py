@@ -11,10 +11,13 @@ N = 1  workload "C2" (the configuration BASELINE.json's metric is quoted on): on
        (the welch() call of ofdm_cr_tools.py:342): welch4096ws kernel + the cross-workgroup finalize.
        Extra keys on the same line: `host_visible_ms_per_step` (the same step through the host-output entry point:
        launch to PSD in host memory, SURVEY 8d's end point), `sweep_c4` (the N > 1 workload run on this one GPU, so
-       that the N-GPU speed-up is a plain division), `csd_c3` (BASELINE config 3: two-channel cross spectrum /
-       coherence, 2 x 2^26 samples, csd4096ws kernel, 16 B per sample pair), `scan_c5` (BASELINE config 5: 64 channel
-       streams x 2^22 samples, 16384-pt rectangular |X|^2/N^2 mean + the device decision stage, welch16k kernel),
-       each with its own `roofline`; `h2d_inclusive` (host buffer -> PSD through the streaming entry point);
+       that the N-GPU speed-up is a plain division), `sweep_c4_ref` (the same sweep through the call the reference's
+       block actually makes, spectrum_sweeper.py:263: flattop, nperseg = 1024 zero-padded to 4096, step 512),
+       `csd_c3` (BASELINE config 3: two-channel cross spectrum / coherence, 2 x 2^26 samples, 16 B per sample
+       pair), `scan_c5` (BASELINE config 5: 64 channel streams x 2^22 samples, 16384-pt rectangular |X|^2/N^2 mean +
+       the device decision stage), each with its own `roofline` whose `kernel` is the recipe the library recorded for
+       the launch (oth__debug_last_recipe) and whose `traffic` is the figure of the builder's rocprofv3 PMC passes of
+       the same configuration (profiles/traffic.json: not measured by this run); `h2d_inclusive` (host buffer -> PSD through the streaming entry point);
        `cpu_baseline` (+ `_parallel`, `_c5`).
 N > 1  workload "C4" (BASELINE config 4 = the north star's 8-segment sweep), STRONG scaling: a FIXED sweep of
        8 RF segments x 2^27 samples, segment i on rank i mod N, the same Welch parameters + fftshift + 256-bin
@@ -308,8 +311,27 @@ def main():
                 fn()
             torch.cuda.synchronize(dev)
 
+    def profile_traffic(cfg, alg_bytes):
+        """HBM bytes per launch of configuration `cfg` as the builder's rocprofv3 PMC passes measured them (FETCH_SIZE x 2
+        + WRITE_SIZE per the guide), scaled to this run's launch size by the algorithmic bytes - NOT measured by this run."""
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get(cfg)
+        except (OSError, ValueError, AttributeError):
+            tj = None
+        if not tj:
+            return None, None
+        ratio = tj['ratio_to_algorithmic']
+        return ratio * alg_bytes, ('%s: %.3f x algorithmic (builder box; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
+                                   'tools/prof_driver.py %s, not measured by this run)' % (tj.get('source', 'profiles/'), ratio, cfg))
+
+    def wflattop(n):
+        return windows.get_window('flattop', n)
+
     # ---------------------------------------------------------------- the 8-segment sweep (C4) ----------
-    def sweep_bench(steps, warmup):
+    def sweep_bench(steps, warmup, ref_call=False):
+        """ref_call: the call spectrum_sweeper's stitcher actually makes (spectrum_sweeper.py:263: flattop, nperseg =
+        fft_len / 4 zero-padded to fft_len, SciPy's default 50 % overlap of nperseg) instead of the Hann nperseg = 4096 form
+        BASELINE's metric is quoted on - four transforms per 2048 new samples: VALU-bound by construction."""
         S = 1 << args.sweep_log2_samples
         trim = 256
         nbins = NFFT - 2 * trim
@@ -318,7 +340,8 @@ def main():
         for i in mine:                                   # this rank's RF segments, resident in HBM
             seg[i] = torch.empty((S, 2), dtype=torch.float32, device=dev)
             ctx.synth_iq(seg[i].data_ptr(), S, 2000 + i, TONES, DC)
-        plan = ctx.welch_plan(NFFT, window=hann, fs=2.0e6, fftshift=True, trim_bins=trim, db=True)
+        pkw = dict(nperseg=NFFT // 4, window=wflattop(NFFT // 4)) if ref_call else dict(window=hann)
+        plan = ctx.welch_plan(NFFT, fs=2.0e6, fftshift=True, trim_bins=trim, db=True, **pkw)
         pipe = sweep.SweepPipeline(SWEEP_SEGMENTS, nbins, dev, rank, world)
 
         def compute(i, out_row):
@@ -349,21 +372,30 @@ def main():
         if rank == 0:
             from oracle import ref_cpu as R
             pre = seg[0][:1 << 20].cpu().numpy().view(np.complex64).reshape(-1)
-            _, ref = R.welch_np(pre, fs=2.0e6, nperseg=NFFT, nfft=NFFT)
-            ref = np.fft.fftshift(ref)[trim:-trim]
-            chk = ctx.welch_plan(NFFT, window=hann, fs=2.0e6, fftshift=True, trim_bins=trim, db=True)
+            if ref_call:
+                ref = 10 ** (R.sweeper_src_power(pre, NFFT, 2.0e6, trim) / 10)      # the reference's _src_power restated
+            else:
+                _, ref = R.welch_np(pre, fs=2.0e6, nperseg=NFFT, nfft=NFFT)
+                ref = np.fft.fftshift(ref)[trim:-trim]
+            chk = ctx.welch_plan(NFFT, fs=2.0e6, fftshift=True, trim_bins=trim, db=True, **pkw)
             err = float(np.max(np.abs(10 ** (chk.exec(pre).astype(np.float64) / 10) - ref) / ref))
         med = statistics.median(per)
         total = SWEEP_SEGMENTS * S
         kavg = kern_ms / max(launches, 1)
         ach = 8.0 * S / (kavg * 1e-3) / 1e9 if kavg else 0.0
+        traffic, tsrc = profile_traffic('C4ref' if ref_call else 'C4', 8 * S)
         out = {'value': total / (med * 1e-3) / 1e6, 'unit': 'Msamples/s', 'ms_per_sweep': med,
                'wall_ms_per_sweep': 1e3 * wall / steps, 'segments': SWEEP_SEGMENTS, 'samples_per_segment': S,
                'segments_on_rank0': len(mine), 'steps': steps,
                'kernel_avg_ms': kavg, 'launches': int(launches),
+               'config': {'workload': ('C4 as the reference block calls it: %d RF segments x 2^%d samples, flattop nperseg = 1024 '
+                                       'zero-padded to nfft = 4096, step 512 (spectrum_sweeper.py:263), fftshift + 256-bin trim + dB'
+                                       if ref_call else 'C4: %d RF segments x 2^%d samples, 4096-pt Hann Welch 50%% overlap, fftshift + '
+                                       '256-bin trim + dB') % (SWEEP_SEGMENTS, args.sweep_log2_samples)},
                'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                            'frac': ach / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'welch4096ws_kernel (one launch per '
-                            'RF segment)', 'kernel_avg_ms': kavg, 'launches': int(launches),
+                            'frac': ach / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': tsrc,
+                            'kernel': plan.last_recipe() + ' (one launch per RF segment)',
+                            'kernel_avg_ms': kavg, 'launches': int(launches),
                             'algorithmic_bytes_per_launch': 8 * S,
                             'whole_sweep_frac': 8.0 * total / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                'parity_prefix_max_rel_err': err}
@@ -424,12 +456,14 @@ def main():
         med = statistics.median(per)
         kavg = kern_ms / max(launches, 1)
         ach = 16.0 * n / (kavg * 1e-3) / 1e9 if kavg else 0.0
+        traffic, tsrc = profile_traffic('C3', 16 * n)
         return {'value': n / (med * 1e-3) / 1e6, 'unit': 'Msample-pairs/s', 'ms_per_step': med,
                 'wall_ms_per_step': 1e3 * wall / steps, 'steps': steps, 'kernel_avg_ms': kavg, 'launches': int(launches),
                 'config': {'workload': 'C3: two complex64 streams x 2^26 samples (y = 0.7 x delayed by 5 + noise), 4096-pt '
                                        'Hann, 50% overlap, detrend constant -> Pxx, Pyy, Pxy, Cxy on the device'},
                 'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                             'frac': ach / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'csd4096ws_kernel',
+                             'frac': ach / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': tsrc,
+                             'kernel': plan.last_recipe(),
                              'kernel_avg_ms': kavg, 'launches': int(launches), 'algorithmic_bytes_per_launch': 16 * n,
                              'whole_step_frac': 16.0 * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                 'parity_prefix_max_err': err}
@@ -491,13 +525,17 @@ def main():
         kavg = kern_ms / max(launches, 1)
         total = nch * S
         ach = 8.0 * total / (kavg * 1e-3) / 1e9 if kavg else 0.0
+        traffic, tsrc = profile_traffic('C5', 8 * total)
         return {'value': total / (med * 1e-3) / 1e6, 'unit': 'Msamples/s', 'ms_per_step': med,
                 'wall_ms_per_step': 1e3 * wall / steps, 'steps': steps, 'kernel_avg_ms': kavg, 'launches': int(launches),
                 'config': {'workload': 'C5: 64 channel streams x 2^22 samples, 16384-pt rectangular |X|^2/N^2 mean per stream '
                                        '(multichannel_scanner.py:78-86) + moving average, noise floor, per-bin mask and %d '
                                        'channel sums on the device (oth_scan_decide_dev_out)' % len(lo)},
                 'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                             'frac': ach / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'welch16k_kernel',
+                             'frac': ach / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': tsrc,
+                             'kernel': bp.plan.last_recipe(),
+                             'kernel_note': 'kernel_avg_ms brackets the transform launch only; finalize_l4 and the two '
+                                            'decision-stage launches are in ms_per_step / whole_step_frac',
                              'kernel_avg_ms': kavg, 'launches': int(launches), 'algorithmic_bytes_per_launch': 8 * total,
                              'whole_step_frac': 8.0 * total / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                 'parity_prefix_max_rel_err': err}
@@ -522,7 +560,8 @@ def main():
                            'nfft': NFFT, 'noverlap': NFFT // 2, 'window': 'hann', 'segments': SWEEP_SEGMENTS,
                            'samples_per_segment': S, 'parallelism': 'segment-per-gpu x%d' % world},
                 'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                             'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'welch4096ws_kernel',
+                             'frac': achieved / HBM_PEAK_GBPS, 'traffic': sw['roofline']['traffic'],
+                             'traffic_source': sw['roofline']['traffic_source'], 'kernel': sw['roofline']['kernel'],
                              'kernel_avg_ms': kavg, 'launches': sw['launches'],
                              'algorithmic_bytes_per_launch': 8 * S},
                 'parity_prefix_max_rel_err': sw['parity_prefix_max_rel_err'],
@@ -558,18 +597,8 @@ def main():
         kavg_ms = kern_ms / max(launches, 1)
         achieved = 8.0 * n / (kavg_ms * 1e-3) / 1e9
         # HBM bytes per launch: NOT measured by this run (PMC counters need rocprofv3 around the process) - the
-        # figure of the builder's last profile of the same kernel and size, labelled as such
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get('log2_samples') == args.log2_samples:
-                    traffic = tj.get('hbm_bytes_per_launch')
-                    traffic_source = 'profiles/traffic.json (builder box, %s; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE ' \
-                                     'passes, not measured by this run)' % tj.get('source', 'profiles/')
-            except (OSError, ValueError):
-                pass
+        # figure of the builder's last profile of the same kernel, labelled as such
+        traffic, traffic_source = profile_traffic('C2', 8 * n)
         # sanity / parity on a prefix, outside the timed region
         from oracle import ref_cpu as R
         pre = iq[:1 << 20].cpu().numpy().view(np.complex64).reshape(-1)
@@ -589,7 +618,10 @@ def main():
                        'segments_per_gpu': nseg, 'parallelism': 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_source,
-                         'kernel': 'welch4096ws_kernel', 'kernel_avg_ms': kavg_ms, 'launches': int(launches),
+                         'kernel': plan.last_recipe(),
+                         'kernel_note': 'one launch per step: the pilot of the constant detrend is formed in this kernel\'s '
+                                        'prologue (round 5), so kernel_avg_ms covers it; finalize_wide_kernel is in ms_per_step',
+                         'kernel_avg_ms': kavg_ms, 'launches': int(launches),
                          'algorithmic_bytes_per_launch': 8 * n,
                          'read_probe_GBps': 8.0 * n / (probe_ms * 1e-3) / 1e9},
             'parity_prefix_max_rel_err': err,
@@ -608,8 +640,9 @@ def main():
             result['host_visible_ms_per_step'] = statistics.median(hv)
             result['host_visible_value'] = n / (statistics.median(hv) * 1e-3) / 1e6
             result['host_visible_note'] = ('oth_welch_exec(src_is_device=1): launch -> float32[4096] PSD in host memory, '
-                                           'one blocking call per step (no overlap between steps), median of %d host-clock '
-                                           'times; `value` is the pipelined device-side rate' % len(hv))
+                                           'one blocking call per step (no overlap between steps; the finalize launch writes '
+                                           'the row and a completion word into pinned memory, the call polls the word), median '
+                                           'of %d host-clock times; `value` is the pipelined device-side rate' % len(hv))
             # host buffer -> PSD on the host through the streaming entry point (pinned staging ring, asynchronous
             # H2D + kernels): the PCIe-inclusive rate; never `value`
             # sixteen DISTINCT 32 MiB chunks (512 MiB of host memory: well past the CPU's last-level cache, so the
@@ -641,6 +674,9 @@ def main():
             torch.cuda.empty_cache()
             sw, _ = sweep_bench(max(10, args.steps // 4), max(3, args.warmup // 4))
             result['sweep_c4'] = sw
+            torch.cuda.empty_cache()
+            swr, _ = sweep_bench(max(5, args.steps // 10), max(2, args.warmup // 10), ref_call=True)
+            result['sweep_c4_ref'] = swr
             torch.cuda.empty_cache()
             result['csd_c3'] = csd_bench(max(10, args.steps // 4), max(3, args.warmup // 4))
             torch.cuda.empty_cache()

@@ -24,18 +24,22 @@ __device__ __forceinline__ int bin_pos(int pos, int layout) {
 }
 
 // Completion word for a polling host (FinalizeArgs.host_seq; round 5).  Called by EVERY thread of the block after its
-// last output store: the fence holds each wave until its own stores have been performed at system scope (the outputs of
-// such a launch are pinned host memory), the block barrier collects the waves, and thread 0 arrives on the device
-// counter.  Whoever arrives last has, through that counter, all other blocks' fences before it: it re-arms the counter
-// for the next launch and publishes the sequence value with a system-scope release store.  The host (oth_welch_exec /
-// _poll / _wait in api.hip) reads the word with acquire semantics and then the rows.
+// last output store (the outputs of such a launch are pinned host memory).  Every wave that stored outputs makes them
+// visible at system scope with a RELEASE fence (L2 write-back + wait for the wave's stores; no acquire: an acquire would
+// also invalidate the XCD's L2 under the blocks that are still reading partial rows - the first form of this, a full
+// __threadfence_system() in all four waves of every block, took the 256-block finalize from 4.4 to ~28 us), the block
+// barrier collects the waves where more than wave 0 stores (ALL_WAVES), and thread 0 arrives on the device counter.
+// Whoever arrives last has, through that counter, every other block's fence before it: it re-arms the counter for the
+// next launch and publishes the sequence value with a system-scope release store.  The host (oth_welch_exec / _poll /
+// _wait in api.hip) reads the word with acquire semantics and then the rows.
+template <bool ALL_WAVES>
 __device__ __forceinline__ void finalize_signal(const FinalizeArgs &a) {
     if (!a.host_seq) return;      // launch-uniform
-    __threadfence_system();
-    __syncthreads();
+    if (ALL_WAVES || threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (ALL_WAVES) __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned nblocks = gridDim.x * gridDim.y;
-        const unsigned prev = __hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned prev = __hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == nblocks - 1) {
             __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.host_seq, a.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
             if (a.out3) a.out3[o] = (float)((s[2] * s[2] + s[3] * s[3]) / (s[0] * s[1]));
         }
     }
-    finalize_signal(a);
+    finalize_signal<false>(a);      // the stores above are wave 0's (slice 0)
 }
 
 // One-launch form for many partial rows (the headline Welch path; NCH = 4: the two-channel path, round 4 - it went
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void finalize_wide_kernel(FinalizeArgs a) {
             if (a.out3) a.out3[o] = (float)((t[2] * t[2] + t[3] * t[3]) / (t[0] * t[1]));
         }
     }
-    finalize_signal(a);
+    finalize_signal<false>(a);      // the stores above are wave 0's (threads < POS)
 }
 
 // Stage 1 of the cross-workgroup reduction when there are many partial rows: row group g of
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void finalize_l4_kernel(FinalizeArgs a) {
             a.out0[o] = a.db ? (float)(10.0 * log10(v)) : (float)v;
         }
     }
-    finalize_signal(a);
+    finalize_signal<true>(a);
 }
 
 hipError_t launch_finalize(const FinalizeArgs &a_in, int nstreams, hipStream_t s) {

@@ -950,3 +950,113 @@ def test_bench_gpus_2_spawns_its_own_ranks(tmp_path):
     assert r['n_gpus'] == 2 and r['steps'] == 5 and r['scaling'] == 'strong' and r['value'] > 0
     assert r['ranks_seen']['world_size'] == 2 and len(r['ranks_seen']['devices']) == 2
     assert 'sweep_c4.value' in r['scaling_base'] and r['parity_prefix_max_rel_err'] < RTOL
+
+
+def test_full_size_config4_sweep_properties(ctx):
+    """BASELINE config 4 at its own shape - 8 RF segments of 2^25 samples each (2 GiB on the device; the oracle cannot run
+    there) - through the block's sharded sweep (spectrum_sweeper.sweep_once_sharded, the reference's own call: flattop,
+    nperseg = 1024 zero-padded to 4096, spectrum_sweeper.py:260-276) and through the pipelined form bench.py times
+    (sweep.SweepPipeline, Hann nperseg = 4096), at world 1:
+      (1) the stitched PSD is the eight per-segment rows in TUNE order (every segment has its own seed and its own tone);
+      (2) tuned against the independent coverage kernel on every segment, both calls (2e-5);
+      (3) Parseval per segment: sum_k P[k] fs / nfft = the segment's sample variance (2e-3: a Welch estimate);
+      (4) the 2^20-sample prefix of every segment against the float64 oracle (1e-4), both calls;
+      (5) the pipeline's second sweep on the other buffer set equals its first."""
+    import torch
+    import ofdm_tools
+    from ofdm_tools import _hip, sweep, windows
+    nseg_rf, S, N, Sf, tSf, trim = 8, 1 << 25, 4096, 2000000, 1750000, 256
+    dev = torch.device('cuda', 0)
+    rx = FakeReceiver()
+    blk = ofdm_tools.spectrum_sweeper(rx, 'rtl', N, Sf, tSf, 100e6, 100e6 + tSf * nseg_rf - 1, 15, 0.0, 8, 0, 1472, ctx=ctx,
+                                      threaded=False)
+    assert len(blk.tune_frequencies) == nseg_rf and blk.excess_bins == trim
+    nb = N - 2 * trim
+    seg = []
+    for i in range(nseg_rf):                                   # segment i: seed 2000 + i and a marker tone of its own
+        t = torch.empty((S, 2), dtype=torch.float32, device=dev)
+        ctx.synth_iq(t.data_ptr(), S, 2000 + i, ((0.5, 0.1234), (2.0, -0.35 + 0.1 * i)), 0.1 + 0.05j)
+        seg.append(t)
+    torch.cuda.synchronize()
+    asked = []
+
+    def capture(i, f):
+        asked.append((i, f))
+        return seg[i]
+    wide = blk.sweep_once_sharded(capture, 0, 1, dev)
+    assert asked == list(enumerate(blk.tune_frequencies))
+    assert wide.shape == (nseg_rf * nb,) and np.all(np.isfinite(wide))
+    rows = 10 ** (wide.reshape(nseg_rf, nb) / 10)
+    fl = windows.get_window('flattop', N // 4)
+    hn = windows.get_window('hann', N)
+    calls = {'ref': dict(nperseg=N // 4, window=fl), 'hann': dict(window=hn)}
+    out = torch.empty(nb, dtype=torch.float32, device=dev)
+    full = torch.empty(N, dtype=torch.float32, device=dev)
+    pipe_rows = None
+    for name, kw in calls.items():
+        tuned = ctx.welch_plan(N, fs=float(Sf), fftshift=True, trim_bins=trim, db=True, kernel=_hip.KERNEL_TUNED, **kw)
+        gen = ctx.welch_plan(N, fs=float(Sf), fftshift=True, trim_bins=trim, db=True, kernel=_hip.KERNEL_GENERIC, **kw)
+        whole = ctx.welch_plan(N, fs=float(Sf), **kw)                      # untrimmed, linear: Parseval
+        if name == 'hann':                                                  # (5) the pipelined form, two sweeps
+            pipe = sweep.SweepPipeline(nseg_rf, nb, dev, 0, 1)
+
+            def compute(i, out_row):
+                sweep.torch_then_ctx(ctx, dev)
+                tuned.exec_dev(seg[i].data_ptr(), S, out_row.data_ptr())
+                sweep.ctx_then_torch(ctx)
+            a = pipe.wideband(pipe.run(compute)).cpu().numpy().reshape(nseg_rf, nb)
+            b = pipe.wideband(pipe.run(compute)).cpu().numpy().reshape(nseg_rf, nb)
+            pipe.drain()
+            assert relerr(10 ** (b / 10.0), 10 ** (a / 10.0)) < 2e-5      # (dynamic schedule: last bits may differ)
+            pipe_rows = 10 ** (a.astype(np.float64) / 10)
+        for i in range(nseg_rf):
+            sweep.torch_then_ctx(ctx, dev)
+            gen.exec_dev(seg[i].data_ptr(), S, out.data_ptr())
+            whole.exec_dev(seg[i].data_ptr(), S, full.data_ptr())
+            sweep.ctx_then_torch(ctx)
+            g = 10 ** (out.cpu().numpy().astype(np.float64) / 10)
+            mine = rows[i] if name == 'ref' else pipe_rows[i]
+            assert relerr(mine, g) < 2e-5, (name, i, relerr(mine, g))                         # (1) + (2)
+            # the segment's own marker tone sits where its seed says (tune order, not launch order)
+            f0 = -0.35 + 0.1 * i
+            kc = int(round(f0 * N)) % N
+            ks = ((kc + N // 2) % N) - trim
+            assert abs(int(np.argmax(mine)) - ks) <= 1, (name, i)
+            mean, var = ctx.iq_power(seg[i].data_ptr(), S)
+            p = full.cpu().numpy().astype(np.float64)
+            assert abs(p.sum() * Sf / N - var) / var < 2e-3, (name, i)                         # (3)
+            pre = seg[i][:1 << 20].cpu().numpy().view(np.complex64).reshape(-1)                # (4)
+            if name == 'ref':
+                want = 10 ** (R.sweeper_src_power(pre, N, float(Sf), trim) / 10)
+            else:
+                _, w = R.welch_np(pre, fs=float(Sf), nperseg=N, nfft=N)
+                want = np.fft.fftshift(w)[trim:-trim]
+            assert relerr(10 ** (tuned.exec(pre).astype(np.float64) / 10), want) < RTOL, (name, i)
+        for pl in (tuned, gen, whole):
+            pl.close()
+    del seg
+    torch.cuda.empty_cache()
+
+
+def test_bench_gpus_4_rehearsal_two_segments_per_rank(tmp_path):
+    """The N > 1 bench at world 4 on this one-GPU box (BENCH_REHEARSE=1: every rank on device 0 over gloo; the box allows
+    six GPU processes, this test process is one of them, so the 8-rank spawn itself cannot be rehearsed here - the
+    8-rank partition runs over gloo on the CPU, tests/test_host_logic_cpu.py): four children, two RF segments each (the
+    G = 4 column of SURVEY 8e), tune order after the all-gather, ranks_seen, rank 0's single line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['BENCH_REHEARSE'] = '1'
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '4', '--warmup', '1',
+                        '--sweep-log2-samples', '20', '--ramp-ms', '10'], env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 4 and r['steps'] == 4 and r['scaling'] == 'strong' and r['value'] > 0
+    assert r['ranks_seen']['world_size'] == 4 and len(r['ranks_seen']['devices']) == 4
+    assert r['ranks_seen']['distinct_devices'] == 1 and r['ranks_seen']['backend'] == 'gloo'
+    assert 'parallelism' in r['config'] and r['config']['parallelism'] == 'segment-per-gpu x4'
+    assert r['parity_prefix_max_rel_err'] < RTOL and 'kernel=welch4096:ws' in r['roofline']['kernel']
