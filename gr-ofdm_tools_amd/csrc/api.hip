@@ -498,11 +498,14 @@ bool window_spectrum_table_16k(const std::vector<float> &w, int n, std::vector<f
     return true;
 }
 
-// The table for welch16k1x_half_kernel (N = 16384): thread tid = 64 k0 + 4 k1 + q corrects register k2 = 0 - bin k0 when
-// k1 = 0, q = 0 - and register k2 = 15 - bin N - 16 + k0 when k1 = 15, q = 3, where the quad butterfly leaves i X - so the
-// table exists when the window's spectrum is confined to |k| < 16 (all periodic cosine-sum windows; boxcar).
-bool window_spectrum_table_16k1x(const std::vector<float> &w, std::vector<float> &fd) {
-    const int n = 16384, lg = 14;
+// The table for welch16k1x_half_kernel.  N = 16384: thread tid = 64 k0 + 4 k1 + q corrects register k2 = 0 - bin k0 when
+// k1 = 0, q = 0 - and register k2 = 15 - bin N - 16 + k0 when k1 = 15, q = 3, where the quad butterfly leaves i X.
+// N = 8192 (the 8-wave form, round 5): wave k0' holds k0 = 2 k0' + h; register k2 = 0 of lane 32 h is bin k0, register
+// k2 = 15 of lane 32 h + 31 (k1 = 7, q = 3) is bin N - 16 + k0.  Either way the table exists when the window's spectrum is
+// confined to |k| < 16 (all periodic cosine-sum windows; boxcar).
+bool window_spectrum_table_1x(const std::vector<float> &w, int n, std::vector<float> &fd) {
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
     std::vector<double> re(n), im(n, 0.0);
     double s2 = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -526,9 +529,10 @@ bool window_spectrum_table_16k1x(const std::vector<float> &w, std::vector<float>
     }
     for (int k = 16; k < n - 16; ++k)
         if (re[k] * re[k] + im[k] * im[k] > 1e-10 * s2) return false;
-    fd.assign((size_t)4 * 1024, 0.f);
+    fd.assign((size_t)4 * (n / 16), 0.f);
     for (int k0 = 0; k0 < 16; ++k0) {
-        const int lo = 64 * k0 + 4 * 0 + 0, hi = 64 * k0 + 4 * 15 + 3;
+        const int lo = n == 16384 ? 64 * k0 : 64 * (k0 >> 1) + 32 * (k0 & 1);
+        const int hi = n == 16384 ? 64 * k0 + 63 : 64 * (k0 >> 1) + 32 * (k0 & 1) + 31;
         fd[4 * lo] = (float)re[k0];
         fd[4 * lo + 1] = (float)im[k0];
         const int kh = n - 16 + k0;                       // i (re + i im) = -im + i re
@@ -682,11 +686,13 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
         r.two_runs = !strcmp(r.variant->tag, "ws2");
     } else if (want_tuned && big_size && (p.nperseg == p.nfft || p.nperseg * 4 == p.nfft)) {      // (nfft / 4: the sweeper's zero padding)
         r.kern = RK_W16K;
-        if (p.nfft == 16384 && p.nperseg == 16384 && tv != "16k4") {
-            // one cross-wave exchange per segment: vectors that do not overlap without a detrend (the scanner of BASELINE
-            // config 5), and 50 % overlap with the kept half in registers (a constant detrend needs the |k| < 16 table)
-            if (p.step >= 16384 && !p.detrend) r.kern = RK_W16K1X;
-            else if (p.step == 8192 && (!p.detrend || fd1x)) r.kern = RK_W16K1X_HALF;
+        if (p.nperseg == p.nfft && tv != "16k4") {
+            // one cross-wave exchange per segment (16384: 16 waves, one workgroup per CU; 8192, round 5: 8 waves, two
+            // radix-8 butterflies in pass 2, two workgroups per CU): vectors that do not overlap without a detrend (the
+            // scanner of BASELINE config 5; at 8192 points the pipelined rectangular build only), and 50 % overlap with
+            // the kept half in registers (a constant detrend needs the |k| < 16 table)
+            if (p.step >= p.nfft && !p.detrend && (p.nfft == 16384 || (p.rect_window && tv != "16kplain"))) r.kern = RK_W16K1X;
+            else if (p.step * 2 == p.nfft && (!p.detrend || fd1x)) r.kern = RK_W16K1X_HALF;
         }
     } else if (want_tuned && seg_size && seg_padded_supported(p.nfft, p.nperseg)) {
         r.kern = RK_SEGPAD;      // nperseg = nfft / 4 (the sweeper's call, spectrum_sweeper.py:263) or nfft / 2 at 1024 / 2048
@@ -735,7 +741,7 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
         r.W = (int)(w > r.nseg_run ? r.nseg_run : (w < 1 ? 1 : w));
     }
     r.layout = (r.kern == RK_W4096 || r.kern == RK_CSD4096 || r.kern == RK_CSD4096WS) ? 1
-               : (r.kern == RK_W16K1X || r.kern == RK_W16K1X_HALF) ? 4
+               : (r.kern == RK_W16K1X || r.kern == RK_W16K1X_HALF) ? (p.nfft == 16384 ? 4 : 5)
                : (r.kern == RK_W16K ? (p.nfft == 16384 ? 2 : 3) : 0);
     // ---- schedule and chunks (tuned kernels only; the coverage kernel walks contiguous runs)
     if (r.kern != RK_GENERIC) {
@@ -776,6 +782,8 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
             if (r.kern == RK_W16K1X && per_team >= 8) r.sched = OTH_SCHED_CONTIGUOUS;
             // 16384 points at 50 % overlap: contiguous runs (no chunk head is read twice): 30.8 % against 29.3 % with tickets
             if (big && p.nfft == 16384 && half_step && p.nperseg == p.nfft) r.sched = OTH_SCHED_CONTIGUOUS;
+            // the one-exchange 50 %-overlap build prefetches across its run, and a chunk head costs it a synchronous load
+            if (r.kern == RK_W16K1X_HALF) r.sched = OTH_SCHED_CONTIGUOUS;
             // 8192 (round 4): contiguous runs take the same time as tickets over chunks of 16 and read no chunk head twice
             if (big && p.nfft == 8192 && half_step && p.nperseg == p.nfft && per_team >= 16) r.sched = OTH_SCHED_CONTIGUOUS;
         }
@@ -940,8 +948,8 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
             case RK_W4096: HIPCHK(c, r.variant->launch(a, c->stream)); break;
             case RK_CSD4096WS: HIPCHK(c, launch_csd_tuned4096ws(a, c->stream)); break;
             case RK_CSD4096: HIPCHK(c, launch_csd_tuned4096(a, c->stream)); break;
-            case RK_W16K1X_HALF: HIPCHK(c, launch_welch_tuned16k1x_half(a, c->stream)); break;
-            case RK_W16K1X: HIPCHK(c, launch_welch_tuned16k1x(a, r.x1_window, r.x1_plain, c->stream)); break;
+            case RK_W16K1X_HALF: HIPCHK(c, launch_welch_tuned16k1x_half(p->nfft, a, c->stream)); break;
+            case RK_W16K1X: HIPCHK(c, launch_welch_tuned16k1x(p->nfft, a, r.x1_window, r.x1_plain, c->stream)); break;
             case RK_W16K: HIPCHK(c, launch_welch_tuned16k(p->nfft, a, c->stream)); break;
             default: HIPCHK(c, launch_welch_generic(p->nfft, a, c->stream)); break;
         }
@@ -1304,8 +1312,8 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
             e = hipMemcpyAsync(p->d_fd, fd.data(), sizeof(float) * fd.size(), hipMemcpyHostToDevice, c->stream);
     }
     std::vector<float> fd1x;
-    if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT && nfft == 16384 && nperseg == 16384 &&
-        window_spectrum_table_16k1x(w, fd1x)) {
+    if (e == hipSuccess && detrend == OTH_DETREND_CONSTANT && (nfft == 16384 || nfft == 8192) && nperseg == nfft &&
+        window_spectrum_table_1x(w, nfft, fd1x)) {
         e = hipMalloc(&p->d_fd1x, sizeof(float) * fd1x.size());
         if (e == hipSuccess)
             e = hipMemcpyAsync(p->d_fd1x, fd1x.data(), sizeof(float) * fd1x.size(), hipMemcpyHostToDevice, c->stream);
@@ -2116,15 +2124,19 @@ static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec
         groups = chain_tail_groups((int)W, N);
         if (groups && (rc = ensure(c, &h->d_tail, &h->tail_cap, sizeof(float) * (size_t)groups * N))) return rc;
     }
-    // 16384 points: the one-exchange pipelined loop (welch16k1x.hip, round 4); OTH_CHAIN16K=old keeps the 4 x 4096 build (A/B)
+    // 16384 points: the one-exchange pipelined loop (welch16k1x.hip, round 4); OTH_CHAIN16K=old keeps the 4 x 4096 build
+    // (A/B).  At 8192 points the chain stays on the 2 x 4096 build: the 8-wave one-exchange loop with the chain's epilogue
+    // spills 20 registers and measured 48.8-49.3 % against 53.4-54.1 % (windowed), 52.5 against 53.0 % (rectangular) on
+    // the same box (round 5, tools/ab_8k.sh; OTH_CHAIN16K=x1 selects it for the A/B)
     static const char *chain16k_mode = getenv("OTH_CHAIN16K");
-    const bool x1 = N == 16384 && !(chain16k_mode && !strcmp(chain16k_mode, "old"));
+    const bool x1 = (N == 16384 && !(chain16k_mode && !strcmp(chain16k_mode, "old"))) ||
+                    (N == 8192 && chain16k_mode && !strcmp(chain16k_mode, "x1"));
     {
         Timed tm(c);      // the whole push: transform kernel + cross-team reduction + state / rows
-        HIPCHK(c, big ? (x1 ? launch_chain16k1x(a, h->rect, c->stream) : launch_chain16k(N, a, h->rect, c->stream))
+        HIPCHK(c, big ? (x1 ? launch_chain16k1x(N, a, h->rect, c->stream) : launch_chain16k(N, a, h->rect, c->stream))
                       : launch_seg(N, a, 2, false, c->stream));
         if (a.acc_mode != 3)
-            HIPCHK(c, launch_chain_tail(h->d_partial, groups ? h->d_tail : nullptr, (int)W, N, big ? (x1 ? 4 : (N == 16384 ? 2 : 3)) : 0,
+            HIPCHK(c, launch_chain_tail(h->d_partial, groups ? h->d_tail : nullptr, (int)W, N, big ? (x1 ? (N == 16384 ? 4 : 5) : (N == 16384 ? 2 : 3)) : 0,
                                         h->fftshift, a.acc_mode, a.acc_end,
                                         h->alpha, h->kdb, h->d_iir, h->d_peak, h->d_rows, h->do_iir ? give : 0, rows_last,
                                         c->stream));
@@ -2672,7 +2684,7 @@ int oth__debug_recipe(int nfft, int nperseg, int noverlap, int window_class, int
     // the tables oth_welch_plan builds: 4096 / 2048 / 8192 / 16384 points, nperseg = nfft, a confined window spectrum
     const bool table_size = (nfft == 4096 || nfft == 2048 || nfft == 8192 || nfft == 16384) && nperseg == nfft;
     sh.fd_ok = sh.detrend && table_size && (window_class == 0 || window_class == 1 || window_class == 3);
-    sh.fd1x_ok = sh.detrend && nfft == 16384 && nperseg == nfft && (window_class == 0 || window_class == 1);
+    sh.fd1x_ok = sh.detrend && (nfft == 16384 || nfft == 8192) && nperseg == nfft && (window_class == 0 || window_class == 1);
     sh.rect_window = window_class == 0;
     sh.kernel = kernel_pref;
     sh.sched = sched_pref;

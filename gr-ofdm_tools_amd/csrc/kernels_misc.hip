@@ -14,10 +14,13 @@ namespace oth {
 //   layout 1: welch4096 / csd4096 leave bin k0 + 16 k1 + 256 k2 at 16 k0 + k1 + 256 k2
 //   layout 2: welch16k leaves bin k' + 4 q at 4096 k' + (layout-1 position of q); layout 3 (8192 points): k' + 2 q
 //   layout 4: welch16k1x leaves bin k0 + 16 k1 + 256 k2 + 4096 bitrev2(q) at 1024 k2 + 64 k0 + 4 k1 + q
+//   layout 5: its 8-wave form (8192 points) leaves bin k0 + 16 k1 + 128 k2 + 2048 bitrev2(q) at 512 k2 + 64 (k0 >> 1) + 4 (8 (k0 & 1) + k1) + q
 __device__ __forceinline__ int bin_pos(int pos, int layout) {
     if (layout == 0) return pos;
     if (layout == 4)
         return ((pos >> 6) & 15) + 16 * ((pos >> 2) & 15) + 256 * (pos >> 10) + 4096 * (((pos & 1) << 1) | ((pos >> 1) & 1));
+    if (layout == 5)      // 8192 points: pos = 512 k2 + 64 k0' + 4 (8 h + k1) + q holds bin (2 k0' + h) + 16 k1 + 128 k2 + 2048 bitrev2(q)
+        return 2 * ((pos >> 6) & 7) + ((pos >> 5) & 1) + 16 * ((pos >> 2) & 7) + 128 * (pos >> 9) + 2048 * (((pos & 1) << 1) | ((pos >> 1) & 1));
     const int r = pos & 4095;
     const int q = ((r & 15) << 4) | ((r >> 4) & 15) | (r & ~255);
     return layout == 1 ? q : (pos >> 12) + (layout == 2 ? 4 : 2) * q;

@@ -108,7 +108,7 @@ struct FinalizeArgs {
     int W;
     int nfft;
     int nch;                // 1 or 4
-    int layout;             // 0 natural, 1 welch4096 digit order, 2 / 3 welch16k order at 16384 / 8192, 4 welch16k1x order
+    int layout;             // 0 natural, 1 welch4096 digit order, 2 / 3 welch16k order at 16384 / 8192, 4 / 5 welch16k1x order at 16384 / 8192
                             // (kernels_misc.hip bin_pos)
     int fftshift;
     int trim;
@@ -163,14 +163,14 @@ int csd4096ws_blocks_per_cu();
 hipError_t launch_welch_tuned16k(int nfft, const WelchArgs &a, hipStream_t s);
 // welch16k1x.hip: nfft = nperseg = 16384, no detrend, whole-segment loads (the scanner's non-overlapping vectors): one
 // cross-wave exchange, two workgroup barriers per segment; partial rows in finalize layout 4
-hipError_t launch_welch_tuned16k1x(const WelchArgs &a, bool window, bool plain, hipStream_t s);
+hipError_t launch_welch_tuned16k1x(int nfft, const WelchArgs &a, bool window, bool plain, hipStream_t s);
 // the same transform at step = 8192 (50 % overlap, the kept half in registers); WelchArgs.fd = window_spectrum_table_16k1x
-hipError_t launch_welch_tuned16k1x_half(const WelchArgs &a, hipStream_t s);
+hipError_t launch_welch_tuned16k1x_half(int nfft, const WelchArgs &a, hipStream_t s);
 // the fused periodogram chain at 8192 / 16384 points (one workgroup per segment; workgroups per CU: 2 / 1)
 hipError_t launch_chain16k(int nfft, const SegArgs &a, bool rect, hipStream_t s);
 // the same chain at 16384 points on the one-exchange pipelined loop (welch16k1x.hip); partial rows in layout 4; needs
 // chunks of at least two segments
-hipError_t launch_chain16k1x(const SegArgs &a, bool rect, hipStream_t s);
+hipError_t launch_chain16k1x(int nfft, const SegArgs &a, bool rect, hipStream_t s);
 hipError_t launch_pgram(int nfft, const PgramArgs &a, hipStream_t s);
 // segfft.hip
 bool seg_supported(int nfft);

@@ -81,38 +81,6 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F f)
     }
 }
 
-// 8-point DFT, natural order in and out; the sqrt(1/2) of W8^1 and W8^3 rides on the last layer's additions
-// (PLAIN: multiplied out first, as dft16_layer2<true>)
-template <bool PLAIN = kDft16Plain>
-__device__ __forceinline__ void dft8(float2 (&v)[8]) {
-    dft4<false>(v[0], v[2], v[4], v[6]);
-    dft4<false>(v[1], v[3], v[5], v[7]);
-    const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-    const float2 o0 = v[1], o2 = mul_w4(v[5]);                                   // W8^k = W16^(2k)
-    if constexpr (PLAIN) {
-        const float2 o1 = mul_w2(v[3]), o3 = mul_w6(v[7]);
-        v[0] = cadd(e0, o0);
-        v[4] = csub(e0, o0);
-        v[1] = cadd(e1, o1);
-        v[5] = csub(e1, o1);
-        v[2] = cadd(e2, o2);
-        v[6] = csub(e2, o2);
-        v[3] = cadd(e3, o3);
-        v[7] = csub(e3, o3);
-        return;
-    }
-    const float2 p1 = make_float2(v[3].x + v[3].y, v[3].y - v[3].x);             // W8^1 o = RH p1
-    const float2 p3 = make_float2(v[7].y - v[7].x, -v[7].x - v[7].y);            // W8^3 o = RH p3
-    v[0] = cadd(e0, o0);
-    v[4] = csub(e0, o0);
-    v[1] = make_float2(fmaf(RH, p1.x, e1.x), fmaf(RH, p1.y, e1.y));
-    v[5] = make_float2(fmaf(-RH, p1.x, e1.x), fmaf(-RH, p1.y, e1.y));
-    v[2] = cadd(e2, o2);
-    v[6] = csub(e2, o2);
-    v[3] = make_float2(fmaf(RH, p3.x, e3.x), fmaf(RH, p3.y, e3.y));
-    v[7] = make_float2(fmaf(-RH, p3.x, e3.x), fmaf(-RH, p3.y, e3.y));
-}
-
 // v[r16(k)] * W^k for k = 0..15 handed to put(k, value).  W^k = W^(4i) W^j (k = 4i + j) from the six stored
 // powers W, W^2, W^3, W^4, W^8, W^12 (correctly rounded table values): at most ONE complex product per twiddle.
 // Rebuilding all fifteen from W and W^4 (scatter_pow16 of the 4096 kernels) chains up to three products; with a

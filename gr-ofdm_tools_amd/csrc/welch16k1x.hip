@@ -36,6 +36,9 @@
 #ifndef OTH_X1_PPLACES
 #define OTH_X1_PPLACES 0x22222222u     // the same for the pipelined kernel (places: see its `spread`)
 #endif
+#ifndef OTH_X1H_WIN_EARLY
+#define OTH_X1H_WIN_EARLY 0  // 50 %-overlap kernel, A/B: 1 = the window values of a step are requested at the end of the step before (no gain: 16384 points 0.3874-0.3907 against 0.3855-0.3876 ms, 8192 points 0.3694-0.3753 against 0.3789 ms on the builds without a pilot, and the PILOT builds then spill 16 registers)
+#endif
 #ifndef OTH_X1_DIAG
 #define OTH_X1_DIAG 0        // 1: per-wave phase cycle counters behind the partial sums (tools/diag_x1.py)
 #endif
@@ -63,9 +66,22 @@ namespace {
 constexpr int XROW = 68;                       // float2 per exchange-B row (64 + 4 pad)
 constexpr int XREG = 16 * XROW;                // float2 per wave region (1088: exchange A uses [0, 1024))
 constexpr int X1_RED = 8;                      // chunk tickets (two slots, by chunk parity)
-constexpr size_t x1_lds_bytes() { return (16 * XREG + X1_RED) * sizeof(float2); }
+// NW = waves per workgroup = N / 1024: 16 (N = 16384, one workgroup per CU) or 8 (N = 8192, two per CU; round 5)
+template <int NW = 16> constexpr size_t x1_lds_bytes() { return (NW * XREG + X1_RED) * sizeof(float2); }
 // the pipelined kernel adds its twiddle tables (passes 2 and 3) and the quad-butterfly constants
-constexpr size_t x1p_lds_bytes() { return x1_lds_bytes() + (16 * 64 + 16 * 4) * sizeof(float2) + 4 * sizeof(float4); }
+template <int NW = 16> constexpr size_t x1p_lds_bytes() {
+    return x1_lds_bytes<NW>() + (16 * 64 + 16 * 4) * sizeof(float2) + 4 * sizeof(float4);
+}
+
+// The 8-wave form (N = 8192 = 16 x 8 x 16 x 4): pass 1 still leaves sixteen k0 per thread, but there are only eight
+// waves to take them, so wave k0' takes k0 = 2 k0' and 2 k0' + 1 - sixteen exchange-A rows [k0 & 1][w] of 64 lanes in its
+// region - and pass 2 is TWO radix-8 butterflies over w (register 8 h + k1, natural order) instead of one radix-16; the
+// exchange-B row of a register is c = 8 h + k1, lane (c, q) then holds the sixteen g of (k0 = 2 k0' + h, k1, q) and passes
+// 3 and 4 run as at 16384 points.  Bin k0 + 16 k1 + 128 k2 + 2048 bitrev2(q) sits at 512 k2 + tid (finalize layout 5).
+//   exa_off: float2 offset of pass-1 output k0 of thread tid relative to lds + tid
+//   p2reg:   register that holds pass-2 output (= table row) k
+template <int NW> __host__ __device__ constexpr int exa_off(int k) { return NW == 16 ? XREG * k : XREG * (k >> 1) + 512 * (k & 1); }
+template <int NW> __host__ __device__ constexpr int p2reg(int k) { return NW == 16 ? r16(k) : k; }
 
 // Non-temporal 8-byte load at (uniform row base in scalar registers) + (lane offset): one lane-offset register serves
 // all sixteen rows of a segment, and the compiler can neither move the load nor gather it with its neighbours - the
@@ -115,6 +131,39 @@ __device__ __forceinline__ void twiddle6(float2 (&v)[16], float2 *out, const Pow
         const float2 r = cmul(v[r16(k)], tw);
         if (STORE) out[STRIDE * k] = r;
         else v[r16(k)] = r;
+    }
+}
+
+// exchange-A writes of either form: out[exa_off<NW>(k)] = v[r16(k)] W^k from the six stored powers
+template <int NW> __device__ __forceinline__ void twiddle6_exa(float2 (&v)[16], float2 *out, const Pow6x &w) {
+    float2 wj[4], wi[4];
+    wj[1] = w.j1, wj[2] = w.j2, wj[3] = w.j3;
+    wi[1] = w.i1, wi[2] = w.i2, wi[3] = w.i3;
+    asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wj[2].x), "+v"(wj[2].y), "+v"(wj[3].x), "+v"(wj[3].y));
+    out[0] = v[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const int i = k >> 2, j = k & 3;
+        const float2 tw = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
+        out[exa_off<NW>(k)] = cmul(v[r16(k)], tw);
+    }
+}
+// the same from two seeds (the 50 %-overlap kernel: no room for six)
+template <int NW> __device__ __forceinline__ void scatter_pow16_exa(const float2 (&v)[16], float2 *out, float2 p1, float2 p4) {
+    float2 wj[4], wi[4];
+    wj[1] = p1;
+    wi[1] = p4;
+    asm volatile("" : "+v"(wj[1].x), "+v"(wj[1].y), "+v"(wi[1].x), "+v"(wi[1].y));
+    wj[2] = cmul(wj[1], wj[1]);
+    wj[3] = cmul(wj[2], wj[1]);
+    wi[2] = cmul(wi[1], wi[1]);
+    wi[3] = cmul(wi[2], wi[1]);
+    out[0] = v[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const int i = k >> 2, j = k & 3;
+        const float2 w = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
+        out[exa_off<NW>(k)] = cmul(v[r16(k)], w);
     }
 }
 
@@ -300,7 +349,7 @@ __device__ __forceinline__ void tw_wait(TwBatch &b) {
                  : "memory");
 }
 // v[r16(k)] *= W^k from the table (batch A already issued into `a`); STORE: out[STRIDE * k] = the product instead
-template <int TS, int STRIDE, bool STORE>
+template <int TS, int STRIDE, bool STORE, int NW = 16>      // NW: which register holds row k (p2reg; pass 3 always r16)
 __device__ __forceinline__ void twiddle_table16(float2 (&v)[16], float2 *out, const float2 *tab, TwBatch &a) {
     TwBatch b;
     tw_wait(a);
@@ -308,16 +357,47 @@ __device__ __forceinline__ void twiddle_table16(float2 (&v)[16], float2 *out, co
     if (STORE) out[0] = v[0];
 #pragma unroll
     for (int k = 1; k <= 8; ++k) {
-        const float2 r = cmul(v[r16(k)], make_float2(a.w[k - 1].x, a.w[k - 1].y));
+        const float2 r = cmul(v[p2reg<NW>(k)], make_float2(a.w[k - 1].x, a.w[k - 1].y));
         if (STORE) out[STRIDE * k] = r;
-        else v[r16(k)] = r;
+        else v[p2reg<NW>(k)] = r;
     }
     tw_wait(b);
 #pragma unroll
     for (int k = 9; k < 16; ++k) {
-        const float2 r = cmul(v[r16(k)], make_float2(b.w[k - 9].x, b.w[k - 9].y));
+        const float2 r = cmul(v[p2reg<NW>(k)], make_float2(b.w[k - 9].x, b.w[k - 9].y));
         if (STORE) out[STRIDE * k] = r;
-        else v[r16(k)] = r;
+        else v[p2reg<NW>(k)] = r;
+    }
+}
+
+// Pass 2 on the sixteen exchange-A rows of this wave's region (base[64 i]): one radix-16 butterfly over w at 16 waves,
+// two radix-8 butterflies (rows 0..7: k0 even, rows 8..15: k0 odd; natural order in and out) at 8 waves.
+template <int NW, class F, class M>
+__device__ __forceinline__ void pass2_from_lds(float2 (&v)[16], const float2 *base, F issued, M mid) {
+    if constexpr (NW == 16) {
+        dft16_from_lds<64>(v, base, issued, mid);
+    } else {
+        const unsigned addr = (unsigned)(unsigned long long)base;
+        double r[16];
+#define OTH_LDS_READ(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[i]) : "v"(addr), "n"(8 * 64 * (i)))
+        OTH_LDS_READ(0); OTH_LDS_READ(2); OTH_LDS_READ(4); OTH_LDS_READ(6);      // the first butterfly layer of dft8 takes 0, 2, 4, 6
+        OTH_LDS_READ(1); OTH_LDS_READ(3); OTH_LDS_READ(5); OTH_LDS_READ(7);
+        OTH_LDS_READ(8); OTH_LDS_READ(10); OTH_LDS_READ(12); OTH_LDS_READ(14);
+        OTH_LDS_READ(9); OTH_LDS_READ(11); OTH_LDS_READ(13); OTH_LDS_READ(15);
+#undef OTH_LDS_READ
+        issued();
+        float2 h0[8], h1[8];
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h0[i] = __builtin_bit_cast(float2, r[i]);
+        dft8(h0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(h0[0].x));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h1[i] = __builtin_bit_cast(float2, r[8 + i]);
+        mid();
+        dft8(h1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = h0[i], v[8 + i] = h1[i];
     }
 }
 
@@ -367,10 +447,10 @@ __device__ __forceinline__ void load_win(float &dst, unsigned lane_off, const ch
 
 // The pipelined transform loop.  `epi.take(v, s)` receives segment s after pass 4 (v[r16(k2)] = bin k0 + 16 k1 + 256 k2
 // + 4096 bitrev2(q) of thread (wave k0, lane 4 k1 + q), times 1, -1, -1 or i); the first call has s = -1 and zeros.
-template <bool WINDOW, class Epi>
+template <int NW, bool WINDOW, class Epi>
 __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, const X1Sched &sc, int wg, int W, const float *win,
                                              const float2 *tw, float2 *lds, Epi &epi, unsigned long long *diag_out) {
-    int *lnext = reinterpret_cast<int *>(lds + 16 * XREG);
+    int *lnext = reinterpret_cast<int *>(lds + NW * XREG);
     const int tid = threadIdx.x;
     const int wv = tid >> 6, l = tid & 63, g = l >> 2, q = l & 3;
     const long long s0 = (sc.nseg * wg) / W, s1 = (sc.nseg * (wg + 1)) / W;
@@ -379,12 +459,14 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
     // 2 and 3 depend on the lane only and are read from LDS tables where they are used (tabB[k1][l] = W_1024^(k1 l),
     // 8 KiB; tabC[k2][q] = W_64^(k2 q), 512 B) - no products to rebuild them, none of their seeds in registers; the
     // quad-butterfly constants sit there too.
-    float2 *tabB = lds + 16 * XREG + X1_RED;                                   // [16][64]
+    float2 *tabB = lds + NW * XREG + X1_RED;                                   // [16][64]
     float2 *tabC = tabB + 16 * 64;                                              // [16][4]
     float4 *quadK = reinterpret_cast<float4 *>(tabC + 16 * 4);                  // [4]: s1, alpha, beta, -beta
     {
-        tabB[tid] = tw[16 * ((tid >> 6) * (tid & 63))];                         // k1 = tid >> 6, l = tid & 63
-        if (tid < 64) tabC[tid] = tw[256 * ((tid >> 2) * (tid & 3))];           // k2 = tid >> 2, q = tid & 3
+        // row i of tabB multiplies pass-2 output i: k1 = i at 16 waves, k1 = i & 7 (register 8 h + k1) at 8; in both
+        // W_(N/16)^(k1 l) = W_N^(16 k1 l)
+        for (int i = tid; i < 1024; i += 64 * NW) tabB[i] = tw[16 * (((i >> 6) & (NW - 1)) * (i & 63))];
+        if (tid < 64) tabC[tid] = tw[16 * NW * ((tid >> 2) * (tid & 3))];       // k2 = tid >> 2, q = tid & 3: W_64 = W_N^(N / 64)
         if (tid < 4) {
             const float be = tid >= 2 ? 1.0f : 0.0f;
             quadK[tid] = make_float4(tid < 2 ? 1.0f : -1.0f, tid == 0 ? 1.0f : (tid == 1 ? -1.0f : 0.0f), be, -be);
@@ -417,7 +499,7 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
     if (live) {
         const char *x0 = reinterpret_cast<const char *>(xb + s * step);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) load_row_nt(pfr[r], 8u * tid, x0 + 8192 * r);
+        for (int r = 0; r < 16; ++r) load_row_nt(pfr[r], 8u * tid, x0 + 512 * NW * r);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     auto tail = [&](auto hook1, auto hook2) {      // pass 3, twiddles, pass 4 of the segment whose exchange-B values sit in rB
@@ -443,7 +525,7 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
             float wv16[16];
             const char *wbase = reinterpret_cast<const char *>(win);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * tid, wbase + 4096 * r);
+            for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * tid, wbase + 256 * NW * r);
             asm volatile("s_waitcnt vmcnt(0)"
                          : "+v"(wv16[0]), "+v"(wv16[1]), "+v"(wv16[2]), "+v"(wv16[3]), "+v"(wv16[4]), "+v"(wv16[5]), "+v"(wv16[6]),
                            "+v"(wv16[7]), "+v"(wv16[8]), "+v"(wv16[9]), "+v"(wv16[10]), "+v"(wv16[11]), "+v"(wv16[12]), "+v"(wv16[13]),
@@ -464,7 +546,7 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
         X1_STAMP(2);
         const bool first_of_chunk = s == sb;
         if (sched == 2 && first_of_chunk && tid == 0) lnext[par] = (int)atomicAdd(sc.queue, 1u);
-        twiddle6<XREG, true>(pf, wa, a6);                      // WA
+        twiddle6_exa<NW>(pf, wa, a6);                          // WA
         X1_STAMP(3);
         // The segment after this one: its loads go out two at a time over the whole step.  A ticket (dynamic schedule)
         // is drawn with a chunk's FIRST segment and published before barrier 2 of that segment, so at the chunk's last
@@ -506,7 +588,7 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
             if constexpr (cnt > 0) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = first; r < first + cnt; ++r) load_row_nt(pfr[r], voff, xn + 8192 * r);
+                for (int r = first; r < first + cnt; ++r) load_row_nt(pfr[r], voff, xn + 512 * NW * r);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -522,14 +604,14 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
         {                                                      // RA
             float2 v[16];
             TwBatch ta;
-            dft16_from_lds<64>(v, ra, [] { prio_compute(); }, [&] {
+            pass2_from_lds<NW>(v, ra, [] { prio_compute(); }, [&] {
                 spread(integral_constant<int, 5>{});
                 tw_read_a<64>(ta, tabB + l);
             });
             prio_latency();
             spread(integral_constant<int, 6>{});
             wave_lds_sync();
-            twiddle_table16<64, XROW, true>(v, wb, tabB + l, ta);
+            twiddle_table16<64, XROW, true, NW>(v, wb, tabB + l, ta);
             spread(integral_constant<int, 7>{});
             wave_lds_sync();
             lds_issue16<4>(rB, rb);
@@ -565,9 +647,9 @@ struct X1WelchEpi {
     }
 };
 
-template <bool WINDOW>      // (the scanner passes `()` as its window; windowed Welch plans take the plain kernel)
-__global__ __launch_bounds__(1024) void welch16k1x_pipe_kernel(WelchArgs p) {
-    constexpr int N = 16384;
+template <int NW, bool WINDOW>      // (the scanner passes `()` as its window; windowed Welch plans take the plain kernel)
+__global__ __launch_bounds__(64 * NW, 4) void welch16k1x_pipe_kernel(WelchArgs p) {
+    constexpr int N = 1024 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
     const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
@@ -579,10 +661,10 @@ __global__ __launch_bounds__(1024) void welch16k1x_pipe_kernel(WelchArgs p) {
 #if OTH_X1_DIAG
     diag = reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * N) + 128 * ((size_t)stream * W + wg);
 #endif
-    x1_pipe_body<WINDOW>(p.x + (size_t)stream * p.stream_stride, p.step, sc, wg, W, p.win, p.tw, lds, epi, diag);
+    x1_pipe_body<NW, WINDOW>(p.x + (size_t)stream * p.stream_stride, p.step, sc, wg, W, p.win, p.tw, lds, epi, diag);
     float *dst = p.partial + ((size_t)stream * W + wg) * N + threadIdx.x;
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) dst[1024 * k2] = epi.acc[k2];
+    for (int k2 = 0; k2 < 16; ++k2) dst[64 * NW * k2] = epi.acc[k2];      // finalize layout 4 (16384) / 5 (8192)
 }
 
 // The fused periodogram chain (stream_to_vector -> keep_one_in_n -> fft_vcc(window, shift) -> |X| or |X|^2 [x 1/N^2] -> IIR
@@ -592,7 +674,8 @@ __global__ __launch_bounds__(1024) void welch16k1x_pipe_kernel(WelchArgs p) {
 struct X1ChainEpi {
     float acc[16];
     const SegArgs *p;
-    int kb;              // bin of register k2: kb + 256 k2
+    int kb;              // bin of register k2: kb + kstride k2
+    int kstride, n;      // 256 / 128 (N / 64); N
     size_t row_base;     // stream offset into p->rows, in rows
     __device__ __forceinline__ void take(const float2 (&v)[16], long long s) {
         if (s < 0) return;      // the priming call
@@ -613,10 +696,10 @@ struct X1ChainEpi {
             }
         }
         if (s >= a.store_from) {
-            float *row = a.rows + (row_base + (size_t)(s - a.store_from)) * 16384;
-            const int sh = a.fftshift ? 8192 : 0;
+            float *row = a.rows + (row_base + (size_t)(s - a.store_from)) * n;
+            const int sh = a.fftshift ? n / 2 : 0;
 #pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) row[(kb + 256 * k2 + sh) & 16383] = val[k2];
+            for (int k2 = 0; k2 < 16; ++k2) row[(kb + kstride * k2 + sh) & (n - 1)] = val[k2];
         }
         if (s < a.acc_end) {
             if (a.acc_mode == 1) {
@@ -632,9 +715,9 @@ struct X1ChainEpi {
     }
 };
 
-template <bool WINDOW>
-__global__ __launch_bounds__(1024) void chain16k1x_kernel(SegArgs p) {
-    constexpr int N = 16384;
+template <int NW, bool WINDOW>
+__global__ __launch_bounds__(64 * NW, 4) void chain16k1x_kernel(SegArgs p) {
+    constexpr int N = 1024 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
     const int tid = threadIdx.x, l = tid & 63, q = l & 3;
@@ -643,24 +726,28 @@ __global__ __launch_bounds__(1024) void chain16k1x_kernel(SegArgs p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) epi.acc[k] = 0.f;
     epi.p = &p;
-    epi.kb = (tid >> 6) + 16 * (l >> 2) + 4096 * (((q & 1) << 1) | (q >> 1));
+    // thread (wave k0', lane 4 c + q): 16 waves: k0 = k0', k1 = c; 8 waves: k0 = 2 k0' + (c >> 3), k1 = c & 7
+    const int c = l >> 2, k3 = ((q & 1) << 1) | (q >> 1);
+    epi.kb = NW == 16 ? (tid >> 6) + 16 * c + 4096 * k3 : 2 * (tid >> 6) + (c >> 3) + 16 * (c & 7) + 2048 * k3;
+    epi.kstride = N / 64;
+    epi.n = N;
     epi.row_base = (size_t)stream * (size_t)(p.nseg - p.store_from);
     const X1Sched sc{p.nseg, p.nbig, p.chunk, p.tail_chunk, p.sched, p.queue ? p.queue + stream : nullptr};
-    x1_pipe_body<WINDOW>(p.x + (size_t)stream * p.stream_stride + p.first, p.step, sc, wg, W, p.win, p.tw, lds, epi, nullptr);
+    x1_pipe_body<NW, WINDOW>(p.x + (size_t)stream * p.stream_stride + p.first, p.step, sc, wg, W, p.win, p.tw, lds, epi, nullptr);
     if (p.partial) {
         float *dst = p.partial + ((size_t)stream * W + wg) * N + tid;
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) dst[1024 * k2] = epi.acc[k2];
+        for (int k2 = 0; k2 < 16; ++k2) dst[64 * NW * k2] = epi.acc[k2];
     }
 }
 
-template <bool WINDOW> static hipError_t launch1x_pipe(const WelchArgs &a, hipStream_t s) {
+template <int NW, bool WINDOW> static hipError_t launch1x_pipe(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
-    constexpr size_t lds = x1p_lds_bytes();
-    const void *fn = reinterpret_cast<const void *>(welch16k1x_pipe_kernel<WINDOW>);
+    constexpr size_t lds = x1p_lds_bytes<NW>();
+    const void *fn = reinterpret_cast<const void *>(welch16k1x_pipe_kernel<NW, WINDOW>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((welch16k1x_pipe_kernel<WINDOW>), grid, dim3(1024), lds, s, a);
+    hipLaunchKernelGGL((welch16k1x_pipe_kernel<NW, WINDOW>), grid, dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
 
@@ -674,15 +761,20 @@ template <bool WINDOW> static hipError_t launch1x_pipe(const WelchArgs &a, hipSt
 // per-wave sums of the new half go to LDS by step parity, wave 0 adds them up behind barrier 1 and every thread picks
 // the segment total up at the end of the step (as welch16k_kernel<2, ...>).  Twiddles of passes 2 and 3 from LDS tables.
 constexpr int XH_RED = 48;      // 16 wave sums x 2 parities, tickets [32..33], segment totals [40..41]
-constexpr size_t x1h_lds_bytes() { return (16 * XREG + XH_RED + 16 * 64 + 16 * 4) * sizeof(float2) + 4 * sizeof(float4); }
+template <int NW = 16> constexpr size_t x1h_lds_bytes() {
+    return (NW * XREG + XH_RED + 16 * 64 + 16 * 4) * sizeof(float2) + 4 * sizeof(float4);
+}
 
-template <int DET, bool PILOT = false>
-__global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
+// NW = 8: the same at 8192 points (round 5; two workgroups per CU).  The bins |k| < 16 the detrend corrects are then
+// register k2 = 0 of lanes 0 and 32 (k1 = 0, q = 0 of k0 = 2 k0' and 2 k0' + 1) and register k2 = 15 of lanes 31 and 63
+// (k1 = 7, q = 3) of each wave (window_spectrum_table_1x in api.hip).
+template <int NW, int DET, bool PILOT = false>
+__global__ __launch_bounds__(64 * NW, 4) void welch16k1x_half_kernel(WelchArgs p) {
     static_assert(DET == 2 || !PILOT, "the pilot belongs to the detrend");
-    constexpr int N = 16384;
+    constexpr int N = 1024 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
-    float2 *red = lds + 16 * XREG;
+    float2 *red = lds + NW * XREG;
     int *lnext = reinterpret_cast<int *>(red + 32);
     float2 *tabB = red + XH_RED;                                                // [16][64]: W_1024^(k1 l)
     float2 *tabC = tabB + 16 * 64;                                              // [16][4]:  W_64^(k2 q)
@@ -696,8 +788,8 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
     const float2 *xb = p.x + (size_t)stream * p.stream_stride;
 
     {
-        tabB[tid] = p.tw[16 * ((tid >> 6) * (tid & 63))];
-        if (tid < 64) tabC[tid] = p.tw[256 * ((tid >> 2) * (tid & 3))];
+        for (int i = tid; i < 1024; i += 64 * NW) tabB[i] = p.tw[16 * (((i >> 6) & (NW - 1)) * (i & 63))];      // as x1_pipe_body
+        if (tid < 64) tabC[tid] = p.tw[16 * NW * ((tid >> 2) * (tid & 3))];
         if (tid < 4) {
             const float be = tid >= 2 ? 1.0f : 0.0f;
             quadK[tid] = make_float4(tid < 2 ? 1.0f : -1.0f, tid == 0 ? 1.0f : (tid == 1 ? -1.0f : 0.0f), be, -be);
@@ -737,22 +829,35 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
             const char *x0 = reinterpret_cast<const char *>(xb + sb * p.step);
             f2v first[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) load_row_nt(first[r], voff, x0 + 8192 * r);
+            for (int r = 0; r < 8; ++r) load_row_nt(first[r], voff, x0 + 512 * NW * r);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) load_row_nt(nxt[r], voff, x0 + 8192 * (8 + r));
+            for (int r = 0; r < 8; ++r) load_row_nt(nxt[r], voff, x0 + 512 * NW * (8 + r));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 8; ++r) keep[r] = make_float2(first[r].x, first[r].y);
         }
+#if OTH_X1H_WIN_EARLY      // A/B (no gain, see the macro): the window values of a step requested at the END of the step before
+        float wv16[16];
+        auto request_window = [&]() {
+            const char *wbase = reinterpret_cast<const char *>(p.win);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * tid, wbase + 256 * NW * r);
+        };
+        request_window();
+#endif
         for (long long s = sb; s < se; ++s) {
             float2 v[16];
             prio_latency();
-            float wv16[16];
+#if !OTH_X1H_WIN_EARLY
+            float wv16[16];      // (declared per step: held across the loop edge they cost the PILOT builds 17 spilled registers)
             {
                 const char *wbase = reinterpret_cast<const char *>(p.win);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * tid, wbase + 4096 * r);
-                // ... and the new half prefetched during the step before (or loaded above)
+                for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * tid, wbase + 256 * NW * r);
+            }
+#endif
+            {
+                // the window values and the new half, both requested during the step before (or above)
                 asm volatile("s_waitcnt vmcnt(0)"
                              : "+v"(wv16[0]), "+v"(wv16[1]), "+v"(wv16[2]), "+v"(wv16[3]), "+v"(wv16[4]), "+v"(wv16[5]), "+v"(wv16[6]),
                                "+v"(wv16[7]), "+v"(wv16[8]), "+v"(wv16[9]), "+v"(wv16[10]), "+v"(wv16[11]), "+v"(wv16[12]), "+v"(wv16[13]),
@@ -780,11 +885,11 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
             }
             // the new half of the segment after this one (behind the chunk's last segment the same rows once more: an
             // unconditional definition keeps the registers free - a conditional one keeps their old values alive)
-            const char *xn = reinterpret_cast<const char *>(xb + (s + 1 < se ? s + 1 : s) * p.step) + 8192 * 8;
+            const char *xn = reinterpret_cast<const char *>(xb + (s + 1 < se ? s + 1 : s) * p.step) + 512 * NW * 8;
             auto prefetch = [&](int r0) {
                 __builtin_amdgcn_sched_barrier(0);
-                load_row_nt(nxt[r0], voff, xn + 8192 * r0);
-                load_row_nt(nxt[r0 + 1], voff, xn + 8192 * (r0 + 1));
+                load_row_nt(nxt[r0], voff, xn + 512 * NW * r0);
+                load_row_nt(nxt[r0 + 1], voff, xn + 512 * NW * (r0 + 1));
                 __builtin_amdgcn_sched_barrier(0);
             };
             const int par = (int)(s & 1);
@@ -809,20 +914,20 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
                 float2 part = make_float2(0.f, 0.f);
                 int slot = l;      // opaque: formed here, not kept (and spilled) across the step
                 asm volatile("" : "+v"(slot));
-                if (slot < 32) part = red[slot];
+                if (slot < 32 && (slot & 15) < NW) part = red[slot];
                 part.x = wave_total_lane63(part.x);
                 part.y = wave_total_lane63(part.y);
                 if (tid == 63) red[40 + par] = part;      // read behind barrier 2, at the end of the step
             }
-            scatter_pow16<XREG>(v, wa, a1, a4);                    // x W_N^(k0 tid) -> [k0][w][l]
+            scatter_pow16_exa<NW>(v, wa, a1, a4);                  // x W_N^(k0 tid) -> [k0][w][l]
             prefetch(0);
             lds_barrier();      // 2
             TwBatch ta;
-            dft16_from_lds<64>(v, ra, [] { prio_compute(); }, [&] { tw_read_a<64>(ta, tabB + l); });     // pass 2
+            pass2_from_lds<NW>(v, ra, [] { prio_compute(); }, [&] { tw_read_a<64>(ta, tabB + l); });     // pass 2
             prio_latency();
             prefetch(2);
             wave_lds_sync();
-            twiddle_table16<64, XROW, true>(v, wb, tabB + l, ta);
+            twiddle_table16<64, XROW, true, NW>(v, wb, tabB + l, ta);
             prefetch(4);
             wave_lds_sync();
             TwBatch tc;
@@ -831,11 +936,14 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
             twiddle_table16<4, 1, false>(v, nullptr, tabC + q, tc);
             prefetch(6);
             quad_dft4_dpp(v, qk.x, qk.y, qk.z, qk.w);              // pass 4
+#if OTH_X1H_WIN_EARLY
+            request_window();      // (in front of the quad butterfly the PILOT builds spilled the kept half: 20 registers)
+#endif
             if (DET == 2) {
                 // X[k] -= mean FFT(w)[k] where FFT(w) is not negligible: register k2 = 0 of lanes (k1 = 0, q = 0) and k2 = 15
                 // of lanes (k1 = 15, q = 3) - lanes 0 and 63 of every wave; their table entries come from L2 when they are
                 // used (held across the step they were four registers of all 1024 threads)
-                if (l == 0 || l == 63) {
+                if (NW == 16 ? (l == 0 || l == 63) : ((l & 31) == 0 || (l & 31) == 31)) {
                     int tfd = tid;      // opaque, as above: the table address is formed inside the branch
                     asm volatile("" : "+v"(tfd));
                     const float4 fd = p.fd[tfd];
@@ -858,23 +966,26 @@ __global__ __launch_bounds__(1024) void welch16k1x_half_kernel(WelchArgs p) {
 
     float *dst = p.partial + ((size_t)stream * W + wg) * N + tid;
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) dst[1024 * k2] = acc[k2];
+    for (int k2 = 0; k2 < 16; ++k2) dst[64 * NW * k2] = acc[k2];
 }
 
-template <int DET, bool PILOT = false> static hipError_t launch1x_half(const WelchArgs &a, hipStream_t s) {
+template <int NW, int DET, bool PILOT = false> static hipError_t launch1x_half(const WelchArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
-    constexpr size_t lds = x1h_lds_bytes();
-    const void *fn = reinterpret_cast<const void *>(welch16k1x_half_kernel<DET, PILOT>);
+    constexpr size_t lds = x1h_lds_bytes<NW>();
+    const void *fn = reinterpret_cast<const void *>(welch16k1x_half_kernel<NW, DET, PILOT>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((welch16k1x_half_kernel<DET, PILOT>), grid, dim3(1024), lds, s, a);
+    hipLaunchKernelGGL((welch16k1x_half_kernel<NW, DET, PILOT>), grid, dim3(64 * NW), lds, s, a);
     return hipGetLastError();
+}
+template <int NW> static hipError_t launch1x_half_n(const WelchArgs &a, hipStream_t s) {
+    if (a.detrend && a.fd) return a.pilot ? launch1x_half<NW, 2, true>(a, s) : launch1x_half<NW, 2>(a, s);
+    return launch1x_half<NW, 0>(a, s);
 }
 
 // step = N / 2; detrend none, or constant through the frequency-domain form (a.fd = the table described above)
-hipError_t launch_welch_tuned16k1x_half(const WelchArgs &a, hipStream_t s) {
-    if (a.detrend && a.fd) return a.pilot ? launch1x_half<2, true>(a, s) : launch1x_half<2>(a, s);
-    return launch1x_half<0>(a, s);
+hipError_t launch_welch_tuned16k1x_half(int nfft, const WelchArgs &a, hipStream_t s) {
+    return nfft == 8192 ? launch1x_half_n<8>(a, s) : launch1x_half_n<16>(a, s);
 }
 
 template <bool WINDOW> static hipError_t launch1x(const WelchArgs &a, hipStream_t s) {
@@ -887,25 +998,28 @@ template <bool WINDOW> static hipError_t launch1x(const WelchArgs &a, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_chain16k1x(const SegArgs &a, bool rect, hipStream_t s) {
+template <int NW, bool WINDOW> static hipError_t launch_chain1x(const SegArgs &a, hipStream_t s) {
     const dim3 grid(a.wg_per_stream, a.nstreams);
-    constexpr size_t lds = x1p_lds_bytes();
-    const void *fn = rect ? reinterpret_cast<const void *>(chain16k1x_kernel<false>) : reinterpret_cast<const void *>(chain16k1x_kernel<true>);
+    constexpr size_t lds = x1p_lds_bytes<NW>();
+    const void *fn = reinterpret_cast<const void *>(chain16k1x_kernel<NW, WINDOW>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (rect)
-        hipLaunchKernelGGL((chain16k1x_kernel<false>), grid, dim3(1024), lds, s, a);
-    else
-        hipLaunchKernelGGL((chain16k1x_kernel<true>), grid, dim3(1024), lds, s, a);
+    hipLaunchKernelGGL((chain16k1x_kernel<NW, WINDOW>), grid, dim3(64 * NW), lds, s, a);
     return hipGetLastError();
+}
+hipError_t launch_chain16k1x(int nfft, const SegArgs &a, bool rect, hipStream_t s) {
+    if (nfft == 16384) return rect ? launch_chain1x<16, false>(a, s) : launch_chain1x<16, true>(a, s);
+    if (nfft == 8192) return rect ? launch_chain1x<8, false>(a, s) : launch_chain1x<8, true>(a, s);
+    return hipErrorInvalidValue;
 }
 
 // plain: the A/B switch (tuning variant "16kplain" / OTH_16K1X_MODE=plain); windowed plans always take the plain kernel
-hipError_t launch_welch_tuned16k1x(const WelchArgs &a, bool window, bool plain, hipStream_t s) {
+hipError_t launch_welch_tuned16k1x(int nfft, const WelchArgs &a, bool window, bool plain, hipStream_t s) {
+    if (nfft == 8192) return (window || plain) ? hipErrorInvalidValue : launch1x_pipe<8, false>(a, s);      // the pipelined rectangular build only
     static const char *mode = getenv("OTH_16K1X_MODE");
     plain = plain || (mode && !strcmp(mode, "plain"));
     if (window) return launch1x<true>(a, s);
-    return plain ? launch1x<false>(a, s) : launch1x_pipe<false>(a, s);
+    return plain ? launch1x<false>(a, s) : launch1x_pipe<16, false>(a, s);
 }
 
 }  // namespace oth

@@ -89,6 +89,16 @@ elif cfg == 'C5':
                           fftshift=True)
     run = lambda: plan.exec_dev(d, S, o, nstreams=nch, stream_stride=stride)      # noqa: E731
     nbytes = 8 * nch * S
+elif cfg == 'scan8192':      # the scanner's vectors at fft_len 8192 (multichannel_scanner.py:78-86): 64 channel streams, rect |X|^2/N^2 mean
+    nch, S, N = 64, 1 << (log2n or 22), 8192
+    d, o = dev(nch * S * 8), dev(nch * N * 4)
+    for i in range(nch):
+        ctx.synth_iq(d + i * S * 8, S, 3000 + i, TONES, DC)
+    plan = welch_plan(N, noverlap=0, window=None, detrend=_hip.DETREND_NONE, scaling=_hip.SCALE_OVER_N2, fftshift=True)
+    if os.environ.get('PROF_VARIANT'):
+        plan.set_tuning(os.environ['PROF_VARIANT'])
+    run = lambda: plan.exec_dev(d, S, o, nstreams=nch, stream_stride=S)      # noqa: E731
+    nbytes = 8 * nch * S
 elif cfg == 'C5d':      # config 5 as bench.py's scan_c5 runs it: PSD rows + the device decision stage (device outputs)
     from ofdm_tools import scan_batch
     nch, S, N = 64, 1 << (log2n or 22), 16384
@@ -109,6 +119,8 @@ elif cfg in ('w1024', 'w2048', 'w512', 'w256', 'w8192', 'w16384'):
     d, o = dev(n * 8), dev(N * 4)
     ctx.synth_iq(d, n, 1002, TONES, DC)
     plan = welch_plan(N, window=hann(N), fs=1.0)
+    if os.environ.get('PROF_VARIANT'):      # e.g. 16k4: the 4 x 4096 / 2 x 4096 kernels of rounds 1-3
+        plan.set_tuning(os.environ['PROF_VARIANT'])
     run = lambda: plan.exec_dev(d, n, o)      # noqa: E731
     nbytes = 8 * n
 elif cfg in ('p1024', 'p2048', 'p8192', 'p16384'):      # the sweeper's call at these sizes: flattop, nperseg = nfft / 4 zero-padded, 50 % overlap
@@ -150,6 +162,10 @@ for _ in range(reps):
     run()
 ms, k = ctx.get_timing()
 ctx.set_timing(False)
+try:
+    print('recipe: ' + plan.last_recipe())
+except NameError:
+    pass
 per_call = ms / reps
 print('%s: timed kernels %.4f ms per call (%d timed scopes / %d calls; chain*: transform + cross-team reduction + state) -> %.1f GB/s algorithmic = %.1f %% of 8 TB/s'
       % (cfg, per_call, k, reps, nbytes / per_call / 1e6, nbytes / per_call / 1e6 / 80.0))
