@@ -630,6 +630,9 @@ def main():
         if not args.no_extras:
             # SURVEY 8d ends the metric at "PSD available on host": the same step through the host-output entry point
             # (oth_welch_exec with a device source: kernels + 16 KiB D2H + stream synchronisation inside the call)
+            # (the prefix parity check above ran on the CPU for a few hundred ms: the device has dropped to its idle clock
+            # and needs the same untimed ramp as every other section - without it this loop read 30-40 us per step more)
+            ramp(step)
             for _ in range(3):
                 plan.exec_device_src(iq.data_ptr(), n)
             hv = []

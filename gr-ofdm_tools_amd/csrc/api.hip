@@ -1484,7 +1484,9 @@ static int stage_host(oth_plan *p, const void *x, const void *y, size_t nsamples
 // hipStreamSynchronize (which also turns a faulted launch into an error code instead of an endless wait).
 // OTH_HOSTWAIT=sync restores the wait of round 4 for the A/B.
 namespace {
-constexpr double kPollSpinUs = 200.0;          // tight polling (pause instructions only)
+constexpr double kPollSpinUs = 2000.0;         // tight polling (pause instructions only): covers a 2^28-sample launch; with
+                                               // sched_yield() from 200 us on, a process with other runnable threads (bench.py
+                                               // under torch) came back 30 us late (0.6256 against 0.595 ms per step)
 constexpr double kPollFallbackMs = 200.0;      // then yield between looks; past this, hipStreamSynchronize
 
 inline double now_us() {

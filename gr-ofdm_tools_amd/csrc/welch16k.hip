@@ -518,7 +518,7 @@ template <int F> hipError_t launch16k_f(const WelchArgs &a, hipStream_t s) {
     if (a.step == 2048 * F) {
         if (!a.detrend) return launch16k<0, F, true>(a, s);
         if (a.fd) return launch16k<2, F, true>(a, s);
-        if (F == 2) return launch16k<1, F, true>(a, s);
+        if constexpr (F == 2) return launch16k<1, F, true>(a, s);      // (constexpr: the 16384-point build of this form spilled 18 registers and was never launched)
     }
     return a.detrend ? launch16k<1, F, false>(a, s) : launch16k<0, F, false>(a, s);
 }

@@ -7,8 +7,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else 'r04'
-ORDER = ['C2', 'C2fast', 'C3', 'C4', 'C4ref', 'C5', 'C5old', 'w256', 'w512', 'w1024', 'w2048', 'w8192', 'w16384', 'p1024',
+rnd = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+ORDER = ['C2', 'C2fast', 'C3', 'C4', 'C4ref', 'C5', 'C5old', 'scan8192', 'w256', 'w512', 'w1024', 'w2048', 'w8192', 'w16384', 'p1024',
          'p2048', 'p8192', 'p16384', 'chain256', 'chain512', 'chain1024', 'chain2048', 'chain4096', 'chain8192', 'chain16384']
 print('| config | kernel | kernel µs | algorithmic GB/s | of 8 TB/s | traffic / algorithmic | VALU issue | clock GHz | whole push |')
 print('|---|---|---|---|---|---|---|---|---|')

@@ -21,7 +21,7 @@ os.makedirs(dst, exist_ok=True)
 # config -> (kernel-name pattern, algorithmic bytes per launch, description)
 CONFIGS = {
     'C2': ('welch4096ws', 8 * 2 ** 28, 'C2: 4096-pt Hann Welch, 50 % overlap, one 2^28-sample stream'),
-    'C3': ('csd4096ws', 16 * 2 ** 26, 'C3: two-channel csd / coherence, 2 x 2^26 samples (16 B per sample pair)'),
+    'C3': ('csd4096ws', 16 * 2 ** 26, 'C3: two-channel csd / coherence, 2 x 2^26 samples (16 B per sample pair); device outputs, launches back to back - the shape of bench.py::csd_bench (round 4 profiled the host-output call, whose idle gaps let the part run the kernel ~10 % faster than it sustains: profiles/r05_c3_bisect.txt)'),
     'C4': ('welch4096ws', 8 * 8 * 2 ** 25, 'C4: sweep of 8 x 2^25 samples on one GPU, Hann 4096, shift + trim + dB'),
     'C2fast': ('welch4096ws', 8 * 2 ** 28, 'C2 with OTH_DETREND_CONSTANT_FAST: the same launch on the build without the pilot (welch4096ws_kernel<true, false>), same box and passes'),
     'C4ref': ('welch4096_kernel', 8 * 8 * 2 ** 25, 'C4 reference-faithful: flattop, nperseg 1024 zero-padded to 4096 '
@@ -33,8 +33,9 @@ CONFIGS = {
     'w512': ('seg_kernel', 8 * 2 ** 27, 'Welch 512-pt Hann 50 % overlap, 2^27 samples (two 32-thread teams per wave)'),
     'w1024': ('segws_kernel', 8 * 2 ** 27, 'Welch 1024-pt Hann 50 % overlap, 2^27 samples'),
     'w2048': ('segws_kernel', 8 * 2 ** 27, 'Welch 2048-pt Hann 50 % overlap, 2^27 samples'),
-    'w8192': ('welch16k', 8 * 2 ** 27, 'Welch 8192-pt Hann 50 % overlap, 2^27 samples (welch16k_kernel<2, 2, HALF>: frequency-domain detrend, overlapped half kept in registers; two transforms per sample)'),
-    'w16384': ('welch16k1x_half', 8 * 2 ** 27, 'Welch 16384-pt Hann 50 % overlap + detrend, 2^27 samples (welch16k1x_half_kernel<2>: one cross-wave exchange, frequency-domain detrend, overlapped half kept in registers, new half prefetched, window from L2; two transforms per sample)'),
+    'w8192': ('welch16k1x_half', 8 * 2 ** 27, 'Welch 8192-pt Hann 50 % overlap, 2^27 samples (welch16k1x_half_kernel<8, 2>, round 5: one cross-wave exchange on 8 waves, two radix-8 butterflies in pass 2, frequency-domain detrend, overlapped half kept in registers, new half prefetched; two transforms per sample)'),
+    'scan8192': ('welch16k1x_pipe', 8 * 64 * 2 ** 22, 'the scanner\'s vectors at fft_len 8192: 64 channel streams x 2^22 samples, rect |X|^2/N^2 mean (welch16k1x_pipe_kernel<8>, round 5: the one-exchange pipelined loop on 8 waves, two workgroups per CU)'),
+    'w16384': ('welch16k1x_half', 8 * 2 ** 27, 'Welch 16384-pt Hann 50 % overlap + detrend, 2^27 samples (welch16k1x_half_kernel<16, 2>: one cross-wave exchange, frequency-domain detrend, overlapped half kept in registers, new half prefetched, window from L2; two transforms per sample)'),
     'p8192': ('welch16k', 8 * 2 ** 27, 'the sweeper call at fft_len 8192: flattop, nperseg 2048 zero-padded to 8192, step 1024: 8 transforms per 8192 new samples (welch16k_kernel<1, 2, false, PAD>)'),
     'p16384': ('welch16k', 8 * 2 ** 27, 'the sweeper call at fft_len 16384: flattop, nperseg 4096 zero-padded to 16384, step 2048 (welch16k_kernel<1, 4, false, PAD>)'),
     'p1024': ('seg_kernel', 8 * 2 ** 27, 'the sweeper call at fft_len 1024 (spectrum_sweeper.py:263): flattop, nperseg 256 zero-padded to 1024, step 128: 8 transforms per 1024 new samples (seg_kernel<4, HALF, ., NA=4>)'),
