@@ -68,11 +68,15 @@ enum { ACC_SUM = 0, ACC_WSUM = 1, ACC_MAX = 2, ACC_NONE = 3 };
 // followed by another lane's read needs no fence; across waves exchange 1 sits between lds_barrier()s.
 
 // the immediate of an asm operand must be a constant expression: template parameter + compile-time loop
-template <int IMM> __device__ __forceinline__ void lds_read_imm(double &dst, unsigned addr) {
+// (a register PAIR as one asm operand: a 2-float vector type.  Through `double` + __builtin_bit_cast the 256 / 512-point
+// whole-segment-load and chain builds kept two 8-byte stack slots - float halves stored, the double loaded back, four
+// scratch accesses per segment - that the register promotion could not remove: 32 B of scratch without a "spill")
+typedef float sf2v __attribute__((ext_vector_type(2)));
+template <int IMM> __device__ __forceinline__ void lds_read_imm(sf2v &dst, unsigned addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
 }
 template <int IMM> __device__ __forceinline__ void lds_write_imm(unsigned addr, float2 val) {
-    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(__builtin_bit_cast(double, val)), "n"(IMM) : "memory");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(sf2v{val.x, val.y}), "n"(IMM) : "memory");
 }
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F f) {
     if constexpr (I < N) {
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
             Pow6 w2 = tw2;
             if (TW2_LDS) w2 = pow6_from(tl2, R);      // older than the sixteen reads below: their counted waits still hold
             {
-                double r[16];
+                sf2v r[16];
                 // rows b with equal (b & KM, b & (R-1)) share one swizzled base
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, b = (i >> 2) + 4 * (i & 3);      // issue order 0,4,8,12, 1,5,9,13, ...
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                     else if (a0 == 2) SEG_WAIT(4, 2, v[1].x);
                     else SEG_WAIT(0, 3, v[2].x);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = __builtin_bit_cast(float2, r[a0 + 4 * j]);
+                    for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = make_float2(r[a0 + 4 * j].x, r[a0 + 4 * j].y);
                     dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
                 }
                 dft16_layer2<PL2>(v);
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                 });
                 // ---- pass 3: thread (k0, j) gathers c for k1 = j + R m ---------------------------------------------
                 {
-                    double r[16];
+                    sf2v r[16];
                     static_for<0, 16>([&](auto ic) {
                         constexpr int i = decltype(ic)::value, c = i / Q, m = i % Q;
                         // row k1 = lo + R m: its (k1 & KM) part beyond lo is (R m) & KM - zero unless R = 2
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                                    "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]),
                                    "+v"(r[15]));
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = __builtin_bit_cast(float2, r[i]);
+                    for (int i = 0; i < 16; ++i) v[i] = make_float2(r[i].x, r[i].y);
                 }
             }
             // X[k0 + 16 (lo + R m) + 256 k2] lands in v[m R + k2] (R = 16: v[r16(k2)]; R = 1: X[k0 + 16 m] in v[r16(m)])
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                 mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
             }
             {
-                double r[16];
+                sf2v r[16];
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, b = (i >> 2) + 4 * (i & 3);
                     lds_read_imm<256 * b>(r[b], (img + b_rw) ^ (8u * (R * (b & KM) + (b & (R - 1)))));
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                     else if (a0 == 2) SEG_WAIT(4, 2, v[1].x);
                     else SEG_WAIT(0, 3, v[2].x);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = __builtin_bit_cast(float2, r[a0 + 4 * j]);
+                    for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = make_float2(r[a0 + 4 * j].x, r[a0 + 4 * j].y);
                     dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
                 }
                 dft16_layer2(v);
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                 lds_write_imm<256 * k1>((img + b_rw) ^ (8u * (R * (k1 & KM) + (k1 & (R - 1)))), cmul(v[r16(k1)], tw2[k1]));
             });
             {
-                double r[16];
+                sf2v r[16];
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, c = i / Q, m = i % Q;
                     lds_read_imm<256 * R * m>(r[m * R + c], (img + b_r2) ^ (8u * c));
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                                "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]),
                                "+v"(r[15]));
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = __builtin_bit_cast(float2, r[i]);
+                for (int i = 0; i < 16; ++i) v[i] = make_float2(r[i].x, r[i].y);
             }
             if (R == 4) {
 #pragma unroll

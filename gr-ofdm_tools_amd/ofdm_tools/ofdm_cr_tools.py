@@ -173,31 +173,33 @@ def welch_power_estimate(vector, nFFT, Sf, ctx=None):
     return float(np.sum(psd, dtype=np.float64))
 
 
+_SCAN_METHODS = {}      # 'welch' / 'fft' -> the PSD + channel-sum routine (filled below the definitions)
+
+
 def fast_spectrum_scan(vct_sample, fc, channel_rate, srch_bw, n_fft, samp_rate, method, thr_leveler,
                        noise_estimate, alpha_avg, show_plot=False, ctx=None):
-    """ofdm_cr_tools.py:471-537 (the matplotlib branch is not carried over)."""
-    npts = len(vct_sample)
-    nFFT = int(2 ** math.ceil(math.log(npts, 2))) if n_fft == 0 else n_fft
-    Fr = float(samp_rate) / float(nFFT)
-    Fstart = fc - _py2div(samp_rate, 2)
-    Ffinish = fc + _py2div(samp_rate, 2)
-    bb_freqs = frange(_py2div(-samp_rate, 2), _py2div(samp_rate, 2), channel_rate)
-    srch_bins = srch_bw / Fr
-    if method == 'welch':
-        psd, axis, power_level_ch = src_power_welch(vct_sample, npts, nFFT, Fr, samp_rate, bb_freqs, srch_bins, ctx)
-    elif method == 'fft':
-        psd, axis, power_level_ch = src_power_fft(vct_sample, npts, nFFT, Fr, samp_rate, bb_freqs, srch_bins, ctx)
-    else:
+    """The legacy sensor's scan (reference: ofdm_cr_tools.py:471-537; its matplotlib branch is not carried over):
+    channel powers by the chosen method on the device, then the noise estimate `ne <- (1 - a) ne + a min(p)`, the
+    threshold `ne * thr_leveler` and the channel frequencies whose power exceeds it.
+    -> (threshold, channel powers, noise estimate, occupied frequencies [Hz])."""
+    try:
+        measure = _SCAN_METHODS[method]
+    except KeyError:
         raise ValueError("method must be 'welch' or 'fft'")
-    ax_ch = frange(Fstart, Ffinish, channel_rate)
-    min_power = np.amin(power_level_ch)
-    noise_estimate = (1 - alpha_avg) * noise_estimate + alpha_avg * min_power
-    thr = noise_estimate * thr_leveler
-    spectrum_constraint_hz = []
-    for i, item in enumerate(power_level_ch):
-        if item > thr:
-            spectrum_constraint_hz.append(ax_ch[i])
-    return thr, power_level_ch, noise_estimate, spectrum_constraint_hz
+    npts = len(vct_sample)
+    nfft = n_fft or int(2 ** math.ceil(math.log(npts, 2)))
+    resolution = float(samp_rate) / float(nfft)
+    half = _py2div(samp_rate, 2)
+    _, _, power = measure(vct_sample, npts, nfft, resolution, samp_rate, frange(_py2div(-samp_rate, 2), half, channel_rate),
+                          srch_bw / resolution, ctx)
+    channel_hz = frange(fc - half, fc + half, channel_rate)
+    noise_estimate = (1 - alpha_avg) * noise_estimate + alpha_avg * np.amin(power)
+    threshold = noise_estimate * thr_leveler
+    occupied = [channel_hz[i] for i in np.flatnonzero(np.asarray(power) > threshold)]
+    return threshold, power, noise_estimate, occupied
+
+
+_SCAN_METHODS.update(welch=src_power_welch, fft=src_power_fft)
 
 
 # the reference keeps its file logger next to the numeric helpers (ofdm_cr_tools.py:1850-2107): same import path here

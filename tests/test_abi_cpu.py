@@ -187,7 +187,12 @@ def test_hot_kernels_have_no_scratch():
            'welch16k1x_half_kernel<16, 2, true>', 'welch16k1x_half_kernel<16, 2, false>', 'welch16k1x_half_kernel<16, 0, false>',
            'welch16k1x_half_kernel<8, 2, true>', 'welch16k1x_half_kernel<8, 2, false>', 'welch16k1x_half_kernel<8, 0, false>',
            'segws_kernel<4, 1, true>', 'segws_kernel<8, 2, true>', 'seg_kernel<1, 0, true, false, 3, 16, true>',
-           'seg_kernel<2, 0, true, false, 3, 16, true>']
+           'seg_kernel<2, 0, true, false, 3, 16, true>',
+           # the fused chain builds 256 ... 4096 and the whole-segment-load Welch builds at 256 / 512
+           'seg_kernel<1, 1, false, true, 3, 16, false>', 'seg_kernel<2, 1, false, true, 3, 16, false>',
+           'seg_kernel<4, 1, false, true, 3, 16, false>', 'seg_kernel<8, 1, false, true, 3, 16, false>',
+           'seg_kernel<16, 1, false, true, 3, 16, false>', 'seg_kernel<1, 1, true, false, 3, 16, true>',
+           'seg_kernel<2, 1, true, false, 3, 16, true>']
     found = {h: [n for n in ks if h + '(' in n.replace('oth::', '')] for h in hot}
     missing = [h for h, n in found.items() if len(n) != 1]
     assert not missing, missing
