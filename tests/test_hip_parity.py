@@ -5,6 +5,8 @@ Tolerance (BASELINE.json north_star): <= 1e-4 relative on linear power over ALL
 bins; coherence <= 1e-4 absolute.  dB outputs are compared after conversion back
 to linear power.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1849,3 +1851,56 @@ def test_recipe_occupancy_table_matches_the_runtime(ctx, hip):
     finally:
         ctx.free(d)
         ctx.free(o)
+
+
+def test_welch_wait_from_another_thread_and_the_synchronising_fallback(ctx, hip, tmp_path):
+    """oth_welch_wait holds no context lock while it polls: a watcher thread waits for tickets that the stream-side thread
+    keeps issuing on the same context (the work() / watcher split of python/spectrum_sensor_v2.py:138-155 applied to the
+    Welch scan).  And OTH_HOSTWAIT=sync - hipStreamSynchronize instead of the polled completion word, the path the
+    200 ms fallback also takes - gives the same PSD (own process: the switch is read once)."""
+    import queue
+    import subprocess
+    import sys
+    import threading
+    from ofdm_tools import windows
+    x = R.synth_iq(1 << 16, 77)
+    plan = ctx.welch_plan(4096, window=windows.get_window('hann', 4096), fs=1.0)
+    plan.set_schedule(hip.SCHED_CONTIGUOUS)
+    want = plan.exec(x)
+    tickets, got, errors = queue.Queue(), [], []
+
+    def watcher():
+        try:
+            while True:
+                t = tickets.get()
+                if t is None:
+                    return
+                got.append(plan.wait(t))
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    th = threading.Thread(target=watcher)
+    th.start()
+    for i in range(24):
+        tickets.put(plan.exec_async(x))
+        while tickets.qsize() > 2:      # the ring keeps four launches: stay inside it
+            pass
+    tickets.put(None)
+    th.join(30)
+    assert not th.is_alive() and not errors, errors
+    assert len(got) == 24 and all(np.array_equal(g, want) for g in got)
+    plan.close()
+    np.save(str(tmp_path / 'x.npy'), x)
+    np.save(str(tmp_path / 'want.npy'), want)
+    code = ('import sys, numpy as np\n'
+            'sys.path.insert(0, %r)\n'
+            'from ofdm_tools import _hip, windows\n'
+            'ctx = _hip.Context(0)\n'
+            'plan = ctx.welch_plan(4096, window=windows.get_window("hann", 4096), fs=1.0)\n'
+            'plan.set_schedule(_hip.SCHED_CONTIGUOUS)\n'
+            'x, want = np.load(%r), np.load(%r)\n'
+            'assert np.array_equal(plan.exec(x), want)\n'
+            'assert np.array_equal(plan.wait(plan.exec_async(x)), want)\n'
+            'print("sync ok")\n') % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gr-ofdm_tools_amd'),
+                                     str(tmp_path / 'x.npy'), str(tmp_path / 'want.npy'))
+    p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, OTH_HOSTWAIT='sync'), capture_output=True, timeout=300)
+    assert p.returncode == 0 and b'sync ok' in p.stdout, p.stderr.decode()[-1500:]
