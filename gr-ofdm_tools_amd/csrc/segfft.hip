@@ -68,15 +68,30 @@ enum { ACC_SUM = 0, ACC_WSUM = 1, ACC_MAX = 2, ACC_NONE = 3 };
 // followed by another lane's read needs no fence; across waves exchange 1 sits between lds_barrier()s.
 
 // the immediate of an asm operand must be a constant expression: template parameter + compile-time loop
-// (a register PAIR as one asm operand: a 2-float vector type.  Through `double` + __builtin_bit_cast the 256 / 512-point
-// whole-segment-load and chain builds kept two 8-byte stack slots - float halves stored, the double loaded back, four
-// scratch accesses per segment - that the register promotion could not remove: 32 B of scratch without a "spill")
-typedef float sf2v __attribute__((ext_vector_type(2)));
-template <int IMM> __device__ __forceinline__ void lds_read_imm(sf2v &dst, unsigned addr) {
+// A register PAIR as one asm operand: a `double`, converted to and from float2 by the by-value helpers below.  Rounds 2-4
+// wrote `v[i] = __builtin_bit_cast(float2, r[i])` on the array element itself; in the 256-point whole-segment-load and
+// chain builds two of those pairs then lived in 8-byte STACK SLOTS - float halves stored, the double loaded back: 32 B of
+// scratch that is not a spill, four scratch accesses per segment - which cost the 256-point chain 17 % (53.6 -> 63 % whole
+// push once they were gone).  Two forms remove the slots: converting through a by-value helper (Pair<false>, shipped), or
+// a 2-float vector type as the asm operand (Pair<true>).  The vector type is SLOWER wherever there was no slot to remove
+// (interleaved same-box A/B: w1024 +8 %, w256 +5.5 %, chain4096 +5.7 %, w2048 +5 %, w512 +4 %; and +1.4 / +4.4 / +0.8 % on
+// C2 / C3 / C5 when tried in dft16_from_lds), the helper form is not: profiles/r05_ab_pair_type_segfft.txt.
+template <bool VEC> struct Pair;
+template <> struct Pair<false> {
+    typedef double type;
+    static __device__ __forceinline__ float2 to_f2(type r) { return __builtin_bit_cast(float2, r); }
+    static __device__ __forceinline__ type from_f2(float2 v) { return __builtin_bit_cast(double, v); }
+};
+template <> struct Pair<true> {
+    typedef float type __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float2 to_f2(type r) { return make_float2(r.x, r.y); }
+    static __device__ __forceinline__ type from_f2(float2 v) { return type{v.x, v.y}; }
+};
+template <int IMM, class PT> __device__ __forceinline__ void lds_read_imm(PT &dst, unsigned addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
 }
-template <int IMM> __device__ __forceinline__ void lds_write_imm(unsigned addr, float2 val) {
-    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(sf2v{val.x, val.y}), "n"(IMM) : "memory");
+template <int IMM, bool VEC = false> __device__ __forceinline__ void lds_write_imm(unsigned addr, float2 val) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(Pair<VEC>::from_f2(val)), "n"(IMM) : "memory");
 }
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F f) {
     if constexpr (I < N) {
@@ -161,6 +176,9 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
     // pass 1 takes it there
     constexpr int PLM = kDft16Plain ? 7 : (CHAIN ? ((OTH_CHAIN_PLAIN_MASK) & (R == 1 ? 1 : 7)) : 0);
     constexpr bool PL1 = (PLM & 1) != 0, PL2 = (PLM & 2) != 0, PL3 = (PLM & 4) != 0;
+    // asm register pairs as 2-float vectors only where the `double` form left stack slots behind (struct Pair above)
+    constexpr bool kPairVec = false;      // (see struct Pair: the by-value converters alone remove the stack slots)
+    using PairT = typename Pair<kPairVec>::type;
     // bin held in slot m R + k2 of the per-thread results
     auto bin_of = [&](int m, int k2) { return R2DPP ? hi + 16 * (m * R + k2) + 256 * lo : hi + 16 * (lo + R * m) + 256 * k2; };
     // WIN_LDS (the chain build): the sixteen window values of a thread live in LDS as four float4 and are read
@@ -361,14 +379,14 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
             prio_latency();
             twiddle_pow16(v, w1, [&](auto kc, float2 val) {
                 constexpr int k0 = decltype(kc)::value;
-                lds_write_imm<8 * (512 * (k0 >> P) + R * (k0 & KP & ~KM))>(a_w1 ^ (8u * R * (k0 & KM)), val);
+                lds_write_imm<8 * (512 * (k0 >> P) + R * (k0 & KP & ~KM)), kPairVec>(a_w1 ^ (8u * R * (k0 & KM)), val);
             });
             if (G::WAVES > 1) lds_barrier();     // B
             // ---- pass 2: thread (k0, c) gathers b -----------------------------------------------------------
             Pow6 w2 = tw2;
             if (TW2_LDS) w2 = pow6_from(tl2, R);      // older than the sixteen reads below: their counted waits still hold
             {
-                sf2v r[16];
+                PairT r[16];
                 // rows b with equal (b & KM, b & (R-1)) share one swizzled base
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, b = (i >> 2) + 4 * (i & 3);      // issue order 0,4,8,12, 1,5,9,13, ...
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                     else if (a0 == 2) SEG_WAIT(4, 2, v[1].x);
                     else SEG_WAIT(0, 3, v[2].x);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = make_float2(r[a0 + 4 * j].x, r[a0 + 4 * j].y);
+                    for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = Pair<kPairVec>::to_f2(r[a0 + 4 * j]);
                     dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
                 }
                 dft16_layer2<PL2>(v);
@@ -412,11 +430,11 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                 // in place: the R lanes that share k0 sit in one wave and have issued their reads of region k0 above
                 twiddle_pow16(v, w2, [&](auto kc, float2 val) {
                     constexpr int k1 = decltype(kc)::value;
-                    lds_write_imm<256 * k1>(a_rw ^ (8u * (R * (k1 & KM) + (k1 & (R - 1)))), val);
+                    lds_write_imm<256 * k1, kPairVec>(a_rw ^ (8u * (R * (k1 & KM) + (k1 & (R - 1)))), val);
                 });
                 // ---- pass 3: thread (k0, j) gathers c for k1 = j + R m ---------------------------------------------
                 {
-                    sf2v r[16];
+                    PairT r[16];
                     static_for<0, 16>([&](auto ic) {
                         constexpr int i = decltype(ic)::value, c = i / Q, m = i % Q;
                         // row k1 = lo + R m: its (k1 & KM) part beyond lo is (R m) & KM - zero unless R = 2
@@ -428,7 +446,7 @@ __global__ __launch_bounds__(Geo<R>::BLOCK, WPS) void seg_kernel(SegArgs p) {
                                    "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]),
                                    "+v"(r[15]));
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = make_float2(r[i].x, r[i].y);
+                    for (int i = 0; i < 16; ++i) v[i] = Pair<kPairVec>::to_f2(r[i]);
                 }
             }
             // X[k0 + 16 (lo + R m) + 256 k2] lands in v[m R + k2] (R = 16: v[r16(k2)]; R = 1: X[k0 + 16 m] in v[r16(m)])
@@ -753,7 +771,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                 mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
             }
             {
-                sf2v r[16];
+                double r[16];
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, b = (i >> 2) + 4 * (i & 3);
                     lds_read_imm<256 * b>(r[b], (img + b_rw) ^ (8u * (R * (b & KM) + (b & (R - 1)))));
@@ -767,7 +785,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                     else if (a0 == 2) SEG_WAIT(4, 2, v[1].x);
                     else SEG_WAIT(0, 3, v[2].x);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = make_float2(r[a0 + 4 * j].x, r[a0 + 4 * j].y);
+                    for (int j = 0; j < 4; ++j) v[a0 + 4 * j] = Pair<false>::to_f2(r[a0 + 4 * j]);
                     dft4<false>(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
                 }
                 dft16_layer2(v);
@@ -779,7 +797,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                 lds_write_imm<256 * k1>((img + b_rw) ^ (8u * (R * (k1 & KM) + (k1 & (R - 1)))), cmul(v[r16(k1)], tw2[k1]));
             });
             {
-                sf2v r[16];
+                double r[16];
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, c = i / Q, m = i % Q;
                     lds_read_imm<256 * R * m>(r[m * R + c], (img + b_r2) ^ (8u * c));
@@ -790,7 +808,7 @@ __global__ __launch_bounds__(32 * R, 4) void segws_kernel(SegArgs p) {
                                "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]),
                                "+v"(r[15]));
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = make_float2(r[i].x, r[i].y);
+                for (int i = 0; i < 16; ++i) v[i] = Pair<false>::to_f2(r[i]);
             }
             if (R == 4) {
 #pragma unroll
