@@ -45,6 +45,9 @@
 #ifndef OTH_WS_POW6
 #define OTH_WS_POW6 1
 #endif
+#ifndef OTH_WS_SPREAD
+#define OTH_WS_SPREAD 0      // A/B: 2 = four loads before and four after the producer's butterfly; 3 = 2 + 4 + 2 (after the exchange writes)
+#endif
 #ifndef OTH_WS_DIAG
 #define OTH_WS_DIAG 0        // 1: per-wave phase cycle counters behind the partial sums (tools/diag_ws.py)
 #endif
@@ -223,14 +226,23 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
                 if (FIRST) ticket = atomicAdd(p.queue + stream, 1u);
                 if (publish) ctrl[4] = (int)ticket;
             }
-            if (MODE == 0) {
-                const float2 *xn = xb + (size_t)uni(s + 2) * 2048;
+            const float2 *xn = xb + (size_t)uni(s + 2) * 2048;      // (MODE 0 only)
+            auto load_pairs = [&](int j0, int j1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = j0; j < j1; ++j) {
                     const float2 *xj = xn + 512 * j;
                     nxt[2 * j] = OTH_WS_LOAD(xj + (unsigned)t);
                     nxt[2 * j + 1] = OTH_WS_LOAD(xj + ((unsigned)t + 256u));
                 }
+            };
+            if (MODE == 0) {
+#if OTH_WS_SPREAD      // A/B (round 5): the eight loads of a step at two / three places instead of one burst
+                __builtin_amdgcn_sched_barrier(0);
+                load_pairs(0, OTH_WS_SPREAD == 2 ? 2 : 1);
+                __builtin_amdgcn_sched_barrier(0);
+#else
+                load_pairs(0, 4);
+#endif
             } else if (MODE == 1) {
                 load_chunk_head(nsb);
             }
@@ -247,6 +259,13 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             dft16(v);
             WS_STAMP(2);
             __builtin_amdgcn_s_setprio(OTH_WS_PAS);
+#if OTH_WS_SPREAD
+            if (MODE == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_pairs(OTH_WS_SPREAD == 2 ? 2 : 1, OTH_WS_SPREAD == 2 ? 4 : 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
 #if OTH_WS_POW6
             scatter_pow16_six<RS>(v, lx + w1, b1, b2, b3, b4, b8, b12);
 #else
@@ -255,6 +274,13 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
 #if OTH_WS_DIAG
             __builtin_amdgcn_s_waitcnt(0xC07F);
             WS_STAMP(3);
+#endif
+#if OTH_WS_SPREAD == 3
+            if (MODE == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_pairs(3, 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #endif
             step_end(ITEM_DATA);
         };
