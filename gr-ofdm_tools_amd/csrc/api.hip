@@ -1495,8 +1495,11 @@ inline double now_us() {
     return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
 }
 
+// The word of a slot only ever grows (tickets t, t + 4, t + 8, ... of that slot, low 32 bits): "reached" is >= in
+// wrap-safe arithmetic, so a waiter whose ticket was overtaken by a newer launch on the slot leaves its loop too (and is
+// then told OTH_ERR_STATE, not that the word was never written).
 inline bool seq_reached(const unsigned *word, unsigned want) {
-    return __atomic_load_n(word, __ATOMIC_ACQUIRE) == want;
+    return (int)(__atomic_load_n(word, __ATOMIC_ACQUIRE) - want) >= 0;
 }
 
 // -> true when the word shows `want` (the row behind it is then visible to this thread)

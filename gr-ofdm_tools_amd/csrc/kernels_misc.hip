@@ -44,6 +44,9 @@ __device__ __forceinline__ void finalize_signal(const FinalizeArgs &a) {
         const unsigned nblocks = gridDim.x * gridDim.y;
         const unsigned prev = __hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == nblocks - 1) {
+            // the one acquire of the scheme: this block has read every other block's arrival; their release fences now
+            // happen-before the publication below (an invalidate in ONE block, after everybody has read the partial rows)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.host_seq, a.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
