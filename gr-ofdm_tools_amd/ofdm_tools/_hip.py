@@ -186,8 +186,22 @@ class Context(object):
 
     def close(self):
         if getattr(self, 'h', None):
+            for plan in self.__dict__.pop('_plans', {}).values():
+                plan.close()
             self.lib.oth_ctx_destroy(self.h)
             self.h = None
+
+    def cached_plan(self, key, make, limit=64):
+        """One plan per (context, key) for callers that ask for the same shape with every request (the legacy helpers of
+        ofdm_cr_tools): a plan owns device tables and scratch, and building one costs allocations and a stream
+        synchronisation.  The cache is closed with the context; past `limit` shapes the oldest goes."""
+        plans = self.__dict__.setdefault('_plans', {})
+        plan = plans.get(key)
+        if plan is None or not plan.h:
+            if len(plans) >= limit:
+                plans.pop(next(iter(plans))).close()
+            plan = plans[key] = make()
+        return plan
 
     def __del__(self):
         try:

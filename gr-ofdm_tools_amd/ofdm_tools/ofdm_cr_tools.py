@@ -26,6 +26,12 @@ def _py2div(a, b):
     return a / b
 
 
+def _welch_plan(ctx, nfft, window_name, Sf):
+    """The reference's `sg.welch(x, Sf, window, nperseg=nfft, nfft=nfft)` + fftshift (ofdm_cr_tools.py:214,322,342)."""
+    return ctx.cached_plan(('welch', nfft, window_name, float(Sf)),
+                 lambda: ctx.welch_plan(nfft, window=windows.get_window(window_name, nfft), fs=float(Sf), fftshift=True))
+
+
 def frange(x, y, jump):
     """ofdm_cr_tools.py:136-141."""
     out = []
@@ -70,12 +76,29 @@ def _plain_channel_sums(psd, Fr, Sf, bb_freqs, srch_bins, ctx):
     return [float(v) for v in ctx.channel_power(psd, 1.0, lo, hi)]
 
 
+def _enqueue_welch(vector, nFFT, Sf, ctx):
+    """src_power_welch's PSD (flattop, nperseg = nfft, ofdm_cr_tools.py:213-216) as a ticket: -> (plan, ticket, post)."""
+    plan = _welch_plan(ctx, nFFT, 'flattop', Sf)
+    return plan, plan.exec_async(vector), None
+
+
+def _enqueue_fft(vector, nFFT, Sf, ctx):
+    """src_power_fft's single flat-top periodogram |FFT(x w, nFFT)|^2 / nFFT (ofdm_cr_tools.py:173-178) as a ticket."""
+    vector = np.asarray(vector)
+    total = len(vector)                   # the reference windows ALL len(vector) samples, then np.fft.fft(., nFFT) keeps the first nFFT
+    vector = vector[:nFFT]
+    npts = len(vector)
+    plan = ctx.cached_plan(('fft', nFFT, total, npts),
+                 lambda: ctx.welch_plan(nFFT, nperseg=npts, noverlap=0, window=windows.flattop(total)[:nFFT],
+                                        detrend=_hip.DETREND_NONE, scaling=_hip.SCALE_RAW, fftshift=True))
+    return plan, plan.exec_async(vector), (lambda psd: psd / np.float32(nFFT))
+
+
 def src_power_welch(vector, npts, nFFT, Fr, Sf, bb_freqs, srch_bins, ctx=None):
     """ofdm_cr_tools.py:213-230."""
     ctx = ctx or _hip.default_context()
-    plan = ctx.welch_plan(nFFT, window=windows.get_window('flattop', nFFT), fs=float(Sf), fftshift=True)
-    psd = plan.exec(vector)
-    plan.close()
+    plan, ticket, _ = _enqueue_welch(vector, nFFT, Sf, ctx)
+    psd = plan.wait(ticket)
     axis = np.fft.fftshift(np.fft.fftfreq(nFFT, 1.0 / Sf))
     return psd, axis, _plain_channel_sums(psd, Fr, Sf, bb_freqs, srch_bins, ctx)
 
@@ -83,15 +106,8 @@ def src_power_welch(vector, npts, nFFT, Fr, Sf, bb_freqs, srch_bins, ctx=None):
 def src_power_fft(vector, npts, nFFT, Fr, Sf, bb_freqs, srch_bins, ctx=None):
     """ofdm_cr_tools.py:173-192: one flat-top periodogram |FFT(x w, nFFT)|^2 / nFFT, shifted."""
     ctx = ctx or _hip.default_context()
-    vector = np.asarray(vector)
-    # the reference windows ALL len(vector) samples, then np.fft.fft(., nFFT) keeps the first nFFT
-    win = windows.flattop(len(vector))[:nFFT]
-    vector = vector[:nFFT]
-    npts = len(vector)
-    plan = ctx.welch_plan(nFFT, nperseg=npts, noverlap=0, window=win,
-                          detrend=_hip.DETREND_NONE, scaling=_hip.SCALE_RAW, fftshift=True)
-    psd = plan.exec(vector) / np.float32(nFFT)
-    plan.close()
+    plan, ticket, post = _enqueue_fft(vector, nFFT, Sf, ctx)
+    psd = post(plan.wait(ticket))
     axis = _py2div(Sf, 2) * np.linspace(-1, 1, nFFT)
     return psd, axis, _plain_channel_sums(psd, Fr, Sf, bb_freqs, srch_bins, ctx)
 
@@ -157,9 +173,7 @@ def fac(data, length, ctx=None):
 def welch_plot_dB(data, Sf, fc, nfft, ctx=None):
     """ofdm_cr_tools.py:321-326 (default Hann window, 50 % overlap)."""
     ctx = ctx or _hip.default_context()
-    plan = ctx.welch_plan(nfft, window=windows.get_window('hann', nfft), fs=float(Sf), fftshift=True)
-    psd = plan.exec(data)
-    plan.close()
+    psd = _welch_plan(ctx, nfft, 'hann', Sf).exec(data)
     axis = np.fft.fftshift(np.fft.fftfreq(nfft, 1.0 / Sf))
     return [item + fc for item in axis], [10 * math.log10(item + 1e-20) for item in psd]
 
@@ -167,39 +181,63 @@ def welch_plot_dB(data, Sf, fc, nfft, ctx=None):
 def welch_power_estimate(vector, nFFT, Sf, ctx=None):
     """ofdm_cr_tools.py:341-345."""
     ctx = ctx or _hip.default_context()
-    plan = ctx.welch_plan(nFFT, window=windows.get_window('hann', nFFT), fs=float(Sf), fftshift=True)
-    psd = plan.exec(vector)
-    plan.close()
-    return float(np.sum(psd, dtype=np.float64))
+    return float(np.sum(_welch_plan(ctx, nFFT, 'hann', Sf).exec(vector), dtype=np.float64))
 
 
-_SCAN_METHODS = {}      # 'welch' / 'fft' -> the PSD + channel-sum routine (filled below the definitions)
+class SpectrumScan(object):
+    """The legacy sensor's scan (reference: ofdm_cr_tools.py:471-537; its matplotlib branch is not carried over), split
+    where the GPU works: the constructor enqueues the PSD of the chosen method ('welch': flat-top Welch, 'fft': one
+    flat-top periodogram) through ``oth_welch_exec_async`` and returns at once - the sample buffer may be reused;
+    ``poll(noise_estimate)`` returns None while the launch is running, ``wait(noise_estimate)`` blocks.  Both finish with
+    the channel sums on the device, the noise estimate ``ne <- (1 - a) ne + a min(p)``, the threshold ``ne * thr_leveler``
+    and the channel frequencies whose power exceeds it: -> (threshold, channel powers, noise estimate, occupied [Hz])."""
+    _ENQUEUE = {'welch': _enqueue_welch, 'fft': _enqueue_fft}
+
+    def __init__(self, vct_sample, fc, channel_rate, srch_bw, n_fft, samp_rate, method, thr_leveler, alpha_avg, ctx=None):
+        try:
+            enqueue = self._ENQUEUE[method]
+        except KeyError:
+            raise ValueError("method must be 'welch' or 'fft'")
+        self.ctx = ctx or _hip.default_context()
+        self.nfft = n_fft or int(2 ** math.ceil(math.log(len(vct_sample), 2)))
+        self.samp_rate, self.thr_leveler, self.alpha_avg = samp_rate, thr_leveler, alpha_avg
+        self.resolution = float(samp_rate) / float(self.nfft)
+        half = _py2div(samp_rate, 2)
+        self.bb_freqs = frange(_py2div(-samp_rate, 2), half, channel_rate)
+        self.srch_bins = srch_bw / self.resolution
+        self.channel_hz = frange(fc - half, fc + half, channel_rate)
+        self._plan, self._ticket, self._post = enqueue(vct_sample, self.nfft, samp_rate, self.ctx)
+        self._result = None
+
+    def _finish(self, psd, noise_estimate):
+        if self._post is not None:
+            psd = self._post(psd)
+        power = _plain_channel_sums(psd, self.resolution, self.samp_rate, self.bb_freqs, self.srch_bins, self.ctx)
+        noise_estimate = (1 - self.alpha_avg) * noise_estimate + self.alpha_avg * np.amin(power)
+        threshold = noise_estimate * self.thr_leveler
+        occupied = [self.channel_hz[i] for i in np.flatnonzero(np.asarray(power) > threshold)]
+        self._result = (threshold, power, noise_estimate, occupied)
+        return self._result
+
+    def poll(self, noise_estimate):
+        if self._result is None:
+            psd = self._plan.poll(self._ticket)
+            if psd is None:
+                return None
+            self._finish(psd, noise_estimate)
+        return self._result
+
+    def wait(self, noise_estimate):
+        if self._result is None:
+            self._finish(self._plan.wait(self._ticket), noise_estimate)
+        return self._result
 
 
 def fast_spectrum_scan(vct_sample, fc, channel_rate, srch_bw, n_fft, samp_rate, method, thr_leveler,
                        noise_estimate, alpha_avg, show_plot=False, ctx=None):
-    """The legacy sensor's scan (reference: ofdm_cr_tools.py:471-537; its matplotlib branch is not carried over):
-    channel powers by the chosen method on the device, then the noise estimate `ne <- (1 - a) ne + a min(p)`, the
-    threshold `ne * thr_leveler` and the channel frequencies whose power exceeds it.
-    -> (threshold, channel powers, noise estimate, occupied frequencies [Hz])."""
-    try:
-        measure = _SCAN_METHODS[method]
-    except KeyError:
-        raise ValueError("method must be 'welch' or 'fft'")
-    npts = len(vct_sample)
-    nfft = n_fft or int(2 ** math.ceil(math.log(npts, 2)))
-    resolution = float(samp_rate) / float(nfft)
-    half = _py2div(samp_rate, 2)
-    _, _, power = measure(vct_sample, npts, nfft, resolution, samp_rate, frange(_py2div(-samp_rate, 2), half, channel_rate),
-                          srch_bw / resolution, ctx)
-    channel_hz = frange(fc - half, fc + half, channel_rate)
-    noise_estimate = (1 - alpha_avg) * noise_estimate + alpha_avg * np.amin(power)
-    threshold = noise_estimate * thr_leveler
-    occupied = [channel_hz[i] for i in np.flatnonzero(np.asarray(power) > threshold)]
-    return threshold, power, noise_estimate, occupied
-
-
-_SCAN_METHODS.update(welch=src_power_welch, fft=src_power_fft)
+    """ofdm_cr_tools.py:471-537 with the reference's arguments and return value: SpectrumScan, waited for."""
+    return SpectrumScan(vct_sample, fc, channel_rate, srch_bw, n_fft, samp_rate, method, thr_leveler, alpha_avg,
+                        ctx).wait(noise_estimate)
 
 
 # the reference keeps its file logger next to the numeric helpers (ofdm_cr_tools.py:1850-2107): same import path here

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _hip
 from .gr_compat import pdu_parts, sync_block, to_msg
-from .ofdm_cr_tools import fast_spectrum_scan
+from .ofdm_cr_tools import SpectrumScan, fast_spectrum_scan
 
 
 class _RequestLog(object):
@@ -35,7 +35,8 @@ class _RequestLog(object):
 
 class spectrum_sensor(sync_block):
     def __init__(self, block_length, sample_rate=1, fft_len=1, channel_space=1, search_bw=1, method='fft',
-                 thr_leveler=10, tune_freq=0, alpha_avg=1, source=None, log=False, ctx=None, log_dir='/tmp'):
+                 thr_leveler=10, tune_freq=0, alpha_avg=1, source=None, log=False, ctx=None, log_dir='/tmp',
+                 async_scan=False):
         sync_block.__init__(self, 'spectrum_sensor', [np.complex64], None)
         self.block_length = block_length
         self.sample_rate = sample_rate
@@ -60,6 +61,11 @@ class spectrum_sensor(sync_block):
             self.log_file.row('sample_rate', sample_rate, 'channel_space', channel_space, 'channel_bw', search_bw,
                               'tune_freq', tune_freq)
         self.ctx = ctx
+        # async_scan (not in the reference, whose handler runs sg.welch on the scheduler's thread): an 'SC' request only
+        # ENQUEUES the scan (oth_welch_exec_async) and the three answers go out from the first work() call that finds the
+        # PSD ready - neither the message handler nor work() ever waits for the GPU
+        self.async_scan = async_scan
+        self._scan = None
         self.message_port_register_out('PDU spect_msg')
         self.message_port_register_in('PDU from_cogeng')
         self.set_msg_handler('PDU from_cogeng', self.cogeng_rx)
@@ -67,7 +73,23 @@ class spectrum_sensor(sync_block):
     def work(self, input_items, output_items):
         in0 = input_items[0][0:self.block_length]
         self.set_vector_sample(np.array(in0, np.complex64))      # the caller's buffer dies after the call
+        if self._scan is not None:
+            self.collect_scan(wait=False)
         return len(in0)
+
+    def collect_scan(self, wait=True):
+        """async_scan: publish the pending 'SC' answers if the scan has finished (wait=True: when it has).  -> True
+        when nothing is pending any more."""
+        scan = self._scan
+        if scan is None:
+            return True
+        result = scan.wait(self.get_noise_estimate()) if wait else scan.poll(self.get_noise_estimate())
+        if result is None:
+            return False
+        self._scan = None
+        self.threshold, self.power_level_ch, self.noise_estimate, self.spectrum_constraint_hz = result
+        self._publish_spectrum_constraint()
+        return True
 
     # request name (the PDU's body as text) -> method that answers it (python/spectrum_sensor.py:88-120)
     _REQUESTS = {'PAPR': '_answer_papr', 'SC': '_answer_spectrum_constraint'}
@@ -86,7 +108,17 @@ class spectrum_sensor(sync_block):
             self.log_file.row('papr', self.get_papr())
 
     def _answer_spectrum_constraint(self):
+        if self.async_scan:
+            if self._scan is not None:          # a request while one is in flight: answer the older one first
+                self.collect_scan(wait=True)
+            self._scan = SpectrumScan(self.get_vector_sample(), self.tune_freq, self.channel_space, self.search_bw,
+                                      self.fft_len, self.sample_rate, self.method, self.thr_leveler, self.get_alpha_avg(),
+                                      self.ctx)
+            return
         self.set_spectrum_constraint_hz(self.get_vector_sample())
+        self._publish_spectrum_constraint()
+
+    def _publish_spectrum_constraint(self):
         for field, value in (('thre', self.get_threshold()), ('nois', self.get_noise_estimate()),
                              ('cons', self.get_spectrum_constraint_hz())):
             self.send_msg(field, value)

@@ -373,6 +373,50 @@ def test_legacy_spectrum_sensor_request_response(ctx, tmp_path):
         assert np.isclose(float(rows[2][3]), 10 * np.log10(thr + 1e-20), atol=1e-3) and rows[4][3] == str(cons)
 
 
+def test_legacy_spectrum_sensor_async_scan(ctx):
+    """async_scan=True: 'SC' only enqueues (oth_welch_exec_async); the three PDUs leave from work() once the PSD is on the
+    host, equal to the blocking block's; a second request while one is pending answers the older one first; the helpers'
+    plans are built once per shape and reused."""
+    import ofdm_tools
+    from ofdm_tools import ofdm_cr_tools
+    Sf, N = 1000000, 1024
+    x = R.synth_iq(3 * 8192, 43)
+    for method in ('welch', 'fft'):
+        kw = dict(sample_rate=Sf, fft_len=N, channel_space=50e3, search_bw=25e3, method=method, thr_leveler=5,
+                  tune_freq=0, alpha_avg=0.5, ctx=ctx)
+        ref, blk = ofdm_tools.spectrum_sensor(8192, **kw), ofdm_tools.spectrum_sensor(8192, async_scan=True, **kw)
+        want, out = [], []
+        ref.msg_connect('PDU spect_msg', want.append)
+        blk.msg_connect('PDU spect_msg', out.append)
+        for k in range(3):                                  # the noise estimate carries from scan to scan
+            seg = x[k * 8192:(k + 1) * 8192]
+            ref.work([seg], [])
+            ref.post('PDU from_cogeng', ({}, 'SC'))
+            blk.work([seg], [])
+            n_before = len(out)
+            blk.post('PDU from_cogeng', ({}, 'SC'))
+            assert len(out) == n_before                     # nothing published by the handler itself
+            if k == 1:
+                blk.post('PDU from_cogeng', ({}, 'SC'))     # a second request: the pending one is answered first
+                assert len(out) == n_before + 3
+                ref.post('PDU from_cogeng', ({}, 'SC'))
+            for _ in range(2000):                           # work() never waits: poll it like the scheduler would
+                blk.work([seg], [])
+                if blk._scan is None:
+                    break
+            assert blk._scan is None and blk.collect_scan()
+        assert [f for f, _ in out] == [f for f, _ in want] == ['thre', 'nois', 'cons'] * 4
+        for (f, a), (_, b) in zip(out, want):
+            assert a == b, (method, f)                      # the same kernels on the same samples: identical
+        assert np.array_equal(blk.get_power_level_ch(), ref.get_power_level_ch())
+    made = len(ctx._plans)
+    ofdm_cr_tools.fast_spectrum_scan(x[:8192], 0, 50e3, 25e3, N, Sf, 'welch', 5, 1e-11, 1, ctx=ctx)
+    ofdm_cr_tools.fast_spectrum_scan(x[:8192], 0, 50e3, 25e3, N, Sf, 'fft', 5, 1e-11, 1, ctx=ctx)
+    assert len(ctx._plans) == made >= 2                     # the two scans above built nothing new
+    with pytest.raises(ValueError):
+        ofdm_cr_tools.SpectrumScan(x[:8192], 0, 50e3, 25e3, N, Sf, 'bogus', 5, 1, ctx)
+
+
 def test_ref_legacy_spectrum_sensor_session(ctx, golden, tmp_path):
     """f3 against the reference's OWN spectrum_sensor methods (spectrum_sensor.py:73-206, ref_legacy_sensor.npz): one
     scripted session - SC, PAPR, an unknown request, two logged setters, a second SC whose noise estimate carries
