@@ -197,6 +197,12 @@ __device__ __forceinline__ float2 load_once(const float2 *p) {
 
 // Chunk c of the segment schedule: the first `nbig` chunks have `chunk` segments, the rest `tail_chunk`
 // (smaller chunks for the last round even out the finish of the dynamic schedule).
+// 4-byte non-temporal-free load of a window value at (uniform row base) + (lane offset), pinned like load_row_nt: the
+// compiler would hoist sixteen loop-invariant window loads into sixteen registers the two segments in flight need
+__device__ __forceinline__ void load_win(float &dst, unsigned lane_off, const char *row) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
+}
+
 __device__ __forceinline__ long long chunk_count(const WelchArgs &p) {
     const long long rest = p.nseg - p.nbig * p.chunk;
     return p.nbig + (rest + p.tail_chunk - 1) / p.tail_chunk;
@@ -211,13 +217,13 @@ __device__ __forceinline__ void chunk_range(const WelchArgs &p, long long c, lon
     }
 }
 
-// the same schedule for kernels that do not take a WelchArgs (segfft.hip)
-__device__ __forceinline__ long long chunk_count_of(long long nseg, long long nbig, int chunk, int tail_chunk) {
-    const long long rest = nseg - nbig * chunk;
+// the same schedule for kernels that do not take a WelchArgs (segfft.hip); I = int where the launcher has checked that
+// the segment count fits (welch16k1x.hip: ten 64-bit loop variables cost the kernel its last scalar registers)
+template <class I> __device__ __forceinline__ I chunk_count_of(I nseg, I nbig, int chunk, int tail_chunk) {
+    const I rest = nseg - nbig * chunk;
     return nbig + (rest + tail_chunk - 1) / tail_chunk;
 }
-__device__ __forceinline__ void chunk_range_of(long long nseg, long long nbig, int chunk, int tail_chunk, long long c,
-                                               long long &sb, long long &se) {
+template <class I> __device__ __forceinline__ void chunk_range_of(I nseg, I nbig, int chunk, int tail_chunk, I c, I &sb, I &se) {
     if (c < nbig) {
         sb = c * chunk;
         se = sb + chunk;

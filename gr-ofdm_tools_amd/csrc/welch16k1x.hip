@@ -434,16 +434,10 @@ template <int STRIDE> __device__ __forceinline__ void lds_issue16(f2v (&r)[16], 
 // of one segment and the exchange-B values of the one before, 32 + 32.
 // The segment schedule as the body below takes it (WelchArgs and SegArgs both carry these fields)
 struct X1Sched {
-    long long nseg, nbig;
+    int nseg, nbig;       // 32-bit: launch1x_* refuse a launch of 2^31 segments (2^44 samples) or more
     int chunk, tail_chunk, sched;
     unsigned *queue;      // this stream's ticket word (dynamic schedule) or nullptr
 };
-
-// 4-byte non-temporal-free load of a window value at (uniform row base) + (lane offset), pinned like load_row_nt: the
-// compiler would hoist sixteen loop-invariant window loads into sixteen registers the two segments in flight need
-__device__ __forceinline__ void load_win(float &dst, unsigned lane_off, const char *row) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
-}
 
 // The pipelined transform loop.  `epi.take(v, s)` receives segment s after pass 4 (v[r16(k2)] = bin k0 + 16 k1 + 256 k2
 // + 4096 bitrev2(q) of thread (wave k0, lane 4 k1 + q), times 1, -1, -1 or i); the first call has s = -1 and zeros.
@@ -453,7 +447,9 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
     int *lnext = reinterpret_cast<int *>(lds + NW * XREG);
     const int tid = threadIdx.x;
     const int wv = tid >> 6, l = tid & 63, g = l >> 2, q = l & 3;
-    const long long s0 = (sc.nseg * wg) / W, s1 = (sc.nseg * (wg + 1)) / W;
+    // segment indices are 32-bit in this loop (X1Sched): its ten loop variables as 64-bit pairs took the chain build past
+    // the scalar register file (11 SGPRs parked in a VGPR, round 4)
+    const int s0 = (int)(((long long)sc.nseg * wg) / W), s1 = (int)(((long long)sc.nseg * (wg + 1)) / W);
 
     // Twiddles: pass 1 (W_N^(k0 tid), a different set per thread) is rebuilt from six register-resident powers; passes
     // 2 and 3 depend on the lane only and are read from LDS tables where they are used (tabB[k1][l] = W_1024^(k1 l),
@@ -481,11 +477,11 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
     const float2 *rb = lds + XREG * wv + XROW * g + q;
 
     const int sched = sc.sched;
-    const long long nchunks = sched ? chunk_count_of(sc.nseg, sc.nbig, sc.chunk, sc.tail_chunk) : 1;
-    long long cur = sched ? wg : 0, sb = s0, se = s1;
+    const int nchunks = sched ? chunk_count_of(sc.nseg, sc.nbig, sc.chunk, sc.tail_chunk) : 1;
+    int cur = sched ? wg : 0, sb = s0, se = s1;
     if (sched && cur < nchunks) chunk_range_of(sc.nseg, sc.nbig, sc.chunk, sc.tail_chunk, cur, sb, se);
     bool live = sched ? cur < nchunks : s0 < s1;
-    long long s = sb, sp = -1;      // this segment, the one before (whose tail runs in this step)
+    int s = sb, sp = -1;            // this segment, the one before (whose tail runs in this step)
     int par = 0;
 #if OTH_X1_DIAG
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -497,7 +493,7 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
     for (int i = 0; i < 16; ++i) rB[i] = f2v{0.f, 0.f};
     bool have_prev = false;
     if (live) {
-        const char *x0 = reinterpret_cast<const char *>(xb + s * step);
+        const char *x0 = reinterpret_cast<const char *>(xb + (long long)s * step);
 #pragma unroll
         for (int r = 0; r < 16; ++r) load_row_nt(pfr[r], 8u * tid, x0 + 512 * NW * r);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -552,13 +548,13 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
         // is drawn with a chunk's FIRST segment and published before barrier 2 of that segment, so at the chunk's last
         // segment it is known here - the launcher never makes one-segment chunks except the very last one of a stream,
         // behind which no ticket can name another chunk.
-        long long ns = s + 1;
+        int ns = s + 1;
         bool more = true;
         if (ns >= se) {
             if (sched == 0 || (sched == 2 && first_of_chunk)) {
                 more = false;
             } else {
-                cur = (sched == 1) ? cur + W : (long long)W + __builtin_amdgcn_readfirstlane(lnext[par]);
+                cur = (sched == 1) ? cur + W : W + __builtin_amdgcn_readfirstlane(lnext[par]);
                 par ^= 1;
                 more = cur < nchunks;
                 if (more) {
@@ -570,7 +566,7 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
         // uniform row base (scalar registers) + one lane offset: no per-load address registers.  Behind the last
         // segment the same loads run once more on the segment just done: an unconditional definition keeps the sixteen
         // registers free between pass 1 and the first group of loads (a conditional one keeps their OLD values alive).
-        const char *xn = reinterpret_cast<const char *>(xb + (more ? ns : s) * step);
+        const char *xn = reinterpret_cast<const char *>(xb + (long long)(more ? ns : s) * step);
         const unsigned voff = 8u * tid;
         auto spread = [&](auto gc) {
             // place grp of the step (0: after the exchange-A writes, 1: after the tail's butterflies, 2: after its
@@ -638,7 +634,7 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
 // Welch average: sum of |X|^2 per bin; partial rows in finalize layout 4
 struct X1WelchEpi {
     float acc[16];
-    __device__ __forceinline__ void take(const float2 (&v)[16], long long) {      // (the priming call adds zeros)
+    __device__ __forceinline__ void take(const float2 (&v)[16], int) {      // (the priming call adds zeros)
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             const float2 X = v[r16(k2)];
@@ -656,7 +652,7 @@ __global__ __launch_bounds__(64 * NW, 4) void welch16k1x_pipe_kernel(WelchArgs p
     X1WelchEpi epi;
 #pragma unroll
     for (int k = 0; k < 16; ++k) epi.acc[k] = 0.f;
-    const X1Sched sc{p.nseg, p.nbig, p.chunk, p.tail_chunk, p.sched, p.queue ? p.queue + stream : nullptr};
+    const X1Sched sc{(int)p.nseg, (int)p.nbig, p.chunk, p.tail_chunk, p.sched, p.queue ? p.queue + stream : nullptr};
     unsigned long long *diag = nullptr;
 #if OTH_X1_DIAG
     diag = reinterpret_cast<unsigned long long *>(p.partial + (size_t)p.nstreams * W * N) + 128 * ((size_t)stream * W + wg);
@@ -677,7 +673,7 @@ struct X1ChainEpi {
     int kb;              // bin of register k2: kb + kstride k2
     int kstride, n;      // 256 / 128 (N / 64); N
     size_t row_base;     // stream offset into p->rows, in rows
-    __device__ __forceinline__ void take(const float2 (&v)[16], long long s) {
+    __device__ __forceinline__ void take(const float2 (&v)[16], int s) {
         if (s < 0) return;      // the priming call
         const SegArgs &a = *p;
         float val[16];
@@ -732,7 +728,7 @@ __global__ __launch_bounds__(64 * NW, 4) void chain16k1x_kernel(SegArgs p) {
     epi.kstride = N / 64;
     epi.n = N;
     epi.row_base = (size_t)stream * (size_t)(p.nseg - p.store_from);
-    const X1Sched sc{p.nseg, p.nbig, p.chunk, p.tail_chunk, p.sched, p.queue ? p.queue + stream : nullptr};
+    const X1Sched sc{(int)p.nseg, (int)p.nbig, p.chunk, p.tail_chunk, p.sched, p.queue ? p.queue + stream : nullptr};
     x1_pipe_body<NW, WINDOW>(p.x + (size_t)stream * p.stream_stride + p.first, p.step, sc, wg, W, p.win, p.tw, lds, epi, nullptr);
     if (p.partial) {
         float *dst = p.partial + ((size_t)stream * W + wg) * N + tid;
@@ -742,6 +738,7 @@ __global__ __launch_bounds__(64 * NW, 4) void chain16k1x_kernel(SegArgs p) {
 }
 
 template <int NW, bool WINDOW> static hipError_t launch1x_pipe(const WelchArgs &a, hipStream_t s) {
+    if (a.nseg > 0x7fffffffLL) return hipErrorInvalidValue;      // x1_pipe_body counts segments in 32 bits
     const dim3 grid(a.wg_per_stream, a.nstreams);
     constexpr size_t lds = x1p_lds_bytes<NW>();
     const void *fn = reinterpret_cast<const void *>(welch16k1x_pipe_kernel<NW, WINDOW>);
@@ -999,6 +996,7 @@ template <bool WINDOW> static hipError_t launch1x(const WelchArgs &a, hipStream_
 }
 
 template <int NW, bool WINDOW> static hipError_t launch_chain1x(const SegArgs &a, hipStream_t s) {
+    if (a.nseg > 0x7fffffffLL) return hipErrorInvalidValue;      // x1_pipe_body counts segments in 32 bits
     const dim3 grid(a.wg_per_stream, a.nstreams);
     constexpr size_t lds = x1p_lds_bytes<NW>();
     const void *fn = reinterpret_cast<const void *>(chain16k1x_kernel<NW, WINDOW>);

@@ -93,9 +93,19 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
     const float2 *xb = p.x + (size_t)stream * p.stream_stride;
 
     // thread-constant tables
+#if OTH_W4096_PIPE
+    // window rows 0..7 live in registers; rows 8..15 come from L2 with every segment (pinned loads, see load_win):
+    // with the kept half and the prefetch next to the data the sixteen values did not fit into 128 VGPRs (round 4's
+    // build spilled 6-12 registers inside the segment loop)
+    float win[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) win[a] = p.win[256 * a + t];
+    const char *const win_hi = reinterpret_cast<const char *>(p.win + 2048);
+#else
     float win[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) win[a] = p.win[256 * a + t];
+#endif
 #if OTH_W4096_PIPE
     const float2 b1 = p.tw[t], b4 = p.tw[4 * t];      // W4096^t, W4096^(4t)
     float2 keep[8], nxt[8];
@@ -155,6 +165,9 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
             v[8 + a] = PILOT ? csub(nxt[a], pv) : nxt[a];
             keep[a] = v[8 + a];
         }
+        float wu[8];        // window rows 8..15: issued in front of the prefetch, awaited where they are used
+#pragma unroll
+        for (int a = 0; a < 8; ++a) load_win(wu[a], 4u * t, win_hi + 1024 * a);
         if (s + 1 < se) {   // the half the NEXT segment adds; lands while this segment is transformed
             const float2 *xn = xb + (s + 2) * 2048 + t;
 #pragma unroll
@@ -214,8 +227,23 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
             mean = make_float2((s01.x + s23.x) * (1.0f / (256.0f * NA)), (s01.y + s23.y) * (1.0f / (256.0f * NA)));
 #endif
         }
+#if OTH_W4096_PIPE
+        // the eight window loads are the oldest vector-memory operations in flight: at most the eight prefetch loads
+        // (and the ticket draw) are younger, so vmcnt(8) has them home without draining the prefetch
+        if (s + 1 < se)
+            asm volatile("s_waitcnt vmcnt(8)"
+                         : "+v"(wu[0]), "+v"(wu[1]), "+v"(wu[2]), "+v"(wu[3]), "+v"(wu[4]), "+v"(wu[5]), "+v"(wu[6]), "+v"(wu[7]));
+        else
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(wu[0]), "+v"(wu[1]), "+v"(wu[2]), "+v"(wu[3]), "+v"(wu[4]), "+v"(wu[5]), "+v"(wu[6]), "+v"(wu[7]));
+#pragma unroll
+        for (int a = 0; a < 8; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) v[8 + a] = make_float2((v[8 + a].x - mean.x) * wu[a], (v[8 + a].y - mean.y) * wu[a]);
+#else
 #pragma unroll
         for (int a = 0; a < NA; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
+#endif
 
         // pass 1: DFT over a, twiddle W4096^(k0 t), scatter to region k0
         dft16(v);
