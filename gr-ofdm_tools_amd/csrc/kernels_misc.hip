@@ -212,7 +212,20 @@ __global__ __launch_bounds__(256) void finalize_l4_kernel(FinalizeArgs a) {
     const int t = threadIdx.x, k2 = blockIdx.x, stream = blockIdx.y;
     const float *base = a.partial + (size_t)stream * a.W * a.nfft + 1024 * k2 + 4 * t;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int w = 0; w < a.W; ++w) {
+    int w = 0;
+    for (; w + 4 <= a.W; w += 4) {      // four rows in flight (config 5 has exactly four per stream); same order of addition
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4 *>(base + (size_t)(w + i) * a.nfft);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s0 += v[i].x;
+            s1 += v[i].y;
+            s2 += v[i].z;
+            s3 += v[i].w;
+        }
+    }
+    for (; w < a.W; ++w) {
         const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)w * a.nfft);
         s0 += v.x;
         s1 += v.y;
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(256) void bin_threshold_ma_kernel(const float *psd,
 
 // ---- decision stage of the batched scanner, many rows (oth_scan_decide_dev*) ------------------------------------------
 // movingaverage (ofdm_cr_tools.py:168-170) as a SLIDING sum: a thread forms the M-tap sum of its first output directly
-// and moves on by + x[in] - x[out] for the other 15; 12 adds per output instead of M = 163 at config 5's search
+// and moves on by + x[in] - x[out] for the others of its run; a dozen adds per output instead of M = 163 at config 5's search
 // bandwidth.  A double sum of M float32 values is EXACT - and the sliding sum then IS the direct one - while the taps of
 // a window span less than 2^(28 - log2 M) in magnitude (62 dB of power at M = 163).  Beyond that every add / subtract
 // of a large tap rounds at 2^-53 of it, and what a strong carrier leaves behind when it slides out of the window stays in
@@ -635,9 +648,12 @@ __global__ __launch_bounds__(256) void bin_threshold_ma_kernel(const float *psd,
 // the per-thread runs, 16 apart, fall into different banks): the taps then cost LDS reads, not dependent global loads
 // (35 us -> 5 us for 64 rows of 16384 at M = 163).
 #ifndef OTH_MA_RUN
-#define OTH_MA_RUN 16
+#define OTH_MA_RUN 8       // outputs per thread: 8.9 us for config 5's 64 rows of 16384 against 11.2 at 16 and 15.4 at 32 (tile 4096;
+#endif                   // tiles of 1024 / 2048 at 4-16 per thread: 7.8-10.3 us - the kernel is a latency chain, tools/decide_probe.py)
+#ifndef OTH_MA_TILE
+#define OTH_MA_TILE 4096
 #endif
-constexpr int kMaTile = 4096, kMaRun = OTH_MA_RUN, kMaMaxM = 1024, kMaThreads = kMaTile / kMaRun;
+constexpr int kMaTile = OTH_MA_TILE, kMaRun = OTH_MA_RUN, kMaMaxM = 1024, kMaThreads = kMaTile / kMaRun;
 __device__ __forceinline__ int ma_pad(int k) { return k + k / kMaRun; }      // one pad word per run: a thread stride of kMaRun + 1 words
 __global__ __launch_bounds__(kMaThreads) void movavg_run_kernel(const float *psd, int nfft, double srch_bins, double *movavg,
                                                          float *tile_min) {
@@ -645,6 +661,14 @@ __global__ __launch_bounds__(kMaThreads) void movavg_run_kernel(const float *psd
     __shared__ double ys[kMaTile + kMaTile / kMaRun];      // the outputs, written back coalesced (a thread's own run of 16
                                                        // doubles is 64 different cache lines per store instruction)
     __shared__ float red[kMaThreads / 64];
+    // sums / largest magnitudes of the staged inputs in blocks of kMaRun (round 5): a thread's run starts on a block
+    // boundary, so its first M-tap sum is M / kMaRun block sums + M % kMaRun taps - 23 LDS reads at M = 163 where the
+    // tap-by-tap sum made 163 in 21 dependent trips (measured: no faster by itself - the kernel's 9-11 us are launch,
+    // staging and write-back latency, see OTH_MA_RUN).  A double sum of float32 taps is exact over the same range as before, so the order in
+    // which it is formed does not show.
+    constexpr int kMaBlocks = (kMaTile + kMaMaxM) / kMaRun + 1;
+    __shared__ double bsum[kMaBlocks];
+    __shared__ float bmax[kMaBlocks];
     const float *x = psd + (size_t)blockIdx.y * nfft;
     double *out = movavg + (size_t)blockIdx.y * nfft;
     const int M = (int)srch_bins, half = (M - 1) / 2;
@@ -663,11 +687,25 @@ __global__ __launch_bounds__(kMaThreads) void movavg_run_kernel(const float *psd
             if (k0 + kMaThreads * u < count) xs[ma_pad(k0 + kMaThreads * u)] = a[u];
     }
     __syncthreads();
+    for (int b = threadIdx.x; b * kMaRun < count; b += kMaThreads) {      // taps behind `count` were never staged: skip them
+        float a[kMaRun];
+#pragma unroll
+        for (int u = 0; u < kMaRun; ++u) a[u] = (b * kMaRun + u < count) ? xs[ma_pad(b * kMaRun + u)] : 0.f;
+        double d = 0.0;
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < kMaRun; u += 4) {
+            d += ((double)a[u] + a[u + 1]) + ((double)a[u + 2] + a[u + 3]);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(a[u]), fabsf(a[u + 1]))), fmaxf(fabsf(a[u + 2]), fabsf(a[u + 3])));
+        }
+        bsum[b] = d;
+        bmax[b] = m;
+    }
+    __syncthreads();
     const int t0 = threadIdx.x * kMaRun, i0 = base + t0;              // output i0 + r takes xs[t0 + r .. t0 + r + M - 1]
     float mn = 3.4e38f;
     if (i0 < nfft) {
         double s = 0.0;
-        int j = 0;
         float big = 0.f;                  // largest |tap| this run has added so far
         auto direct = [&](int first) {    // M-tap sum of xs[first ..]: eight independent LDS reads per trip (one read per
             double d = 0.0;               // trip waited ~100 cycles each)
@@ -687,25 +725,43 @@ __global__ __launch_bounds__(kMaThreads) void movavg_run_kernel(const float *psd
             }
             return d;
         };
-        s = direct(t0);
-        (void)j;
+        {   // the run's first output from the block sums (the lambda above serves the rare re-start in mid-run)
+            const int nb = M / kMaRun;
+            for (int b = 0; b < nb; ++b) {
+                s += bsum[threadIdx.x + b];
+                big = fmaxf(big, bmax[threadIdx.x + b]);
+            }
+            for (int jj = nb * kMaRun; jj < M; ++jj) {
+                const float a = xs[ma_pad(t0 + jj)];
+                big = fmaxf(big, fabsf(a));
+                s += (double)a;
+            }
+        }
         double v = fabs(s * inv);
         ys[ma_pad(t0)] = v;
         mn = (float)v;
-#pragma unroll 4
-        for (int r = 1; r < kMaRun && i0 + r < nfft; ++r) {
-            const float in = xs[ma_pad(t0 + r + M - 1)];
+        // the taps that enter and leave over the run, read in one batch: inside the loop each pair of LDS reads was waited
+        // for on its own (the re-start branch keeps the compiler from moving them up), ~500 cycles per output
+        float tin[kMaRun], tout[kMaRun];
+#pragma unroll
+        for (int r = 1; r < kMaRun; ++r) {
+            tin[r] = xs[ma_pad(t0 + r + M - 1)];
+            tout[r] = xs[ma_pad(t0 + r - 1)];
+        }
+#pragma unroll
+        for (int r = 1; r < kMaRun; ++r) {
+            const float in = tin[r];
             big = fmaxf(big, fabsf(in));
             s += (double)in;
-            s -= (double)xs[ma_pad(t0 + r - 1)];
+            s -= (double)tout[r];
             if (fabs(s) < (double)big * (1.0 / 16777216.0)) {      // a carrier > 2^24 x the window's content has just left
                 big = 0.f;
                 s = direct(t0 + r);
             }
             v = fabs(s * inv);
             ys[ma_pad(t0 + r)] = v;
-            mn = fminf(mn, (float)v);
-        }
+            if (i0 + r < nfft) mn = fminf(mn, (float)v);          // (nfft is a multiple of the run in practice; ys[] behind
+        }                                                          // the row's end is never copied out)
     }
     __syncthreads();
     for (int k = threadIdx.x; k < kMaTile && base + k < nfft; k += kMaThreads) out[base + k] = ys[ma_pad(k)];
