@@ -38,13 +38,16 @@ class logger(object):
     def start_file_logger(self):
         if self._fl_thread is not None:
             return
+        self._prepare_file_logger()
+        self._fl_stop.clear()
+        self._fl_thread = threading.Thread(target=self._file_logger_run, daemon=True)
+        self._fl_thread.start()
+
+    def _prepare_file_logger(self):
         if self.directory is None:       # ~/sensing-<yymmdd>-<HHMM>/ (ofdm_cr_tools.py:1855-1859)
             self.directory = os.path.join(os.path.expanduser('~'), 'sensing-%s-%s' % (self.start_dat,
                                                                                          time.strftime('%H%M')))
         self.stop_time = datetime.datetime.now() + datetime.timedelta(seconds=self.test_duration)
-        self._fl_stop.clear()
-        self._fl_thread = threading.Thread(target=self._file_logger_run, daemon=True)
-        self._fl_thread.start()
 
     def _file_logger_run(self):
         while True:                      # file_logger.run (:2010-2071)

@@ -237,6 +237,7 @@ def reference_fixtures():
     reference_legacy_sensor_fixture(E, T, scan)
     reference_flank_fixture(E, T)
     reference_fft_plot_fixture(E)
+    reference_logger_fixture(E)
 
 
 def reference_thread_fixtures(E, T, S):
@@ -567,6 +568,146 @@ def reference_fft_plot_fixture(E):
         out[tag + '_td_power'] = np.array(F['td_power_estimate'](v, Sf))
     save('ref_fft_plot.npz', source=np.array('reference'), input_from=np.array('welch_flattop_2048.npz'), Sf=Sf, fc=fc,
          nfft=nfft, **out)
+
+
+LOGGER_SESSION = dict(
+    # one scripted campaign of the stats / psd / waterfall watchers against the sensing log (f2): values the watchers
+    # hand over before the first write, during the first sleep and during the second; the clock is frozen and ticks
+    # one stamp per strftime pair; the test duration ends during the second sleep
+    fft_len=8, periodicity=5, test_duration=7,
+    stamps=[('240131', '235958', '2359'), ('240131', '235959'), ('240201', '000004')],
+    settings={'date': '24-01-31', 'time': '23:59:58', 'fft_len': 8, 'sample_rate': 1000000},
+    phases=[
+        dict(cumulative_psd=[1e-9, 2e-9, 3e-9, 4e-9, 5e-7, 6e-9, 7e-9, 8e-9],
+             periodic_psd_peaks=[1e-9, 2e-9, 3e-9, 4e-9, 5e-7, 6e-9, 7e-9, 8e-9],
+             cumulative_statistics={100000000.0: 2, 100025000.0: 0}, periodic_statistic={100000000.0: 2},
+             cumulative_max_power=[1.5e-6, 2.5e-8], periodic_max_power=[1.5e-6, 2.5e-8], n_measurements_period=2,
+             cumulative_waterfall=[[1.234e-5, 6.5e-7, 1e-12], [2.0, 3.0, 4.0]]),
+        dict(cumulative_psd=[1e-9, 2e-9, 3e-9, 4e-9, 5e-7, 6e-9, 7e-8, 8e-9],
+             periodic_psd_peaks=[5e-10, 2e-10, 3e-10, 4e-10, 5e-10, 6e-10, 7e-8, 8e-10],
+             cumulative_statistics={100000000.0: 3, 100025000.0: 1}, periodic_statistic={100000000.0: 1, 100025000.0: 1},
+             cumulative_max_power=[1.5e-6, 7.5e-8], n_measurements_period=1,
+             cumulative_waterfall=[[9.87e-3, 0.0, 5.55e-5]]),
+        dict(cumulative_statistics={100000000.0: 4, 100025000.0: 1}, periodic_statistic={100000000.0: 1},
+             periodic_max_power=[2.5e-7, 1.0e-9], cumulative_waterfall=[]),
+    ])
+
+
+def logger_session_apply(lg, phase):
+    """The watchers' hand-over of one phase through the logger's setters (ofdm_cr_tools.py:1914-1956)."""
+    for key, val in phase.items():
+        if key in ('cumulative_psd', 'periodic_psd_peaks', 'cumulative_max_power', 'periodic_max_power'):
+            val = np.array(val, np.float32 if 'psd' in key else np.float64)
+        elif key == 'cumulative_waterfall':
+            val = [np.array(r, np.float32) for r in val]
+        getattr(lg, 'set_' + key)(val)
+
+
+def reference_logger_fixture(E):
+    """ref_sensing_log.npz (f2): the reference's OWN ``logger`` (ofdm_cr_tools.py:1850-1956) and ``file_logger``
+    (:1958-2107) - constructor, setters, reset and the thread body ``run`` - executed on LOGGER_SESSION with a frozen
+    clock, a scratch home directory and a thread base class that does not start; every file they leave behind goes into
+    the fixture, name and bytes.  Environment of their day (ref_extract's docstring): ``open(path, 'w')`` gave a file
+    that takes the byte strings ``np.save`` writes (Python-2 ``str``); here it is opened in binary mode and encodes text."""
+    import io
+    import shutil
+    import tempfile
+    from contextlib import redirect_stdout
+    S = LOGGER_SESSION
+    home = tempfile.mkdtemp(prefix='ref_logger_')
+    stamps = [list(t) for t in S['stamps']]
+
+    class Clock(object):               # time.strftime / time.sleep of the session
+        def __init__(self):
+            self.k, self.slept = 0, []
+
+        def strftime(self, fmt):
+            dat, tim = stamps[self.k][0], stamps[self.k][1]
+            if fmt == '%y%m%d':
+                return dat
+            if fmt == '%H%M':          # the directory name, constructor only
+                return stamps[0][2]
+            assert fmt == '%H%M%S', fmt
+            self.k += 1                # a pair (date, time) is one stamp; the time is asked for last
+            return tim
+
+        def sleep(self, seconds):
+            self.slept.append(seconds)
+            logger_session_apply(lg, S['phases'][len(self.slept)])
+
+    clock = Clock()
+    t0 = 1000.0
+
+    class FakeDatetimeModule(object):  # datetime.datetime.now() + datetime.timedelta(seconds=..) on a counter
+        class datetime(object):
+            @staticmethod
+            def now():
+                return t0 + S['periodicity'] * len(clock.slept)
+
+        @staticmethod
+        def timedelta(seconds):
+            return seconds
+
+    opened = []
+
+    class File2(object):               # the file object of its day: takes text and byte strings alike
+        def __init__(self, path, mode='r'):
+            self.fh = open(path, mode + 'b')
+            opened.append(self.fh)
+
+        def write(self, data):
+            return self.fh.write(data.encode('latin-1') if isinstance(data, str) else data)
+
+        def __getattr__(self, name):
+            return getattr(self.fh, name)
+
+        def __repr__(self):
+            return '<open file>'
+
+    class Thread(object):              # _threading.Thread that is never started: run() is called below
+        def __init__(self):
+            pass
+
+        def setDaemon(self, flag):
+            pass
+
+        def start(self):
+            pass
+
+    ns = {'time': clock, 'datetime': FakeDatetimeModule, 'open': File2, 'os': os, 'np': np,
+          'expanduser': lambda tilde: home, '_threading': type('M', (), {'Thread': Thread})}
+    fl_methods = {n: E.load_method('ofdm_cr_tools.py', 'file_logger', n, ns, py2_print=True) for n in ('__init__', 'run')}
+    ns['file_logger'] = type('Ref_file_logger', (Thread,), fl_methods)
+    names = ['__init__', 'reset_periodic_vars'] + ['set_' + k for k in (
+        'cumulative_psd', 'periodic_psd_peaks', 'settings', 'n_measurements_period', 'cumulative_statistics',
+        'periodic_statistic', 'cumulative_max_power', 'periodic_max_power', 'cumulative_waterfall')]
+    RefLogger = type('Ref_logger', (object,),
+                     {n: E.load_method('ofdm_cr_tools.py', 'logger', n, ns, py2_print=True) for n in names})
+    said = io.StringIO()
+    with redirect_stdout(said):
+        lg = RefLogger(S['fft_len'], S['periodicity'], S['test_duration'])
+        lg.set_settings(S['settings'])
+        logger_session_apply(lg, S['phases'][0])
+        lg._file_logger.run()
+    assert clock.slept == [S['periodicity']] * 2 and 'test expired' in said.getvalue()
+    # The reference never closes a file: it re-binds ``self.psd_file = open(path, 'w')`` and lets CPython's reference
+    # count close (and only then flush) the object it replaces, i.e. AFTER the new ``open`` has truncated the file; the
+    # last objects are flushed when the interpreter exits.  File2 objects die the same way here; what is still open now
+    # is closed in the order it was opened.  (Consequence, not exercised by this session and not part of the format: a
+    # rewritten file that got SHORTER keeps the tail of its previous content.)
+    for fh in opened:
+        fh.close()
+    files = {}
+    for root, _, fns in os.walk(home):
+        for fn in fns:
+            with open(os.path.join(root, fn), 'rb') as fh:
+                files[os.path.relpath(os.path.join(root, fn), home)] = np.frombuffer(fh.read(), np.uint8)
+    shutil.rmtree(home)
+    order = sorted(files)
+    save('ref_sensing_log.npz', source=np.array('reference'), names=np.array(order), session=np.array(repr(S)),
+         said=np.array(said.getvalue().replace(home, '~')),
+         **{'file_%d' % i: files[n] for i, n in enumerate(order)})
+    print('  ' + '\n  '.join('%s (%d B)' % (n, len(files[n])) for n in order))
 
 
 def consumer_fixture():

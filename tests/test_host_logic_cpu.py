@@ -622,6 +622,76 @@ def test_sensing_log_file_formats(tmp_path):
     assert np.load(out2['periodic_psd'], allow_pickle=True).item() is None
 
 
+def test_ref_f2_sensing_log_session_against_the_reference_logger(golden, tmp_path, monkeypatch):
+    """f2 against the reference's OWN ``logger`` + ``file_logger`` (ofdm_cr_tools.py:1850-2107; ref_sensing_log.npz holds
+    every file they left behind for one scripted campaign on a frozen clock): the product logger, driven through the
+    same setters at the same moments, must leave the same directory - names, statistics text and waterfall rows byte
+    for byte, the np.save files value for value (dtype and shape included; ``None`` where a period saw no update)."""
+    import ast
+    import io
+    from ofdm_tools import sensing_log
+    g = golden('ref_sensing_log.npz')
+    S = ast.literal_eval(str(g['session']))
+    stamps, slept = S['stamps'], []
+
+    class Clock(object):
+        k = 0
+
+        def strftime(self, fmt):
+            if fmt == '%y%m%d':
+                return stamps[self.k][0]
+            if fmt == '%H%M':
+                return stamps[0][2]
+            self.k += 1
+            return stamps[self.k - 1][1]
+
+    def apply(lg, phase):
+        for key, val in phase.items():
+            if key in ('cumulative_psd', 'periodic_psd_peaks', 'cumulative_max_power', 'periodic_max_power'):
+                val = np.array(val, np.float32 if 'psd' in key else np.float64)
+            elif key == 'cumulative_waterfall':
+                val = [np.array(r, np.float32) for r in val]
+            getattr(lg, 'set_' + key)(val)
+
+    class FakeDatetime(object):
+        class datetime(object):
+            @staticmethod
+            def now():
+                return 1000.0 + S['periodicity'] * len(slept)
+
+        @staticmethod
+        def timedelta(seconds):
+            return seconds
+
+    monkeypatch.setattr(sensing_log, 'time', Clock())
+    monkeypatch.setattr(sensing_log, 'datetime', FakeDatetime)
+    monkeypatch.setenv('HOME', str(tmp_path))
+    lg = sensing_log.logger(S['fft_len'], S['periodicity'], S['test_duration'])
+    lg.set_settings(S['settings'])
+    apply(lg, S['phases'][0])
+
+    def wait(seconds):                      # the file_logger thread's sleep: the watchers hand over the next phase
+        slept.append(seconds)
+        apply(lg, S['phases'][len(slept)])
+        return False
+
+    lg._fl_stop.wait = wait
+    lg._prepare_file_logger()
+    lg._file_logger_run()
+    assert slept == [S['periodicity']] * 2 and lg.files_written == 3
+    got = sorted(os.path.relpath(os.path.join(r, f), str(tmp_path)) for r, _, fs in os.walk(str(tmp_path)) for f in fs)
+    assert got == list(g['names'])
+    for i, name in enumerate(g['names']):
+        want = bytes(g['file_%d' % i])
+        have = open(os.path.join(str(tmp_path), name), 'rb').read()
+        if name.endswith('.log') or 'waterfall' in name:
+            assert have == want, name
+        else:
+            a, b = np.load(io.BytesIO(have), allow_pickle=True), np.load(io.BytesIO(want), allow_pickle=True)
+            assert a.dtype == b.dtype and a.shape == b.shape, name
+            assert (a.item() is None and b.item() is None) if a.dtype == object else np.array_equal(a, b), name
+
+
 # ---- multi-rank long-stream Welch / coherence and the batched scanner over gloo (SURVEY.md 8e rows 2-4) ----
 
 GLOO_LONG_STREAM = r'''
