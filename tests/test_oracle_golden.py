@@ -203,14 +203,14 @@ def test_reference_fixtures_are_tagged(golden):
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'ref_*.npz')))
     assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_fft_plot.npz', 'ref_flank.npz',
                      'ref_legacy_sensor.npz',
-                     'ref_scanner_seq.npz',
+                     'ref_scanner_seq.npz', 'ref_sensing_log.npz',
                      'ref_src_power_cases.npz',
                      'ref_src_power_fft.npz', 'ref_src_power_welch_2048.npz', 'ref_sweeper_src_power.npz',
                      'ref_threads.npz', 'ref_welch_hann_4096.npz', 'ref_xcorr_fac.npz']
     for n in names:
         g = golden(n)
         assert str(g['source']) == 'reference'
-        if n not in ('ref_ascii_plot.npz', 'ref_flank.npz'):      # (carry their own input rows)
+        if n not in ('ref_ascii_plot.npz', 'ref_flank.npz', 'ref_sensing_log.npz'):      # (carry their own inputs)
             assert os.path.exists(os.path.join(os.path.dirname(__file__), 'golden', str(g['input_from'])))
 
 
