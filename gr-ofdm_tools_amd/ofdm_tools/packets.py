@@ -84,9 +84,11 @@ class FragmentReassembler(object):
     (sdr_webserver/sdr_webserver_ws.py:235-287, ``header=10``: it strips the ZMQ/PMT header first):
       * a frame with n_frags == 1 is decoded on its own and does not touch the pending payload;
       * otherwise payloads are appended in ARRIVAL order (frag_id only marks the end, :140-141), so a lost middle
-        fragment shortens the vector and a lost final fragment glues two vectors together - the consumers have
-        that weakness and a drop-in keeps the format, so ``strict=True`` is offered for hosts that would rather drop
-        such a vector (frag_ids must run 0 .. n-1) than plot it;
+        fragment shortens the payload (at the usual max_tu of 1470 + 2, not a multiple of four, float32 then ends in
+        the error branch below) and a lost final fragment glues two vectors together - the consumers have that
+        weakness (tests/golden/ref_consumers.npz holds what the reference's own two consumers made of such a stream)
+        and a drop-in keeps the format, so ``strict=True`` is offered for hosts that would rather drop such a vector
+        (frag_ids must run 0 .. n-1) than plot it;
       * a payload whose length is not a multiple of the item size is discarded (np.fromstring raises there and the
         consumers print an error, :132-133,161-162); the web consumer then clears the pending payload (:279), the Qt
         one keeps it - ``clear_on_error`` says which;

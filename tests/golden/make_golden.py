@@ -238,6 +238,7 @@ def reference_fixtures():
     reference_flank_fixture(E, T)
     reference_fft_plot_fixture(E)
     reference_logger_fixture(E)
+    reference_consumer_fixture(E)
 
 
 def reference_thread_fixtures(E, T, S):
@@ -708,6 +709,93 @@ def reference_logger_fixture(E):
          said=np.array(said.getvalue().replace(home, '~')),
          **{'file_%d' % i: files[n] for i, n in enumerate(order)})
     print('  ' + '\n  '.join('%s (%d B)' % (n, len(files[n])) for n in order))
+
+
+def reference_consumer_fixture(E):
+    """ref_consumers.npz (f1, receiving side): the reference's OWN consumers of the fragment format -
+    ``data_processor.run`` of the web server (sdr_webserver/sdr_webserver_ws.py:235-287; strips the 10-byte ZMQ / PMT
+    header, forwards the reassembled payload) and ``remote_client_qt.handler`` (python/remote_client_qt.py:100-164; decodes,
+    peak hold, two curves) - fed frame by frame from a stand-in socket / as stand-in PDUs: complete vectors, a vector
+    that fits one fragment, a lost middle fragment, a lost LAST fragment (two vectors glued), a payload of ragged
+    length (the error branch: the web consumer drops what is pending, the Qt one keeps it).  Stored: every frame, and
+    per consumer the index of each frame that completed something with what came out."""
+    import io
+    import struct
+    from contextlib import redirect_stdout
+    from types import SimpleNamespace as NS
+    hdr = lambda fr: R.zmq_pdu_header(len(fr)) + fr      # noqa: E731
+    rows = [(np.arange(2048, dtype=np.float32) * 0.02 - 95 + 3 * k + np.sin(np.arange(2048) * (k + 1))).astype('<f4')
+            for k in range(5)]
+    small = (np.arange(256, dtype=np.float32) - 120).astype('<f4')
+    f32 = [R.worker_fragments(r, 1470, 2048, True) for r in rows]            # six fragments per vector
+    i8 = [R.worker_fragments(r, 1470, 2048, False) for r in rows]            # two
+    one = R.worker_fragments(small, 1470, 256, True)                          # one
+    sw = [R.sweeper_fragments(r.tobytes(), 1470) for r in rows[:2]]
+    lossy = (f32[0] + f32[1][:2] + f32[1][3:]            # middle fragment lost: a shorter vector
+             + f32[2][:-1] + f32[3]                       # last fragment lost: glued to the next vector
+             + f32[4][:-1] + [f32[4][-1][:-3]]            # ragged last payload: the error branch
+             + one + f32[0])                              # what the next vectors look like after it
+    streams = {'f32': sum(f32[:3], []) + one, 'i8': sum(i8, []), 'sweeper': sum(sw, []), 'lossy': lossy}
+    npd = E.NumpyOfItsDay()
+    npd.fromstring = lambda s, dt: np.frombuffer(s.encode('latin-1') if isinstance(s, str) else bytes(s), dt)
+    out = {}
+
+    # ---- the web server's thread body
+    run = E.load_method('../sdr_webserver/sdr_webserver_ws.py', 'data_processor', 'run',
+                        {'np': npd, 'struct': struct, 'sys': sys, 'getThreadId': lambda: 0}, py2_print=True,
+                        fixers=('print', 'except'))
+    for tag, dt in (('f32', np.float32), ('sweeper', np.float32), ('lossy', np.float32)):
+        frames, got, said = [hdr(fr) for fr in streams[tag]], [], []
+        me = NS(logger=NS(info=said.append), device='stand-in', keep_running=True, reasembled_frame='', data_type=dt,
+                max_fft_data=np.array([]), strt=True, k=-1)
+
+        def recv():
+            me.k += 1
+            me.keep_running = me.k + 1 < len(frames)
+            return E.Str2(frames[me.k])
+        me.zmq_sub = NS(recv=recv)
+        me.shared_queue_data = NS(put=lambda v: got.append((me.k, bytes(v))))
+        run(me)
+        out['web_%s_at' % tag] = np.array([k for k, _ in got])
+        for j, (_, b) in enumerate(got):
+            out['web_%s_out_%d' % (tag, j)] = np.frombuffer(b, np.uint8)
+        out['web_%s_errors' % tag] = np.array(sum('error' in line for line in said))
+
+    # ---- the Qt client's message handler
+    pmt = NS(cdr=lambda m: m[1], car=lambda m: m[0], u8vector_elements=lambda v: list(v), to_python=lambda v: v)
+    struct2 = NS(unpack=lambda fmt, s: struct.unpack(fmt, s.encode('latin-1') if isinstance(s, str) else s))
+    handler = E.load_method('remote_client_qt.py', 'remote_client_qt', 'handler',
+                            {'np': npd, 'struct': struct2, 'pmt': pmt, 'QtCore': NS(SIGNAL=lambda s: s)}, py2_print=True)
+    for tag, dt in (('f32', np.float32), ('i8', np.int8), ('lossy', np.float32)):
+        got, said = [], io.StringIO()
+        me = NS(data_type=dt, max_fft_data=np.array([]), strt=True, reasembled_frame='', hold_max=True,
+                sample_rate=2.0e6, tune_freq=100.0e6, curve_data=[([], []), ([], [])], k=-1)
+
+        def emit(signal, arg):
+            # :127-129 / :154-156 - a one-fragment vector puts the data on curve 0 and the peak on 1, a reassembled
+            # one the other way round
+            a, b = me.curve_data[0][1], me.curve_data[1][1]
+            got.append((me.k, np.array(me.max_fft_data), np.array(a), np.array(b), np.array(me.curve_data[0][0])))
+        me.emit = emit
+        with redirect_stdout(said):
+            for k, fr in enumerate(streams[tag]):
+                me.k = k
+                handler(me, (None, bytearray(fr)))
+        out['qt_%s_at' % tag] = np.array([k for k, *_ in got])
+        for j, (_, peak, c0, c1, axis) in enumerate(got):
+            out['qt_%s_peak_%d' % (tag, j)] = peak
+            out['qt_%s_curve0_%d' % (tag, j)] = c0
+            out['qt_%s_curve1_%d' % (tag, j)] = c1
+        out['qt_%s_axis_mhz' % tag] = got[-1][4]
+        out['qt_%s_errors' % tag] = np.array(said.getvalue().count('error reassembling'))
+        out['qt_%s_pending' % tag] = np.array(len(me.reasembled_frame))
+    for tag, frames in streams.items():
+        out['frames_%s_len' % tag] = np.array([len(fr) for fr in frames])
+        out['frames_%s' % tag] = np.frombuffer(b''.join(frames), np.uint8)
+    save('ref_consumers.npz', source=np.array('reference'), **out)
+    for k in sorted(out):
+        if k.endswith('_at') or k.endswith('_errors') or k.endswith('_pending'):
+            print('  %s = %s' % (k, out[k]))
 
 
 def consumer_fixture():

@@ -28,6 +28,9 @@ receivers and ports, and against two more pieces of the environment of their day
     number, so the first ``np.maximum`` returned the data (``NumpyOfItsDay.maximum``);
   * ``ord(frame[i])`` over a byte string: indexing a Python-2 ``str`` gives a 1-character ``str``, indexing Python-3
     ``bytes`` gives the ``int`` already (``py2_ord``).
+The two consumers of the fragment format (round 5: ``remote_client_qt.handler``, ``data_processor.run`` of the web
+server) take a received frame as a Python-2 ``str``: ``Str2`` is that type (bytes whose elements are 1-byte strings);
+``np.fromstring(bytes, dtype)`` - removed from NumPy 2 - is ``np.frombuffer`` (same ValueError on a ragged length).
 """
 import ast
 import math
@@ -76,13 +79,14 @@ def py2_ord(c):
     return c if isinstance(c, int) else ord(c)
 
 
-def _fix_py2_print(text):
-    """The cut text with Python-2 print statements rewritten as calls - lib2to3's fix_print and nothing else."""
+def _fix_py2_print(text, fixers=('print',)):
+    """The cut text with Python-2 print statements rewritten as calls - lib2to3's fix_print and nothing else (round 5:
+    or the named fixers - ``except`` for ``except Exception, e:``, which does not parse under Python 3 either)."""
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         from lib2to3 import refactor
-        tool = refactor.RefactoringTool(['lib2to3.fixes.fix_print'])
+        tool = refactor.RefactoringTool(['lib2to3.fixes.fix_' + f for f in fixers])
         return str(tool.refactor_string(text if text.endswith('\n') else text + '\n', '<reference>'))
 
 
@@ -133,7 +137,7 @@ def load(module, names, namespace=None):
     return out
 
 
-def load_method(module, cls, name, namespace=None, py2_print=False):
+def load_method(module, cls, name, namespace=None, py2_print=False, fixers=('print',)):
     """A method of a reference class as a plain function taking ``self`` (the caller passes a stand-in object
     carrying the attributes the method reads): the ``def`` is cut by its indentation inside ``class cls``.
     py2_print: the method holds Python-2 print statements - see the module docstring."""
@@ -163,7 +167,7 @@ def load_method(module, cls, name, namespace=None, py2_print=False):
             break
     text = ''.join(ln[len(indent):] if ln.startswith(indent) else ln.lstrip() for ln in lines[start:end])
     if py2_print:
-        text = _fix_py2_print(text)
+        text = _fix_py2_print(text, fixers)
     tree = ast.parse(text)
     assert len(tree.body) == 1 and isinstance(tree.body[0], ast.FunctionDef) and tree.body[0].name == name
     ns = {'np': np, 'sg': sg, 'math': math, '__builtins__': __builtins__}
@@ -171,6 +175,21 @@ def load_method(module, cls, name, namespace=None, py2_print=False):
         ns.update(namespace)
     exec(compile('\n' * start + text, path, 'exec'), ns)
     return ns[name]
+
+
+class Str2(bytes):
+    """A Python-2 ``str``: a byte string whose elements are 1-byte strings (``s[0]`` goes to ``struct.unpack``) and
+    that concatenates with the empty text literal the consumers start from (``self.reasembled_frame = ''``)."""
+
+    def __getitem__(self, i):
+        return Str2(bytes.__getitem__(self, slice(i, i + 1 if i != -1 else None) if isinstance(i, int) else i))
+
+    def __add__(self, other):
+        return Str2(bytes.__add__(self, other))
+
+    def __radd__(self, other):
+        assert other == '' or isinstance(other, bytes), 'only the empty text literal starts a byte string'
+        return Str2(bytes(other or b'') + bytes(self))
 
 
 CR_TOOLS = ('frange', 'clc_power_freq', 'movingaverage', 'src_power', 'src_power_welch', 'welch_plot_dB',

@@ -91,6 +91,50 @@ def read_consumer_fixture():
     return streams
 
 
+def test_ref_f1_consumers_against_the_reference_handlers(golden):
+    """f1, receiving side, against the reference's OWN consumers (ref_consumers.npz: ``data_processor.run`` of
+    sdr_webserver_ws.py:235-287 and ``remote_client_qt.handler`` of remote_client_qt.py:100-164, run frame by frame):
+    the product reassembler must complete a vector at the same frames with the same bytes, hold the same peak, count
+    the same errors - also where fragments are lost.  What the lossy stream shows of the format: max_tu = 1470 is
+    not a multiple of four, so a lost middle fragment leaves a ragged payload (the error branch, not a shorter
+    vector); the web consumer then drops what is pending, the Qt client keeps it and glues the next vectors to it."""
+    from ofdm_tools import packets
+    g = golden('ref_consumers.npz')
+
+    def frames_of(tag):
+        raw, out, pos = bytes(g['frames_' + tag]), [], 0
+        for n in g['frames_%s_len' % tag]:
+            out.append(raw[pos:pos + int(n)])
+            pos += int(n)
+        return out
+    hdr = lambda fr: R.zmq_pdu_header(len(fr)) + fr      # noqa: E731
+    for tag in ('f32', 'sweeper', 'lossy'):               # the web server: header stripped, pending dropped on error
+        ra = packets.FragmentReassembler(True, header=10, clear_on_error=True)
+        got = [(k, v) for k, v in ((k, ra.push(hdr(fr))) for k, fr in enumerate(frames_of(tag))) if v is not None]
+        assert [k for k, _ in got] == list(g['web_%s_at' % tag]), tag
+        for j, (_, v) in enumerate(got):
+            assert v.tobytes() == bytes(g['web_%s_out_%d' % (tag, j)]), (tag, j)
+        assert ra.errors == int(g['web_%s_errors' % tag])
+    for tag, precision in (('f32', True), ('i8', False), ('lossy', True)):      # the Qt client: bare frames, pending kept
+        ra = packets.FragmentReassembler(precision, header=0, clear_on_error=False)
+        frames, j = frames_of(tag), 0
+        for k, fr in enumerate(frames):
+            v = ra.push(fr)
+            if v is None:
+                continue
+            assert k == int(g['qt_%s_at' % tag][j]), (tag, k)
+            data, peak = ('curve0', 'curve1') if fr[0] == 1 else ('curve1', 'curve0')      # :127-129 against :154-156
+            assert v.dtype == g['qt_%s_%s_%d' % (tag, data, j)].dtype
+            assert v.tobytes() == g['qt_%s_%s_%d' % (tag, data, j)].tobytes()      # (a glued vector holds NaN patterns)
+            assert np.array_equal(ra.max_data, g['qt_%s_%s_%d' % (tag, peak, j)], equal_nan=True)
+            assert np.array_equal(ra.max_data, g['qt_%s_peak_%d' % (tag, j)], equal_nan=True)
+            j += 1
+        assert j == len(g['qt_%s_at' % tag]) and ra.errors == int(g['qt_%s_errors' % tag])
+        assert len(ra.pending) == int(g['qt_%s_pending' % tag])
+    # the axis the client plots against (:125): sample_rate / 2 * linspace(-1, 1, n) + tune_freq, in MHz
+    assert np.allclose(g['qt_f32_axis_mhz'], (2.0e6 / 2 * np.linspace(-1, 1, 256) + 100.0e6) / 1e6, rtol=0, atol=1e-9)
+
+
 def test_fragment_consumers_int8_float_and_zmq_header():
     """remote_client_qt.py:100-164 / sdr_webserver_ws.py:235-287: the stream reassembler against the byte fixture
     (float32 frames behind the 10-byte ZMQ/PMT header, bare int8 frames, sweeper frames with their floor+1 count)."""

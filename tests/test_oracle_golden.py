@@ -152,6 +152,29 @@ def test_fragment_consumer_restatement_against_the_byte_fixture():
     assert R.zmq_pdu_header(1472) == bytes([7, 6, 10, 0, 0, 0, 5, 0xc0, 1, 0]) and len(R.zmq_pdu_header(5)) == 10
 
 
+def test_ref_fragment_consumer_restatement_against_the_reference_consumers(golden):
+    """oracle.consumer_handler against what the reference's own consumers did with the same frames (ref_consumers.npz):
+    vectors in completion order and the final peak, with the 10-byte header / cleared pending payload of the web server
+    and the bare frames / kept pending payload of the Qt client - lost fragments and the error branch included."""
+    g = golden('ref_consumers.npz')
+
+    def frames_of(tag):
+        raw, out, pos = bytes(g['frames_' + tag]), [], 0
+        for n in g['frames_%s_len' % tag]:
+            out.append(raw[pos:pos + int(n)])
+            pos += int(n)
+        return out
+    for tag in ('f32', 'sweeper', 'lossy'):
+        frames = [R.zmq_pdu_header(len(fr)) + fr for fr in frames_of(tag)]
+        got, _ = R.consumer_handler(frames, '<f4', 10, clear_on_error=True)
+        assert [v.tobytes() for v in got] == [bytes(g['web_%s_out_%d' % (tag, j)]) for j in range(len(g['web_%s_at' % tag]))]
+    for tag, dt in (('f32', '<f4'), ('i8', np.int8), ('lossy', '<f4')):
+        got, peak = R.consumer_handler(frames_of(tag), dt, 0, clear_on_error=False)
+        n = len(g['qt_%s_at' % tag])
+        assert len(got) == n
+        assert np.array_equal(peak, g['qt_%s_peak_%d' % (tag, n - 1)], equal_nan=True)
+
+
 def test_fragment_wire_format(golden):
     path = os.path.join(os.path.dirname(__file__), 'golden', 'fragments.bin')
     raw = open(path, 'rb').read()
@@ -201,7 +224,7 @@ def test_known_answers():
 def test_reference_fixtures_are_tagged(golden):
     import glob
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'ref_*.npz')))
-    assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_fft_plot.npz', 'ref_flank.npz',
+    assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_consumers.npz', 'ref_fft_plot.npz', 'ref_flank.npz',
                      'ref_legacy_sensor.npz',
                      'ref_scanner_seq.npz', 'ref_sensing_log.npz',
                      'ref_src_power_cases.npz',
@@ -210,7 +233,7 @@ def test_reference_fixtures_are_tagged(golden):
     for n in names:
         g = golden(n)
         assert str(g['source']) == 'reference'
-        if n not in ('ref_ascii_plot.npz', 'ref_flank.npz', 'ref_sensing_log.npz'):      # (carry their own inputs)
+        if n not in ('ref_ascii_plot.npz', 'ref_consumers.npz', 'ref_flank.npz', 'ref_sensing_log.npz'):      # (carry their own inputs)
             assert os.path.exists(os.path.join(os.path.dirname(__file__), 'golden', str(g['input_from'])))
 
 
