@@ -239,6 +239,7 @@ def reference_fixtures():
     reference_fft_plot_fixture(E)
     reference_logger_fixture(E)
     reference_consumer_fixture(E)
+    reference_psd_logger_fixture(E)
 
 
 def reference_thread_fixtures(E, T, S):
@@ -709,6 +710,41 @@ def reference_logger_fixture(E):
          said=np.array(said.getvalue().replace(home, '~')),
          **{'file_%d' % i: files[n] for i, n in enumerate(order)})
     print('  ' + '\n  '.join('%s (%d B)' % (n, len(files[n])) for n in order))
+
+
+def reference_psd_logger_fixture(E):
+    """ref_psd_logger.npz (a2, the host side): the reference's own ``_queue_watcher.run`` (psd_logger.py:70-88) on
+    stand-in messages - the |X| rows of the committed a2 input, one vector per message, then one message of two
+    vectors.  It records what the watcher saved after every message (the peak starts from ``None``: the first vector IS
+    the first peak) and how it ends: the two-vector message reaches ``s = s[start:start + itemsize]`` with ``s``
+    never assigned (:79-81) and the thread dies with UnboundLocalError - which is why the product block states the
+    last-vector rule of the other watchers instead (psd_logger.py header)."""
+    from types import SimpleNamespace as NS
+    g = np.load(os.path.join(HERE, 'gr_chain_bh_mag_peak_4096.npz'))
+    mag = g['expected_mag'].astype(np.float32)
+    saved = []
+    npd = E.NumpyOfItsDay()
+    npd.fromstring = lambda s, dt: np.frombuffer(bytes(s), dt)
+    npd.save = lambda path, arr: saved.append((path, np.array(arr)))
+    run = E.load_method('psd_logger.py', '_queue_watcher', 'run', {'np': npd})
+    msgs = [(4 * mag.shape[1], 1, mag[i].tobytes()) for i in range(mag.shape[0])]
+    msgs.append((4 * mag.shape[1], 2, mag[:2].tobytes()))
+    me = NS(keep_running=True, mat_file='/tmp/psd_log-stand-in.mat', k=-1)
+
+    def delete_head():
+        me.k += 1
+        size, n, payload = msgs[me.k]
+        return NS(arg1=lambda: size, arg2=lambda: n, to_string=lambda: payload)
+    me.rcvd_data = NS(delete_head=delete_head)
+    try:
+        run(me)
+        ended = 'returned'
+    except Exception as exc:      # noqa: BLE001 - the fixture records how the reference's thread ends
+        ended = type(exc).__name__
+    assert len(saved) == mag.shape[0] and all(p == me.mat_file for p, _ in saved)
+    save('ref_psd_logger.npz', source=np.array('reference'), input_from=np.array('gr_chain_bh_mag_peak_4096.npz'),
+         saved_peaks=np.array([a for _, a in saved]), ended=np.array(ended), died_at_message=np.array(me.k))
+    print('  %d saves, then the %d-vector message: %s' % (len(saved), msgs[-1][1], ended))
 
 
 def reference_consumer_fixture(E):

@@ -115,9 +115,17 @@ def test_psd_logger_peak_file(ctx, golden, tmp_path):
     path = str(tmp_path / 'psd_log.npy')
     blk = ofdm_tools.psd_logger(4096, 1000, 4096 * 1000, ctx=ctx, threaded=False, mat_file=path)
     assert blk.decimation == 1
+    saves, inner = [], blk._on_vector
+    blk._on_vector = lambda row: (inner(row), saves.append(np.load(path)))
     blk.feed(g['x'], max_items=4096)
     assert relerr(blk.peak_vals, g['expected_peak'][-1]) < RTOL
     assert relerr(np.load(path), g['expected_peak'][-1]) < RTOL
+    # every file the reference's OWN watcher body saved for these vectors (psd_logger.py:70-88 on stand-in messages,
+    # ref_psd_logger.npz): one save per vector, the first vector is the first peak
+    ref = golden('ref_psd_logger.npz')
+    assert len(saves) == len(ref['saved_peaks']) == 16
+    for got, want in zip(saves, ref['saved_peaks']):
+        assert got.dtype == want.dtype == np.float32 and relerr(got, want) < RTOL
 
 
 def test_local_worker_pdus(ctx, golden):

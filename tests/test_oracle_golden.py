@@ -152,6 +152,17 @@ def test_fragment_consumer_restatement_against_the_byte_fixture():
     assert R.zmq_pdu_header(1472) == bytes([7, 6, 10, 0, 0, 0, 5, 0xc0, 1, 0]) and len(R.zmq_pdu_header(5)) == 10
 
 
+def test_ref_psd_logger_watcher_peak_rule(golden):
+    """a2, host side: oracle.chain_psd_logger's running peak against what the reference's own ``_queue_watcher.run``
+    saved message by message (ref_psd_logger.npz; psd_logger.py:70-88) - and how that thread ends at its first
+    two-vector message (``s`` used before assignment, :79-81)."""
+    ref = golden('ref_psd_logger.npz')
+    g = golden(str(ref['input_from']))
+    _, peak = R.chain_psd_logger(g['x'], int(g['nfft']))
+    assert peak.shape == ref['saved_peaks'].shape and np.allclose(peak, ref['saved_peaks'], rtol=1e-6, atol=0)
+    assert str(ref['ended']) == 'UnboundLocalError' and int(ref['died_at_message']) == 16
+
+
 def test_ref_fragment_consumer_restatement_against_the_reference_consumers(golden):
     """oracle.consumer_handler against what the reference's own consumers did with the same frames (ref_consumers.npz):
     vectors in completion order and the final peak, with the 10-byte header / cleared pending payload of the web server
@@ -225,7 +236,7 @@ def test_reference_fixtures_are_tagged(golden):
     import glob
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'ref_*.npz')))
     assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_consumers.npz', 'ref_fft_plot.npz', 'ref_flank.npz',
-                     'ref_legacy_sensor.npz',
+                     'ref_legacy_sensor.npz', 'ref_psd_logger.npz',
                      'ref_scanner_seq.npz', 'ref_sensing_log.npz',
                      'ref_src_power_cases.npz',
                      'ref_src_power_fft.npz', 'ref_src_power_welch_2048.npz', 'ref_sweeper_src_power.npz',
