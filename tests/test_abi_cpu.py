@@ -182,6 +182,10 @@ def test_hot_kernels_have_no_scratch():
         pytest.skip('library not built yet')
     ks = kernel_resources.kernels(_hip.LIB_PATH)
     hot = ['welch4096ws_kernel<true, true>', 'welch4096ws_kernel<true, false>', 'welch4096ws_kernel<false, false>',
+           # welch4096.hip, both builds (any step / zero-padded segments - C4 as the reference block calls it - and the
+           # 50 % pipeline for windows whose spectrum is not confined; same names, the larger figure counts)
+           'welch4096_kernel<true, 16, true>', 'welch4096_kernel<true, 16, false>', 'welch4096_kernel<false, 16, false>',
+           'welch4096_kernel<true, 4, true>', 'welch4096_kernel<true, 4, false>',
            'csd4096ws_kernel<true, true>', 'csd4096ws_kernel<true, false>',
            'welch16k1x_pipe_kernel<16, false>', 'welch16k1x_pipe_kernel<8, false>',
            'welch16k1x_half_kernel<16, 2, true>', 'welch16k1x_half_kernel<16, 2, false>', 'welch16k1x_half_kernel<16, 0, false>',

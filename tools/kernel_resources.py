@@ -71,9 +71,13 @@ def kernels(path=DEFAULT_LIB):
             if not name:
                 continue
             num = lambda k: int(get(k).group(1)) if get(k) else 0      # noqa: E731
-            res[name.group(1)] = dict(vgpr=num('vgpr_count'), agpr=num('agpr_count'), sgpr=num('sgpr_count'),
-                                      spill_vgpr=num('vgpr_spill_count'), spill_sgpr=num('sgpr_spill_count'),
-                                      scratch=num('private_segment_fixed_size'), lds=num('group_segment_fixed_size'))
+            one = dict(vgpr=num('vgpr_count'), agpr=num('agpr_count'), sgpr=num('sgpr_count'),
+                       spill_vgpr=num('vgpr_spill_count'), spill_sgpr=num('sgpr_spill_count'),
+                       scratch=num('private_segment_fixed_size'), lds=num('group_segment_fixed_size'))
+            # two translation units may hold a kernel of the same name (welch4096.hip is built twice, `dpp` and `pipe`,
+            # in an anonymous namespace): report the larger figure of each
+            old = res.get(name.group(1))
+            res[name.group(1)] = one if old is None else {k: max(v, old[k]) for k, v in one.items()}
     if res:
         names = list(res)
         dem = subprocess.run(['c++filt'] + names, stdout=subprocess.PIPE,
