@@ -612,7 +612,8 @@ int table_bpc(const OccupancyKey &k) {
             const int tpw = k.nfft == 256 ? 4 : (k.nfft == 512 ? 2 : 1), wpt = k.nfft <= 1024 ? 1 : k.nfft / 1024;
             return 4 * (k.seg_wps4 ? 4 : 3) * tpw / wpt;
         }
-        case RK_SEGPAD: return k.nfft == 1024 ? 16 : (k.nperseg * 4 == k.nfft ? 8 : 6);      // 2048: NA = 4 at four waves per SIMD, NA = 8 at three
+        case RK_SEGPAD:      // 2048: NA = 4 at four waves per SIMD; NA = 8 at three, where the half-load pilot build takes 130 VGPRs
+            return k.nfft == 1024 ? 16 : (k.nperseg * 4 == k.nfft ? 8 : (k.seg_kind == 0 ? 6 : 8));
         case RK_W16K: case RK_W16K1X: case RK_W16K1X_HALF: return k.nfft == 8192 ? 2 : 1;
         default: return 0;
     }

@@ -909,9 +909,23 @@ template <int R, int NA> hipError_t launch_pad(const SegArgs &a, int kind, hipSt
     if (kind == 0) return a.detrend ? launch_one<R, LOAD_HALF, true, false, WPS, NA>(a, s) : launch_one<R, LOAD_HALF, false, false, WPS, NA>(a, s);
     return a.detrend ? launch_one<R, LOAD_FULL, true, false, WPS, NA>(a, s) : launch_one<R, LOAD_FULL, false, false, WPS, NA>(a, s);
 }
+template <int R, int LOAD, bool DETREND, bool CHAIN, int WPS, int NA> int occupancy_one_pilot() {
+    int n = 0;
+    constexpr size_t lds = seg_lds_bytes<R, CHAIN>();
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_kernel<R, LOAD, DETREND, CHAIN, WPS, NA, true>, Geo<R>::BLOCK, lds) !=
+            hipSuccess || n < 1)
+        n = 1;
+    return n * Geo<R>::TPB;
+}
+// The grid is sized once per plan shape, the launch then takes the build with or without the pilot: the smaller of the
+// two occupancies counts (at three waves per SIMD the NA = 8 builds sit at 126-130 VGPRs, i.e. on both sides of the
+// step between eight and six resident workgroups per CU).
 template <int R, int NA> int occupancy_pad(int kind) {
     constexpr int WPS = NA == 4 ? 4 : 3;
-    return kind == 0 ? occupancy_one<R, LOAD_HALF, true, false, WPS, NA>() : occupancy_one<R, LOAD_FULL, true, false, WPS, NA>();
+    const int plain = kind == 0 ? occupancy_one<R, LOAD_HALF, true, false, WPS, NA>() : occupancy_one<R, LOAD_FULL, true, false, WPS, NA>();
+    const int pilot = kind == 0 ? occupancy_one_pilot<R, LOAD_HALF, true, false, WPS, NA>()
+                                : occupancy_one_pilot<R, LOAD_FULL, true, false, WPS, NA>();
+    return plain < pilot ? plain : pilot;
 }
 
 // kind: 0 Welch step = N/2 (half kept in registers), 1 Welch any step, 2 chain.  wps4: the 128-VGPR build of kind 0.
