@@ -721,6 +721,65 @@ def test_full_size_256M_properties(ctx, hip):
         ctx.free(d_in)
 
 
+def test_one_launch_over_16_GiB_sample_offsets_beyond_2_31(ctx, hip):
+    """A stream of 2^31 + 2^22 samples (16 GiB) in ONE launch: sample indices pass 2^31 and byte offsets 2^34 inside the
+    kernels.  The last 2^22 samples carry a tone 30 dB above everything before them, so a segment fetched from a wrapped
+    offset shows; the sums of a Welch average are additive over runs of segments, so
+        nseg P(whole) = k_A P(first k_A segments) + k_B P(the rest)
+    with the rest launched on its own from a pointer 16 GiB into the buffer.  Checked for the builds the BASELINE
+    configurations route to: 4096 role-split, 256, 1024 role-split, 16384 one-exchange with and without overlap."""
+    head, tail = 1 << 31, 1 << 22
+    n = head + tail
+    d = ctx.alloc(n * 8)
+    try:
+        ctx.synth_iq(d, head, 1002, R.TONES, R.DC)
+        ctx.synth_iq(d + head * 8, tail, 77, ((30.0, 0.2003),), 0j)
+        cases = [(4096, hann(4096), None, hip.DETREND_CONSTANT, 'welch4096:ws'),
+                 (256, hann(256), None, hip.DETREND_CONSTANT, 'seg'),
+                 (1024, hann(1024), None, hip.DETREND_CONSTANT, 'segws'),
+                 (16384, hann(16384), None, hip.DETREND_CONSTANT, 'welch16k1x_half'),
+                 (16384, None, 0, hip.DETREND_NONE, 'welch16k1x')]
+        for nfft, win, noverlap, det, kern in cases:
+            plan = ctx.welch_plan(nfft, window=win, noverlap=noverlap, detrend=det, fs=1.0, kernel=hip.KERNEL_TUNED)
+            step = nfft if noverlap == 0 else nfft // 2
+            whole = plan.exec_device_src(d, n).astype(np.float64)
+            nseg = plan.last_nseg
+            assert kern in plan.last_recipe(), plan.last_recipe()
+            assert nseg == (n - (nfft - step)) // step
+            k_a = head // step                                   # segments that start in front of the tail
+            a = plan.exec_device_src(d, k_a * step + (nfft - step)).astype(np.float64)
+            assert plan.last_nseg == k_a
+            b = plan.exec_device_src(d + head * 8, tail).astype(np.float64)
+            k_b = plan.last_nseg
+            assert k_a + k_b == nseg
+            both = (k_a * a + k_b * b) / nseg
+            assert relerr(whole, both) < 2e-5, (nfft, noverlap)
+            # and the tail's tone is where it belongs, at the power its share of the segments gives it
+            k0 = int(round(0.2003 * nfft))
+            assert np.argmax(b) == k0 and whole[k0] > 100 * np.median(whole)
+            plan.close()
+        # the two-channel kernel on the same buffer: y = x delayed by five samples, both streams 16 GiB long
+        delay, N, step = 5, 4096, 2048
+        plan = ctx.welch_plan(N, window=hann(N), fs=1.0, kernel=hip.KERNEL_TUNED)
+        m = n - delay
+        whole = [v.astype(np.complex128) for v in plan.csd_device_src(d + 8 * delay, d, m)[:3]]
+        nseg = plan.last_nseg
+        assert 'csd4096ws' in plan.last_recipe() and nseg == (m - step) // step
+        k_a = head // step
+        a = [v.astype(np.complex128) for v in plan.csd_device_src(d + 8 * delay, d, k_a * step + step)[:3]]
+        assert plan.last_nseg == k_a
+        b = [v.astype(np.complex128) for v in plan.csd_device_src(d + 8 * (delay + head), d + 8 * head, m - head)[:3]]
+        k_b = plan.last_nseg
+        assert k_a + k_b == nseg
+        for w, pa, pb in zip(whole, a, b):
+            both = (k_a * pa + k_b * pb) / nseg
+            assert np.max(np.abs(w - both)) / np.max(np.abs(both)) < 2e-5
+            assert np.max(np.abs(w - both) / np.maximum(np.abs(both), 1e-3 * np.median(np.abs(both)))) < 1e-3
+        plan.close()
+    finally:
+        ctx.free(d)
+
+
 def test_full_size_config3_csd_properties(ctx, hip):
     """BASELINE config 3 at its full size (2 x 2^26 samples on the device; the oracle cannot run there): y is x delayed by
     five samples (the same buffer, five samples in), so the truth is known in closed form -
