@@ -589,6 +589,7 @@ struct OccupancyKey {
     const char *variant;      // RK_W4096
     int nfft, nperseg, seg_kind;
     bool seg_wps4;
+    bool half_ws;             // RK_W16K1X_HALF at 8192 points: the role-split build (one 1024-thread workgroup per CU)
 };
 int runtime_bpc(const OccupancyKey &k) {
     switch (k.kern) {
@@ -598,7 +599,7 @@ int runtime_bpc(const OccupancyKey &k) {
         case RK_SEG: return seg_teams_per_cu(k.nfft, k.seg_kind, k.seg_wps4);
         case RK_SEGWS: return segws_teams_per_cu(k.nfft);
         case RK_SEGPAD: return seg_padded_teams_per_cu(k.nfft, k.nperseg, k.seg_kind);
-        case RK_W16K: case RK_W16K1X: case RK_W16K1X_HALF: return k.nfft == 8192 ? 2 : 1;      // 70 / 139 KiB of LDS
+        case RK_W16K: case RK_W16K1X: case RK_W16K1X_HALF: return k.nfft == 8192 && !k.half_ws ? 2 : 1;      // 70 / 139 (145) KiB of LDS
         default: return 0;
     }
 }
@@ -614,7 +615,7 @@ int table_bpc(const OccupancyKey &k) {
         }
         case RK_SEGPAD:      // 2048: NA = 4 at four waves per SIMD; NA = 8 at three, where the half-load pilot build takes 130 VGPRs
             return k.nfft == 1024 ? 16 : (k.nperseg * 4 == k.nfft ? 8 : (k.seg_kind == 0 ? 6 : 8));
-        case RK_W16K: case RK_W16K1X: case RK_W16K1X_HALF: return k.nfft == 8192 ? 2 : 1;
+        case RK_W16K: case RK_W16K1X: case RK_W16K1X_HALF: return k.nfft == 8192 && !k.half_ws ? 2 : 1;
         default: return 0;
     }
 }
@@ -629,6 +630,7 @@ struct LaunchRecipe {
     int seg_kind = 0, seg_det = 0;
     bool seg_wps4 = false;
     bool x1_window = false, x1_plain = false;      // RK_W16K1X: windowed build / the un-pipelined loop
+    bool half_ws = false;                          // RK_W16K1X_HALF, 8192 points: welch8kws_kernel
     int bpc = 0;                 // resident workgroups (teams) per CU (0: generic grid rule)
     int W = 1, rows = 1, nch = 1, layout = 0;
     int sched = 0, chunk = 1, tail_chunk = 1;
@@ -693,7 +695,13 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
             // scanner of BASELINE config 5; at 8192 points the pipelined rectangular build only), and 50 % overlap with
             // the kept half in registers (a constant detrend needs the |k| < 16 table)
             if (p.step >= p.nfft && !p.detrend && (p.nfft == 16384 || (p.rect_window && tv != "16kplain"))) r.kern = RK_W16K1X;
-            else if (p.step * 2 == p.nfft && (!p.detrend || fd1x)) r.kern = RK_W16K1X_HALF;
+            else if (p.step * 2 == p.nfft && (!p.detrend || fd1x)) {
+                r.kern = RK_W16K1X_HALF;
+                // the role-split build at 8192 points walks contiguous runs only (what this shape takes by default)
+                const bool contiguous = (p.tune_sched < 0 && p.sched == OTH_SCHED_DYNAMIC) ||
+                                        (p.tune_sched >= 0 ? p.tune_sched : p.sched) == OTH_SCHED_CONTIGUOUS;
+                r.half_ws = p.nfft == 8192 && contiguous && nseg < (1LL << 31) && tv == "8kws";
+            }
         }
     } else if (want_tuned && seg_size && seg_padded_supported(p.nfft, p.nperseg)) {
         r.kern = RK_SEGPAD;      // nperseg = nfft / 4 (the sweeper's call, spectrum_sweeper.py:263) or nfft / 2 at 1024 / 2048
@@ -735,7 +743,7 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
     if (r.kern == RK_GENERIC) {
         r.W = generic_wg_for(cu_count, p.nfft, nseg, nstreams);
     } else {
-        const OccupancyKey key{r.kern, r.kern == RK_W4096 ? r.variant->tag : "", p.nfft, p.nperseg, r.seg_kind, r.seg_wps4};
+        const OccupancyKey key{r.kern, r.kern == RK_W4096 ? r.variant->tag : "", p.nfft, p.nperseg, r.seg_kind, r.seg_wps4, r.half_ws};
         r.bpc = bpc_of(key);
         if (r.bpc < 1) r.bpc = 1;
         const long long w = ((long long)cu_count * r.bpc + nstreams - 1) / nstreams;
@@ -833,6 +841,7 @@ std::string recipe_text(const LaunchRecipe &r, int nfft) {
     if (r.kern == RK_SEG) k += std::string(r.seg_kind ? ":full" : ":half") + (r.seg_wps4 ? ":wps4" : "");
     if (r.kern == RK_SEGPAD) k += r.seg_kind ? ":full" : ":half";
     if (r.kern == RK_W16K1X) k += std::string(r.x1_plain || r.x1_window ? ":plain" : ":pipe") + (r.x1_window ? ":window" : "");
+    if (r.kern == RK_W16K1X_HALF && r.half_ws) k += ":ws";
     snprintf(buf, sizeof buf, "kernel=%s nfft=%d form=%s pilot=%s sched=%s chunk=%d tail=%d nbig=%lld bpc=%d W=%d rows=%d nch=%d layout=%d",
              k.c_str(), nfft, kForm[r.form], kPilot[r.pilot], kSched[r.sched], r.chunk, r.tail_chunk, r.nbig, r.bpc, r.W, r.rows,
              r.nch, r.layout);
@@ -949,7 +958,9 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
             case RK_W4096: HIPCHK(c, r.variant->launch(a, c->stream)); break;
             case RK_CSD4096WS: HIPCHK(c, launch_csd_tuned4096ws(a, c->stream)); break;
             case RK_CSD4096: HIPCHK(c, launch_csd_tuned4096(a, c->stream)); break;
-            case RK_W16K1X_HALF: HIPCHK(c, launch_welch_tuned16k1x_half(p->nfft, a, c->stream)); break;
+            case RK_W16K1X_HALF:
+                HIPCHK(c, r.half_ws ? launch_welch_tuned8kws(a, c->stream) : launch_welch_tuned16k1x_half(p->nfft, a, c->stream));
+                break;
             case RK_W16K1X: HIPCHK(c, launch_welch_tuned16k1x(p->nfft, a, r.x1_window, r.x1_plain, c->stream)); break;
             case RK_W16K: HIPCHK(c, launch_welch_tuned16k(p->nfft, a, c->stream)); break;
             default: HIPCHK(c, launch_welch_generic(p->nfft, a, c->stream)); break;
@@ -1397,8 +1408,9 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
                      !strcmp(variant, "csd1") ||                                // the one-role two-channel kernel
                      !strcmp(variant, "fd") || !strcmp(variant, "td") ||        // detrend form only (run_average)
                      !strcmp(variant, "plaunch") ||                             // pilot from its own launch (run_average)
-                     !strcmp(variant, "16k4") || !strcmp(variant, "16kplain");  // 16384 points: the 4 x 4096 build / the
+                     !strcmp(variant, "16k4") || !strcmp(variant, "16kplain") ||  // 16384 points: the 4 x 4096 build / the
                                                                                 // un-pipelined one-exchange build
+                     !strcmp(variant, "8kws") || !strcmp(variant, "8k1role");   // 8192 points, 50 % overlap: role-split / one-role
         for (const auto &v : kVariants) known = known || !strcmp(variant, v.tag);
         if (!known) return fail(p->ctx, OTH_ERR_UNSUPPORTED, std::string("unknown kernel build: ") + variant);
     }

@@ -166,6 +166,7 @@ hipError_t launch_welch_tuned16k(int nfft, const WelchArgs &a, hipStream_t s);
 hipError_t launch_welch_tuned16k1x(int nfft, const WelchArgs &a, bool window, bool plain, hipStream_t s);
 // the same transform at step = 8192 (50 % overlap, the kept half in registers); WelchArgs.fd = window_spectrum_table_16k1x
 hipError_t launch_welch_tuned16k1x_half(int nfft, const WelchArgs &a, hipStream_t s);
+hipError_t launch_welch_tuned8kws(const WelchArgs &a, hipStream_t s);      // 8192 points, 50 % overlap, role-split (contiguous runs only)
 // the fused periodogram chain at 8192 / 16384 points (one workgroup per segment; workgroups per CU: 2 / 1)
 hipError_t launch_chain16k(int nfft, const SegArgs &a, bool rect, hipStream_t s);
 // the same chain at 16384 points on the one-exchange pipelined loop (welch16k1x.hip); partial rows in layout 4; needs

@@ -91,6 +91,42 @@ __device__ __forceinline__ void load_row_nt(f2v &dst, unsigned lane_off, const c
     asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
 }
 
+// ---- waiting for pinned loads ------------------------------------------------------------------------------------------
+// A register written by an inline-asm load is NOT valid until the s_waitcnt that covers it, and the compiler does not
+// know: to it the value exists from the asm on.  Two things follow (tools/isa_async_hazard.py checks the shipped code
+// objects for both, tests/test_abi_cpu.py runs it):
+//   * a wait has to NAME the registers it makes valid, or nothing keeps an instruction that reads them behind it (the
+//     bare `s_waitcnt lgkmcnt(0)` in front of the last segment's tail was overtaken by the sixty instructions of its
+//     first butterfly layer - late round 5; it only worked because a vmcnt wait happened to stand in between);
+//   * naming them as in-out operands ("+v") is not enough when the value has to end up somewhere else (the kept half of
+//     the 50 %-overlap builds): the compiler then copies the INPUT of the wait into the register it wants, i.e. reads
+//     the loading register in front of the wait.  arrive8 / arrive16 take the loading registers as inputs only and hand
+//     out fresh ones, wait and copies in one statement.
+#define OTH_IO8(r) "+v"((r)[0]), "+v"((r)[1]), "+v"((r)[2]), "+v"((r)[3]), "+v"((r)[4]), "+v"((r)[5]), "+v"((r)[6]), "+v"((r)[7])
+#define OTH_IO16(r) OTH_IO8(r), "+v"((r)[8]), "+v"((r)[9]), "+v"((r)[10]), "+v"((r)[11]), "+v"((r)[12]), "+v"((r)[13]), "+v"((r)[14]), "+v"((r)[15])
+// every vector-memory load of this wave has landed; r[0..15] are valid behind this statement (in place)
+__device__ __forceinline__ void vm_arrived16(f2v (&r)[16]) { asm volatile("s_waitcnt vmcnt(0)" : OTH_IO16(r) : : "memory"); }
+// every LDS read of this wave has landed (with the workgroup barrier: lds_barrier() for a wave that holds reads in flight)
+__device__ __forceinline__ void lds_arrived16(f2v (&r)[16]) { asm volatile("s_waitcnt lgkmcnt(0)" : OTH_IO16(r) : : "memory"); }
+__device__ __forceinline__ void lds_barrier_arrived16(f2v (&r)[16]) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : OTH_IO16(r) : : "memory");
+}
+// wait, then out[i] = in[i] in fresh registers (eight pairs)
+__device__ __forceinline__ void vm_arrive8(float2 (&out)[8], const f2v (&in)[8]) {
+    f2v o[8];
+    asm volatile("s_waitcnt vmcnt(0)\n\t"
+                 "v_mov_b64 %0, %8\n\tv_mov_b64 %1, %9\n\tv_mov_b64 %2, %10\n\tv_mov_b64 %3, %11\n\t"
+                 "v_mov_b64 %4, %12\n\tv_mov_b64 %5, %13\n\tv_mov_b64 %6, %14\n\tv_mov_b64 %7, %15"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                 : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]), "v"(in[4]), "v"(in[5]), "v"(in[6]), "v"(in[7])
+                 : "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = make_float2(o[i].x, o[i].y);
+}
+// the sixteen window values of a step (load_win): valid in place behind this statement; they are used up inside the step,
+// nothing of them lives across a loop edge
+__device__ __forceinline__ void vm_arrived_win16(float (&w)[16]) { asm volatile("s_waitcnt vmcnt(0)" : OTH_IO16(w) : : "memory"); }
+
 // v[r16(k)] *= W^k, k = 1..15, W^k rebuilt from p1 = W and p4 = W^4 as in scatter_pow16
 __device__ __forceinline__ void twiddle_pow16_inplace(float2 (&v)[16], float2 p1, float2 p4) {
     float2 wj[4], wi[4];
@@ -496,7 +532,7 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
         const char *x0 = reinterpret_cast<const char *>(xb + (long long)s * step);
 #pragma unroll
         for (int r = 0; r < 16; ++r) load_row_nt(pfr[r], 8u * tid, x0 + 512 * NW * r);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vm_arrived16(pfr);
     }
     auto tail = [&](auto hook1, auto hook2) {      // pass 3, twiddles, pass 4 of the segment whose exchange-B values sit in rB
         float2 v[16];
@@ -522,12 +558,7 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
             const char *wbase = reinterpret_cast<const char *>(win);
 #pragma unroll
             for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * tid, wbase + 256 * NW * r);
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(wv16[0]), "+v"(wv16[1]), "+v"(wv16[2]), "+v"(wv16[3]), "+v"(wv16[4]), "+v"(wv16[5]), "+v"(wv16[6]),
-                           "+v"(wv16[7]), "+v"(wv16[8]), "+v"(wv16[9]), "+v"(wv16[10]), "+v"(wv16[11]), "+v"(wv16[12]), "+v"(wv16[13]),
-                           "+v"(wv16[14]), "+v"(wv16[15])
-                         :
-                         : "memory");
+            vm_arrived_win16(wv16);
 #pragma unroll
             for (int r = 0; r < 16; ++r) pf[r] = make_float2(pf[r].x * wv16[r], pf[r].y * wv16[r]);
         }
@@ -538,7 +569,7 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
         dft16(pf);                                             // P1
         prio_latency();
         X1_STAMP(1);
-        lds_barrier();      // 1 (also waits for this wave's exchange-B reads of the segment before)
+        lds_barrier_arrived16(rB);      // 1 (also waits for this wave's exchange-B reads of the segment before: rB valid)
         X1_STAMP(2);
         const bool first_of_chunk = s == sb;
         if (sched == 2 && first_of_chunk && tid == 0) lnext[par] = (int)atomicAdd(sc.queue, 1u);
@@ -617,10 +648,10 @@ __device__ __forceinline__ void x1_pipe_body(const float2 *xb, long long step, c
         live = more;
         sp = s;
         s = ns;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the sixteen pinned loads of this step: the next pass 1 reads them
+        vm_arrived16(pfr);      // the sixteen pinned loads of this step: the next pass 1 reads them
     }
     if (have_prev) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_arrived16(rB);
         tail([] {}, [] {});
     }
 #if OTH_X1_DIAG
@@ -829,9 +860,7 @@ __global__ __launch_bounds__(64 * NW, 4) void welch16k1x_half_kernel(WelchArgs p
             for (int r = 0; r < 8; ++r) load_row_nt(first[r], voff, x0 + 512 * NW * r);
 #pragma unroll
             for (int r = 0; r < 8; ++r) load_row_nt(nxt[r], voff, x0 + 512 * NW * (8 + r));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < 8; ++r) keep[r] = make_float2(first[r].x, first[r].y);
+            vm_arrive8(keep, first);      // (nxt has landed as well; the step below says so where it takes it)
         }
 #if OTH_X1H_WIN_EARLY      // A/B (no gain, see the macro): the window values of a step requested at the END of the step before
         float wv16[16];
@@ -853,16 +882,12 @@ __global__ __launch_bounds__(64 * NW, 4) void welch16k1x_half_kernel(WelchArgs p
                 for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * tid, wbase + 256 * NW * r);
             }
 #endif
-            {
-                // the window values and the new half, both requested during the step before (or above)
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(wv16[0]), "+v"(wv16[1]), "+v"(wv16[2]), "+v"(wv16[3]), "+v"(wv16[4]), "+v"(wv16[5]), "+v"(wv16[6]),
-                               "+v"(wv16[7]), "+v"(wv16[8]), "+v"(wv16[9]), "+v"(wv16[10]), "+v"(wv16[11]), "+v"(wv16[12]), "+v"(wv16[13]),
-                               "+v"(wv16[14]), "+v"(wv16[15]), "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]),
-                               "+v"(nxt[5]), "+v"(nxt[6]), "+v"(nxt[7])
-                             :
-                             : "memory");
-            }
+            // the new half (requested during the step before, or above) and the window values: the new half comes out of
+            // its loading registers in the same statement that waits for it (vm_arrive8: it outlives the next loads into
+            // them as the kept half, and a copy the compiler makes for that may not stand in front of the wait)
+            float2 fresh[8];
+            vm_arrive8(fresh, nxt);
+            vm_arrived_win16(wv16);
             float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
             if (s == sb) {      // the chunk's first half arrives raw
 #pragma unroll
@@ -873,7 +898,7 @@ __global__ __launch_bounds__(64 * NW, 4) void welch16k1x_half_kernel(WelchArgs p
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                float2 nw = make_float2(nxt[r].x, nxt[r].y);
+                float2 nw = fresh[r];
                 if (PILOT) nw = csub(nw, pv);
                 v[r] = make_float2(keep[r].x * wv16[r], keep[r].y * wv16[r]);
                 v[8 + r] = make_float2(nw.x * wv16[8 + r], nw.y * wv16[8 + r]);
@@ -983,6 +1008,188 @@ template <int NW> static hipError_t launch1x_half_n(const WelchArgs &a, hipStrea
 // step = N / 2; detrend none, or constant through the frequency-domain form (a.fd = the table described above)
 hipError_t launch_welch_tuned16k1x_half(int nfft, const WelchArgs &a, hipStream_t s) {
     return nfft == 8192 ? launch1x_half_n<8>(a, s) : launch1x_half_n<16>(a, s);
+}
+
+// ---- 8192 points, 50 % overlap, ROLE-SPLIT (late round 5) ------------------------------------------------------------
+// The 8-wave loop above runs every phase of a segment on all of its waves, two barriers per step; two workgroups per CU
+// overlap each other's phases only by chance.  Here one 1024-thread workgroup per CU is split as in welch4096ws.hip:
+//   producers (threads 0..511)     loads, pilot, window, per-wave sums, pass 1, its twiddles, exchange-A writes of
+//                                  segment s into image s & 1
+//   consumers (threads 512..1023)  exchange-A reads of segment s - 1, pass 2 (two radix-8), exchange B inside the wave,
+//                                  passes 3 and 4, the frequency-domain detrend, the accumulation
+// one LDS-only barrier per step; the loads of one role overlap the butterflies of the other by construction.  Two
+// images of 68 KiB + tables: 145 of the CU's 160 KiB.  Contiguous runs of segments only (the schedule this shape takes
+// by default); anything else stays on the one-role kernel.
+constexpr int X8W_RED = 24;      // [2][8] per-wave sums of a segment (both halves), by image parity; 8 spare
+constexpr size_t x8ws_lds_bytes() {
+    return (2 * 8 * XREG + X8W_RED + 16 * 64 + 16 * 4) * sizeof(float2) + 4 * sizeof(float4);
+}
+
+template <int DET, bool PILOT = false>
+__global__ __launch_bounds__(1024, 4) void welch8kws_kernel(WelchArgs p) {
+    static_assert(DET == 2 || !PILOT, "the pilot belongs to the detrend");
+    constexpr int NW = 8, N = 8192;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *lds = reinterpret_cast<float2 *>(smem);
+    float2 *red = lds + 2 * NW * XREG;
+    float2 *tabB = red + X8W_RED;                                               // [16][64]
+    float2 *tabC = tabB + 16 * 64;                                              // [16][4]
+    float4 *quadK = reinterpret_cast<float4 *>(tabC + 16 * 4);
+
+    const int tid = threadIdx.x;
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 9);
+    const int t = tid & 511;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63, g = l >> 2, q = l & 3;
+    const int wg = blockIdx.x, W = p.wg_per_stream, stream = blockIdx.y;
+    const int s0 = (int)((p.nseg * wg) / W), s1 = (int)((p.nseg * (wg + 1)) / W);      // (the launcher checks nseg < 2^31)
+    const float2 *xb = p.x + (size_t)stream * p.stream_stride;
+    {
+        for (int i = tid; i < 1024; i += 1024) tabB[i] = p.tw[16 * (((i >> 6) & (NW - 1)) * (i & 63))];      // as x1_pipe_body
+        if (tid < 64) tabC[tid] = p.tw[16 * NW * ((tid >> 2) * (tid & 3))];
+        if (tid < 4) {
+            const float be = tid >= 2 ? 1.0f : 0.0f;
+            quadK[tid] = make_float4(tid < 2 ? 1.0f : -1.0f, tid == 0 ? 1.0f : (tid == 1 ? -1.0f : 0.0f), be, -be);
+        }
+    }
+    __syncthreads();
+
+    if (role == 0) {
+        // ---------------------------------------------------------------------------------------------- producer
+        const float2 a1 = p.tw[t], a4 = p.tw[4 * t];
+        float2 keep[8];
+        f2v nxt[8];
+        const unsigned voff = 8u * t;
+        const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, blockIdx.y);
+        float2 prev_new = make_float2(0.f, 0.f);      // lane 63: this wave's sum of the previous segment's new half
+        if (s0 < s1) {      // the run's first segment: both halves now
+            const char *x0 = reinterpret_cast<const char *>(xb + (long long)s0 * p.step);
+            f2v first[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) load_row_nt(first[r], voff, x0 + 512 * NW * r);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) load_row_nt(nxt[r], voff, x0 + 512 * NW * (8 + r));
+            vm_arrive8(keep, first);
+        }
+        for (int s = s0; s < s1; ++s) {
+            const int par = (s - s0) & 1;
+            float2 *wa = lds + par * NW * XREG + t;
+            float2 v[16];
+            prio_latency();
+            float wv16[16];      // the window from L2, where it is used (load_win)
+            {
+                const char *wbase = reinterpret_cast<const char *>(p.win);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * t, wbase + 256 * NW * r);
+            }
+            float2 fresh[8];
+            vm_arrive8(fresh, nxt);      // wait + copy out of the loading registers in one statement (see vm_arrive8)
+            vm_arrived_win16(wv16);
+            float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
+            if (s == s0) {      // the run's first half arrives raw
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (PILOT) keep[r] = csub(keep[r], pv);
+                    sumf = cadd(sumf, keep[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float2 nw = fresh[r];
+                if (PILOT) nw = csub(nw, pv);
+                v[r] = make_float2(keep[r].x * wv16[r], keep[r].y * wv16[r]);
+                v[8 + r] = make_float2(nw.x * wv16[8 + r], nw.y * wv16[8 + r]);
+                keep[r] = nw;
+                sum = cadd(sum, nw);
+            }
+            const char *xn = reinterpret_cast<const char *>(xb + (long long)(s + 1 < s1 ? s + 1 : s) * p.step) + 512 * NW * 8;
+            auto prefetch = [&](int r0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_row_nt(nxt[r0], voff, xn + 512 * NW * r0);
+                load_row_nt(nxt[r0 + 1], voff, xn + 512 * NW * (r0 + 1));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            prefetch(0);
+            if (DET == 2) {      // per-wave sums of both halves of this segment, for the consumers
+                sum.x = wave_total_lane63(sum.x);
+                sum.y = wave_total_lane63(sum.y);
+                float2 other = prev_new;
+                if (s == s0) other = make_float2(wave_total_lane63(sumf.x), wave_total_lane63(sumf.y));
+                if (l == 63) red[8 * par + wv] = cadd(sum, other);
+                prev_new = sum;
+            }
+            prefetch(2);
+            prio_compute();
+            dft16(v);                                              // pass 1: r -> k0
+            prio_latency();
+            prefetch(4);
+            scatter_pow16_exa<NW>(v, wa, a1, a4);                  // x W_N^(k0 t) -> [k0][w][l] of this image
+            prefetch(6);
+            lds_barrier();
+        }
+    } else {
+        // ---------------------------------------------------------------------------------------------- consumer
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int s = s0; s < s1; ++s) {
+            lds_barrier();      // image (s - s0) & 1 and its sums are complete
+            const int par = (s - s0) & 1;
+            float2 *im = lds + par * NW * XREG;
+            const float2 *ra = im + XREG * wv + l;
+            float2 *wb = im + XREG * wv + l;
+            const float2 *rb = im + XREG * wv + XROW * g + q;
+            float2 v[16];
+            prio_latency();
+            TwBatch ta;
+            pass2_from_lds<NW>(v, ra, [] { prio_compute(); }, [&] { tw_read_a<64>(ta, tabB + l); });     // pass 2
+            prio_latency();
+            wave_lds_sync();
+            twiddle_table16<64, XROW, true, NW>(v, wb, tabB + l, ta);
+            wave_lds_sync();
+            TwBatch tc;
+            dft16_from_lds<4>(v, rb, [] { prio_compute(); }, [&] { tw_read_a<4>(tc, tabC + q); });        // pass 3
+            const float4 qk = quadK[q];
+            twiddle_table16<4, 1, false>(v, nullptr, tabC + q, tc);
+            quad_dft4_dpp(v, qk.x, qk.y, qk.z, qk.w);              // pass 4
+            if (DET == 2) {
+                if ((l & 31) == 0 || (l & 31) == 31) {      // the lanes whose registers 0 / 15 lie where FFT(w) is not negligible
+                    int tfd = t;      // opaque: the table address is formed inside the branch
+                    asm volatile("" : "+v"(tfd));
+                    const float4 fd = p.fd[tfd];
+                    float2 tot = red[8 * par];
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) tot = cadd(tot, red[8 * par + w]);
+                    const float2 mean = make_float2(tot.x * (1.0f / N), tot.y * (1.0f / N));
+                    v[0] = make_float2(v[0].x - (mean.x * fd.x - mean.y * fd.y), v[0].y - (mean.x * fd.y + mean.y * fd.x));
+                    v[15] = make_float2(v[15].x - (mean.x * fd.z - mean.y * fd.w), v[15].y - (mean.x * fd.w + mean.y * fd.z));
+                }
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const float2 X = v[r16(k2)];
+                acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
+            }
+        }
+        float *dst = p.partial + ((size_t)stream * W + wg) * N + t;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) dst[64 * NW * k2] = acc[k2];
+    }
+}
+
+template <int DET, bool PILOT = false> static hipError_t launch8kws(const WelchArgs &a, hipStream_t s) {
+    const dim3 grid(a.wg_per_stream, a.nstreams);
+    constexpr size_t lds = x8ws_lds_bytes();
+    const void *fn = reinterpret_cast<const void *>(welch8kws_kernel<DET, PILOT>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((welch8kws_kernel<DET, PILOT>), grid, dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+// 8192 points, step = N / 2, contiguous runs; detrend none, or constant through the frequency-domain form (a.fd)
+hipError_t launch_welch_tuned8kws(const WelchArgs &a, hipStream_t s) {
+    if (a.sched != 0 || a.nseg > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (a.detrend && a.fd) return a.pilot ? launch8kws<2, true>(a, s) : launch8kws<2>(a, s);
+    return a.detrend ? hipErrorInvalidValue : launch8kws<0>(a, s);
 }
 
 template <bool WINDOW> static hipError_t launch1x(const WelchArgs &a, hipStream_t s) {

@@ -168,8 +168,11 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
         float wu[8];        // window rows 8..15: issued in front of the prefetch, awaited where they are used
 #pragma unroll
         for (int a = 0; a < 8; ++a) load_win(wu[a], 4u * t, win_hi + 1024 * a);
-        if (s + 1 < se) {   // the half the NEXT segment adds; lands while this segment is transformed
-            const float2 *xn = xb + (s + 2) * 2048 + t;
+        {   // the half the NEXT segment adds; lands while this segment is transformed.  Behind the chunk's last segment
+            // the same loads run once more on the half just taken: always eight loads younger than the window's, so
+            // ONE counted wait serves every step (two waits in two branches made the compiler merge their operands
+            // with copies in FRONT of the waits - tools/isa_async_hazard.py)
+            const float2 *xn = xb + (s + 1 < se ? s + 2 : s + 1) * 2048 + t;
 #pragma unroll
             for (int a = 0; a < 8; ++a) nxt[a] = load_once(xn + 256 * a);      // read once: non-temporal
         }
@@ -230,12 +233,8 @@ __global__ __launch_bounds__(T4, OTH_W4096_PIPE ? 4 : 1) void welch4096_kernel(W
 #if OTH_W4096_PIPE
         // the eight window loads are the oldest vector-memory operations in flight: at most the eight prefetch loads
         // (and the ticket draw) are younger, so vmcnt(8) has them home without draining the prefetch
-        if (s + 1 < se)
-            asm volatile("s_waitcnt vmcnt(8)"
-                         : "+v"(wu[0]), "+v"(wu[1]), "+v"(wu[2]), "+v"(wu[3]), "+v"(wu[4]), "+v"(wu[5]), "+v"(wu[6]), "+v"(wu[7]));
-        else
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(wu[0]), "+v"(wu[1]), "+v"(wu[2]), "+v"(wu[3]), "+v"(wu[4]), "+v"(wu[5]), "+v"(wu[6]), "+v"(wu[7]));
+        asm volatile("s_waitcnt vmcnt(8)"
+                     : "+v"(wu[0]), "+v"(wu[1]), "+v"(wu[2]), "+v"(wu[3]), "+v"(wu[4]), "+v"(wu[5]), "+v"(wu[6]), "+v"(wu[7]));
 #pragma unroll
         for (int a = 0; a < 8; ++a) v[a] = make_float2((v[a].x - mean.x) * win[a], (v[a].y - mean.y) * win[a]);
 #pragma unroll

@@ -170,6 +170,30 @@ def test_launch_recipes_table():
     assert fields(nfft=4096, nperseg=4096, noverlap=2048, nseg=20000, nstreams=100)['sched'] == 'interleaved'
 
 
+def test_no_instruction_reads_a_register_whose_load_is_in_flight():
+    """The one-exchange kernels issue sample / window / exchange loads from inline asm and wait for them with explicit
+    s_waitcnt statements.  The compiler takes a register for valid from the asm that loads it: a copy it makes in front
+    of the wait (a register shuffle at a loop edge, the input of an in-out operand) or an instruction it moves across a
+    wait that does not name the register reads a register whose load may still be in flight - garbage, depending on
+    timing.  Late in round 5 exactly that was found in the shipped 16384 / 8192 builds (the role-split 8192 kernel's
+    first build failed outright; the others had only ever been lucky).  tools/isa_async_hazard.py disassembles every
+    code object of the built library, follows every load to the wait that covers it along every path, and reports
+    anything that touches its destination before: there must be nothing."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import isa_async_hazard
+    from ofdm_tools import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        pytest.skip('library not built yet')
+    found, n = [], 0
+    for kname, ins, labels in isa_async_hazard.objdump_kernels(_hip.LIB_PATH):
+        if kname.startswith('_Z'):
+            n += 1
+            isa_async_hazard.walk(ins, labels, kname, found)
+    assert n > 150, n
+    assert not found, sorted(set((k[-50:], t) for k, t, _ in found))[:5]
+
+
 def test_hot_kernels_have_no_scratch():
     """A spilled register comes back at memory latency in every step (12 % of the two-channel kernel in round
     2; round 4's verdict found 2-25 spilled VGPRs in five default builds).  The code objects inside the shipped library
