@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(1024, 4) void welch8kws_kernel(WelchArgs p) {
 
     if (role == 0) {
         // ---------------------------------------------------------------------------------------------- producer
-        const float2 a1 = p.tw[t], a4 = p.tw[4 * t];
+        const Pow6x a6 = pow6_load(p.tw, t);      // W^1,2,3,4,8,12 of this thread: nine products per segment instead of thirteen
         float2 keep[8];
         f2v nxt[8];
         const unsigned voff = 8u * t;
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(1024, 4) void welch8kws_kernel(WelchArgs p) {
             dft16(v);                                              // pass 1: r -> k0
             prio_latency();
             prefetch(4);
-            scatter_pow16_exa<NW>(v, wa, a1, a4);                  // x W_N^(k0 t) -> [k0][w][l] of this image
+            twiddle6_exa<NW>(v, wa, a6);                           // x W_N^(k0 t) -> [k0][w][l] of this image
             prefetch(6);
             lds_barrier();
         }
@@ -1131,6 +1131,11 @@ __global__ __launch_bounds__(1024, 4) void welch8kws_kernel(WelchArgs p) {
         float acc[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        // the pass-2 twiddles W_1024^(k1 l) of this lane stay in registers (the one-role kernel reads them from the LDS
+        // table every step: it has no registers left, this role has)
+        float2 tw2[16];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tw2[k] = tabB[64 * k + l];
         for (int s = s0; s < s1; ++s) {
             lds_barrier();      // image (s - s0) & 1 and its sums are complete
             const int par = (s - s0) & 1;
@@ -1140,14 +1145,15 @@ __global__ __launch_bounds__(1024, 4) void welch8kws_kernel(WelchArgs p) {
             const float2 *rb = im + XREG * wv + XROW * g + q;
             float2 v[16];
             prio_latency();
-            TwBatch ta;
-            pass2_from_lds<NW>(v, ra, [] { prio_compute(); }, [&] { tw_read_a<64>(ta, tabB + l); });     // pass 2
+            pass2_from_lds<NW>(v, ra, [] { __builtin_amdgcn_s_setprio(1); }, [] {});     // pass 2 (above the producers' butterflies)
             prio_latency();
             wave_lds_sync();
-            twiddle_table16<64, XROW, true, NW>(v, wb, tabB + l, ta);
+            wb[0] = v[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) wb[XROW * k] = cmul(v[p2reg<NW>(k)], tw2[k]);
             wave_lds_sync();
             TwBatch tc;
-            dft16_from_lds<4>(v, rb, [] { prio_compute(); }, [&] { tw_read_a<4>(tc, tabC + q); });        // pass 3
+            dft16_from_lds<4>(v, rb, [] { __builtin_amdgcn_s_setprio(1); }, [&] { tw_read_a<4>(tc, tabC + q); });        // pass 3
             const float4 qk = quadK[q];
             twiddle_table16<4, 1, false>(v, nullptr, tabC + q, tc);
             quad_dft4_dpp(v, qk.x, qk.y, qk.z, qk.w);              // pass 4
