@@ -756,6 +756,74 @@ def test_welch8192_role_split_variant_against_the_oracle(ctx, hip):
     assert ':ws' not in plan.last_recipe()
 
 
+def test_results_do_not_depend_on_timing_under_a_bandwidth_hog(ctx, hip):
+    """A register read in front of the wait for its load gives the right answer as long as the load happens to be back -
+    the latent kind of bug tools/isa_async_hazard.py looks for statically.  This is the dynamic side: every tuned build
+    with a static (bit-reproducible) schedule is run alone, then again and again while a second context streams 8 GiB
+    reads over the same HBM from another stream, which stretches every load's latency; the results must be IDENTICAL bit
+    for bit (Welch / two-channel sums) resp. row for row (fused chain)."""
+    import threading
+    n = 1 << 24
+    d = ctx.alloc((n + 5) * 8)
+    rows_d = 0
+    hog = hip.Context(0)
+    hog_bytes = 8 << 30
+    hog_buf = hog.alloc(hog_bytes)
+    try:
+        ctx.synth_iq(d, n + 5, 4242, R.TONES, R.DC)
+        cases = []
+        for nfft in (256, 512, 1024, 2048, 4096, 8192, 16384):
+            for det in (hip.DETREND_CONSTANT, hip.DETREND_CONSTANT_FAST, hip.DETREND_NONE):
+                cases.append(('welch %d det %d' % (nfft, det), dict(nfft=nfft, window=hann(nfft), detrend=det), None))
+        cases.append(('welch 8192 role-split', dict(nfft=8192, window=hann(8192)), '8kws'))
+        cases.append(('welch 4096 pipe', dict(nfft=4096, window=hann(4096)), 'pipe'))
+        cases.append(('welch 4096 zero-padded', dict(nfft=4096, nperseg=1024, window=flattop(1024)), None))
+        for nfft in (8192, 16384):      # the scanner's vectors: no overlap, rectangular
+            cases.append(('scan %d' % nfft, dict(nfft=nfft, noverlap=0, window=None, detrend=hip.DETREND_NONE,
+                                                 scaling=hip.SCALE_OVER_N2), None))
+        plans = []
+        for name, kw, variant in cases:
+            plan = ctx.welch_plan(fs=1.0, kernel=hip.KERNEL_TUNED, **kw)
+            plan.set_schedule(hip.SCHED_CONTIGUOUS)
+            if variant:
+                try:
+                    plan.set_tuning(variant)
+                except hip.HipError:      # (an A/B library of an earlier commit, tools/ab_*.sh)
+                    continue
+            plans.append((name, plan, lambda p=plan: p.exec_device_src(d, n)))
+        csd = ctx.welch_plan(4096, window=hann(4096), fs=1.0, kernel=hip.KERNEL_TUNED)
+        csd.set_schedule(hip.SCHED_CONTIGUOUS)
+        plans.append(('csd 4096', csd, lambda: np.concatenate([np.asarray(v).view(np.float32).ravel()
+                                                             for v in csd.csd_device_src(d + 40, d, n)])))
+        chains = []
+        for nfft in (1024, 4096, 8192, 16384):
+            ch = ctx.chain(nfft, None, True, hip.EPI_MAG2, 64)
+            chains.append(ch)
+            plans.append(('chain %d' % nfft, ch, lambda c=ch: c.push(ctx.d2h(d, (1 << 20,), np.complex64), 4)[0].ravel()))
+        quiet = [run().copy() for _, _, run in plans]
+        stop = threading.Event()
+
+        def stream_reads():
+            while not stop.is_set():
+                hog.stream_read_probe(hog_buf, hog_bytes, 4)
+        th = threading.Thread(target=stream_reads, daemon=True)
+        th.start()
+        try:
+            for rep in range(10):
+                for (name, _, run), want in zip(plans, quiet):
+                    got = run()
+                    assert got.tobytes() == want.tobytes(), (name, rep, float(np.max(np.abs(got - want) / np.abs(want))))
+        finally:
+            stop.set()
+            th.join(60)
+        for _, plan, _ in plans:
+            plan.close()
+    finally:
+        ctx.free(d)
+        hog.free(hog_buf)
+        hog.close()
+
+
 def test_one_launch_over_16_GiB_sample_offsets_beyond_2_31(ctx, hip):
     """A stream of 2^31 + 2^22 samples (16 GiB) in ONE launch: sample indices pass 2^31 and byte offsets 2^34 inside the
     kernels.  The last 2^22 samples carry a tone 30 dB above everything before them, so a segment fetched from a wrapped
