@@ -800,7 +800,13 @@ def test_results_do_not_depend_on_timing_under_a_bandwidth_hog(ctx, hip):
             ch = ctx.chain(nfft, None, True, hip.EPI_MAG2, 64)
             chains.append(ch)
             plans.append(('chain %d' % nfft, ch, lambda c=ch: c.push(ctx.d2h(d, (1 << 20,), np.complex64), 4)[0].ravel()))
+        # the default (ticket) schedules: the summation order follows the timing, the values may move by rounding only
+        loose = []
+        for nfft in (1024, 2048, 4096):
+            plan = ctx.welch_plan(nfft, window=hann(nfft), fs=1.0, kernel=hip.KERNEL_TUNED)
+            loose.append(('welch %d default schedule' % nfft, plan, lambda p=plan: p.exec_device_src(d, n)))
         quiet = [run().copy() for _, _, run in plans]
+        quiet_loose = [run().astype(np.float64) for _, _, run in loose]
         stop = threading.Event()
 
         def stream_reads():
@@ -813,10 +819,12 @@ def test_results_do_not_depend_on_timing_under_a_bandwidth_hog(ctx, hip):
                 for (name, _, run), want in zip(plans, quiet):
                     got = run()
                     assert got.tobytes() == want.tobytes(), (name, rep, float(np.max(np.abs(got - want) / np.abs(want))))
+                for (name, _, run), want in zip(loose, quiet_loose):
+                    assert relerr(run(), want) < 5e-6, (name, rep)
         finally:
             stop.set()
             th.join(60)
-        for _, plan, _ in plans:
+        for _, plan, _ in plans + loose:
             plan.close()
     finally:
         ctx.free(d)
