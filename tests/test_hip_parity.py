@@ -832,6 +832,57 @@ def test_results_do_not_depend_on_timing_under_a_bandwidth_hog(ctx, hip):
         hog.close()
 
 
+def test_two_contexts_in_two_threads_agree_with_the_serial_run(hip):
+    """include/ofdm_tools_hip.h: a context is used from one thread at a time, DIFFERENT contexts from different threads
+    freely (no global mutable state in the library).  Two host threads, each with its own context, stream and plans
+    (one- and two-channel Welch at several sizes, the fused chain, the decision stage), run the same work first one
+    after the other and then at the same time: static schedules, so every result must be identical bit for bit."""
+    import threading
+    n = 1 << 22
+
+    def work(seed, out, rounds):
+        c = hip.Context(0)
+        d = c.alloc((n + 5) * 8)
+        try:
+            c.synth_iq(d, n + 5, seed, R.TONES, R.DC)
+            plans = []
+            for nfft in (256, 1024, 4096, 16384):
+                p = c.welch_plan(nfft, window=hann(nfft), fs=1.0, kernel=hip.KERNEL_TUNED)
+                p.set_schedule(hip.SCHED_CONTIGUOUS)
+                plans.append(p)
+            ch = c.chain(2048, None, True, hip.EPI_MAG2, 16)
+            x = c.d2h(d, (1 << 18,), np.complex64)
+            for _ in range(rounds):
+                res = [p.exec_device_src(d, n).copy() for p in plans]
+                res.append(np.concatenate([np.asarray(v).view(np.float32).ravel() for v in plans[2].csd_device_src(d + 40, d, n)]))
+                res.append(ch.push(x, 4)[0].ravel().copy())
+                pw, ma = c.channel_power(res[2], 25.0, [0, 100, 2000], [50, 300, 4096], want_movavg=True)
+                res.append(np.asarray(ma).ravel().copy())
+                res.append(np.asarray(pw).ravel().copy())
+                out.append(res)
+            for p in plans:
+                p.close()
+        finally:
+            c.free(d)
+            c.close()
+
+    serial = {7: [], 8: []}
+    for seed in serial:
+        work(seed, serial[seed], 1)
+    both = {7: [], 8: []}
+    threads = [threading.Thread(target=work, args=(seed, both[seed], 4)) for seed in both]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+        assert not t.is_alive()
+    for seed in serial:
+        assert len(both[seed]) == 4
+        for res in both[seed]:
+            for a, b in zip(res, serial[seed][0]):
+                assert a.tobytes() == b.tobytes(), seed
+
+
 def test_one_launch_over_16_GiB_sample_offsets_beyond_2_31(ctx, hip):
     """A stream of 2^31 + 2^22 samples (16 GiB) in ONE launch: sample indices pass 2^31 and byte offsets 2^34 inside the
     kernels.  The last 2^22 samples carry a tone 30 dB above everything before them, so a segment fetched from a wrapped
