@@ -68,5 +68,38 @@ for it in range(cases):
     if flag or it % 25 == 0:
         print('case %3d nfft %5d nperseg %5d nov %5d %-7s det %d streams %2d nseg %4d sched %2d chunk %2d  err %.1e  %s%s' % (
             it, nfft, nperseg, nov, wname, det, nstreams, nseg, sched, chunk, err, rec.split(' nfft')[0], flag), flush=True)
+# ---- two-channel form: y = the same buffer a few samples in
+for it in range(cases // 4):
+    nfft = int(rng.choice([256, 1024, 2048, 4096, 4096, 8192]))
+    nov = int(rng.choice([0, nfft // 2, nfft // 2, int(rng.integers(0, nfft))]))
+    step = nfft - nov
+    wname = str(rng.choice(['hann', 'flattop', 'hamming']))
+    win = (0.54 - 0.46 * np.cos(2 * np.pi * np.arange(nfft) / (nfft - 1)) if wname == 'hamming' else windows.get_window(wname, nfft))
+    det = int(rng.choice([_hip.DETREND_NONE, _hip.DETREND_CONSTANT, _hip.DETREND_CONSTANT_FAST]))
+    nseg = int(rng.choice([7, 33, 257, 1000, 3000]))
+    n = nfft + step * (nseg - 1) + int(rng.integers(0, step))
+    delay = int(rng.integers(1, 9))
+    if n + delay > cap or nseg * step < 7 * nfft:
+        continue
+    try:
+        a = ctx.welch_plan(nfft, noverlap=nov, window=win, detrend=det, fs=1.0, kernel=_hip.KERNEL_AUTO)
+        b = ctx.welch_plan(nfft, noverlap=nov, window=win, detrend=det, fs=1.0, kernel=_hip.KERNEL_GENERIC)
+        ra = a.csd_device_src(d + 8 * delay, d, n)
+        rec = a.last_recipe()
+        rb = b.csd_device_src(d + 8 * delay, d, n)
+        a.close(), b.close()
+    except _hip.HipError as e:
+        print('csd case %d: %s' % (it, e))
+        bad += 1
+        continue
+    norm = np.sqrt(rb[0].astype(np.float64) * rb[1])
+    errs = [float(np.max(np.abs(ra[0].astype(np.float64) - rb[0]) / rb[0])), float(np.max(np.abs(ra[1].astype(np.float64) - rb[1]) / rb[1])),
+            float(np.max(np.abs(ra[2].astype(np.complex128) - rb[2]) / norm))]
+    flag = '' if max(errs) < 3e-5 else '   <-- MISMATCH'
+    if flag:
+        bad += 1
+    if flag or it % 10 == 0:
+        print('csd %3d nfft %5d nov %5d %-7s det %d nseg %4d delay %d  err %.1e %.1e %.1e  %s%s' % (
+            it, nfft, nov, wname, det, nseg, delay, errs[0], errs[1], errs[2], rec.split(' nfft')[0], flag), flush=True)
 print('%d cases, %d mismatches' % (cases, bad))
 sys.exit(1 if bad else 0)
