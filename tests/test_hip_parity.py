@@ -832,6 +832,40 @@ def test_results_do_not_depend_on_timing_under_a_bandwidth_hog(ctx, hip):
         hog.close()
 
 
+@pytest.mark.parametrize('nfft', [256, 1024, 4096, 8192, 16384])
+def test_chain_random_ragged_pushes_carry_their_state(ctx, hip, nfft):
+    """The streaming state of the fused chain - the samples of a vector split across pushes, the phase of keep_one_in_n,
+    the peak and the filter - over twenty pushes of random length (shorter than a vector, empty, thousands of vectors),
+    for random keep values and both window / shift forms: the number of rows of every push, the mean of ALL rows, the
+    final peak and the last rows against the oracle run once over the concatenated samples."""
+    from ofdm_tools import windows
+    rng = np.random.default_rng(nfft)
+    for trial in range(3):
+        keep = int(rng.choice([1, 2, 3, 7]))
+        shift = bool(rng.integers(0, 2))
+        w = windows.blackmanharris(nfft) if rng.integers(0, 2) else None
+        total = nfft * int(rng.integers(150, 400)) + int(rng.integers(0, nfft))
+        x = R.synth_iq(total, 7000 + nfft + trial)
+        cuts = np.sort(np.r_[0, rng.integers(0, total, 17), rng.integers(0, total, 1).repeat(2), total])      # (one empty push)
+        X = R.gr_fft_vcc(R.gr_kept_vectors(x, nfft, keep), w, shift)
+        want = X.real ** 2 + X.imag ** 2
+        ch = ctx.chain(nfft, w, shift, hip.EPI_MAG2, keep)
+        ch.set_peak_hold(True)
+        got, produced = [], 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            rows, n = ch.push(x[a:b], max_rows=(b - a) // nfft + 2)
+            vectors_so_far = b // nfft
+            assert produced + n == vectors_so_far // keep, (trial, a, b)
+            assert len(rows) == n
+            produced += n
+            got.append(rows)
+        got = np.concatenate(got)
+        assert got.shape == want.shape
+        assert relerr(got.astype(np.float64).mean(axis=0), want.mean(axis=0)) < RTOL
+        assert relerr(ch.peak(), want.max(axis=0)) < RTOL
+        check_single_rows(got[-3:], want[-3:])
+
+
 def test_random_plan_shapes_tuned_route_against_the_coverage_kernel():
     """tools/fuzz_shapes.py: 300 random plans (size, nperseg = nfft, nfft / 2, nfft / 4, any overlap, four windows, three
     detrend modes, 1 ... 64 streams with padded strides, 1 ... 4000 segments, forced schedules and chunk sizes) - whatever
