@@ -32,10 +32,11 @@ for it in range(cases):
     nseg = int(rng.choice([1, 2, 7, 33, 257, 1000, 4000]))
     n = nperseg + step * (nseg - 1) + int(rng.integers(0, step))
     stride = n + int(rng.integers(0, 3)) * 64
-    if stride * nstreams > cap:
-        nstreams = max(1, cap // stride)
-        if stride > cap:
+    if stride * nstreams + 8 > cap:
+        nstreams = max(1, (cap - 8) // stride)
+        if stride + 8 > cap:
             continue
+    base = d + 8 * int(rng.integers(0, 8))      # any sample offset: nothing may assume more than the 8-byte alignment of a sample
     sched = int(rng.choice([-1, -1, _hip.SCHED_CONTIGUOUS, _hip.SCHED_INTERLEAVED, _hip.SCHED_DYNAMIC]))
     chunk = int(rng.choice([0, 0, 1, 2, 3, 5, 8, 16, 32]))
     kw = dict(nperseg=nperseg, noverlap=nov, window=win, detrend=det, fs=1.0)
@@ -46,10 +47,10 @@ for it in range(cases):
             a.set_schedule(sched)
         if chunk:
             a.set_tuning(None, chunk=chunk)
-        ka = a.exec_dev(d, n, out, nstreams=nstreams, stream_stride=stride)
+        ka = a.exec_dev(base, n, out, nstreams=nstreams, stream_stride=stride)
         ga = ctx.d2h(out, (nstreams, nfft), np.float32).astype(np.float64)
         rec = a.last_recipe()
-        kb = b.exec_dev(d, n, out, nstreams=nstreams, stream_stride=stride)
+        kb = b.exec_dev(base, n, out, nstreams=nstreams, stream_stride=stride)
         gb = ctx.d2h(out, (nstreams, nfft), np.float64 if False else np.float32).astype(np.float64)
         a.close(), b.close()
     except _hip.HipError as e:
