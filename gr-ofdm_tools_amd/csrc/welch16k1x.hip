@@ -704,8 +704,58 @@ struct X1ChainEpi {
     int kb;              // bin of register k2: kb + kstride k2
     int kstride, n;      // 256 / 128 (N / 64); N
     size_t row_base;     // stream offset into p->rows, in rows
+    bool halves;         // the epilogue eight bins at a time (the 8-wave build: see take_halves)
+    // Eight bins at a time - value, row store, accumulation - with the lane's place in the row formed at the store: the
+    // 8-wave loop has no registers for sixteen values and a 64-bit lane address next to the transform (84 B of scratch in
+    // the form below; 8 B in this one).  The 16-wave build is 5 % FASTER with the form below and its one spilled
+    // address (profiles/r05_ab_x1_idx32.txt), so each takes its own.
+    __device__ __forceinline__ void take_halves(const float2 (&v)[16], int s) {
+        const SegArgs &a = *p;
+        const int store_from = (int)a.store_from, acc_end = (int)a.acc_end;       // both within [0, nseg]
+        const bool store = s >= store_from, accumulate = s < acc_end;
+        float *row = a.rows + (row_base + (size_t)(s - store_from)) * n;           // launch-uniform
+        float w = 1.0f;
+        if (accumulate && a.acc_mode == 1) {
+            const int kk = acc_end - 1 - s;
+            w = kk == 0 ? 1.0f : exp2f(a.l2 * (float)kk);
+        }
+#pragma unroll
+        for (int h = 0; h < 16; h += 8) {
+            float val[8];
+            if (a.epilogue == 0) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const float2 X = v[r16(h + k2)];
+                    val[k2] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));
+                }
+            } else {
+                const float sc = a.scale;
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const float2 X = v[r16(h + k2)];
+                    val[k2] = fmaf(X.x, X.x, X.y * X.y) * sc;
+                }
+            }
+            if (store) {
+                unsigned k = (unsigned)((kb + (a.fftshift ? n / 2 : 0)) & (n - 1));      // (the shift moves whole quarter rows; a
+                asm volatile("" : "+v"(k));                                             // thread's bins lie inside one)
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) row[k + (unsigned)(kstride * (h + k2))] = val[k2];
+            }
+            if (accumulate) {
+                if (a.acc_mode == 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[h + k] = fmaf(w, val[k], acc[h + k]);
+                } else if (a.acc_mode == 2) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[h + k] = fmaxf(acc[h + k], val[k]);
+                }
+            }
+        }
+    }
     __device__ __forceinline__ void take(const float2 (&v)[16], int s) {
         if (s < 0) return;      // the priming call
+        if (halves) return take_halves(v, s);
         const SegArgs &a = *p;
         float val[16];
         if (a.epilogue == 0) {
@@ -758,6 +808,7 @@ __global__ __launch_bounds__(64 * NW, 4) void chain16k1x_kernel(SegArgs p) {
     epi.kb = NW == 16 ? (tid >> 6) + 16 * c + 4096 * k3 : 2 * (tid >> 6) + (c >> 3) + 16 * (c & 7) + 2048 * k3;
     epi.kstride = N / 64;
     epi.n = N;
+    epi.halves = NW == 8;
     epi.row_base = (size_t)stream * (size_t)(p.nseg - p.store_from);
     const X1Sched sc{(int)p.nseg, (int)p.nbig, p.chunk, p.tail_chunk, p.sched, p.queue ? p.queue + stream : nullptr};
     x1_pipe_body<NW, WINDOW>(p.x + (size_t)stream * p.stream_stride + p.first, p.step, sc, wg, W, p.win, p.tw, lds, epi, nullptr);
