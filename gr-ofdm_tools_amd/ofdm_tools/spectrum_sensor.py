@@ -38,23 +38,13 @@ class spectrum_sensor(sync_block):
                  thr_leveler=10, tune_freq=0, alpha_avg=1, source=None, log=False, ctx=None, log_dir='/tmp',
                  async_scan=False):
         sync_block.__init__(self, 'spectrum_sensor', [np.complex64], None)
-        self.block_length = block_length
-        self.sample_rate = sample_rate
-        self.fft_len = fft_len
-        self.channel_space = channel_space
-        self.search_bw = search_bw
-        self.method = method
-        self.thr_leveler = thr_leveler
-        self.tune_freq = tune_freq
-        self.vector_sample = [0, 0]
-        self.papr = 1e-10
-        self.spectrum_constraint_hz = []
-        self.threshold = 0
-        self.power_level_ch = []
-        self.noise_estimate = 1e-11
-        self.alpha_avg = alpha_avg
-        self.source = source
-        self.log = log
+        # the reference's public attributes (:41-58), under its names
+        self.__dict__.update(block_length=block_length, sample_rate=sample_rate, fft_len=fft_len, channel_space=channel_space,
+                             search_bw=search_bw, method=method, thr_leveler=thr_leveler, tune_freq=tune_freq,
+                             alpha_avg=alpha_avg, source=source, log=log)
+        # state the requests fill in: the last captured block, PAPR, occupied channels, threshold, channel powers, noise
+        self.__dict__.update(vector_sample=[0, 0], papr=1e-10, spectrum_constraint_hz=[], threshold=0, power_level_ch=[],
+                             noise_estimate=1e-11)
         self.log_file = None
         if self.log:                                                                    # :59-62
             self.log_file = _RequestLog(log_dir)
@@ -150,78 +140,41 @@ class spectrum_sensor(sync_block):
         peak = max(measure * np.conjugate(measure))
         self.papr = 10 * np.log10((peak / mean_square).real + 1e-20)
 
-    def get_papr(self):
-        return self.papr
-
-    def get_spectrum_constraint_hz(self):
-        return self.spectrum_constraint_hz
-
-    def get_threshold(self):
-        return self.threshold
-
-    def get_noise_estimate(self):
-        return self.noise_estimate
-
-    def get_alpha_avg(self):
-        return self.alpha_avg
-
-    def get_power_level_ch(self):
-        return self.power_level_ch
-
-    def get_tune_freq(self):
-        return self.tune_freq
-
     def _log_setter(self, field, value):
         """The setters the reference logs (:172-201): ``Time,<HHMMSS>,<field>,<value>``."""
         if self.log:
             self.log_file.row(field, value)
 
-    def set_tune_freq(self, tune_freq):
-        self.tune_freq = tune_freq
-        self._log_setter('set_tune_freq', tune_freq)
 
-    def set_block_length(self, block_length):
-        self.block_length = block_length
+# The reference block's one-line accessors (python/spectrum_sensor.py:153-206) as a table: attribute, whether it has a
+# getter / a setter there, and the field name under which the setter writes a request-log row (None: not logged).
+# set_papr and set_spectrum_constraint_hz above are the two "setters" that compute.
+_ACCESSORS = (
+    ('papr', True, False, None), ('spectrum_constraint_hz', True, False, None), ('threshold', True, False, None),
+    ('noise_estimate', True, False, None), ('power_level_ch', True, False, None),
+    ('alpha_avg', True, True, None), ('vector_sample', True, True, None), ('block_length', False, True, None),
+    ('time_observation', False, True, None), ('fft_len', False, True, None),
+    ('tune_freq', True, True, 'set_tune_freq'), ('sample_rate', True, True, 'set_samp_rate'),
+    ('channel_space', True, True, 'set_channel_space'), ('search_bw', True, True, 'set_search_bw'),
+    ('thr_leveler', True, True, 'set_thr_leveler'),
+)
 
-    def set_time_observation(self, time_observation):                                    # :166-167
-        self.time_observation = time_observation
 
-    def get_sample_rate(self):
-        return self.sample_rate
+def _install_accessors(cls):
+    def getter(name):
+        return lambda self: getattr(self, name)
 
-    def set_sample_rate(self, sample_rate):
-        self.sample_rate = sample_rate
-        self._log_setter('set_samp_rate', sample_rate)
+    def setter(name, field):
+        def set_(self, value):
+            setattr(self, name, value)
+            if field:
+                self._log_setter(field, value)
+        return set_
+    for name, has_get, has_set, field in _ACCESSORS:
+        if has_get:
+            setattr(cls, 'get_' + name, getter(name))
+        if has_set:
+            setattr(cls, 'set_' + name, setter(name, field))
 
-    def set_fft_len(self, fft_len):
-        self.fft_len = fft_len
 
-    def set_channel_space(self, channel_space):
-        self.channel_space = channel_space
-        self._log_setter('set_channel_space', channel_space)
-
-    def get_channel_space(self):
-        return self.channel_space
-
-    def set_search_bw(self, search_bw):
-        self.search_bw = search_bw
-        self._log_setter('set_search_bw', search_bw)
-
-    def get_search_bw(self):
-        return self.search_bw
-
-    def set_thr_leveler(self, thr_leveler):
-        self.thr_leveler = thr_leveler
-        self._log_setter('set_thr_leveler', thr_leveler)
-
-    def get_thr_leveler(self):
-        return self.thr_leveler
-
-    def set_alpha_avg(self, alpha_avg):
-        self.alpha_avg = alpha_avg
-
-    def set_vector_sample(self, v):
-        self.vector_sample = v
-
-    def get_vector_sample(self):
-        return self.vector_sample
+_install_accessors(spectrum_sensor)
