@@ -700,7 +700,7 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
                 // the role-split build at 8192 points walks contiguous runs only (what this shape takes by default)
                 const bool contiguous = (p.tune_sched < 0 && p.sched == OTH_SCHED_DYNAMIC) ||
                                         (p.tune_sched >= 0 ? p.tune_sched : p.sched) == OTH_SCHED_CONTIGUOUS;
-                r.half_ws = p.nfft == 8192 && contiguous && nseg < (1LL << 31) && tv == "8kws";
+                r.half_ws = p.nfft == 8192 && contiguous && nseg < (1LL << 31) && tv != "8k1role";      // ("8k1role": the A/B)
             }
         }
     } else if (want_tuned && seg_size && seg_padded_supported(p.nfft, p.nperseg)) {

@@ -1112,6 +1112,11 @@ __global__ __launch_bounds__(1024, 4) void welch8kws_kernel(WelchArgs p) {
         const unsigned voff = 8u * t;
         const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, blockIdx.y);
         float2 prev_new = make_float2(0.f, 0.f);      // lane 63: this wave's sum of the previous segment's new half
+        // the sixteen window values of this thread stay in registers for the whole run: this role has them (the one-role
+        // kernel reloads them from L2 with every step, and waits for them at the top of it)
+        float wv16[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wv16[r] = p.win[64 * NW * r + t];
         if (s0 < s1) {      // the run's first segment: both halves now
             const char *x0 = reinterpret_cast<const char *>(xb + (long long)s0 * p.step);
             f2v first[8];
@@ -1126,15 +1131,8 @@ __global__ __launch_bounds__(1024, 4) void welch8kws_kernel(WelchArgs p) {
             float2 *wa = lds + par * NW * XREG + t;
             float2 v[16];
             prio_latency();
-            float wv16[16];      // the window from L2, where it is used (load_win)
-            {
-                const char *wbase = reinterpret_cast<const char *>(p.win);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * t, wbase + 256 * NW * r);
-            }
             float2 fresh[8];
             vm_arrive8(fresh, nxt);      // wait + copy out of the loading registers in one statement (see vm_arrive8)
-            vm_arrived_win16(wv16);
             float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
             if (s == s0) {      // the run's first half arrives raw
 #pragma unroll

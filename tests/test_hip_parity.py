@@ -722,8 +722,8 @@ def test_full_size_256M_properties(ctx, hip):
 
 
 def test_welch8192_role_split_variant_against_the_oracle(ctx, hip):
-    """The role-split 8192-point build (csrc/welch16k1x.hip `welch8kws_kernel`, tuning variant "8kws"; not the default -
-    it measured within 2 % of the one-role kernel): producers and consumers one segment apart on two LDS images.  Runs of
+    """The role-split 8192-point build (csrc/welch16k1x.hip `welch8kws_kernel`; the default at 50 % overlap since late
+    round 5, "8k1role" selects the one-role kernel): producers and consumers one segment apart on two LDS images.  Runs of
     one, two, a few and many segments per workgroup, detrend through the pilot / raw / none, a DC offset 30 x the noise -
     against the float64 oracle and against the one-role build."""
     N = 8192
@@ -745,7 +745,9 @@ def test_welch8192_role_split_variant_against_the_oracle(ctx, hip):
             assert e.max() < bound, (nseg, det, e.max(), int(np.argmax(e)))
             if det != hip.DETREND_CONSTANT_FAST:
                 one = ctx.welch_plan(N, window=hann(N), detrend=det, fs=1.0, kernel=hip.KERNEL_TUNED)
+                one.set_tuning('8k1role')
                 assert relerr(got, one.exec(x)) < (2e-5 if nseg >= 8 else 1e-3)      # (few segments: the default is the time-domain form)
+                assert ':ws' not in one.last_recipe()
                 one.close()
             plan.close()
     # a schedule the build does not walk falls back to the one-role kernel
@@ -775,7 +777,8 @@ def test_results_do_not_depend_on_timing_under_a_bandwidth_hog(ctx, hip):
         for nfft in (256, 512, 1024, 2048, 4096, 8192, 16384):
             for det in (hip.DETREND_CONSTANT, hip.DETREND_CONSTANT_FAST, hip.DETREND_NONE):
                 cases.append(('welch %d det %d' % (nfft, det), dict(nfft=nfft, window=hann(nfft), detrend=det), None))
-        cases.append(('welch 8192 role-split', dict(nfft=8192, window=hann(8192)), '8kws'))
+        cases.append(('welch 8192 one-role', dict(nfft=8192, window=hann(8192)), '8k1role'))
+        cases.append(('welch 8192 one-role, detrend none', dict(nfft=8192, window=hann(8192), detrend=hip.DETREND_NONE), '8k1role'))
         cases.append(('welch 4096 pipe', dict(nfft=4096, window=hann(4096)), 'pipe'))
         cases.append(('welch 4096 zero-padded', dict(nfft=4096, nperseg=1024, window=flattop(1024)), None))
         for nfft in (8192, 16384):      # the scanner's vectors: no overlap, rectangular

@@ -8,7 +8,7 @@ set -u
 TAG=$1; shift
 ONLY=" $* "
 for spec in "C2:welch4096ws" "C2fast:welch4096ws" "C3:csd4096ws" "C4:welch4096ws" "C4ref:welch4096_kernel" "C5:welch16k1x_pipe" "C5old:welch16k_kernel" \
-            "scan8192:welch16k1x_pipe" "w256:seg_kernel" "w512:seg_kernel" "w1024:segws_kernel" "w2048:segws_kernel" "w8192:welch16k1x_half" \
+            "scan8192:welch16k1x_pipe" "w256:seg_kernel" "w512:seg_kernel" "w1024:segws_kernel" "w2048:segws_kernel" "w8192:welch8kws" \
             "w16384:welch16k1x_half" "p1024:seg_kernel" "p2048:seg_kernel" "p8192:welch16k" "p16384:welch16k" \
             "chain256:seg_kernel" "chain512:seg_kernel" "chain1024:seg_kernel" "chain2048:seg_kernel" "chain4096:seg_kernel" \
             "chain8192:chain16k" "chain16384:chain16k"; do

@@ -33,7 +33,7 @@ CONFIGS = {
     'w512': ('seg_kernel', 8 * 2 ** 27, 'Welch 512-pt Hann 50 % overlap, 2^27 samples (two 32-thread teams per wave)'),
     'w1024': ('segws_kernel', 8 * 2 ** 27, 'Welch 1024-pt Hann 50 % overlap, 2^27 samples'),
     'w2048': ('segws_kernel', 8 * 2 ** 27, 'Welch 2048-pt Hann 50 % overlap, 2^27 samples'),
-    'w8192': ('welch16k1x_half', 8 * 2 ** 27, 'Welch 8192-pt Hann 50 % overlap, 2^27 samples (welch16k1x_half_kernel<8, 2>, round 5: one cross-wave exchange on 8 waves, two radix-8 butterflies in pass 2, frequency-domain detrend, overlapped half kept in registers, new half prefetched; two transforms per sample)'),
+    'w8192': ('welch8kws', 8 * 2 ** 27, 'Welch 8192-pt Hann 50 % overlap, 2^27 samples (welch8kws_kernel<2, true>, late round 5: the one-exchange transform split into eight producer and eight consumer waves one segment apart, window and pass-2 twiddles in registers, frequency-domain detrend, overlapped half kept in registers, new half prefetched; two transforms per sample)'),
     'scan8192': ('welch16k1x_pipe', 8 * 64 * 2 ** 22, 'the scanner\'s vectors at fft_len 8192: 64 channel streams x 2^22 samples, rect |X|^2/N^2 mean (welch16k1x_pipe_kernel<8>, round 5: the one-exchange pipelined loop on 8 waves, two workgroups per CU)'),
     'w16384': ('welch16k1x_half', 8 * 2 ** 27, 'Welch 16384-pt Hann 50 % overlap + detrend, 2^27 samples (welch16k1x_half_kernel<16, 2>: one cross-wave exchange, frequency-domain detrend, overlapped half kept in registers, new half prefetched, window from L2; two transforms per sample)'),
     'p8192': ('welch16k', 8 * 2 ** 27, 'the sweeper call at fft_len 8192: flattop, nperseg 2048 zero-padded to 8192, step 1024: 8 transforms per 8192 new samples (welch16k_kernel<1, 2, false, PAD>)'),
