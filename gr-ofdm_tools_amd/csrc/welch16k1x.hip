@@ -36,6 +36,9 @@
 #ifndef OTH_X1_PPLACES
 #define OTH_X1_PPLACES 0x22222222u     // the same for the pipelined kernel (places: see its `spread`)
 #endif
+#ifndef OTH_X1H_FAKEWIN
+#define OTH_X1H_FAKEWIN 0
+#endif
 #ifndef OTH_X1H_WIN_EARLY
 #define OTH_X1H_WIN_EARLY 0  // 50 %-overlap kernel, A/B: 1 = the window values of a step are requested at the end of the step before (no gain: 16384 points 0.3874-0.3907 against 0.3855-0.3876 ms, 8192 points 0.3694-0.3753 against 0.3789 ms on the builds without a pilot, and the PILOT builds then spill 16 registers)
 #endif
@@ -927,18 +930,27 @@ __global__ __launch_bounds__(64 * NW, 4) void welch16k1x_half_kernel(WelchArgs p
             prio_latency();
 #if !OTH_X1H_WIN_EARLY
             float wv16[16];      // (declared per step: held across the loop edge they cost the PILOT builds 17 spilled registers)
+#if OTH_X1H_FAKEWIN      // timing experiment only (wrong values): what the window loads and their wait cost
+            float ax = a1.x, ay = a1.y;
+            asm volatile("" : "+v"(ax), "+v"(ay));      // (not loop-invariant to the compiler: no sixteen hoisted registers)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wv16[r] = fmaf(ax, 0.03f * (float)r, 0.5f - ay * 0.01f * (float)r);
+#else
             {
                 const char *wbase = reinterpret_cast<const char *>(p.win);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) load_win(wv16[r], 4u * tid, wbase + 256 * NW * r);
             }
 #endif
+#endif
             // the new half (requested during the step before, or above) and the window values: the new half comes out of
             // its loading registers in the same statement that waits for it (vm_arrive8: it outlives the next loads into
             // them as the kept half, and a copy the compiler makes for that may not stand in front of the wait)
             float2 fresh[8];
             vm_arrive8(fresh, nxt);
+#if !OTH_X1H_FAKEWIN
             vm_arrived_win16(wv16);
+#endif
             float2 sum = make_float2(0.f, 0.f), sumf = make_float2(0.f, 0.f);
             if (s == sb) {      // the chunk's first half arrives raw
 #pragma unroll
