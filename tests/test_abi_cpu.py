@@ -212,6 +212,7 @@ def test_hot_kernels_have_no_scratch():
            'welch4096_kernel<true, 4, true>', 'welch4096_kernel<true, 4, false>',
            'csd4096ws_kernel<true, true>', 'csd4096ws_kernel<true, false>',
            'welch16k1x_pipe_kernel<16, false>', 'welch16k1x_pipe_kernel<8, false>',
+           'welch8kws_kernel<2, true>', 'welch8kws_kernel<2, false>', 'welch8kws_kernel<0, false>',
            'welch16k1x_half_kernel<16, 2, true>', 'welch16k1x_half_kernel<16, 2, false>', 'welch16k1x_half_kernel<16, 0, false>',
            'welch16k1x_half_kernel<8, 2, true>', 'welch16k1x_half_kernel<8, 2, false>', 'welch16k1x_half_kernel<8, 0, false>',
            'segws_kernel<4, 1, true>', 'segws_kernel<8, 2, true>', 'seg_kernel<1, 0, true, false, 3, 16, true>',
