@@ -728,7 +728,8 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
         r.form = after ? 2 : 1;
         r.use_fd1x = r.kern == RK_W16K1X_HALF;
         if (!p.fast_detrend) {
-            const bool can_inline = ((r.kern == RK_W4096 && r.variant->inline_pilot) || r.kern == RK_CSD4096WS) &&
+            const bool can_inline = ((r.kern == RK_W4096 && r.variant->inline_pilot) || r.kern == RK_CSD4096WS ||
+                                     r.kern == RK_W16K1X_HALF) &&
                                     !p.pilot_launch && tv != "plaunch";
             r.pilot = can_inline ? 2 : 1;
         }

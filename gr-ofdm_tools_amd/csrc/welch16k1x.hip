@@ -902,8 +902,21 @@ __global__ __launch_bounds__(64 * NW, 4) void welch16k1x_half_kernel(WelchArgs p
     float2 keep[8];
     f2v nxt[8];
     const unsigned voff = 8u * tid;
-    // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot comes off every sample as it arrives
-    const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, blockIdx.y);
+    // PILOT (every detrending plan but OTH_DETREND_CONSTANT_FAST): WelchArgs.pilot comes off every sample as it arrives.
+    // pilot_inline (late round 5): formed here from the eight 2 KiB probes of fft4096.hip.h by the first four waves - every
+    // workgroup for itself, 16 KiB of L2 traffic each - instead of by pilot_mean_kernel in front of the launch
+    float2 pv = make_float2(0.f, 0.f);
+    if (PILOT && !p.pilot_inline) pv = load_pilot(p.pilot, blockIdx.y);
+    if (PILOT && p.pilot_inline) {
+        float2 *slot = red;      // [8][4] per-wave probe totals; the sums of the first step are written behind barrier below
+        if (wv < 4) {
+            const PilotProbes probes = inline_pilot_load(xb, p.nseg, (int)p.step, tid);
+            inline_pilot_store(probes, tid, slot);
+        }
+        lds_barrier();
+        pv = inline_pilot_value(slot);
+        lds_barrier();           // every wave has read the slots before the first step's sums overwrite them
+    }
     for (long long cur = sched ? wg : 0; cur < nchunks;) {
         long long sb = s0, se = s1;
         if (sched) chunk_range(p, cur, sb, se);
@@ -1064,7 +1077,7 @@ template <int NW, int DET, bool PILOT = false> static hipError_t launch1x_half(c
     return hipGetLastError();
 }
 template <int NW> static hipError_t launch1x_half_n(const WelchArgs &a, hipStream_t s) {
-    if (a.detrend && a.fd) return a.pilot ? launch1x_half<NW, 2, true>(a, s) : launch1x_half<NW, 2>(a, s);
+    if (a.detrend && a.fd) return (a.pilot || a.pilot_inline) ? launch1x_half<NW, 2, true>(a, s) : launch1x_half<NW, 2>(a, s);
     return launch1x_half<NW, 0>(a, s);
 }
 
@@ -1083,7 +1096,7 @@ hipError_t launch_welch_tuned16k1x_half(int nfft, const WelchArgs &a, hipStream_
 // one LDS-only barrier per step; the loads of one role overlap the butterflies of the other by construction.  Two
 // images of 68 KiB + tables: 145 of the CU's 160 KiB.  Contiguous runs of segments only (the schedule this shape takes
 // by default); anything else stays on the one-role kernel.
-constexpr int X8W_RED = 24;      // [2][8] per-wave sums of a segment (both halves), by image parity; 8 spare
+constexpr int X8W_RED = 48;      // [2][8] per-wave sums of a segment (both halves), by image parity; [16..47]: the pilot's probe totals
 constexpr size_t x8ws_lds_bytes() {
     return (2 * 8 * XREG + X8W_RED + 16 * 64 + 16 * 4) * sizeof(float2) + 4 * sizeof(float4);
 }
@@ -1122,7 +1135,17 @@ __global__ __launch_bounds__(1024, 4) void welch8kws_kernel(WelchArgs p) {
         float2 keep[8];
         f2v nxt[8];
         const unsigned voff = 8u * t;
-        const float2 pv = load_pilot(PILOT ? p.pilot : nullptr, blockIdx.y);
+        float2 pv = make_float2(0.f, 0.f);
+        if (PILOT && !p.pilot_inline) pv = load_pilot(p.pilot, blockIdx.y);
+        if (PILOT && p.pilot_inline) {      // the pilot from eight probes, by the first four producer waves (as in the one-role kernel)
+            float2 *slot = red + 16;
+            if (wv < 4) {
+                const PilotProbes probes = inline_pilot_load(xb, p.nseg, (int)p.step, t);
+                inline_pilot_store(probes, t, slot);
+            }
+            lds_barrier();      // (the consumers stand at the same barrier)
+            pv = inline_pilot_value(slot);
+        }
         float2 prev_new = make_float2(0.f, 0.f);      // lane 63: this wave's sum of the previous segment's new half
         // the sixteen window values of this thread stay in registers for the whole run: this role has them (the one-role
         // kernel reloads them from L2 with every step, and waits for them at the top of it)
@@ -1197,6 +1220,7 @@ __global__ __launch_bounds__(1024, 4) void welch8kws_kernel(WelchArgs p) {
         float2 tw2[16];
 #pragma unroll
         for (int k = 1; k < 16; ++k) tw2[k] = tabB[64 * k + l];
+        if (PILOT && p.pilot_inline) lds_barrier();      // the producers' pilot barrier
         for (int s = s0; s < s1; ++s) {
             lds_barrier();      // image (s - s0) & 1 and its sums are complete
             const int par = (s - s0) & 1;
@@ -1255,7 +1279,7 @@ template <int DET, bool PILOT = false> static hipError_t launch8kws(const WelchA
 // 8192 points, step = N / 2, contiguous runs; detrend none, or constant through the frequency-domain form (a.fd)
 hipError_t launch_welch_tuned8kws(const WelchArgs &a, hipStream_t s) {
     if (a.sched != 0 || a.nseg > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (a.detrend && a.fd) return a.pilot ? launch8kws<2, true>(a, s) : launch8kws<2>(a, s);
+    if (a.detrend && a.fd) return (a.pilot || a.pilot_inline) ? launch8kws<2, true>(a, s) : launch8kws<2>(a, s);
     return a.detrend ? hipErrorInvalidValue : launch8kws<0>(a, s);
 }
 
