@@ -886,7 +886,10 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     int rc = ensure(c, &p->d_partial, &p->partial_cap,
                     sizeof(float) * (size_t)nstreams * r.W * r.rows * r.nch * p->nfft + 1024 * (size_t)nstreams * r.W * r.rows);
     p->last_W = r.W * r.rows * nstreams;
-    if (!rc) rc = ensure(c, &p->d_reduce, &p->reduce_cap, sizeof(float) * (size_t)nstreams * kReduceGroups * r.nch * p->nfft);
+    {
+        const int groups = std::max(kReduceGroups, finalize_row_groups(p->nfft, r.W * r.rows, r.nch));
+        if (!rc) rc = ensure(c, &p->d_reduce, &p->reduce_cap, sizeof(float) * (size_t)nstreams * groups * r.nch * p->nfft);
+    }
     if (rc) return rc;
     const float4 *fd_tab = r.form == 2 ? (r.use_fd1x ? p->d_fd1x : p->d_fd) : nullptr;
     // the pilot of every stream (WelchArgs.pilot): from its own launch, or formed in the kernel's prologue

@@ -262,6 +262,14 @@ hipError_t launch_finalize(const FinalizeArgs &a_in, int nstreams, hipStream_t s
         hipLaunchKernelGGL(finalize_l4_kernel, dim3(16, nstreams), dim3(256), 0, s, a);
         return hipGetLastError();
     }
+    if (const int groups = a.scratch ? finalize_row_groups(a.nfft, a.W, a.nch) : 0) {
+        // many short rows: 256 workgroups sum them into `groups` rows first (fixed order inside a group and across groups)
+        const int rpg = (a.W + groups - 1) / groups;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(a.nfft / 256, groups, nstreams), dim3(256), 0, s, a.partial, a.scratch,
+                           a.W, 1, a.nfft, rpg);
+        a.partial = a.scratch;
+        a.W = groups;
+    }
     if (a.nch == 1 && a.W >= 64 && (a.nfft % 16) == 0) {
         // 16 positions per block: 5.2 us for 512 rows of 4096 against 6.8 us with 32 (half as many blocks)
         hipLaunchKernelGGL((finalize_wide_kernel<16, 1>), dim3(a.nfft / 16, nstreams), dim3(256), 0, s, a);

@@ -96,6 +96,14 @@ struct PgramArgs {
 };
 
 constexpr int kReduceGroups = 16;   // row groups of the two-stage partial-sum reduction
+// Many SHORT partial rows (256 ... 1024 points: 2048 ... 12288 teams' rows of 1 ... 4 KiB): the one-launch reduction has
+// nfft / 16 = 16 ... 64 workgroups to read 8-12 MiB with (63 / 33 / 13 us at 256 / 512 / 1024 points, late round 5).
+// There the rows go through `finalize_row_groups(nfft, W)` groups first - enough for 256 workgroups - and the one-launch
+// kernel then takes the group rows.  0: not this shape.
+inline int finalize_row_groups(int nfft, int W, int nch) {
+    if (nch != 1 || nfft > 1024 || (nfft % 256) != 0 || W < 1024) return 0;
+    return 65536 / nfft;      // (nfft / 256) x groups = 256 workgroups: 256 / 128 / 64 groups
+}
 
 struct FinalizeArgs {
     const float *partial;   // [nstreams][W][nch][nfft]
