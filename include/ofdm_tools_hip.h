@@ -182,7 +182,9 @@ int oth_plan_out_len(oth_plan *plan, int *n);
 /* Launch tuning for A/B tools and the parity suite: which build of the 4096-point kernel ("dpp", "pipe", "ws") or
  * of the 256 ... 2048-point kernels ("seg3", "seg4": registers held to 3 / 4 waves per SIMD; NULL or "" = the
  * library's choice), or only the detrend form of the size's default kernel ("fd": after the transform even below 8
- * segments per stream of an OTH_DETREND_CONSTANT_FAST plan; "td": before it at any length), a schedule override (-1 = the plan's), segments per chunk and per tail chunk
+ * segments per stream of an OTH_DETREND_CONSTANT_FAST plan; "td": before it at any length), the one-role kernel at 8192 points /
+ * 50 % overlap instead of the role-split default ("8k1role"), the pilot from its own launch ("plaunch"), a schedule override
+ * (-1 = the plan's), segments per chunk and per tail chunk
  * (0 = default).  The OTH_W4096_VARIANT / _SCHED / _CHUNK / _TAIL environment variables give the initial values
  * and are read once, in oth_welch_plan(). */
 int oth_plan_set_tuning(oth_plan *plan, const char *variant, int sched, int chunk, int tail_chunk);
