@@ -932,6 +932,37 @@ def test_two_contexts_in_two_threads_agree_with_the_serial_run(hip):
                 assert a.tobytes() == b.tobytes(), seed
 
 
+def test_known_answers_independent_of_any_library(ctx, hip):
+    """SURVEY 8c's checks that need no oracle, on the HIP path itself:
+      * a pure tone on bin k0 through the rectangular |X|^2 / N^2 chain puts A^2 into bin k0 and nothing elsewhere;
+      * unit-power white noise has a flat two-sided density 1 / fs (Parseval: the bins sum to the power);
+      * x against itself has magnitude-squared coherence 1 on every bin;
+      * two independent noises have E[Cxy] of the order 1 / (number of averages)."""
+    N, k0, A = 4096, 517, 0.75
+    tone = (A * np.exp(2j * np.pi * k0 * np.arange(8 * N) / N)).astype(np.complex64)
+    ch = ctx.chain(N, None, True, hip.EPI_MAG2_OVER_N2, 1)
+    rows, n = ch.push(tone, 8)
+    assert n == 8
+    for row in rows:
+        assert abs(row[N // 2 + k0] - A * A) < 2e-6 * A * A and (row.astype(np.float64).sum() - row[N // 2 + k0]) < 1e-9
+    rng = np.random.default_rng(77)
+    fs, nseg = 2.0e6, 400
+    n_ = N + (N // 2) * (nseg - 1)
+    x = ((rng.standard_normal(n_) + 1j * rng.standard_normal(n_)) / np.sqrt(2)).astype(np.complex64)
+    y = ((rng.standard_normal(n_) + 1j * rng.standard_normal(n_)) / np.sqrt(2)).astype(np.complex64)
+    plan = ctx.welch_plan(N, window=hann(N), fs=fs, kernel=hip.KERNEL_TUNED)
+    p = plan.exec(x).astype(np.float64)
+    assert abs(p.sum() * fs / N - 1.0) < 0.01                        # Parseval
+    flat = np.delete(p, [0, 1, N - 1]) * fs          # (the constant detrend takes the mean out of bins 0, +-1)
+    assert abs(np.median(flat) - 1.0) < 0.05 and flat.max() < 1.4 and flat.min() > 0.7      # 400 averages, 4096 bins
+    pxx, pyy, pxy, cxy = plan.csd(x, x)
+    assert np.max(np.abs(cxy - 1.0)) < 1e-5 and np.max(np.abs(pxy.imag)) < 1e-6 * np.max(pxx)
+    _, _, _, cxy = plan.csd(x, y)
+    # 400 Hann segments at 50 % overlap are worth about 400 / 1.06 ... 400 / 1.9 independent averages
+    assert 1.0 / nseg < cxy.mean() < 2.5 / nseg, cxy.mean() * nseg
+    plan.close()
+
+
 def test_one_launch_over_16_GiB_sample_offsets_beyond_2_31(ctx, hip):
     """A stream of 2^31 + 2^22 samples (16 GiB) in ONE launch: sample indices pass 2^31 and byte offsets 2^34 inside the
     kernels.  The last 2^22 samples carry a tone 30 dB above everything before them, so a segment fetched from a wrapped
