@@ -54,6 +54,18 @@ struct oth_ctx {
     hipEvent_t bounds_ev = nullptr;    // behind the last upload: the pinned words may be rewritten after it
 };
 
+// Device tables and scratch of the any-length route (fft_any.hip) of one plan / chain
+struct AnyTables {
+    AnyShape sh{};                     // kind ANY_NONE: not in use
+    const float2 *tw = nullptr;        // W_L^k, L entries (the context's table cache owns it)
+    float2 *chirp = nullptr;           // Bluestein c[n] = exp(-i pi n^2 / nfft), nfft entries
+    float2 *midtab = nullptr;          // Bluestein FFT_M(conj c) / M, M entries by natural index
+    float2 *ws = nullptr;              // workspace [channel][segment of the chunk][L]
+    size_t ws_cap = 0;
+    float4 *mean = nullptr;            // [channel][segment of the chunk] hi / lo means
+    size_t mean_cap = 0;
+};
+
 struct oth_plan {
     oth_ctx *ctx = nullptr;
     int nfft = 0, nperseg = 0, noverlap = 0, step = 0, detrend = 0, scaling = 0, fftshift = 0, trim = 0;
@@ -103,6 +115,7 @@ struct oth_plan {
     size_t h_ring_cap[4] = {0, 0, 0, 0};
     hipEvent_t h_ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned h_ring_next = 0;
+    AnyTables any;                     // any.sh.kind != ANY_NONE: the plan's length runs through fft_any.hip
 };
 
 struct oth_chain {
@@ -140,6 +153,7 @@ struct oth_chain {
     uint64_t ticket_of[kRing] = {0, 0, 0, 0};
     uint64_t nrows_of[kRing] = {0, 0, 0, 0};
     uint64_t next_ticket = 1;
+    AnyTables any;                     // any.sh.kind != ANY_NONE: the chain's length runs through fft_any.hip
 };
 
 namespace {
@@ -548,6 +562,246 @@ int segments(const oth_plan *p, size_t nsamples, long long *nseg) {
     return OTH_OK;
 }
 
+// ---- the any-length route (fft_any.hip, round 6) -----------------------------------------------------------------------
+// Lengths the power-of-two kernels do not take: any_describe() picks direct / two-level / Bluestein; the tables below are
+// built once per plan or chain, any_run() drives the launches of one averaging (or periodogram-row) request.
+void host_fft_pow2(std::vector<double> &re, std::vector<double> &im) {      // in place, forward, n a power of two
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(re[i], re[j]);
+            std::swap(im[i], im[j]);
+        }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / (double)len;
+        for (size_t j = 0; j < len / 2; ++j) {
+            const double c = cos(ang * (double)j), sn = sin(ang * (double)j);
+            for (size_t i = j; i < n; i += len) {
+                const size_t b = i + len / 2;
+                const double tr = re[b] * c - im[b] * sn, ti = re[b] * sn + im[b] * c;
+                re[b] = re[i] - tr;
+                im[b] = im[i] - ti;
+                re[i] += tr;
+                im[i] += ti;
+            }
+        }
+    }
+}
+
+void any_tables_free(AnyTables &t) {
+    if (t.chirp) hipFree(t.chirp);
+    if (t.midtab) hipFree(t.midtab);
+    if (t.ws) hipFree(t.ws);
+    if (t.mean) hipFree(t.mean);
+    t = AnyTables{};
+}
+
+// tables of a length-nfft transform; the caller synchronises the stream before the host vectors die (done here)
+int any_tables_init(oth_ctx *c, int nfft, AnyTables *t) {
+    if (any_describe(nfft, &t->sh))
+        return fail(c, OTH_ERR_UNSUPPORTED, "transform length outside [1, 1048576] (lengths that are not 2-3-5-7-smooth or exceed "
+                                            "16384 without being a power of two run as Bluestein transforms of 2^ceil(log2(2 n - 1)) "
+                                            "<= 1048576 points: n <= 524288)");
+    int rc = get_twiddles(c, t->sh.L, &t->tw);
+    if (rc) return rc;
+    if (t->sh.kind == ANY_BLUESTEIN || t->sh.kind == ANY_BLUESTEIN2) {
+        const int N = nfft, M = t->sh.L;
+        std::vector<float2> ch(N), mt(M);
+        std::vector<double> bre(M, 0.0), bim(M, 0.0);
+        for (int n = 0; n < N; ++n) {
+            const long long q = ((long long)n * (long long)n) % (2LL * N);      // the chirp's phase, reduced exactly
+            const double a = M_PI * (double)q / (double)N;
+            ch[n] = make_float2((float)cos(a), (float)-sin(a));                  // c[n] = exp(-i pi n^2 / N)
+            bre[n] = cos(a);                                                     // b[n] = conj(c[n]), b[M - n] = b[n]
+            bim[n] = sin(a);
+            if (n) {
+                bre[M - n] = bre[n];
+                bim[M - n] = bim[n];
+            }
+        }
+        host_fft_pow2(bre, bim);
+        for (int k = 0; k < M; ++k) mt[k] = make_float2((float)(bre[k] / M), (float)(bim[k] / M));
+        hipError_t e = hipMalloc(&t->chirp, sizeof(float2) * N);
+        if (e == hipSuccess) e = hipMalloc(&t->midtab, sizeof(float2) * M);
+        if (e == hipSuccess) e = hipMemcpyAsync(t->chirp, ch.data(), sizeof(float2) * N, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(t->midtab, mt.data(), sizeof(float2) * M, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            any_tables_free(*t);
+            return fail(c, OTH_ERR_HIP, std::string("any-length tables: ") + hipGetErrorString(e));
+        }
+    }
+    return OTH_OK;
+}
+
+// partial rows (per stream) an averaging launch of this shape leaves; pure host logic (the recipe text carries it)
+int any_partial_rows(const AnyShape &sh, long long nseg, int cu_count) {
+    long long w;
+    if (sh.kind == ANY_DIRECT || sh.kind == ANY_BLUESTEIN) {
+        long long occ = 65536 / ((long long)sh.L * 8);      // workgroups per CU by LDS footprint
+        occ = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
+        w = (long long)cu_count * occ;
+    } else {
+        w = 32;
+    }
+    if (w > nseg) w = nseg;
+    if (w > 65535) w = 65535;
+    return (int)(w < 1 ? 1 : w);
+}
+
+constexpr size_t kAnyWsBytes = 64u << 20;      // workspace of a chunk: it and the chunk's samples stay in the Infinity Cache
+constexpr int kAnyRowTile = 16;                // rows of L2 points a K2 workgroup transforms together
+
+// nseg segments starting at x[first + s seg_step] (nperseg samples, window win, optional constant detrend) -> either the
+// W x nch partial rows of |X|^2 (cross) sums (rows == nullptr; layout 0, or 6 = [k1][k2] for the two-level route), or one
+// periodogram row per segment (rows != nullptr: epilogue / scale / fftshift as PgramArgs).  nbins = t.sh.nfft.
+int any_run(oth_ctx *c, AnyTables &t, const float2 *x, const float2 *y, long long first, long long seg_step, int nperseg,
+            const float *win, bool detrend, long long nseg, float *partial, int W, float *rows, int epilogue, float scale,
+            int fftshift) {
+    const AnyShape &sh = t.sh;
+    const int nch = y ? 2 : 1, N = sh.nfft, L = sh.L;
+    const bool two = sh.kind == ANY_TWOLEVEL || sh.kind == ANY_BLUESTEIN2, blu = sh.kind == ANY_BLUESTEIN || sh.kind == ANY_BLUESTEIN2;
+    const int acc_store = y ? 2 : 1;
+    long long B = two ? (long long)(kAnyWsBytes / (sizeof(float2) * (size_t)L * nch)) : (1LL << 20);
+    if (B < 1) B = 1;
+    if (B > nseg) B = nseg;
+    int rc;
+    if (two && (rc = ensure(c, &t.ws, &t.ws_cap, sizeof(float2) * (size_t)L * nch * (size_t)B))) return rc;
+    if (detrend && (rc = ensure(c, &t.mean, &t.mean_cap, sizeof(float4) * nch * (size_t)B))) return rc;
+    AnyFftDesc d_one{}, d_col{}, d_row{};
+    if (two) {
+        any_make_desc(sh.L1, sh.C, t.tw, L, &d_col);
+        any_make_desc(sh.L2, kAnyRowTile, t.tw, L, &d_row);
+    } else {
+        any_make_desc(L, 1, t.tw, L, &d_one);
+    }
+    for (long long s0 = 0; s0 < nseg; s0 += B) {
+        const long long nb = nseg - s0 < B ? nseg - s0 : B;
+        const long long cfirst = first + s0 * seg_step;
+        if (detrend) HIPCHK(c, launch_any_mean(x, y, cfirst, seg_step, nperseg, nb, t.mean, (size_t)B, c->stream));
+        AnyArgs a{};
+        // what every launch of the chunk shares
+        a.nseg = nb;
+        a.x = x;
+        a.y = y;
+        a.first = cfirst;
+        a.seg_step = seg_step;
+        a.nperseg = nperseg;
+        a.win = win;
+        a.mean = detrend ? t.mean : nullptr;
+        a.mean_ch_stride = (size_t)B;
+        a.ws = t.ws;
+        a.ws_seg_stride = (size_t)L;
+        a.ws_ch_stride = (size_t)L * (size_t)B;
+        a.midtab = t.midtab;
+        a.partial = partial;
+        a.nbins = N;
+        a.first_chunk = s0 == 0;
+        a.conj_out = blu ? 1 : 0;
+        a.rows = rows ? rows + (size_t)s0 * N : nullptr;
+        a.epilogue = epilogue;
+        a.scale = scale;
+        a.fftshift = fftshift;
+        const int gy_rows = (int)(nb < 65535 ? nb : 65535);
+        if (!two) {
+            // one launch: a workgroup per segment (rows W of the partial buffer), nothing leaves LDS
+            a.f = d_one;
+            a.es = 1, a.tile_stride = 0, a.cs = 1, a.inv_n = 1.0f / (float)L;
+            a.load_op = 1;
+            a.chirp = blu ? t.chirp : nullptr;
+            a.mid_op = blu ? 1 : 0;
+            a.nat_i = 1, a.pp_i = 1;
+            HIPCHK(c, launch_any_fft(a, 1, rows ? gy_rows : W, 1, rows ? 3 : acc_store, c->stream));
+            continue;
+        }
+        // K1: tiles of C columns (stride L2) of every segment, transform along L1, x W_L^(k1 n2), into the workspace
+        AnyArgs k1 = a;
+        k1.f = d_col;
+        k1.es = sh.L2, k1.tile_stride = sh.C, k1.cs = 1, k1.inv_n = 1.0f / (float)sh.L1;
+        k1.load_op = 1;
+        k1.chirp = blu ? t.chirp : nullptr;
+        k1.twbig = t.tw;
+        k1.tw_t = sh.C, k1.tw_c = 1;
+        HIPCHK(c, launch_any_fft(k1, sh.L2 / sh.C, gy_rows, nch, 0, c->stream));
+        // K2: tiles of kAnyRowTile rows k1 (L2 contiguous points each), transform along L2: bins k1 + L1 k2
+        AnyArgs k2 = a;
+        k2.f = d_row;
+        k2.es = 1, k2.tile_stride = kAnyRowTile * sh.L2, k2.cs = sh.L2, k2.inv_n = 1.0f / (float)sh.L2;
+        k2.load_op = 0;
+        k2.nat_i = sh.L1, k2.nat_t = kAnyRowTile, k2.nat_c = 1;
+        if (!blu) {
+            k2.pp_i = 1, k2.pp_t = kAnyRowTile * sh.L2, k2.pp_c = sh.L2;      // partial rows in [k1][k2] order (finalize layout 6)
+            HIPCHK(c, launch_any_fft(k2, sh.L1 / kAnyRowTile, rows ? gy_rows : W, 1, rows ? 3 : acc_store, c->stream));
+            continue;
+        }
+        // Bluestein: K2 = row transform, x B / M, conj, row transform, x W_L^(n2 k1), in place ...
+        k2.mid_op = 1;
+        k2.twbig = t.tw;
+        k2.tw_t = kAnyRowTile, k2.tw_c = 1;
+        HIPCHK(c, launch_any_fft(k2, sh.L1 / kAnyRowTile, gy_rows, nch, 0, c->stream));
+        // ... K3 = column transform along L1 -> natural order n1 L2 + n2; the first nfft outputs are (conj of) X
+        AnyArgs k3 = a;
+        k3.f = d_col;
+        k3.es = sh.L2, k3.tile_stride = sh.C, k3.cs = 1, k3.inv_n = 1.0f / (float)sh.L1;
+        k3.load_op = 0;
+        k3.nat_i = sh.L2, k3.nat_t = sh.C, k3.nat_c = 1;
+        k3.pp_i = sh.L2, k3.pp_t = sh.C, k3.pp_c = 1;
+        HIPCHK(c, launch_any_fft(k3, sh.L2 / sh.C, rows ? gy_rows : W, 1, rows ? 3 : acc_store, c->stream));
+    }
+    return OTH_OK;
+}
+
+// Forward transform of ONE length-L vector, natural order in and out, in place in `data` (L points); L is a power of two
+// or smooth (kind ANY_DIRECT / ANY_TWOLEVEL of `sh`); tmp: L points (the two-level route's reordering).
+int any_fft_nat_inner(oth_ctx *c, const AnyShape &sh, const float2 *tw, float2 *data, float2 *tmp) {
+    AnyArgs a{};
+    a.nseg = 1;
+    a.ws = data;
+    a.load_op = 0;
+    if (sh.kind == ANY_DIRECT) {
+        any_make_desc(sh.L, 1, tw, sh.L, &a.f);
+        a.es = 1, a.cs = 1, a.inv_n = 1.0f / (float)sh.L;
+        HIPCHK(c, launch_any_fft(a, 1, 1, 1, 0, c->stream));
+        return OTH_OK;
+    }
+    AnyArgs k1 = a;
+    any_make_desc(sh.L1, sh.C, tw, sh.L, &k1.f);
+    k1.es = sh.L2, k1.tile_stride = sh.C, k1.cs = 1, k1.inv_n = 1.0f / (float)sh.L1;
+    k1.twbig = tw;
+    k1.tw_t = sh.C, k1.tw_c = 1;
+    HIPCHK(c, launch_any_fft(k1, sh.L2 / sh.C, 1, 1, 0, c->stream));
+    AnyArgs k2 = a;
+    any_make_desc(sh.L2, kAnyRowTile, tw, sh.L, &k2.f);
+    k2.es = 1, k2.tile_stride = kAnyRowTile * sh.L2, k2.cs = sh.L2, k2.inv_n = 1.0f / (float)sh.L2;
+    HIPCHK(c, launch_any_fft(k2, sh.L1 / kAnyRowTile, 1, 1, 0, c->stream));
+    HIPCHK(c, launch_any_ew(3, tmp, data, nullptr, nullptr, sh.L, sh.L, sh.L1, sh.L2, c->stream));      // [k1][k2] -> k1 + L1 k2
+    HIPCHK(c, hipMemcpyAsync(data, tmp, sizeof(float2) * (size_t)sh.L, hipMemcpyDeviceToDevice, c->stream));
+    return OTH_OK;
+}
+
+// points of scratch any_fft_nat() needs behind the data
+size_t any_fft_nat_scratch(const AnyShape &sh) { return 2 * (size_t)sh.L; }
+
+// np.fft.fft of one length-nfft vector in `data` (natural order, in place) for every route; scratch as above
+int any_fft_nat(oth_ctx *c, const AnyTables &t, float2 *data, float2 *scratch) {
+    const AnyShape &sh = t.sh;
+    if (sh.kind == ANY_DIRECT || sh.kind == ANY_TWOLEVEL) return any_fft_nat_inner(c, sh, t.tw, data, scratch);
+    AnyShape in{};
+    if (any_describe(sh.L, &in)) return fail(c, OTH_ERR_INTERNAL, "Bluestein length has no route");
+    float2 *A = scratch, *tmp = scratch + sh.L;
+    int rc;
+    HIPCHK(c, launch_any_ew(0, A, data, nullptr, t.chirp, sh.L, sh.nfft, 0, 0, c->stream));      // a = x c, zero padded to M
+    if ((rc = any_fft_nat_inner(c, in, t.tw, A, tmp))) return rc;
+    HIPCHK(c, launch_any_ew(1, A, A, nullptr, t.midtab, sh.L, sh.L, 0, 0, c->stream));            // conj(A B / M)
+    if ((rc = any_fft_nat_inner(c, in, t.tw, A, tmp))) return rc;
+    HIPCHK(c, launch_any_ew(2, data, A, nullptr, t.chirp, sh.nfft, sh.nfft, 0, 0, c->stream));    // X = conj(.) c
+    return OTH_OK;
+}
+
 // ---- routing as data (round 5) ---------------------------------------------------------------------------------------
 // Which kernel build runs a launch, with which detrend form, pilot, schedule, chunk sizes, grid and partial-row layout,
 // is decided by resolve_recipe() from the plan's shape and the launch's segment count - pure host logic, no HIP call, so
@@ -564,9 +818,11 @@ enum RecipeKernel {
     RK_SEG,              // seg_kernel<R, ...>
     RK_SEGWS,            // segws_kernel<R, DET>
     RK_SEGPAD,           // seg_kernel<R, ..., NA> zero-padded
+    RK_ANY,              // any_fft_kernel launches (fft_any.hip): lengths the kernels above do not take
 };
 const char *const kRecipeKernelName[] = {"welch_generic", "welch4096", "csd4096", "csd4096ws", "welch16k", "welch16k1x",
-                                         "welch16k1x_half", "seg", "segws", "seg_padded"};
+                                         "welch16k1x_half", "seg", "segws", "seg_padded", "anyfft"};
+const char *const kAnyKindName[] = {"none", "direct", "twolevel", "bluestein", "bluestein2"};
 
 // what resolve_recipe() needs to know of a plan (oth_plan holds the same fields; the debug entry builds one by hand)
 struct PlanShape {
@@ -579,6 +835,7 @@ struct PlanShape {
     bool pilot_launch = false;
     std::string tune_variant;
     int tune_sched = -1, tune_chunk = 0, tune_tail = 0;
+    AnyShape any{};              // kind != ANY_NONE: the any-length route
 };
 
 // resident workgroups (teams) per CU of a tuned build: the runtime asks the occupancy calculator (needs a device), the
@@ -637,6 +894,7 @@ struct LaunchRecipe {
     long long nbig = 0, nseg_run = 0;
     bool tickets = false;        // draws chunk tickets from the context's queue
     bool two_runs = false;       // "ws2": the stream cut into two runs of segments
+    int any_kind = 0;            // RK_ANY: AnyKind
 };
 
 int generic_wg_for(int cu_count, int nfft, long long nseg, int nstreams) {
@@ -658,6 +916,22 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
     LaunchRecipe r;
     r.csd = csd;
     r.nch = csd ? 4 : 1;
+    if (p.any.kind != ANY_NONE) {
+        // lengths outside the power-of-two kernels: detrend in the time domain from each segment's own mean (no pilot),
+        // contiguous strided rows of segments, partial rows in natural order (two-level: [k1][k2], finalize layout 6)
+        if (p.kernel == OTH_KERNEL_TUNED) {
+            if (why) *why = "tuned kernel does not cover this plan";
+            return OTH_ERR_UNSUPPORTED;
+        }
+        r.kern = RK_ANY;
+        r.any_kind = p.any.kind;
+        r.form = p.detrend ? 1 : 0;
+        r.W = any_partial_rows(p.any, nseg, cu_count);
+        r.layout = p.any.kind == ANY_TWOLEVEL ? 6 : 0;
+        r.nseg_run = nseg;
+        *out = r;
+        return OTH_OK;
+    }
     const std::string &tv = p.tune_variant;
     const bool want_tuned = p.kernel != OTH_KERNEL_GENERIC;
     const bool half_step = p.step * 2 == p.nperseg;
@@ -843,6 +1117,7 @@ std::string recipe_text(const LaunchRecipe &r, int nfft) {
     if (r.kern == RK_SEGPAD) k += r.seg_kind ? ":full" : ":half";
     if (r.kern == RK_W16K1X) k += std::string(r.x1_plain || r.x1_window ? ":plain" : ":pipe") + (r.x1_window ? ":window" : "");
     if (r.kern == RK_W16K1X_HALF && r.half_ws) k += ":ws";
+    if (r.kern == RK_ANY) k += std::string(":") + kAnyKindName[r.any_kind];
     snprintf(buf, sizeof buf, "kernel=%s nfft=%d form=%s pilot=%s sched=%s chunk=%d tail=%d nbig=%lld bpc=%d W=%d rows=%d nch=%d layout=%d",
              k.c_str(), nfft, kForm[r.form], kPilot[r.pilot], kSched[r.sched], r.chunk, r.tail_chunk, r.nbig, r.bpc, r.W, r.rows,
              r.nch, r.layout);
@@ -866,6 +1141,7 @@ PlanShape shape_of(const oth_plan *p) {
     s.tune_sched = p->tune_sched;
     s.tune_chunk = p->tune_chunk;
     s.tune_tail = p->tune_tail;
+    s.any = p->any.sh;
     return s;
 }
 
@@ -907,7 +1183,15 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         c->queue_clean = false;      // until the finalize launch that follows has re-zeroed them
         c->queue_used = nstreams;
     }
-    if (r.kern == RK_SEG || r.kern == RK_SEGWS || r.kern == RK_SEGPAD) {
+    if (r.kern == RK_ANY) {
+        Timed tm(c);
+        for (int st = 0; st < nstreams; ++st) {
+            rc = any_run(c, p->any, x + (size_t)st * stride, csd ? y + (size_t)st * stride : nullptr, 0, p->step, p->nperseg, p->d_win,
+                         p->detrend != OTH_DETREND_NONE, nseg, p->d_partial + (size_t)st * r.W * r.nch * p->nfft, r.W, nullptr, 0,
+                         1.0f, 0);
+            if (rc) return rc;
+        }
+    } else if (r.kern == RK_SEG || r.kern == RK_SEGWS || r.kern == RK_SEGPAD) {
         SegArgs g{};
         g.x = x;
         g.stream_stride = stride;
@@ -1263,8 +1547,8 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     CtxGuard guard_(c);
     if (!c || !out) return fail(c, OTH_ERR_INVALID, "ctx/out is NULL");
     *out = nullptr;
-    if (!is_pow2(nfft) || !generic_supported(nfft))
-        return fail(c, OTH_ERR_UNSUPPORTED, "nfft must be a power of two in [64, 16384]");
+    if (nfft < 1) return fail(c, OTH_ERR_INVALID, "nfft must be positive");
+    const bool any_route = !generic_supported(nfft);      // not a power of two in [64, 16384]: fft_any.hip
     if (nperseg < 1 || nperseg > nfft) return fail(c, OTH_ERR_INVALID, "need 1 <= nperseg <= nfft");
     if (noverlap < 0 || noverlap >= nperseg) return fail(c, OTH_ERR_INVALID, "need 0 <= noverlap < nperseg");
     if (detrend != OTH_DETREND_NONE && detrend != OTH_DETREND_CONSTANT && detrend != OTH_DETREND_CONSTANT_EXACT &&
@@ -1309,7 +1593,7 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
         case OTH_SCALE_SPECTRUM: p->scale = 1.0 / (s1 * s1); break;
         default: p->scale = 1.0;
     }
-    int rc = get_twiddles(c, nfft, &p->d_tw);
+    int rc = any_route ? any_tables_init(c, nfft, &p->any) : get_twiddles(c, nfft, &p->d_tw);
     if (rc) {
         delete p;
         return rc;
@@ -1363,6 +1647,7 @@ int oth_plan_destroy(oth_plan *p) {
     if (p->d_stage) hipFree(p->d_stage);
     if (p->d_sum) hipFree(p->d_sum);
     if (p->d_stream) hipFree(p->d_stream);
+    any_tables_free(p->any);
     for (int i = 0; i < 4; ++i) {
         if (p->h_ring[i]) hipHostFree(p->h_ring[i]);
         if (p->h_ring_ev[i]) hipEventDestroy(p->h_ring_ev[i]);
@@ -1456,6 +1741,7 @@ static int welch_exec_dev_impl(oth_plan *p, const void *iq_dev, size_t nsamples,
     f.nfft = p->nfft;
     f.nch = 1;
     f.layout = layout;
+    f.l1 = p->any.sh.L1, f.l2 = p->any.sh.L2;
     f.fftshift = p->fftshift;
     f.trim = p->trim;
     f.db = p->db;
@@ -1705,6 +1991,7 @@ int oth_welch_partial_dev(oth_plan *p, const void *iq_dev, size_t nsamples, floa
     f.nfft = p->nfft;
     f.nch = 1;
     f.layout = layout;
+    f.l1 = p->any.sh.L1, f.l2 = p->any.sh.L2;
     f.nout = p->nfft;
     if (int frc = finalize_and_rearm(c, f, 1)) return frc;
     if (nseg_out) *nseg_out = (uint64_t)nseg;
@@ -1793,6 +2080,7 @@ int oth_welch_accumulate(oth_plan *p, const void *iq_host, size_t nsamples) {
     f.nfft = p->nfft;
     f.nch = 1;
     f.layout = layout;
+    f.l1 = p->any.sh.L1, f.l2 = p->any.sh.L2;
     f.nout = p->nfft;
     f.accumulate = 1;
     if (int frc = finalize_and_rearm(c, f, 1)) return frc;
@@ -1859,6 +2147,7 @@ static int csd_run(oth_plan *p, const float2 *dx, const float2 *dy, size_t nsamp
     f.nfft = p->nfft;
     f.nch = 4;
     f.layout = layout;
+    f.l1 = p->any.sh.L1, f.l2 = p->any.sh.L2;
     f.fftshift = raw ? 0 : p->fftshift;
     f.trim = raw ? 0 : p->trim;
     f.nout = raw ? p->nfft : p->nfft - 2 * p->trim;
@@ -1945,8 +2234,8 @@ int oth_chain_create(oth_ctx *c, int nfft, const float *window, int fftshift, in
     CtxGuard guard_(c);
     if (!c || !out) return fail(c, OTH_ERR_INVALID, "ctx/out is NULL");
     *out = nullptr;
-    if (!is_pow2(nfft) || !generic_supported(nfft))
-        return fail(c, OTH_ERR_UNSUPPORTED, "nfft must be a power of two in [64, 16384]");
+    if (nfft < 1) return fail(c, OTH_ERR_INVALID, "nfft must be positive");
+    const bool any_route = !generic_supported(nfft);      // not a power of two in [64, 16384]: fft_any.hip
     if (epilogue < OTH_EPI_MAG || epilogue > OTH_EPI_MAG2_OVER_N2) return fail(c, OTH_ERR_INVALID, "unknown epilogue");
     if (keep_one_in_n < 1) return fail(c, OTH_ERR_INVALID, "keep_one_in_n must be >= 1");
     if (use_device(c)) return OTH_ERR_HIP;
@@ -1957,7 +2246,7 @@ int oth_chain_create(oth_ctx *c, int nfft, const float *window, int fftshift, in
     h->fftshift = fftshift != 0;
     h->epilogue = epilogue;
     h->keep_n = h->count = keep_one_in_n;
-    int rc = get_twiddles(c, nfft, &h->d_tw);
+    int rc = any_route ? any_tables_init(c, nfft, &h->any) : get_twiddles(c, nfft, &h->d_tw);
     if (rc) {
         delete h;
         return rc;
@@ -2003,6 +2292,7 @@ int oth_chain_destroy(oth_chain *h) {
     if (h->d_partial) hipFree(h->d_partial);
     if (h->d_tail) hipFree(h->d_tail);
     if (h->d_out) hipFree(h->d_out);
+    any_tables_free(h->any);
     for (int i = 0; i < oth_chain::kRing; ++i) {
         if (h->h_in[i]) hipHostFree(h->h_in[i]);
         if (h->h_row[i]) hipHostFree(h->h_row[i]);
@@ -2196,7 +2486,12 @@ static int chain_launch(oth_chain *h, const float2 *x, long long first_vec, long
     a.fftshift = h->fftshift;
     a.epilogue = h->epilogue;
     a.scale = h->epilogue == OTH_EPI_MAG2_OVER_N2 ? (float)(1.0 / ((double)N * (double)N)) : 1.0f;
-    {
+    if (h->any.sh.kind != ANY_NONE) {      // lengths outside the power-of-two kernels (fft_any.hip)
+        Timed tm(c);
+        if ((rc = any_run(c, h->any, x, nullptr, first_vec * N, (long long)h->keep_n * N, N, h->d_win, false, nrows, nullptr, 0,
+                          h->d_rows, a.epilogue, a.scale, a.fftshift)))
+            return rc;
+    } else {
         Timed tm(c);
         HIPCHK(c, launch_pgram(N, a, c->stream));
     }
@@ -2615,11 +2910,50 @@ int oth_scan_decide_dev_out(oth_ctx *c, const float *psd_rows_dev, int nrows, in
     OTH_CATCH(c)
 }
 
+// xcorr / fac at the lengths the one-workgroup kernel does not take: np.fft calls composed from any_fft_nat()
+static int xcorr_any(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, int L, float *out, int mode) {
+    AnyTables t;
+    int rc = any_tables_init(c, L, &t);
+    if (rc) return rc;
+    const size_t nsc = any_fft_nat_scratch(t.sh), nout = (size_t)(L - L / 2);
+    rc = ensure(c, &c->scratch, &c->scratch_cap, sizeof(float2) * (2 * (size_t)L + nsc) + sizeof(float) * nout);
+    if (!rc) {
+        float2 *A = (float2 *)c->scratch, *Bv = A + L, *sc = Bv + L;
+        float *o = (float *)(sc + nsc);
+        auto run = [&]() -> int {
+            int r;
+            HIPCHK(c, hipMemsetAsync(A, 0, sizeof(float2) * 2 * (size_t)L, c->stream));
+            HIPCHK(c, hipMemcpyAsync(A, a, sizeof(float2) * na, hipMemcpyHostToDevice, c->stream));
+            if ((r = any_fft_nat(c, t, A, sc))) return r;                                                  // e = fft(a, L)
+            if (mode == 0) {
+                HIPCHK(c, hipMemcpyAsync(Bv, b, sizeof(float2) * nb, hipMemcpyHostToDevice, c->stream));
+                if ((r = any_fft_nat(c, t, Bv, sc))) return r;                                             // f = fft(b, L)
+                HIPCHK(c, launch_any_ew(4, A, A, Bv, nullptr, L, L, 0, 0, c->stream));                    // conj(f conj(e)) = conj(f) e
+                if ((r = any_fft_nat(c, t, A, sc))) return r;                                              // = L conj(ifft(f conj(e)))
+                HIPCHK(c, launch_any_abs(o, A, (int)nout, 1.0f / (float)L, c->stream));                   // |fftshift(h)[L/2:]| = |h[:L - L/2]|
+            } else {
+                HIPCHK(c, launch_any_ew(5, A, A, nullptr, nullptr, L, L, 0, 0, c->stream));               // |fft(d, L)|
+                if ((r = any_fft_nat(c, t, A, sc))) return r;
+                HIPCHK(c, launch_any_abs(o, A, (int)nout, 1.0f, c->stream));
+            }
+            HIPCHK(c, hipMemcpyAsync(out, o, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            return OTH_OK;
+        };
+        rc = run();
+    }
+    if (rc) hipStreamSynchronize(c->stream);
+    any_tables_free(t);
+    return rc;
+}
+
 static int xcorr_impl(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, int L, float *out, int mode) {
     if (!c || !a || !out || (mode == 0 && !b)) return fail(c, OTH_ERR_INVALID, "bad argument");
-    if (!is_pow2(L) || !generic_supported(L)) return fail(c, OTH_ERR_UNSUPPORTED, "L must be a power of two in [64, 16384]");
-    if (na > (size_t)L || nb > (size_t)L) return fail(c, OTH_ERR_INVALID, "input longer than L");
+    if (L < 1) return fail(c, OTH_ERR_INVALID, "L must be positive");
+    if (na > (size_t)L) na = (size_t)L;      // np.fft.fft(a, L) keeps the first L samples of a longer input
+    if (nb > (size_t)L) nb = (size_t)L;
     if (use_device(c)) return OTH_ERR_HIP;
+    if (!generic_supported(L)) return xcorr_any(c, a, na, b, nb, L, out, mode);
     const float2 *tw = nullptr;
     int rc = get_twiddles(c, L, &tw);
     if (rc) return rc;
@@ -2711,6 +3045,8 @@ int oth__debug_recipe(int nfft, int nperseg, int noverlap, int window_class, int
     sh.kernel = kernel_pref;
     sh.sched = sched_pref;
     sh.tune_variant = variant ? variant : "";
+    if (!generic_supported(nfft) && any_describe(nfft, &sh.any))
+        return fail(nullptr, OTH_ERR_UNSUPPORTED, "transform length outside [1, 1048576] (Bluestein: n <= 524288)");
     LaunchRecipe r;
     const char *why = "";
     if (int rc = resolve_recipe(sh, two_channel != 0, nseg, nstreams, cu_count > 0 ? cu_count : 256,

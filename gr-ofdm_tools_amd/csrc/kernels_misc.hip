@@ -15,8 +15,13 @@ namespace oth {
 //   layout 2: welch16k leaves bin k' + 4 q at 4096 k' + (layout-1 position of q); layout 3 (8192 points): k' + 2 q
 //   layout 4: welch16k1x leaves bin k0 + 16 k1 + 256 k2 + 4096 bitrev2(q) at 1024 k2 + 64 k0 + 4 k1 + q
 //   layout 5: its 8-wave form (8192 points) leaves bin k0 + 16 k1 + 128 k2 + 2048 bitrev2(q) at 512 k2 + 64 (k0 >> 1) + 4 (8 (k0 & 1) + k1) + q
-__device__ __forceinline__ int bin_pos(int pos, int layout) {
+//   layout 6: the two-level any-length route (fft_any.hip) leaves bin k1 + l1 k2 at k1 l2 + k2
+__device__ __forceinline__ int bin_pos(int pos, int layout, int l1 = 0, int l2 = 0) {
     if (layout == 0) return pos;
+    if (layout == 6) {
+        const int k1 = pos / l2;
+        return k1 + l1 * (pos - k1 * l2);
+    }
     if (layout == 4)
         return ((pos >> 6) & 15) + 16 * ((pos >> 2) & 15) + 256 * (pos >> 10) + 4096 * (((pos & 1) << 1) | ((pos >> 1) & 1));
     if (layout == 5)      // 8192 points: pos = 512 k2 + 64 k0' + 4 (8 h + k1) + q holds bin (2 k0' + h) + 16 k1 + 128 k2 + 2048 bitrev2(q)
@@ -24,6 +29,17 @@ __device__ __forceinline__ int bin_pos(int pos, int layout) {
     const int r = pos & 4095;
     const int q = ((r & 15) << 4) | ((r >> 4) & 15) | (r & ~255);
     return layout == 1 ? q : (pos >> 12) + (layout == 2 ? 4 : 2) * q;
+}
+
+// np.fft.fftshift for any length: bin k lands at (k + n / 2) mod n (integer division: n odd included)
+__device__ __forceinline__ int shifted(int k, int n) {
+    const int p = k + n / 2;
+    return p >= n ? p - n : p;
+}
+// ... and its inverse: the bin at shifted position ks
+__device__ __forceinline__ int unshifted(int ks, int n) {
+    const int p = ks + n - n / 2;
+    return p >= n ? p - n : p;
 }
 
 // Completion word for a polling host (FinalizeArgs.host_seq; round 5).  Called by EVERY thread of the block after its
@@ -62,8 +78,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     // threads walk partial-sum POSITIONS (coalesced reads); the bin and output slot follow
     const int pos = blockIdx.x * 32 + lane;
     const int stream = blockIdx.y;
-    const int k = bin_pos(pos, a.layout);                 // the digit swap is its own inverse
-    const int ks = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;
+    const int k = bin_pos(pos, a.layout, a.l1, a.l2);     // (layouts 1-3: the digit swap is its own inverse)
+    const int ks = a.fftshift ? shifted(k, a.nfft) : k;
     const int i = ks - a.trim;
     const bool live = pos < a.nfft && i >= 0 && i < a.nout;
     const float *base = a.partial + (size_t)stream * a.W * a.nch * a.nfft + pos;
@@ -135,8 +151,8 @@ __global__ __launch_bounds__(256) void finalize_wide_kernel(FinalizeArgs a) {
         for (int e = 0; e < 4; ++e) red[c][slice][col * 4 + e] = s[c][e];
     __syncthreads();
     const int pos = blockIdx.x * POS + threadIdx.x;
-    const int k = bin_pos(pos, a.layout);
-    const int ks = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;
+    const int k = bin_pos(pos, a.layout, a.l1, a.l2);
+    const int ks = a.fftshift ? shifted(k, a.nfft) : k;
     const int i = ks - a.trim;
     if (threadIdx.x < POS && i >= 0 && i < a.nout) {
         double t[NCH];
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(256) void finalize_l4_kernel(FinalizeArgs a) {
 #pragma unroll
     for (int k3 = 0; k3 < 4; ++k3) {
         const int k = t + 256 * k2 + 4096 * k3;
-        const int ks = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;
+        const int ks = a.fftshift ? shifted(k, a.nfft) : k;
         const int i = ks - a.trim;
         if (i < 0 || i >= a.nout) continue;
         const size_t o = (size_t)stream * a.nout + i;
@@ -297,7 +313,7 @@ __global__ void scale_kernel(const float *sum, float *out, int nfft, double scal
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nout) return;
     const int ks = i + trim;
-    const int k = fftshift ? ((ks + nfft / 2) & (nfft - 1)) : ks;
+    const int k = fftshift ? unshifted(ks, nfft) : ks;
     const double v = (double)sum[k] * scale;
     out[i] = db ? (float)(10.0 * log10(v)) : (float)v;
 }
@@ -317,7 +333,7 @@ __global__ void csd_scale_kernel(const float *sums, int nfft, double scale, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nout) return;
     const int ks = i + trim;
-    const int k = fftshift ? ((ks + nfft / 2) & (nfft - 1)) : ks;
+    const int k = fftshift ? unshifted(ks, nfft) : ks;
     const double xx = sums[k], yy = sums[nfft + k], re = sums[2 * nfft + 2 * k], im = sums[2 * nfft + 2 * k + 1];
     if (pxx) pxx[i] = (float)(xx * scale);
     if (pyy) pyy[i] = (float)(yy * scale);
@@ -448,7 +464,7 @@ __global__ __launch_bounds__(256) void chain_state_kernel(ChainStateArgs a) {
     __syncthreads();
     if (threadIdx.x >= POS) return;
     const int k = bin_pos(blockIdx.x * POS + threadIdx.x, a.layout);                // bin held at this position of a row
-    const int i = a.fftshift ? ((k + a.nfft / 2) & (a.nfft - 1)) : k;               // row position
+    const int i = a.fftshift ? shifted(k, a.nfft) : k;                              // row position
     double t = 0.0;
     for (int q = 0; q < SLICES; ++q) t = mx ? fmax(t, red[q][threadIdx.x]) : t + red[q][threadIdx.x];
     if (mx) {

@@ -116,8 +116,9 @@ struct FinalizeArgs {
     int W;
     int nfft;
     int nch;                // 1 or 4
-    int layout;             // 0 natural, 1 welch4096 digit order, 2 / 3 welch16k order at 16384 / 8192, 4 / 5 welch16k1x order at 16384 / 8192
-                            // (kernels_misc.hip bin_pos)
+    int layout;             // 0 natural, 1 welch4096 digit order, 2 / 3 welch16k order at 16384 / 8192, 4 / 5 welch16k1x order at 16384 / 8192,
+                            // 6 the two-level any-length route: position k1 l2 + k2 holds bin k1 + l1 k2 (kernels_misc.hip bin_pos)
+    int l1, l2;             // layout 6 only
     int fftshift;
     int trim;
     int db;
@@ -232,5 +233,79 @@ hipError_t launch_pilot_mean(const float2 *x, const float2 *y, size_t stream_str
 bool generic_supported(int nfft);
 size_t generic_lds_bytes(int nfft);
 int generic_threads_for(int nfft);
+
+// ---- fft_any.hip: transforms of any length (round 6) -------------------------------------------------------------------
+constexpr int kAnyMaxPasses = 12;            // 2 * 3^8 = 13122 takes nine passes
+constexpr int kAnyMaxTile = 16384;           // points of one LDS tile (128 KiB)
+constexpr int kAnyMaxFft = 1 << 20;          // longest transform (and longest Bluestein M): L1 = 4096 rows of L2 = 256
+enum AnyKind { ANY_NONE = 0, ANY_DIRECT, ANY_TWOLEVEL, ANY_BLUESTEIN, ANY_BLUESTEIN2 };
+
+struct AnyShape {        // pure host description of a length (any_describe): needs no device
+    int nfft;            // the transform the caller asked for
+    int kind;            // AnyKind
+    int L;               // length of the transforms that run (nfft, or Bluestein's M)
+    int L1, L2, C;       // two-level split L = L1 L2 (L2 = row length) and columns per K1 / K3 tile
+};
+int any_describe(int nfft, AnyShape *out);      // 0, or -1 when the length is outside [1, kAnyMaxFft] (Bluestein: M too long)
+bool any_smooth(int n);
+int any_threads_for(int points);
+
+struct AnyPass {
+    int R;               // radix: 16, 8, 4, 2, 3, 5, 7
+    int NS;              // length of the sub-transforms this pass combines
+    int nbf;             // butterflies per column = n / R
+    int inner;           // twiddle index step: n / (NS R) x (table order / n)
+    float inv_ns;
+};
+struct AnyFftDesc {
+    int n, logC, npass;
+    const float2 *tw;    // W_order^k
+    AnyPass pass[kAnyMaxPasses];
+};
+void any_make_desc(int n, int C, const float2 *tw, int order, AnyFftDesc *d);
+
+struct AnyArgs {
+    AnyFftDesc f;
+    // element (i, c) of tile t (blockIdx.x) of segment s sits at  i * es + t * tile_stride + c * cs  of the segment:
+    // column tiles (cs = 1: C adjacent columns, es = the row length) or row tiles (es = 1, cs = the row length)
+    int es, tile_stride, cs;
+    float inv_n;               // 1 / f.n (row tiles)
+    long long nseg;            // segments of this launch (rows blockIdx.y, blockIdx.y + gridDim.y, ...)
+    // load 1 (stage): samples x[first + s seg_step + n], n < nperseg, (x - mean) * win [* chirp], zero padded
+    int load_op;
+    const float2 *x, *y;
+    long long first, seg_step;
+    int nperseg;
+    const float *win;
+    const float4 *mean;        // [channel][segment] (hi.re, hi.im, lo.re, lo.im) or nullptr
+    size_t mean_ch_stride;
+    const float2 *chirp;       // Bluestein c[n] or nullptr
+    // load 0 / store 0: the workspace, [channel][segment][L]
+    float2 *ws;
+    size_t ws_seg_stride, ws_ch_stride;
+    // mid 1: v = conj(v * midtab[nat]) and the transform again
+    int mid_op;
+    const float2 *midtab;
+    // natural index of element (i, c) of tile t: i nat_i + t nat_t + c nat_c; position in a partial row likewise (pp_*)
+    int nat_i, nat_t, nat_c, pp_i, pp_t, pp_c;
+    // store 0: optional four-step twiddle twbig[i (t tw_t + c tw_c)]
+    const float2 *twbig;
+    int tw_t, tw_c;
+    // store 1 / 2: partial[gridDim.y rows][channels][nbins]
+    float *partial;
+    int nbins;                 // bins kept (Bluestein: the first nfft of M)
+    int first_chunk;           // overwrite (1) or add to (0) the partial rows
+    int conj_out;              // the transform leaves conj(X) (Bluestein): matters for the cross term only
+    // store 3: rows[s][nbins]
+    float *rows;
+    int epilogue, fftshift;
+    float scale;
+};
+hipError_t launch_any_fft(const AnyArgs &a, int tiles, int gy, int gz, int store, hipStream_t s);
+hipError_t launch_any_mean(const float2 *x, const float2 *y, long long first, long long seg_step, int nperseg, long long nseg,
+                           float4 *out, size_t ch_stride, hipStream_t s);
+hipError_t launch_any_ew(int op, float2 *dst, const float2 *src, const float2 *src2, const float2 *tab, int n, int nsrc, int L1,
+                         int L2, hipStream_t s);
+hipError_t launch_any_abs(float *out, const float2 *src, int n, float scale, hipStream_t s);
 
 }  // namespace oth

@@ -1,0 +1,261 @@
+"""GPU parity at the transform lengths the reference accepts and the power-of-two kernels do not take (round 6,
+csrc/fft_any.hip): lengths that are not a power of two (mixed radix 2-3-5-7, Bluestein for the rest) and powers of two
+above 16384 (the four-step route) - Welch averages, two-channel sums, the GNU Radio chains, xcorr / fac.
+
+Reference call sites with no length limit: fft.fft_vcc(self.fft_len, ...) (psd_logger.py:48, spectrum_sensor_v2.py:90,
+local_worker.py:62-63), sg.welch(nperseg=nFFT, nfft=nFFT) (ofdm_cr_tools.py:214,322,342), np.fft.fft(., nFFT)
+(ofdm_cr_tools.py:177,157-160), fast_spectrum_scan's own nFFT = 2^ceil(log2(npts)) (ofdm_cr_tools.py:474-475).
+
+Tolerances as everywhere: 1e-4 relative on averaged linear power over all bins (Cxy 1e-4 absolute), the 4-ulp-of-the-peak
+criterion on single periodogram rows (tests/test_hip_parity.py::check_single_rows).
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_cpu as R
+from test_hip_parity import RTOL, check_single_rows, relerr
+
+pytestmark = pytest.mark.gpu
+
+# direct (smooth) | Bluestein in one launch | Bluestein through the four-step route | four-step powers of two | tiny powers of two
+SMOOTH = [96, 1000, 1536, 3000, 6000, 12000, 15000]
+BLUESTEIN = [97, 1021, 4099, 8191]
+BLUESTEIN2 = [10007, 20000]
+BIG = [32768, 65536]
+TINY = [8, 32]
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from ofdm_tools import _hip
+    return _hip
+
+
+@pytest.fixture(scope='module')
+def ctx(hip):
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def _win(name, n):
+    from ofdm_tools import windows
+    return windows.get_window(name, n)
+
+
+def _route(plan):
+    return plan.last_recipe().split()[0]
+
+
+@pytest.mark.parametrize('n', SMOOTH + BLUESTEIN + BLUESTEIN2 + BIG + TINY)
+def test_welch_any_length_against_the_oracle(ctx, hip, n):
+    nseg = 9 if n >= 8192 else 41
+    x = R.synth_iq(n // 2 * (nseg + 1) + 3, 600 + n % 97)
+    _, ref = R.welch_np(x, nperseg=n, nfft=n)
+    plan = ctx.welch_plan(n, window=_win('hann', n))
+    psd = plan.exec(x)
+    assert plan.last_nseg == (len(x) - n // 2) // (n - n // 2)
+    assert 'anyfft' in _route(plan), plan.last_recipe()
+    err = relerr(psd, ref)
+    print('welch n=%d %s nseg=%d: %.2e' % (n, _route(plan), plan.last_nseg, err))
+    assert err < RTOL
+    plan.close()
+
+
+def test_routes_are_the_documented_ones(ctx):
+    want = {96: 'direct', 15000: 'direct', 97: 'bluestein', 8191: 'bluestein', 10007: 'bluestein2', 20000: 'bluestein2',
+            32768: 'twolevel', 131072: 'twolevel', 32: 'direct'}
+    for n, kind in want.items():
+        plan = ctx.welch_plan(n)
+        plan.exec(R.synth_iq(2 * n, 1))
+        assert _route(plan) == 'kernel=anyfft:' + kind, (n, plan.last_recipe())
+        plan.close()
+
+
+@pytest.mark.parametrize('n', [1000, 4099, 20000, 65536])
+def test_welch_flattop_zero_padded_shifted_trimmed_db(ctx, hip, n):
+    """The sweeper's call shape (spectrum_sweeper.py:263-276) at lengths outside the power-of-two kernels: flat-top of
+    nfft / 4 points zero-padded to nfft, fftshift (odd lengths included), excess bins dropped, dB."""
+    nper, trim = n // 4, n // 16
+    x = R.synth_iq(nper * 12 + 5, 77)
+    _, ref = R.welch_np(x, window='flattop', nperseg=nper, nfft=n, fs=2.5e6)
+    ref = np.fft.fftshift(ref)[trim:n - trim]
+    plan = ctx.welch_plan(n, nperseg=nper, window=_win('flattop', nper), fs=2.5e6, fftshift=True, trim_bins=trim, db=True)
+    db = plan.exec(x)
+    assert db.shape == (n - 2 * trim,)
+    assert relerr(10.0 ** (db.astype(np.float64) / 10.0), ref) < RTOL
+    plan.close()
+
+
+@pytest.mark.parametrize('n', [1536, 1021, 20000, 32768])
+def test_welch_detrend_under_a_dc_line_and_without(ctx, hip, n):
+    x = R.synth_iq(n * 6, 5, dc=30 + 20j)            # DC 36 sigma
+    plan = ctx.welch_plan(n, window=_win('hann', n))
+    _, ref = R.welch_np(x, nperseg=n, nfft=n)
+    assert relerr(plan.exec(x), ref) < RTOL
+    plan.close()
+    # without the detrend the line stays in the data: the SURVEY 8d offset (0.1 + 0.05j), as every other no-detrend case
+    # (a float32 transform leaves ~1e-7 of a line's amplitude in every bin: 36 sigma would be 1e-4 of the noise bins)
+    x = R.synth_iq(n * 6, 5)
+    plan = ctx.welch_plan(n, window=_win('hann', n), detrend=hip.DETREND_NONE, scaling=hip.SCALE_SPECTRUM)
+    _, ref = R.welch_np(x, nperseg=n, nfft=n, detrend=False, scaling='spectrum')
+    assert relerr(plan.exec(x), ref) < RTOL
+    plan.close()
+
+
+@pytest.mark.parametrize('n', [96, 3000, 4099, 10007, 32768])
+def test_csd_and_coherence_any_length(ctx, hip, n):
+    nseg = 7 if n >= 8192 else 33
+    x = R.synth_iq(n // 2 * (nseg + 1), 11)
+    noise = R.synth_iq(len(x), 12, tones=(), dc=0)
+    y = 0.7 * np.roll(x, 5) + 0.5 * noise
+    plan = ctx.welch_plan(n, window=_win('hann', n))
+    pxx, pyy, pxy, cxy = plan.csd(x, y)
+    _, c_ref, pxx_ref, pyy_ref, pxy_ref = R.coherence_np(x, y, nperseg=n, nfft=n)
+    assert relerr(pxx, pxx_ref) < RTOL and relerr(pyy, pyy_ref) < RTOL
+    assert np.max(np.abs(pxy - pxy_ref)) / np.max(np.abs(pxy_ref)) < RTOL
+    assert np.max(np.abs(pxy - pxy_ref) / np.sqrt(pxx_ref * pyy_ref)) < RTOL
+    assert np.max(np.abs(cxy - c_ref)) < RTOL
+    plan.close()
+
+
+@pytest.mark.parametrize('n', [1000, 1536, 12000, 1021, 20000, 32768])
+def test_chain_rows_any_length(ctx, hip, n):
+    """a1: rectangular, shifted, |X|^2 / N^2, every 2nd vector kept; single rows by the 4-ulp criterion, the mean of all
+    rows by the plain 1e-4."""
+    nvec = 12
+    x = R.synth_iq(n * nvec + n // 3, 31)
+    ref = R.chain_sensor_v2(x, n, decim=2)
+    ch = ctx.chain(n, window=None, fftshift=True, epilogue=hip.EPI_MAG2_OVER_N2, keep_one_in_n=2)
+    rows, got = ch.push(x)
+    assert got == nvec // 2 and rows.shape == ref.shape
+    # Bluestein rows carry the rounding of two transforms of 2-4 x the length: 8 ulp of the peak
+    check_single_rows(rows, ref, ulps=4 if R_is_smooth_or_pow2(n) else 8)
+    assert relerr(rows.mean(axis=0), ref.mean(axis=0)) < RTOL
+    ch.close()
+
+
+def R_is_smooth_or_pow2(n):
+    for p in (2, 3, 5, 7):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
+@pytest.mark.parametrize('n', [1000, 4099])
+def test_chain_psd_logger_and_local_worker_forms_any_length(ctx, hip, n):
+    x = R.synth_iq(n * 9, 32)
+    bh = R.gr_blackmanharris(n)
+    mag, peak = R.chain_psd_logger(x, n)
+    ch = ctx.chain(n, window=bh, fftshift=False, epilogue=hip.EPI_MAG)
+    ch.set_peak_hold(True)
+    rows, got = ch.push(x)
+    assert got == 9
+    check_single_rows(rows, mag, power=False, ulps=4 if R_is_smooth_or_pow2(n) else 8)
+    assert relerr(ch.peak(), peak[-1]) < RTOL
+    ch.close()
+    lin, db = R.chain_local_worker(x, n, 1e6, 0.3)
+    k = -10 * np.log10(n) - 10 * np.log10(1e6)
+    ch = ctx.chain(n, window=bh, fftshift=True, epilogue=hip.EPI_MAG2)
+    ch.set_iir_log(0.3, k)
+    rows, got = ch.push(x)
+    assert relerr(10 ** ((rows[-1].astype(np.float64) - k) / 10), lin[-1]) < RTOL
+    assert relerr(ch.iir(), lin[-1]) < RTOL
+    ch.close()
+
+
+def test_chain_ragged_pushes_keep_their_state_any_length(ctx, hip):
+    n = 1536
+    x = R.synth_iq(n * 20, 33)
+    ref = R.chain_sensor_v2(x, n, decim=3)
+    ch = ctx.chain(n, window=None, fftshift=True, epilogue=hip.EPI_MAG2_OVER_N2, keep_one_in_n=3)
+    rng = np.random.default_rng(4)
+    got, pos = [], 0
+    while pos < len(x):
+        m = int(rng.integers(1, 3 * n))
+        rows, k = ch.push(x[pos:pos + m])
+        got.extend(rows[:k])
+        pos += m
+    got = np.array(got)
+    assert got.shape == ref.shape
+    check_single_rows(got, ref)
+    ch.close()
+
+
+@pytest.mark.parametrize('L', [100, 1000, 1021, 4099, 20000, 32768, 65536])
+def test_xcorr_fac_any_length(ctx, L):
+    rng = np.random.default_rng(L)
+    na, nb = L - L // 5, L // 2 + 1
+    a = (rng.normal(size=na) + 1j * rng.normal(size=na)).astype(np.complex64)
+    b = np.roll(a, 3)[:nb].copy()
+    ref = R.xcorr(a, b, L)
+    out = ctx.xcorr(a, b, L)
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) / np.max(ref) < RTOL
+    ref = R.fac(a, L)
+    out = ctx.fac(a, L)
+    assert np.max(np.abs(out - ref)) / np.max(ref) < RTOL
+
+
+def test_xcorr_truncates_longer_inputs_like_numpy(ctx):
+    rng = np.random.default_rng(9)
+    a = (rng.normal(size=300) + 1j * rng.normal(size=300)).astype(np.complex64)
+    for L in (256, 200):      # the power-of-two kernel and the any-length route
+        ref = R.xcorr(a, a[::-1].copy(), L)
+        out = ctx.xcorr(a, a[::-1].copy(), L)
+        assert np.max(np.abs(out - ref)) / np.max(ref) < RTOL
+
+
+def test_streaming_accumulate_any_length(ctx, hip):
+    n = 3000
+    x = R.synth_iq(n * 15 + 77, 40)
+    _, ref = R.welch_np(x, nperseg=n, nfft=n)
+    plan = ctx.welch_plan(n, window=_win('hann', n))
+    rng = np.random.default_rng(1)
+    pos = 0
+    while pos < len(x):
+        m = int(rng.integers(100, 2 * n))
+        plan.accumulate(x[pos:pos + m])
+        pos += m
+    assert relerr(plan.finalize(), ref) < RTOL
+    assert plan.last_nseg == (len(x) - n // 2) // (n - n // 2)
+    plan.close()
+
+
+def test_many_streams_and_partials_any_length(ctx, hip):
+    n, ns = 1000, 5
+    per = n * 20
+    x = np.concatenate([R.synth_iq(per, 50 + i) for i in range(ns)])
+    plan = ctx.welch_plan(n, window=_win('hann', n))
+    d = ctx.alloc(x.nbytes)
+    o = ctx.alloc(4 * n * ns)
+    ctx.h2d(d, x.astype(np.complex64))
+    plan.exec_dev(d, per, o, nstreams=ns, stream_stride=per)
+    rows = ctx.d2h(o, (ns, n), np.float32)
+    for i in range(ns):
+        _, ref = R.welch_np(x[i * per:(i + 1) * per], nperseg=n, nfft=n)
+        assert relerr(rows[i], ref) < RTOL
+    # raw partial sums of two halves add up to the whole (time-sharded form)
+    s1, s2 = ctx.alloc(4 * n), ctx.alloc(4 * n)
+    half = (per // 2 // (n // 2)) * (n // 2)
+    k1 = plan.partial_dev(d, half + n // 2, s1)
+    k2 = plan.partial_dev(d + 8 * half, per - half, s2)
+    a, b = ctx.d2h(s1, (n,), np.float32), ctx.d2h(s2, (n,), np.float32)
+    _, ref = R.welch_np(x[:per], nperseg=n, nfft=n, scaling='raw')
+    assert k1 + k2 == (per - n // 2) // (n // 2)
+    assert relerr((a.astype(np.float64) + b) / (k1 + k2), ref) < RTOL
+    for p in (d, o, s1, s2):
+        ctx.free(p)
+    plan.close()
+
+
+def test_tuned_request_and_oversize_are_refused_with_a_reason(ctx, hip):
+    with pytest.raises(hip.HipError) as e:
+        ctx.welch_plan(1000, kernel=hip.KERNEL_TUNED).exec(R.synth_iq(4000, 1))
+    assert e.value.code == -3
+    with pytest.raises(hip.HipError) as e:
+        ctx.welch_plan((1 << 20) + 2)
+    assert e.value.code == -3 and '1048576' in str(e.value)
+    with pytest.raises(hip.HipError) as e:
+        ctx.chain(600000)          # Bluestein M = 2^21
+    assert e.value.code == -3
