@@ -646,14 +646,19 @@ int any_partial_rows(const AnyShape &sh, long long nseg, int cu_count) {
         occ = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
         w = (long long)cu_count * occ;
     } else {
-        w = 32;
+        w = 64;
     }
     if (w > nseg) w = nseg;
     if (w > 65535) w = 65535;
     return (int)(w < 1 ? 1 : w);
 }
 
-constexpr size_t kAnyWsBytes = 64u << 20;      // workspace of a chunk: it and the chunk's samples stay in the Infinity Cache
+// workspace of a chunk: it and the chunk's samples stay in the Infinity Cache (OTH_ANY_WS_MB: A/B of the chunk size)
+size_t any_ws_bytes() {
+    static const char *e = getenv("OTH_ANY_WS_MB");
+    const long mb = e ? atol(e) : 0;
+    return (size_t)(mb > 0 ? mb : 128) << 20;
+}
 constexpr int kAnyRowTile = 16;                // rows of L2 points a K2 workgroup transforms together
 
 // nseg segments starting at x[first + s seg_step] (nperseg samples, window win, optional constant detrend) -> either the
@@ -661,17 +666,19 @@ constexpr int kAnyRowTile = 16;                // rows of L2 points a K2 workgro
 // periodogram row per segment (rows != nullptr: epilogue / scale / fftshift as PgramArgs).  nbins = t.sh.nfft.
 int any_run(oth_ctx *c, AnyTables &t, const float2 *x, const float2 *y, long long first, long long seg_step, int nperseg,
             const float *win, bool detrend, long long nseg, float *partial, int W, float *rows, int epilogue, float scale,
-            int fftshift) {
+            int fftshift, bool coverage_only = false) {
     const AnyShape &sh = t.sh;
     const int nch = y ? 2 : 1, N = sh.nfft, L = sh.L;
     const bool two = sh.kind == ANY_TWOLEVEL || sh.kind == ANY_BLUESTEIN2, blu = sh.kind == ANY_BLUESTEIN || sh.kind == ANY_BLUESTEIN2;
     const int acc_store = y ? 2 : 1;
-    long long B = two ? (long long)(kAnyWsBytes / (sizeof(float2) * (size_t)L * nch)) : (1LL << 20);
+    long long B = two ? (long long)(any_ws_bytes() / (sizeof(float2) * (size_t)L * nch)) : (1LL << 20);
     if (B < 1) B = 1;
     if (B > nseg) B = nseg;
     int rc;
     if (two && (rc = ensure(c, &t.ws, &t.ws_cap, sizeof(float2) * (size_t)L * nch * (size_t)B))) return rc;
-    if (detrend && (rc = ensure(c, &t.mean, &t.mean_cap, sizeof(float4) * nch * (size_t)B))) return rc;
+    // (the fast two-level route keeps sub-block sums there instead: at most B * seg_step / kTlSub + nperseg / kTlSub of them)
+    const size_t nsums = (size_t)B * (size_t)(seg_step / kTlSub + 1) + (size_t)(nperseg / kTlSub) + 1;
+    if (detrend && (rc = ensure(c, &t.mean, &t.mean_cap, sizeof(float4) * std::max(nch * (size_t)B, nsums)))) return rc;
     AnyFftDesc d_one{}, d_col{}, d_row{};
     if (two) {
         any_make_desc(sh.L1, sh.C, t.tw, L, &d_col);
@@ -682,7 +689,6 @@ int any_run(oth_ctx *c, AnyTables &t, const float2 *x, const float2 *y, long lon
     for (long long s0 = 0; s0 < nseg; s0 += B) {
         const long long nb = nseg - s0 < B ? nseg - s0 : B;
         const long long cfirst = first + s0 * seg_step;
-        if (detrend) HIPCHK(c, launch_any_mean(x, y, cfirst, seg_step, nperseg, nb, t.mean, (size_t)B, c->stream));
         AnyArgs a{};
         // what every launch of the chunk shares
         a.nseg = nb;
@@ -707,6 +713,25 @@ int any_run(oth_ctx *c, AnyTables &t, const float2 *x, const float2 *y, long lon
         a.scale = scale;
         a.fftshift = fftshift;
         const int gy_rows = (int)(nb < 65535 ? nb : 65535);
+        if (sh.kind == ANY_TWOLEVEL && tl_supported(L) && !y && !rows && !coverage_only) {
+            // 32768 / 65536 points, one channel, averages: the register radix-16 kernels of fft_tl.hip
+            const bool blocks = detrend && nperseg % kTlSub == 0 && seg_step % kTlSub == 0;      // (t.mean holds B float4 = B double2)
+            TlArgs ta{};
+            ta.x = x, ta.first = cfirst, ta.seg_step = seg_step, ta.nperseg = nperseg, ta.win = win;
+            ta.ws = t.ws, ta.ws_seg_stride = (size_t)L, ta.nseg = nb, ta.tw = t.tw, ta.partial = partial, ta.first_chunk = s0 == 0;
+            if (blocks) {
+                ta.nsub = nperseg / kTlSub, ta.sub_step = (int)(seg_step / kTlSub);
+                ta.bsum = reinterpret_cast<const double2 *>(t.mean);
+                HIPCHK(c, launch_tl_blocksum(x, cfirst, (nb - 1) * ta.sub_step + ta.nsub, reinterpret_cast<double2 *>(t.mean), c->stream));
+            } else if (detrend) {
+                ta.mean = t.mean;
+                HIPCHK(c, launch_tl_mean(x, cfirst, seg_step, nperseg, nb, t.mean, c->stream));
+            }
+            HIPCHK(c, launch_tl_k1(L, ta, c->stream));
+            HIPCHK(c, launch_tl_k2(L, ta, W, c->stream));
+            continue;
+        }
+        if (detrend) HIPCHK(c, launch_any_mean(x, y, cfirst, seg_step, nperseg, nb, t.mean, (size_t)B, c->stream));
         if (!two) {
             // one launch: a workgroup per segment (rows W of the partial buffer), nothing leaves LDS
             a.f = d_one;
@@ -1188,7 +1213,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         for (int st = 0; st < nstreams; ++st) {
             rc = any_run(c, p->any, x + (size_t)st * stride, csd ? y + (size_t)st * stride : nullptr, 0, p->step, p->nperseg, p->d_win,
                          p->detrend != OTH_DETREND_NONE, nseg, p->d_partial + (size_t)st * r.W * r.nch * p->nfft, r.W, nullptr, 0,
-                         1.0f, 0);
+                         1.0f, 0, p->tune_variant == "anycov");
             if (rc) return rc;
         }
     } else if (r.kern == RK_SEG || r.kern == RK_SEGWS || r.kern == RK_SEGPAD) {
@@ -1699,7 +1724,9 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
                      !strcmp(variant, "plaunch") ||                             // pilot from its own launch (run_average)
                      !strcmp(variant, "16k4") || !strcmp(variant, "16kplain") ||  // 16384 points: the 4 x 4096 build / the
                                                                                 // un-pipelined one-exchange build
-                     !strcmp(variant, "8kws") || !strcmp(variant, "8k1role");   // 8192 points, 50 % overlap: role-split / one-role
+                     !strcmp(variant, "8kws") || !strcmp(variant, "8k1role") ||  // 8192 points, 50 % overlap: role-split / one-role
+                     !strcmp(variant, "anycov");                                // 32768 / 65536 points: fft_any.hip's coverage kernels
+                                                                                // instead of fft_tl.hip's
         for (const auto &v : kVariants) known = known || !strcmp(variant, v.tag);
         if (!known) return fail(p->ctx, OTH_ERR_UNSUPPORTED, std::string("unknown kernel build: ") + variant);
     }

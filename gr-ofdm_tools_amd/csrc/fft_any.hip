@@ -418,8 +418,8 @@ int any_describe(int nfft, AnyShape *out) {
         s.kind = M <= kAnyMaxTile ? ANY_BLUESTEIN : ANY_BLUESTEIN2;
     }
     if (s.kind == ANY_TWOLEVEL || s.kind == ANY_BLUESTEIN2) {
-        s.L2 = 256;
-        s.L1 = s.L / 256;
+        s.L2 = s.L == 32768 ? 128 : 256;     // 32768 = 256 x 128: the split fft_tl.hip's kernels take
+        s.L1 = s.L / s.L2;
         int C = kAnyMaxTile / 2 / s.L1;      // tiles of at most 8192 points: two workgroups of 64 KiB per CU
         if (C > 32) C = 32;
         if (C < 4) C = kAnyMaxTile / s.L1;   // 4096 rows: the full 16384-point tile

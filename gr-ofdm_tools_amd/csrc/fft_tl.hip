@@ -1,0 +1,257 @@
+// The four-step route at 32768 and 65536 points with register-resident radix-16 butterflies (round 6): the two lengths above
+// the tuned kernels that fast_spectrum_scan picks for every block of 16 Ki ... 64 Ki samples (ofdm_cr_tools.py:474-475) and a
+// flowgraph reaches with --nfft (sdr_webserver/local_hw_gateway.py:284-285).  fft_any.hip's coverage kernel runs the same
+// four steps from launch arguments (runtime radix list, 128 KiB tiles, table twiddles); here every size is a template
+// argument and a transform of 256 points is sixteen threads x sixteen registers, as in segfft.hip:
+//
+//   L = L1 L2, L1 = 256, L2 = 256 (65536) or 128 (32768); sample n = n1 L2 + n2, bin k = k1 + L1 k2.
+//   tl_k1_kernel   one workgroup = 16 adjacent columns n2 (128 contiguous bytes per row n1) x 16 threads: thread (c, a) loads
+//                  n1 = a + 16 b (window, detrend, zero padding), dft16 over b, x W256^(a kb), exchange through LDS across
+//                  the sixteen a, dft16 over a -> k1 = kb + 16 ka, x W_L^(k1 n2), workspace row k1.  The segment leaves
+//                  the chip once: workspace [segment][k1][n2].
+//   tl_k2_kernel   row k1 of the workspace (L2 contiguous points) per team of 16 (L2 = 256) or 8 (128) lanes of one wave:
+//                  dft16 over b, twiddle, exchange inside the wave, dft16 (two dft8) -> k2; |X|^2 added over the
+//                  workgroup's segments; partial rows in [k1][k2] order (finalize layout 6).
+// The workspace holds a chunk of segments (any_run, api.hip) small enough to stay in the Infinity Cache between the two.
+#include "fft4096.hip.h"
+#include "oth_internal.h"
+
+namespace oth {
+
+namespace {
+constexpr int TL_L1 = 256;
+constexpr int TL_RS = 272;      // float2 per kb region of the K1 exchange image: 16 a x 16 c + 16 (bank rotation)
+}
+
+template <int L2> __global__ __launch_bounds__(256) void tl_k1_kernel(TlArgs p) {
+    constexpr int L = TL_L1 * L2;
+    __shared__ float2 lds[16 * TL_RS];
+    const int tid = threadIdx.x, c = tid & 15, a = tid >> 4;
+    const int n2 = blockIdx.x * 16 + c;
+    // W256^a and W256^(4a): the inner twiddles of the 256-point column transform
+    const float2 w1 = p.tw[a * (L / 256)], w4 = p.tw[4 * a * (L / 256)];
+    // four-step twiddles W_L^((a + 16 ka) n2) = base pw^ka
+    const float2 base = p.tw[a * n2], pw = p.tw[16 * n2];
+    float2 bj[4], wi[4];
+    {
+        const float2 p2 = cmul(pw, pw), p3 = cmul(p2, pw);
+        bj[0] = base;
+        bj[1] = cmul(base, pw);
+        bj[2] = cmul(base, p2);
+        bj[3] = cmul(base, p3);
+        wi[1] = cmul(p2, p2);
+        wi[2] = cmul(wi[1], wi[1]);
+        wi[3] = cmul(wi[2], wi[1]);
+    }
+    for (long long s = blockIdx.y; s < p.nseg; s += gridDim.y) {
+        const float2 *src = p.x + p.first + s * p.seg_step;
+        float2 mhi = make_float2(0.f, 0.f), mlo = make_float2(0.f, 0.f);
+        if (p.bsum) {      // the segment's mean from the sums of its sub-blocks (tl_blocksum_kernel): one read of the chunk's
+            const double2 *bs = p.bsum + s * p.sub_step;      // samples for all the overlapping segments
+            double mr = 0.0, mi = 0.0;
+            for (int j = 0; j < p.nsub; ++j) {
+                mr += bs[j].x;
+                mi += bs[j].y;
+            }
+            mr /= p.nperseg;
+            mi /= p.nperseg;
+            mhi = make_float2((float)mr, (float)mi);
+            mlo = make_float2((float)(mr - (double)mhi.x), (float)(mi - (double)mhi.y));
+        } else if (p.mean) {
+            const float4 m = p.mean[s];
+            mhi = make_float2(m.x, m.y);
+            mlo = make_float2(m.z, m.w);
+        }
+        float2 v[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const int n = (a + 16 * b) * L2 + n2;
+            v[b] = n < p.nperseg ? src[n] : make_float2(0.f, 0.f);      // (plain loads: the overlapped half is read again from L2 / MALL)
+        }
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const int n = (a + 16 * b) * L2 + n2;
+            if (n < p.nperseg) {
+                const float w = p.win[n];
+                const float2 d = csub(csub(v[b], mhi), mlo);
+                v[b] = make_float2(d.x * w, d.y * w);
+            }
+        }
+        dft16(v);                                             // Z_a[kb] at v[r16(kb)]
+        scatter_pow16<TL_RS>(v, lds + a * 16 + c, w1, w4);    // lds[kb][a][c] = Z_a[kb] W256^(a kb)
+        __syncthreads();
+        float2 u[16];                                         // this thread now is (c, kb = a)
+#pragma unroll
+        for (int a2 = 0; a2 < 16; ++a2) u[a2] = lds[a * TL_RS + a2 * 16 + c];
+        __syncthreads();
+        dft16(u);                                             // X1[kb + 16 ka] at u[r16(ka)]
+        float2 *dst = p.ws + (size_t)s * p.ws_seg_stride + (size_t)a * L2 + n2;
+#pragma unroll
+        for (int ka = 0; ka < 16; ++ka) {
+            const int i = ka >> 2, j = ka & 3;
+            const float2 w = i == 0 ? bj[j] : cmul(wi[i], bj[j]);
+            dst[(size_t)(16 * ka) * L2] = cmul(u[r16(ka)], w);
+        }
+    }
+}
+
+template <int L2> __global__ __launch_bounds__(256) void tl_k2_kernel(TlArgs p) {
+    constexpr int L = TL_L1 * L2;
+    constexpr int TEAM = L2 / 16;                 // lanes per row: 16 (256 points) or 8 (128)
+    constexpr int ROWS = 256 / TEAM;              // rows per workgroup
+    constexpr int TS = TEAM + 1;                  // float2 per kb line of a team's exchange image
+    __shared__ float2 lds[ROWS * 16 * TS];
+    const int tid = threadIdx.x, a = tid & (TEAM - 1), r = tid / TEAM;
+    const int k1 = blockIdx.x * ROWS + r;
+    float2 *team = lds + r * 16 * TS;
+    const float2 w1 = p.tw[a * (L / L2)], w4 = p.tw[4 * a * (L / L2)];      // W_L2^a, W_L2^(4a)
+    float acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (long long s = blockIdx.y; s < p.nseg; s += gridDim.y) {
+        const float2 *row = p.ws + (size_t)s * p.ws_seg_stride + (size_t)k1 * L2;
+        float2 v[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) v[b] = row[a + TEAM * b];
+        dft16(v);                                            // Z_a[kb], kb < 16, at v[r16(kb)]
+        scatter_pow16<TS>(v, team + a, w1, w4);              // team[kb][a] = Z_a[kb] W_L2^(a kb)
+        wave_lds_sync();
+        if constexpr (TEAM == 16) {
+            float2 u[16];
+#pragma unroll
+            for (int a2 = 0; a2 < 16; ++a2) u[a2] = team[a * TS + a2];       // kb = a
+            wave_lds_sync();
+            dft16(u);                                        // X2[kb + 16 ka] at u[r16(ka)]
+#pragma unroll
+            for (int ka = 0; ka < 16; ++ka) {
+                const float2 X = u[r16(ka)];
+                acc[ka] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[ka]));
+            }
+        } else {
+            float2 u0[8], u1[8];                             // kb = a and kb = a + 8
+#pragma unroll
+            for (int a2 = 0; a2 < 8; ++a2) {
+                u0[a2] = team[a * TS + a2];
+                u1[a2] = team[(a + 8) * TS + a2];
+            }
+            wave_lds_sync();
+            dft8(u0);
+            dft8(u1);
+#pragma unroll
+            for (int ka = 0; ka < 8; ++ka) {
+                acc[ka] = fmaf(u0[ka].x, u0[ka].x, fmaf(u0[ka].y, u0[ka].y, acc[ka]));
+                acc[8 + ka] = fmaf(u1[ka].x, u1[ka].x, fmaf(u1[ka].y, u1[ka].y, acc[8 + ka]));
+            }
+        }
+    }
+    // partial row g = blockIdx.y, position k1 L2 + k2
+    float *dst = p.partial + (size_t)blockIdx.y * L + (size_t)k1 * L2;
+    if constexpr (TEAM == 16) {
+#pragma unroll
+        for (int ka = 0; ka < 16; ++ka) {
+            float *d = dst + a + 16 * ka;
+            *d = p.first_chunk ? acc[ka] : *d + acc[ka];
+        }
+    } else {
+#pragma unroll
+        for (int ka = 0; ka < 8; ++ka) {
+            float *d0 = dst + a + 16 * ka, *d1 = d0 + 8;
+            *d0 = p.first_chunk ? acc[ka] : *d0 + acc[ka];
+            *d1 = p.first_chunk ? acc[8 + ka] : *d1 + acc[8 + ka];
+        }
+    }
+}
+
+// Segment means for the detrend, wide: 256 threads per segment, four independent loads per trip, sums in double
+// (any_mean_kernel's one wave per segment walks a 32768-point segment in 512 dependent trips).
+__global__ __launch_bounds__(256) void tl_mean_kernel(const float2 *x, long long first, long long seg_step, int nperseg, float4 *out) {
+    __shared__ double red[2][4];
+    const float2 *src = x + first + (long long)blockIdx.x * seg_step;
+    double sr = 0.0, si = 0.0;
+    int n = threadIdx.x;
+    for (; n + 768 < nperseg; n += 1024) {
+        const float2 v0 = src[n], v1 = src[n + 256], v2 = src[n + 512], v3 = src[n + 768];
+        sr += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        si += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; n < nperseg; n += 256) {
+        const float2 v = src[n];
+        sr += (double)v.x;
+        si += (double)v.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_xor(sr, off, 64);
+        si += __shfl_xor(si, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sr;
+        red[1][threadIdx.x >> 6] = si;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double mr = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / nperseg;
+        const double mi = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / nperseg;
+        const float hr = (float)mr, hi = (float)mi;
+        out[blockIdx.x] = make_float4(hr, hi, (float)(mr - (double)hr), (float)(mi - (double)hi));
+    }
+}
+
+// Sums of sub-blocks of kTlSub samples, in double: when the segment length and the step are multiples of kTlSub every
+// segment's mean is the sum of nperseg / kTlSub consecutive sub-block sums, and the samples of overlapping segments are
+// read once for all of them.
+__global__ __launch_bounds__(256) void tl_blocksum_kernel(const float2 *x, long long first, double2 *out) {
+    __shared__ double red[2][4];
+    const float2 *src = x + first + (long long)blockIdx.x * kTlSub;
+    float2 v[kTlSub / 256];
+#pragma unroll
+    for (int q = 0; q < kTlSub / 256; ++q) v[q] = src[threadIdx.x + 256 * q];
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int q = 0; q < kTlSub / 256; ++q) {
+        sr += (double)v[q].x;
+        si += (double)v[q].y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_xor(sr, off, 64);
+        si += __shfl_xor(si, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sr;
+        red[1][threadIdx.x >> 6] = si;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[blockIdx.x] = make_double2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+}
+
+hipError_t launch_tl_blocksum(const float2 *x, long long first, long long nblocks, double2 *out, hipStream_t s) {
+    hipLaunchKernelGGL(tl_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, x, first, out);
+    return hipGetLastError();
+}
+
+bool tl_supported(int L) { return L == 32768 || L == 65536; }
+
+hipError_t launch_tl_mean(const float2 *x, long long first, long long seg_step, int nperseg, long long nseg, float4 *out, hipStream_t s) {
+    hipLaunchKernelGGL(tl_mean_kernel, dim3((unsigned)nseg), dim3(256), 0, s, x, first, seg_step, nperseg, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tl_k1(int L, const TlArgs &a, hipStream_t s) {
+    const int gy = (int)(a.nseg < 65535 ? a.nseg : 65535);
+    if (L == 65536) hipLaunchKernelGGL(tl_k1_kernel<256>, dim3(16, gy), dim3(256), 0, s, a);
+    else if (L == 32768) hipLaunchKernelGGL(tl_k1_kernel<128>, dim3(8, gy), dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// W partial rows: workgroup (row tile, g) adds the segments g, g + W, ...
+hipError_t launch_tl_k2(int L, const TlArgs &a, int W, hipStream_t s) {
+    if (L == 65536) hipLaunchKernelGGL(tl_k2_kernel<256>, dim3(16, W), dim3(256), 0, s, a);
+    else if (L == 32768) hipLaunchKernelGGL(tl_k2_kernel<128>, dim3(8, W), dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace oth

@@ -308,4 +308,27 @@ hipError_t launch_any_ew(int op, float2 *dst, const float2 *src, const float2 *s
                          int L2, hipStream_t s);
 hipError_t launch_any_abs(float *out, const float2 *src, int n, float scale, hipStream_t s);
 
+// ---- fft_tl.hip: the four-step route at 32768 / 65536 points on register radix-16 butterflies ---------------------------
+struct TlArgs {
+    const float2 *x;           // samples; segment s starts at x[first + s seg_step]
+    long long first, seg_step;
+    int nperseg;               // samples per segment (zero padded to L)
+    const float *win;          // nperseg window values (the table holds L)
+    const float4 *mean;        // per segment (hi.re, hi.im, lo.re, lo.im) or nullptr
+    const double2 *bsum;       // or: sums of sub-blocks of kTlSub samples from x[first] on; segment s takes nsub of them
+    int nsub, sub_step;        // from index s * sub_step
+    float2 *ws;                // workspace [segment][k1][n2]
+    size_t ws_seg_stride;
+    long long nseg;
+    const float2 *tw;          // W_L^k
+    float *partial;            // [W][L] sums, position k1 L2 + k2 (finalize layout 6)
+    int first_chunk;
+};
+constexpr int kTlSub = 4096;
+bool tl_supported(int L);
+hipError_t launch_tl_blocksum(const float2 *x, long long first, long long nblocks, double2 *out, hipStream_t s);
+hipError_t launch_tl_mean(const float2 *x, long long first, long long seg_step, int nperseg, long long nseg, float4 *out, hipStream_t s);
+hipError_t launch_tl_k1(int L, const TlArgs &a, hipStream_t s);
+hipError_t launch_tl_k2(int L, const TlArgs &a, int W, hipStream_t s);
+
 }  // namespace oth

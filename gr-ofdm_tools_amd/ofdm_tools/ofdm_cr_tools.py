@@ -26,10 +26,15 @@ def _py2div(a, b):
     return a / b
 
 
-def _welch_plan(ctx, nfft, window_name, Sf):
-    """The reference's `sg.welch(x, Sf, window, nperseg=nfft, nfft=nfft)` + fftshift (ofdm_cr_tools.py:214,322,342)."""
-    return ctx.cached_plan(('welch', nfft, window_name, float(Sf)),
-                 lambda: ctx.welch_plan(nfft, window=windows.get_window(window_name, nfft), fs=float(Sf), fftshift=True))
+def _welch_plan(ctx, nfft, window_name, Sf, npts=None):
+    """The reference's `sg.welch(x, Sf, window, nperseg=nfft, nfft=nfft)` + fftshift (ofdm_cr_tools.py:214,322,342).
+    SciPy shortens nperseg to the input length when the vector is shorter than nfft ("nperseg = N is greater than input
+    length", one zero-padded segment) - which fast_spectrum_scan(n_fft=0) always hits, its nFFT being the next power of
+    two above len(vct_sample) (ofdm_cr_tools.py:474-475)."""
+    nperseg = nfft if npts is None else min(int(nfft), int(npts))
+    return ctx.cached_plan(('welch', nfft, nperseg, window_name, float(Sf)),
+                 lambda: ctx.welch_plan(nfft, nperseg=nperseg, window=windows.get_window(window_name, nperseg), fs=float(Sf),
+                                        fftshift=True))
 
 
 def frange(x, y, jump):
@@ -78,7 +83,7 @@ def _plain_channel_sums(psd, Fr, Sf, bb_freqs, srch_bins, ctx):
 
 def _enqueue_welch(vector, nFFT, Sf, ctx):
     """src_power_welch's PSD (flattop, nperseg = nfft, ofdm_cr_tools.py:213-216) as a ticket: -> (plan, ticket, post)."""
-    plan = _welch_plan(ctx, nFFT, 'flattop', Sf)
+    plan = _welch_plan(ctx, nFFT, 'flattop', Sf, len(vector))
     return plan, plan.exec_async(vector), None
 
 
@@ -173,7 +178,7 @@ def fac(data, length, ctx=None):
 def welch_plot_dB(data, Sf, fc, nfft, ctx=None):
     """ofdm_cr_tools.py:321-326 (default Hann window, 50 % overlap)."""
     ctx = ctx or _hip.default_context()
-    psd = _welch_plan(ctx, nfft, 'hann', Sf).exec(data)
+    psd = _welch_plan(ctx, nfft, 'hann', Sf, len(data)).exec(data)
     axis = np.fft.fftshift(np.fft.fftfreq(nfft, 1.0 / Sf))
     return [item + fc for item in axis], [10 * math.log10(item + 1e-20) for item in psd]
 
@@ -181,7 +186,7 @@ def welch_plot_dB(data, Sf, fc, nfft, ctx=None):
 def welch_power_estimate(vector, nFFT, Sf, ctx=None):
     """ofdm_cr_tools.py:341-345."""
     ctx = ctx or _hip.default_context()
-    return float(np.sum(_welch_plan(ctx, nFFT, 'hann', Sf).exec(vector), dtype=np.float64))
+    return float(np.sum(_welch_plan(ctx, nFFT, 'hann', Sf, len(vector)).exec(vector), dtype=np.float64))
 
 
 class SpectrumScan(object):

@@ -217,6 +217,12 @@ def csd_np(x, y, fs=1.0, window='hann', nperseg=256, noverlap=None, nfft=None,
     same = y is None
     yy = x if same else np.asarray(y).astype(np.complex128)
     nperseg = int(nperseg)
+    if nperseg > len(x) and isinstance(window, str):
+        # scipy.signal._spectral_helper / _triage_segments: "nperseg = N is greater than input length = n, using
+        # nperseg = n" - the window is then built for the shorter length and nfft keeps the caller's value.  This is
+        # what fast_spectrum_scan(n_fft=0) runs into by construction: nFFT = 2^ceil(log2(npts)) >= npts
+        # (ofdm_cr_tools.py:474-475 -> :214).
+        nperseg = len(x)
     if noverlap is None:
         noverlap = nperseg // 2
     if nfft is None:

@@ -233,6 +233,7 @@ def reference_fixtures():
         out['text_%d' % i] = np.frombuffer(text.encode('ascii'), np.uint8)
         out['case_%d' % i] = np.array([W, H, N, Sf, tf], np.float64)
     save('ref_ascii_plot.npz', source=np.array('reference'), n=len(cases), **out)
+    reference_anylen_fixture(E, T, P, scan)
     reference_thread_fixtures(E, T, S)
     reference_legacy_sensor_fixture(E, T, scan)
     reference_flank_fixture(E, T)
@@ -240,6 +241,53 @@ def reference_fixtures():
     reference_logger_fixture(E)
     reference_consumer_fixture(E)
     reference_psd_logger_fixture(E)
+
+
+def reference_anylen_fixture(E, T, P, scan):
+    """ref_anylen.npz (round 6): the reference's own bodies at the transform lengths it accepts and rounds 1-5 refused -
+    fast_spectrum_scan(n_fft=0) choosing nFFT = 2^ceil(log2(npts)) itself (ofdm_cr_tools.py:474-475) on 20 000 and
+    100 000 samples (32768 / 131072 points; 'welch': SciPy shortens nperseg to the input, one zero-padded flat-top
+    segment; 'fft': one flat-top periodogram), a free-integer n_fft (1000, 3000: the web gateway's --nfft,
+    sdr_webserver/local_hw_gateway.py:284-285), welch_plot_dB / welch_power_estimate at lengths that are not powers of
+    two, xcorr / fac at an even and an odd length (Python-2 `len(h)/2`).  Inputs are R.synth_iq seeds (not stored); PSDs
+    are kept every `stride`-th bin (+ their sum) so that the file stays small."""
+    c128 = lambda v: np.asarray(v).astype(np.complex128)      # noqa: E731
+    out, cases = {}, []
+    Sf, cs, sbw, fc = 2000000, 100e3, 50e3, 433.0e6
+    ax_ch = T['frange'](fc - Sf / 2, fc + Sf / 2, cs)
+    i = 0
+    for npts, n_fft, seed in ((20000, 0, 901), (100000, 0, 902), (20000, 1000, 903), (9000, 3000, 904)):
+        x = R.synth_iq(npts, seed)
+        for method in ('welch', 'fft'):
+            nfft = n_fft or int(2 ** np.ceil(np.log2(npts)))
+            Fr = float(Sf) / nfft
+            bb = T['frange'](-Sf / 2, Sf / 2, cs)
+            fn = T['src_power_welch'] if method == 'welch' else P['src_power_fft']
+            psd, _, plc = fn(c128(x), npts, nfft, Fr, Sf, bb, sbw / Fr)
+            thr, plc_s, ne, occ = scan(c128(x), fc, cs, sbw, n_fft, Sf, method, 4, 1e-11, 0.5, False)
+            assert np.array_equal(np.array(plc), np.array(plc_s))
+            stride = max(1, nfft // 2048)
+            cases.append((npts, n_fft, seed, 0 if method == 'welch' else 1, nfft, stride))
+            out['psd_%d' % i] = np.array(psd)[::stride]
+            out['psd_sum_%d' % i] = float(np.sum(psd))
+            out['plc_%d' % i] = np.array(plc_s)
+            out['thr_%d' % i] = thr
+            out['noise_%d' % i] = ne
+            out['occupied_%d' % i] = np.array([1.0 if a in occ else 0.0 for a in ax_ch])
+            i += 1
+    x = R.synth_iq(30000, 905)
+    _, db = T['welch_plot_dB'](c128(x), Sf, fc, 1000)
+    out['plot_db_1000'] = np.array(db)
+    out['power_6000'] = T['welch_power_estimate'](c128(x), 6000, Sf)
+    out['power_1021'] = T['welch_power_estimate'](c128(x), 1021, Sf)
+    out['power_short_40000'] = T['welch_power_estimate'](c128(x), 40000, Sf)      # nFFT > len(x): SciPy's shortened nperseg
+    a, b = R.synth_iq(900, 906, tones=(), dc=0), R.synth_iq(700, 907, tones=(), dc=0)
+    for L in (1000, 1001, 20000):
+        out['xcorr_%d' % L] = P['xcorr'](c128(a), c128(b), L)
+        out['fac_%d' % L] = P['fac'](c128(a), L)
+    save('ref_anylen.npz', source=np.array('reference'), Sf=Sf, channel_rate=cs, srch_bw=sbw, fc=fc, thr_leveler=4,
+         alpha=0.5, noise0=1e-11, cases=np.array(cases), ax_ch=np.array(ax_ch), plot_seed=905, plot_n=30000,
+         xcorr_seeds=np.array([906, 907]), xcorr_lens=np.array([900, 700]), **out)
 
 
 def reference_thread_fixtures(E, T, S):

@@ -62,6 +62,27 @@ def test_welch_any_length_against_the_oracle(ctx, hip, n):
     plan.close()
 
 
+@pytest.mark.parametrize('n', BIG)
+@pytest.mark.parametrize('variant', [None, 'anycov'])
+def test_two_level_routes_across_workspace_chunks(ctx, hip, n, variant):
+    """32768 / 65536 points: fft_tl.hip's register radix-16 kernels (default) and fft_any.hip's coverage kernels
+    ('anycov') on a launch longer than one workspace chunk (64 MiB: 256 / 128 segments), ragged segment count, zero
+    padding inside the last row block, with and without the detrend."""
+    nseg = (64 << 20) // (8 * n) + 37
+    x = R.synth_iq(n // 2 * (nseg + 1) + 11, 71, dc=3 + 2j)
+    for detrend, nper in ((hip.DETREND_CONSTANT, n), (hip.DETREND_NONE, n - 3000)):
+        kw = dict(detrend=False) if detrend == hip.DETREND_NONE else {}
+        xs = x if nper == n else x[:nper * 9]
+        _, ref = R.welch_np(xs, nperseg=nper, nfft=n, **kw)
+        plan = ctx.welch_plan(n, nperseg=nper, window=_win('hann', nper), detrend=detrend)
+        if variant:
+            plan.set_tuning(variant)
+        psd = plan.exec(xs)
+        assert plan.last_nseg == (len(xs) - nper // 2) // (nper - nper // 2)
+        assert relerr(psd, ref) < RTOL, (detrend, nper)
+        plan.close()
+
+
 def test_routes_are_the_documented_ones(ctx):
     want = {96: 'direct', 15000: 'direct', 97: 'bluestein', 8191: 'bluestein', 10007: 'bluestein2', 20000: 'bluestein2',
             32768: 'twolevel', 131072: 'twolevel', 32: 'direct'}
@@ -259,3 +280,40 @@ def test_tuned_request_and_oversize_are_refused_with_a_reason(ctx, hip):
     with pytest.raises(hip.HipError) as e:
         ctx.chain(600000)          # Bluestein M = 2^21
     assert e.value.code == -3
+
+
+def test_ref_any_length_scans_plots_and_xcorr_on_the_gpu(ctx, golden):
+    """ref_anylen.npz - outputs of the reference's OWN fast_spectrum_scan / src_power_welch / src_power_fft /
+    welch_plot_dB / welch_power_estimate / xcorr / fac bodies (tests/golden/make_golden.py --reference) at lengths the
+    library refused before round 6 - against the drop-in helpers of ofdm_tools.ofdm_cr_tools on the GPU:
+    fast_spectrum_scan(n_fft=0) on 20 000 / 100 000 samples (32768 / 131072 points), n_fft 1000 / 3000, both methods."""
+    from ofdm_tools import ofdm_cr_tools as T
+    from test_oracle_golden import anylen_cases
+    g = golden('ref_anylen.npz')
+    Sf, cs, sbw, fc = int(g['Sf']), float(g['channel_rate']), float(g['srch_bw']), float(g['fc'])
+    for i, x, n_fft, method, nfft, stride in anylen_cases(g):
+        Fr = float(Sf) / nfft
+        bb = T.frange(-Sf / 2, Sf / 2, cs)
+        fn = T.src_power_welch if method == 'welch' else T.src_power_fft
+        psd, _, plc = fn(x, len(x), nfft, Fr, Sf, bb, sbw / Fr, ctx=ctx)
+        assert len(psd) == nfft
+        assert relerr(psd[::stride], g['psd_%d' % i]) < RTOL, (i, method, nfft)
+        assert relerr(plc, g['plc_%d' % i]) < RTOL
+        thr, plc_s, ne, occ = T.fast_spectrum_scan(x, fc, cs, sbw, n_fft, Sf, method, int(g['thr_leveler']),
+                                                   float(g['noise0']), float(g['alpha']), ctx=ctx)
+        assert relerr(plc_s, g['plc_%d' % i]) < RTOL
+        assert abs(thr - float(g['thr_%d' % i])) < RTOL * float(g['thr_%d' % i])
+        assert abs(ne - float(g['noise_%d' % i])) < RTOL * float(g['noise_%d' % i])
+        assert [1.0 if a in occ else 0.0 for a in g['ax_ch']] == list(g['occupied_%d' % i])
+    x = R.synth_iq(int(g['plot_n']), int(g['plot_seed']))
+    _, db = T.welch_plot_dB(x, Sf, fc, 1000, ctx=ctx)
+    assert relerr(10 ** (np.array(db) / 10), 10 ** (g['plot_db_1000'] / 10)) < RTOL
+    for key, nfft in (('power_6000', 6000), ('power_1021', 1021), ('power_short_40000', 40000)):
+        assert abs(T.welch_power_estimate(x, nfft, Sf, ctx=ctx) - float(g[key])) < RTOL * float(g[key]), key
+    a = R.synth_iq(int(g['xcorr_lens'][0]), int(g['xcorr_seeds'][0]), tones=(), dc=0)
+    b = R.synth_iq(int(g['xcorr_lens'][1]), int(g['xcorr_seeds'][1]), tones=(), dc=0)
+    for L in (1000, 1001, 20000):
+        ref = g['xcorr_%d' % L]
+        assert np.max(np.abs(T.xcorr(a, b, L, ctx=ctx) - ref)) / np.max(ref) < RTOL
+        ref = g['fac_%d' % L]
+        assert np.max(np.abs(T.fac(a, L, ctx=ctx) - ref)) / np.max(ref) < RTOL

@@ -235,7 +235,7 @@ def test_known_answers():
 def test_reference_fixtures_are_tagged(golden):
     import glob
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'ref_*.npz')))
-    assert names == ['ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_consumers.npz', 'ref_fft_plot.npz', 'ref_flank.npz',
+    assert names == ['ref_anylen.npz', 'ref_ascii_plot.npz', 'ref_coherence_scanner.npz', 'ref_consumers.npz', 'ref_fft_plot.npz', 'ref_flank.npz',
                      'ref_legacy_sensor.npz', 'ref_psd_logger.npz',
                      'ref_scanner_seq.npz', 'ref_sensing_log.npz',
                      'ref_src_power_cases.npz',
@@ -244,7 +244,7 @@ def test_reference_fixtures_are_tagged(golden):
     for n in names:
         g = golden(n)
         assert str(g['source']) == 'reference'
-        if n not in ('ref_ascii_plot.npz', 'ref_consumers.npz', 'ref_flank.npz', 'ref_sensing_log.npz'):      # (carry their own inputs)
+        if n not in ('ref_anylen.npz', 'ref_ascii_plot.npz', 'ref_consumers.npz', 'ref_flank.npz', 'ref_sensing_log.npz'):      # (carry their own inputs / seeds)
             assert os.path.exists(os.path.join(os.path.dirname(__file__), 'golden', str(g['input_from'])))
 
 
@@ -383,6 +383,48 @@ def test_ref_src_power_fft_and_fft_scan(golden):
     assert np.allclose(plc, g['scan_plc'], rtol=1e-12)
     ax_ch = R.frange(float(g['scan_fc']) - Sf / 2, float(g['scan_fc']) + Sf / 2, cs)
     assert [1.0 if a in occ else 0.0 for a in ax_ch] == list(g['scan_occupied'])
+
+
+def anylen_cases(g):
+    """(index, samples, n_fft argument, method, nFFT the reference chose, stride of the stored PSD) of ref_anylen.npz"""
+    for i, (npts, n_fft, seed, m, nfft, stride) in enumerate(g['cases']):
+        yield i, R.synth_iq(int(npts), int(seed)), int(n_fft), ('welch', 'fft')[int(m)], int(nfft), int(stride)
+
+
+def test_ref_any_length_scans_plots_and_xcorr(golden):
+    """Round 6: the reference's own bodies at the lengths it accepts beyond a power of two in [64, 16384] -
+    fast_spectrum_scan(n_fft=0) picking 32768 / 131072 points itself (ofdm_cr_tools.py:474-475; 'welch': SciPy's
+    shortened nperseg, one zero-padded segment), free-integer n_fft (1000, 3000), welch_plot_dB / welch_power_estimate
+    at 1000 / 6000 / 1021 points and with nFFT above the input length, xcorr / fac at 1000, 1001 and 20000 points."""
+    g = golden('ref_anylen.npz')
+    Sf, cs, sbw, fc = int(g['Sf']), float(g['channel_rate']), float(g['srch_bw']), float(g['fc'])
+    seen = set()
+    for i, x, n_fft, method, nfft, stride in anylen_cases(g):
+        Fr = float(Sf) / nfft
+        bb = R.frange(-Sf / 2, Sf / 2, cs)
+        fn = R.src_power_welch if method == 'welch' else R.src_power_fft
+        psd, _, plc = fn(x.astype(np.complex128), len(x), nfft, Fr, Sf, bb, sbw / Fr)
+        assert len(psd) == nfft and relerr(psd[::stride], g['psd_%d' % i]) < 1e-9
+        assert abs(np.sum(psd) - float(g['psd_sum_%d' % i])) < 1e-9 * float(g['psd_sum_%d' % i])
+        thr, plc_s, ne, occ = R.fast_spectrum_scan(x.astype(np.complex128), fc, cs, sbw, n_fft, Sf, method,
+                                                   int(g['thr_leveler']), float(g['noise0']), float(g['alpha']))
+        assert relerr(plc_s, g['plc_%d' % i]) < 1e-9 and relerr(plc, g['plc_%d' % i]) < 1e-9
+        assert np.isclose(thr, float(g['thr_%d' % i]), rtol=1e-9) and np.isclose(ne, float(g['noise_%d' % i]), rtol=1e-9)
+        assert [1.0 if a in occ else 0.0 for a in g['ax_ch']] == list(g['occupied_%d' % i])
+        seen.add(nfft)
+    assert seen == {32768, 131072, 1000, 3000}
+    x = R.synth_iq(int(g['plot_n']), int(g['plot_seed']))
+    _, db = R.welch_plot_dB(x, Sf, fc, 1000)
+    assert relerr(10 ** (np.array(db) / 10), 10 ** (g['plot_db_1000'] / 10)) < 1e-9
+    for key, nfft in (('power_6000', 6000), ('power_1021', 1021), ('power_short_40000', 40000)):
+        assert np.isclose(R.welch_power_estimate(x, nfft, Sf), float(g[key]), rtol=1e-9), key
+    a = R.synth_iq(int(g['xcorr_lens'][0]), int(g['xcorr_seeds'][0]), tones=(), dc=0).astype(np.complex128)
+    b = R.synth_iq(int(g['xcorr_lens'][1]), int(g['xcorr_seeds'][1]), tones=(), dc=0).astype(np.complex128)
+    for L in (1000, 1001, 20000):
+        assert g['xcorr_%d' % L].shape == (L - L // 2,)
+        # (relative to the peak: beyond the inputs' support the correlation is rounding noise around zero)
+        for got, ref in ((R.xcorr(a, b, L), g['xcorr_%d' % L]), (R.fac(a, L), g['fac_%d' % L])):
+            assert np.max(np.abs(got - ref)) < 1e-9 * np.max(ref)
 
 
 def _frames_of(blob):

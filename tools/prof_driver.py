@@ -8,7 +8,7 @@ usage: prof_driver.py <config> [reps] [log2_samples]
   C4        sweep 8 x 2^25, Hann 4096, shift + trim + dB                 (welch4096ws_kernel, 8 streams)
   C4ref     reference-faithful sweep: flattop nperseg 1024 -> nfft 4096  (welch4096_kernel<NA=4>)
   C5        64 channels x 2^22, 16384-pt rect |X|^2/N^2 mean             (welch16k_kernel)
-  w1024 / w2048      Hann Welch 50 % at nfft 1024 / 2048, 2^27 samples
+  w<N>               Hann Welch 50 % at nfft N (256 ... 16384: tuned kernels; any other length: fft_any.hip), 2^27 samples
   chain1024 / chain2048 / chain4096   periodogram chain (BH window, shift, |X|^2, IIR + log), 2^26 samples
 Prints the HIP-event average of the timed kernels (the averaging kernel; for the chains the whole push: transform
 kernel + cross-team reduction + state kernel) and the algorithmic GB/s.
@@ -113,7 +113,7 @@ elif cfg == 'C5d':      # config 5 as bench.py's scan_c5 runs it: PSD rows + the
         bp.psd_rows_dev(d, S, nch, S, o)
         ctx.scan_decide_dev_out(o, nch, N, bp.scanner.srch_bins, bp.thr_leveler, lo, hi, noise, power, mask)
     nbytes = 8 * nch * S
-elif cfg in ('w1024', 'w2048', 'w512', 'w256', 'w8192', 'w16384'):
+elif cfg[0] == 'w' and cfg[1:].isdigit():      # w<N>: Hann Welch, 50 % overlap, any length (w1000, w32768, w65536: fft_any.hip)
     N = int(cfg[1:])
     n = 1 << (log2n or 27)
     d, o = dev(n * 8), dev(N * 4)
