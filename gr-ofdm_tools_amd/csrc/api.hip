@@ -4,6 +4,7 @@
 // fallback.
 #include "../../include/ofdm_tools_hip.h"
 #include "oth_internal.h"
+#include "abi_barrier.h"
 
 #include <sched.h>
 #include <time.h>
@@ -116,6 +117,11 @@ struct oth_plan {
     hipEvent_t h_ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned h_ring_next = 0;
     AnyTables any;                     // any.sh.kind != ANY_NONE: the plan's length runs through fft_any.hip
+    // Blocking oth_welch_exec calls on one plan run one at a time (enqueue + collect under this mutex; the CONTEXT lock is
+    // free while they wait): with the 4-slot output ring a fifth concurrent caller's launch would otherwise rewrite the
+    // first caller's row before it was copied out (advisor, round 5).
+    std::mutex exec_mu;
+    int hostwait = 0;                  // 0 poll the completion word (default), 1 hipStreamSynchronize (oth_plan_set_hostwait)
 };
 
 struct oth_chain {
@@ -229,12 +235,7 @@ int fail_nothrow(oth_ctx *c, int code, const char *what) noexcept {
     return code;
 }
 
-#define OTH_TRY try {
-#define OTH_CATCH(ctxexpr)                                                                                     \
-    }                                                                                                          \
-    catch (const std::bad_alloc &) { return fail_nothrow((ctxexpr), OTH_ERR_NOMEM, "out of host memory"); }    \
-    catch (const std::exception &e_) { return fail_nothrow((ctxexpr), OTH_ERR_INTERNAL, e_.what()); }          \
-    catch (...) { return fail_nothrow((ctxexpr), OTH_ERR_INTERNAL, "unknown C++ exception"); }
+// OTH_TRY / OTH_CATCH(context): csrc/abi_barrier.h (shared with the host-only probe the CPU suite builds)
 
 int use_device(oth_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
@@ -920,6 +921,7 @@ struct LaunchRecipe {
     bool tickets = false;        // draws chunk tickets from the context's queue
     bool two_runs = false;       // "ws2": the stream cut into two runs of segments
     int any_kind = 0;            // RK_ANY: AnyKind
+    bool any_r16 = false;        // ... on fft_tl.hip's register radix-16 kernels (32768 / 65536 points, one channel)
 };
 
 int generic_wg_for(int cu_count, int nfft, long long nseg, int nstreams) {
@@ -950,6 +952,7 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
         }
         r.kern = RK_ANY;
         r.any_kind = p.any.kind;
+        r.any_r16 = p.any.kind == ANY_TWOLEVEL && tl_supported(p.any.L) && !csd && p.tune_variant != "anycov";      // fft_tl.hip
         r.form = p.detrend ? 1 : 0;
         r.W = any_partial_rows(p.any, nseg, cu_count);
         r.layout = p.any.kind == ANY_TWOLEVEL ? 6 : 0;
@@ -1142,7 +1145,7 @@ std::string recipe_text(const LaunchRecipe &r, int nfft) {
     if (r.kern == RK_SEGPAD) k += r.seg_kind ? ":full" : ":half";
     if (r.kern == RK_W16K1X) k += std::string(r.x1_plain || r.x1_window ? ":plain" : ":pipe") + (r.x1_window ? ":window" : "");
     if (r.kern == RK_W16K1X_HALF && r.half_ws) k += ":ws";
-    if (r.kern == RK_ANY) k += std::string(":") + kAnyKindName[r.any_kind];
+    if (r.kern == RK_ANY) k += std::string(":") + kAnyKindName[r.any_kind] + (r.any_r16 ? ":r16" : "");
     snprintf(buf, sizeof buf, "kernel=%s nfft=%d form=%s pilot=%s sched=%s chunk=%d tail=%d nbig=%lld bpc=%d W=%d rows=%d nch=%d layout=%d",
              k.c_str(), nfft, kForm[r.form], kPilot[r.pilot], kSched[r.sched], r.chunk, r.tail_chunk, r.nbig, r.bpc, r.W, r.rows,
              r.nch, r.layout);
@@ -1603,6 +1606,7 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
     if (const char *e = getenv("OTH_W4096_CHUNK")) p->tune_chunk = atoi(e);
     if (const char *e = getenv("OTH_W4096_TAIL")) p->tune_tail = atoi(e);
     if (const char *e = getenv("OTH_PILOT_LAUNCH")) p->pilot_launch = atoi(e) != 0;
+    if (const char *e = getenv("OTH_HOSTWAIT")) p->hostwait = !strcmp(e, "sync") ? 1 : 0;      // initial value of oth_plan_set_hostwait
     std::vector<float> w(nfft, 0.f);   // zero-extended so that kernels may index [0, nfft)
     double s1 = 0.0, s2 = 0.0;
     p->rect_window = true;
@@ -1738,6 +1742,16 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
     OTH_CATCH((p ? p->ctx : nullptr))
 }
 
+int oth_plan_set_hostwait(oth_plan *p, int mode) {
+    OTH_TRY
+    CtxGuard guard_(p ? p->ctx : nullptr);
+    if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
+    if (mode != OTH_HOSTWAIT_POLL && mode != OTH_HOSTWAIT_SYNC) return fail(p->ctx, OTH_ERR_INVALID, "unknown host-wait mode");
+    p->hostwait = mode;
+    return OTH_OK;
+    OTH_CATCH((p ? p->ctx : nullptr))
+}
+
 int oth_plan_out_len(oth_plan *p, int *n) {
     OTH_TRY
     CtxGuard guard_(p ? p->ctx : nullptr);
@@ -1817,7 +1831,17 @@ namespace {
 constexpr double kPollSpinUs = 2000.0;         // tight polling (pause instructions only): covers a 2^28-sample launch; with
                                                // sched_yield() from 200 us on, a process with other runnable threads (bench.py
                                                // under torch) came back 30 us late (0.6256 against 0.595 ms per step)
-constexpr double kPollFallbackMs = 200.0;      // then yield between looks; past this, hipStreamSynchronize
+constexpr double kPollFallbackMs = 20.0;       // then yield between looks; past this, hipStreamSynchronize (round 5: 200 ms -
+                                               // a core per blocked caller for that long; OTH_HOSTWAIT_SYNC / oth_plan_set_hostwait
+                                               // is the mode for flowgraphs with many blocking sensors)
+
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#endif
+}
 
 inline double now_us() {
     timespec ts;
@@ -1839,7 +1863,7 @@ bool poll_seq(const unsigned *word, unsigned want, double budget_ms) {
     for (;;) {
         for (int i = 0; i < 32; ++i) {
             if (seq_reached(word, want)) return true;
-            __builtin_ia32_pause();
+            cpu_relax();
         }
         const double dt = now_us() - t0;
         if (dt > budget_ms * 1e3) return false;
@@ -1934,10 +1958,9 @@ int welch_collect(oth_plan *p, uint64_t ticket, float *psd_out, uint64_t *nseg_o
         word = p->h_seq + 16 * slot;
         nseg = p->out_nseg[slot];
     }
-    static const char *hostwait = getenv("OTH_HOSTWAIT");
     bool done = seq_reached(word, (unsigned)ticket);
     if (!done && wait) {
-        if (!(hostwait && !strcmp(hostwait, "sync"))) done = poll_seq(word, (unsigned)ticket, kPollFallbackMs);
+        if (p->hostwait == 0) done = poll_seq(word, (unsigned)ticket, kPollFallbackMs);
         if (!done) {
             CtxGuard guard_(c);
             if (use_device(c)) return OTH_ERR_HIP;
@@ -1990,6 +2013,7 @@ int oth_welch_exec(oth_plan *p, const void *iq, size_t nsamples, int src_is_devi
     if (!p) return fail(nullptr, OTH_ERR_INVALID, "plan is NULL");
     if (!iq || !psd_out) return fail(p->ctx, OTH_ERR_INVALID, "bad argument");
     uint64_t ticket = 0;
+    std::lock_guard<std::mutex> one_at_a_time(p->exec_mu);      // blocking callers of ONE plan, any number of threads
     {
         CtxGuard guard_(p->ctx);
         if (int rc = welch_enqueue(p, iq, nsamples, src_is_device, true, &ticket)) return rc;
@@ -3002,6 +3026,7 @@ int oth_xcorr(oth_ctx *c, const void *a, size_t na, const void *b, size_t nb, in
     OTH_CATCH(c)
 }
 
+#ifdef OTH_EXPERIMENTS      // the three readers below serve the stamped / diagnostic kernel builds: `make EXP=1` only
 // Not part of the ABI (not in the header): raw bytes behind the partial sums (diagnostic kernel builds).
 int oth__debug_tail(oth_plan *p, void *out, size_t nbytes, int *nwg) {
     OTH_TRY
@@ -3045,8 +3070,8 @@ int oth__debug_partial_raw(oth_plan *p, size_t float_offset, void *out, size_t n
     OTH_CATCH((p ? p->ctx : nullptr))
 }
 
-// Not part of the ABI: raises inside the barrier so that a host without a GPU can check it (tests/test_abi_cpu.py).
-// kind 0 = std::bad_alloc, 1 = std::runtime_error, 2 = a non-std exception, 3 = a real over-sized std::vector.
+#endif      // OTH_EXPERIMENTS
+
 // The launch recipe of a plan shape as text, WITHOUT a device (pure host logic; runtime_occupancy = 0 takes the resident
 // workgroups per CU from the built-in MI355X table, 1 asks the occupancy calculator and needs a GPU).
 //   window_class: 0 all ones, 1 spectrum confined (periodic cosine-sum windows: both detrend tables exist), 2 wide
@@ -3092,21 +3117,6 @@ int oth__debug_last_recipe(oth_plan *p, char *buf, size_t buflen) {
     snprintf(buf, buflen, "%s", p->last_recipe.c_str());
     return OTH_OK;
     OTH_CATCH((p ? p->ctx : nullptr))
-}
-
-int oth__debug_throw(oth_ctx *c, int kind) {
-    OTH_TRY
-    CtxGuard guard_(c);
-    if (kind == 0) throw std::bad_alloc();
-    if (kind == 1) throw std::runtime_error("debug: runtime_error");
-    if (kind == 2) throw 42;
-    if (kind == 3) {
-        std::vector<double> v;
-        v.resize(v.max_size());          // std::length_error or std::bad_alloc, whichever the runtime raises first
-        return (int)v.size();
-    }
-    return OTH_OK;
-    OTH_CATCH(c)
 }
 
 int oth_fac(oth_ctx *c, const void *data, size_t n, int L, float *out) {

@@ -62,20 +62,21 @@ template <int L2> __global__ __launch_bounds__(256) void tl_k1_kernel(TlArgs p) 
             mhi = make_float2(m.x, m.y);
             mlo = make_float2(m.z, m.w);
         }
+        // The window table holds L values, zero behind nperseg: rows of the zero padding read the segment's last sample
+        // (a valid address) and multiply it by 0 - sixteen unconditional loads, no branch per row.
         float2 v[16];
+        float w[16];
+        const int last = p.nperseg - 1;
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
             const int n = (a + 16 * b) * L2 + n2;
-            v[b] = n < p.nperseg ? src[n] : make_float2(0.f, 0.f);      // (plain loads: the overlapped half is read again from L2 / MALL)
+            v[b] = src[n < last ? n : last];      // (plain loads: the overlapped half is read again from L2 / MALL)
+            w[b] = p.win[n];
         }
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
-            const int n = (a + 16 * b) * L2 + n2;
-            if (n < p.nperseg) {
-                const float w = p.win[n];
-                const float2 d = csub(csub(v[b], mhi), mlo);
-                v[b] = make_float2(d.x * w, d.y * w);
-            }
+            const float2 d = csub(csub(v[b], mhi), mlo);
+            v[b] = make_float2(d.x * w[b], d.y * w[b]);
         }
         dft16(v);                                             // Z_a[kb] at v[r16(kb)]
         scatter_pow16<TL_RS>(v, lds + a * 16 + c, w1, w4);    // lds[kb][a][c] = Z_a[kb] W256^(a kb)

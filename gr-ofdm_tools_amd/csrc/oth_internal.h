@@ -313,7 +313,7 @@ struct TlArgs {
     const float2 *x;           // samples; segment s starts at x[first + s seg_step]
     long long first, seg_step;
     int nperseg;               // samples per segment (zero padded to L)
-    const float *win;          // nperseg window values (the table holds L)
+    const float *win;          // L window values, zero behind nperseg (oth_welch_plan's zero-extended table)
     const float4 *mean;        // per segment (hi.re, hi.im, lo.re, lo.im) or nullptr
     const double2 *bsum;       // or: sums of sub-blocks of kTlSub samples from x[first] on; segment s takes nsub of them
     int nsub, sub_step;        // from index s * sub_step

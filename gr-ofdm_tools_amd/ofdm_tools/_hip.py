@@ -16,6 +16,7 @@ SCALE_RAW, SCALE_DENSITY, SCALE_OVER_N2, SCALE_SPECTRUM = 0, 1, 2, 3
 EPI_MAG, EPI_MAG2, EPI_MAG2_OVER_N2 = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TUNED = 0, 1, 2
 SCHED_CONTIGUOUS, SCHED_INTERLEAVED, SCHED_DYNAMIC = 0, 1, 2
+HOSTWAIT_POLL, HOSTWAIT_SYNC = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('OFDM_TOOLS_HIP_LIB',
@@ -65,6 +66,7 @@ SIGNATURES = {
     'oth_plan_set_kernel': (C.c_int, [_p, C.c_int]),
     'oth_plan_set_schedule': (C.c_int, [_p, C.c_int]),
     'oth_plan_out_len': (C.c_int, [_p, C.POINTER(C.c_int)]),
+    'oth_plan_set_hostwait': (C.c_int, [_p, C.c_int]),
     'oth_plan_set_tuning': (C.c_int, [_p, C.c_char_p, C.c_int, C.c_int, C.c_int]),
     'oth_welch_exec': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _f, _u64p]),
     'oth_welch_exec_async': (C.c_int, [_p, _p, C.c_size_t, C.c_int, _u64p]),
@@ -171,6 +173,7 @@ class Context(object):
         self.h = h
         self.device = int(device)
         self.stream = None if stream is None else int(stream)      # the adopted hipStream_t, if any
+        self._plans_lock = threading.Lock()
 
     def on_torch_stream(self):
         """True when this context runs on torch's current stream of its device: kernels and torch ops
@@ -194,14 +197,22 @@ class Context(object):
     def cached_plan(self, key, make, limit=64):
         """One plan per (context, key) for callers that ask for the same shape with every request (the legacy helpers of
         ofdm_cr_tools): a plan owns device tables and scratch, and building one costs allocations and a stream
-        synchronisation.  The cache is closed with the context; past `limit` shapes the oldest goes."""
-        plans = self.__dict__.setdefault('_plans', {})
-        plan = plans.get(key)
-        if plan is None or not plan.h:
-            if len(plans) >= limit:
-                plans.pop(next(iter(plans))).close()
-            plan = plans[key] = make()
-        return plan
+        synchronisation.  GNU Radio block threads share the default context, so the cache is locked; a hit moves to the
+        young end (least-recently-used eviction), and past `limit` shapes the oldest plan WITHOUT an uncollected
+        exec_async() ticket goes - a plan that still owes a result is kept even if that overshoots the limit (closing it
+        would turn the ticket's poll / wait into an error inside work()).  The cache is closed with the context."""
+        with self._plans_lock:
+            plans = self.__dict__.setdefault('_plans', {})
+            plan = plans.pop(key, None)
+            if plan is None or not plan.h:
+                plan = make()
+            plans[key] = plan                  # (re-)inserted at the young end
+            while len(plans) > limit:
+                victim = next((k for k, v in plans.items() if k != key and not getattr(v, 'outstanding', 0)), None)
+                if victim is None:
+                    break
+                plans.pop(victim).close()
+            return plan
 
     def __del__(self):
         try:
@@ -399,6 +410,10 @@ class WelchPlan(object):
     def set_schedule(self, which):
         self.ctx.check(self.ctx.lib.oth_plan_set_schedule(self.h, int(which)), 'oth_plan_set_schedule')
 
+    def set_hostwait(self, sync):
+        """True: exec() / wait() sleep in hipStreamSynchronize instead of polling the completion word (low CPU)."""
+        self.ctx.check(self.ctx.lib.oth_plan_set_hostwait(self.h, HOSTWAIT_SYNC if sync else HOSTWAIT_POLL), 'oth_plan_set_hostwait')
+
     def nseg(self, nsamples):
         return (nsamples - self.noverlap) // self.step if nsamples >= self.nperseg else 0
 
@@ -436,6 +451,7 @@ class WelchPlan(object):
         else:
             rc = self.ctx.lib.oth_welch_exec_async(self.h, C.c_void_p(x), int(nsamples), 1, C.byref(t))
         self.ctx.check(rc, 'oth_welch_exec_async')
+        self.outstanding = getattr(self, 'outstanding', 0) + 1      # tickets not collected yet (Context.cached_plan keeps such a plan)
         return int(t.value)
 
     def poll(self, ticket):
@@ -446,13 +462,17 @@ class WelchPlan(object):
                        'oth_welch_poll')
         if not ready.value:
             return None
+        self.outstanding = max(0, getattr(self, 'outstanding', 0) - 1)
         self.last_nseg = n.value
         return out
 
     def wait(self, ticket):
         out = np.empty(self.out_len, np.float32)
         n = C.c_uint64()
-        self.ctx.check(self.ctx.lib.oth_welch_wait(self.h, int(ticket), _fptr(out), C.byref(n)), 'oth_welch_wait')
+        try:
+            self.ctx.check(self.ctx.lib.oth_welch_wait(self.h, int(ticket), _fptr(out), C.byref(n)), 'oth_welch_wait')
+        finally:
+            self.outstanding = max(0, getattr(self, 'outstanding', 0) - 1)
         self.last_nseg = n.value
         return out
 

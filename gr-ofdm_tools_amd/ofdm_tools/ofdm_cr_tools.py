@@ -26,13 +26,15 @@ def _py2div(a, b):
     return a / b
 
 
-def _welch_plan(ctx, nfft, window_name, Sf, npts=None):
+def _welch_plan(ctx, nfft, window_name, Sf, npts=None, use='exec'):
     """The reference's `sg.welch(x, Sf, window, nperseg=nfft, nfft=nfft)` + fftshift (ofdm_cr_tools.py:214,322,342).
     SciPy shortens nperseg to the input length when the vector is shorter than nfft ("nperseg = N is greater than input
     length", one zero-padded segment) - which fast_spectrum_scan(n_fft=0) always hits, its nFFT being the next power of
     two above len(vct_sample) (ofdm_cr_tools.py:474-475)."""
     nperseg = nfft if npts is None else min(int(nfft), int(npts))
-    return ctx.cached_plan(('welch', nfft, nperseg, window_name, float(Sf)),
+    # `use`: the ticket callers (SpectrumScan: exec_async / poll from work()) keep plans of their own - a plan's output ring
+    # holds the last four launches, and blocking helper calls on a shared plan could push an uncollected ticket out of it
+    return ctx.cached_plan(('welch', use, nfft, nperseg, window_name, float(Sf)),
                  lambda: ctx.welch_plan(nfft, nperseg=nperseg, window=windows.get_window(window_name, nperseg), fs=float(Sf),
                                         fftshift=True))
 
@@ -83,7 +85,7 @@ def _plain_channel_sums(psd, Fr, Sf, bb_freqs, srch_bins, ctx):
 
 def _enqueue_welch(vector, nFFT, Sf, ctx):
     """src_power_welch's PSD (flattop, nperseg = nfft, ofdm_cr_tools.py:213-216) as a ticket: -> (plan, ticket, post)."""
-    plan = _welch_plan(ctx, nFFT, 'flattop', Sf, len(vector))
+    plan = _welch_plan(ctx, nFFT, 'flattop', Sf, len(vector), use='async')
     return plan, plan.exec_async(vector), None
 
 

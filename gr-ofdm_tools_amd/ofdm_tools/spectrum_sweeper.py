@@ -124,8 +124,8 @@ class spectrum_sweeper(sync_block):
         self._wake = threading.Event()
 
     def _launch(self, start_delay, one_sweep, collective=False):
-        if self._stitch_thread is not None:
-            raise RuntimeError('spectrum_sweeper: the stitcher is already running')
+        if self._stitch_thread is not None and self._stitch_thread.is_alive():      # (a stitcher that ended by itself - a
+            raise RuntimeError('spectrum_sweeper: the stitcher is already running')  # finished collective loop, a stored error - is no obstacle)
         self.keep_running = True
         self._wake.clear()
         self._stitch_thread = threading.Thread(target=_stitch_loop, daemon=True,
@@ -194,7 +194,9 @@ class spectrum_sweeper(sync_block):
         self.keep_running = False
         self._wake.set()
         t = self._stitch_thread
-        if t is not None and t is not threading.current_thread():
+        if t is threading.current_thread():      # called from the stitcher itself (a handler it runs): the loop sees keep_running and
+            return True                          # ends; the handle stays until then, so that start() cannot put a second one beside it
+        if t is not None:
             t.join(5.0)
             if t.is_alive():      # still inside a capture / a collective: keep the handle, start() refuses a second stitcher
                 return False

@@ -44,9 +44,25 @@
 extern "C" {
 #endif
 
-#define OTH_ABI_VERSION 5      /* 3 = 2 + oth_chain_ticket_rows, oth_scan_decide_dev_out; 4 = 3 + OTH_ERR_INTERNAL,
+#define OTH_ABI_VERSION 6      /* 3 = 2 + oth_chain_ticket_rows, oth_scan_decide_dev_out; 4 = 3 + OTH_ERR_INTERNAL,
                                   OTH_DETREND_CONSTANT_EXACT, OTH_DETREND_CONSTANT_FAST; 5 = 4 + oth_welch_exec_async /
-                                  _poll / _wait (additions only) */
+                                  _poll / _wait; 6 = 5 + transform lengths outside the powers of two 64 ... 16384
+                                  (TRANSFORM LENGTHS below), oth_plan_set_hostwait (additions only) */
+
+/* TRANSFORM LENGTHS (ABI 6).  The reference puts no limit on a transform length - fft.fft_vcc(self.fft_len, ...)
+ * (psd_logger.py:48, spectrum_sensor_v2.py:90, local_worker.py:62-63), sg.welch(nperseg=nFFT, nfft=nFFT)
+ * (ofdm_cr_tools.py:214,322,342), np.fft.fft(., nFFT) (ofdm_cr_tools.py:177,157-160), fast_spectrum_scan's own
+ * nFFT = 2^ceil(log2(npts)) (ofdm_cr_tools.py:474-475), the web gateway's free --nfft
+ * (sdr_webserver/local_hw_gateway.py:284-285) - and neither do oth_welch_plan, oth_chain_create, oth_xcorr, oth_fac:
+ *   powers of two 64 ... 16384             the tuned kernels and the radix-4 coverage kernels (as before)
+ *   2-3-5-7-smooth lengths up to 16384     one launch, mixed-radix Stockham in LDS               "anyfft:direct"
+ *   powers of two 32768 ... 1048576        four-step L1 x L2 through a workspace in HBM / L2      "anyfft:twolevel"
+ *                                          (32768, 65536: register radix-16 kernels,              "anyfft:twolevel:r16")
+ *   every other length n <= 524288         Bluestein through 2^ceil(log2(2 n - 1)) points         "anyfft:bluestein[2]"
+ * (the quoted names are what oth__debug_last_recipe reports).  Still refused, OTH_ERR_UNSUPPORTED with the reason in
+ * oth_last_error(): powers of two above 1048576 and other lengths above 524288; OTH_KERNEL_TUNED on any of the new
+ * lengths.  Semantics, tolerances and every other argument are unchanged; a constant detrend at these lengths is taken
+ * from each segment's own mean (added in double, removed as a float pair) in every detrend mode. */
 
 #define OTH_OK               0
 #define OTH_ERR_INVALID     -1   /* bad argument */
@@ -106,7 +122,7 @@ extern "C" {
 
 /* kernel selection (diagnostics / parity tests) */
 #define OTH_KERNEL_AUTO      0
-#define OTH_KERNEL_GENERIC   1   /* radix-4 Stockham, any power of two 16..16384 */
+#define OTH_KERNEL_GENERIC   1   /* radix-4 Stockham, powers of two 64 ... 16384 (other lengths: always the any-length kernels) */
 #define OTH_KERNEL_TUNED     2   /* register/LDS radix-16 kernels (nfft 256 ... 16384) */
 
 /* how the tuned kernels hand segments to workgroups */
@@ -170,7 +186,8 @@ int oth_iq_power(oth_ctx *ctx, const void *iq_dev, size_t nsamples, double *mean
  * spectrum_sweeper.py:265-276.  Two-sided, mean over segments.
  *
  * window: nperseg host floats (NULL = rectangular).  trim_bins bins are dropped
- * from each end AFTER the optional fftshift; output length = nfft - 2*trim_bins.
+ * from each end AFTER the optional fftshift (np.fft.fftshift: bin k to (k + nfft / 2) mod nfft, odd nfft included);
+ * output length = nfft - 2*trim_bins.  nfft: any length, see TRANSFORM LENGTHS above.
  */
 int oth_welch_plan(oth_ctx *ctx, int nfft, int nperseg, int noverlap, const float *window,
                    int detrend, int scaling, double fs, int fftshift, int trim_bins, oth_plan **out);
@@ -179,6 +196,15 @@ int oth_plan_set_output_db(oth_plan *plan, int enable);      /* 10*log10 in the 
 int oth_plan_set_kernel(oth_plan *plan, int which);           /* OTH_KERNEL_* */
 int oth_plan_set_schedule(oth_plan *plan, int which);         /* OTH_SCHED_* */
 int oth_plan_out_len(oth_plan *plan, int *n);
+/* How the blocking / waiting host-output calls of this plan (oth_welch_exec, oth_welch_wait) wait for the GPU (ABI 6; a
+ * per-plan setting - round 5 read OTH_HOSTWAIT once per process).  POLL (default): the thread polls the completion word
+ * the last launch writes into pinned memory - pause instructions for at most 2 ms, yielding the CPU between looks up to
+ * 20 ms, then hipStreamSynchronize; the lowest latency (no interrupt wake-up), at the price of a busy core while it
+ * waits.  SYNC: hipStreamSynchronize at once - the mode for a flowgraph with many blocking sensors.  The OTH_HOSTWAIT
+ * environment variable ("sync") gives the initial value and is read once, in oth_welch_plan(). */
+#define OTH_HOSTWAIT_POLL 0
+#define OTH_HOSTWAIT_SYNC 1
+int oth_plan_set_hostwait(oth_plan *plan, int mode);
 /* Launch tuning for A/B tools and the parity suite: which build of the 4096-point kernel ("dpp", "pipe", "ws") or
  * of the 256 ... 2048-point kernels ("seg3", "seg4": registers held to 3 / 4 waves per SIMD; NULL or "" = the
  * library's choice), or only the detrend form of the size's default kernel ("fd": after the transform even below 8
@@ -191,7 +217,8 @@ int oth_plan_set_tuning(oth_plan *plan, const char *variant, int sched, int chun
 
 /* one-shot: nsamples complex64 -> psd_out[nfft - 2*trim] (host).  Blocking: returns when the PSD is in psd_out.  The
  * last launch writes the row and a completion word into pinned host memory and the call polls that word (no interrupt
- * wake-up; after 200 ms it falls back to a stream synchronisation, which also reports a failed launch). */
+ * wake-up; after 20 ms it falls back to a stream synchronisation, which also reports a failed launch;
+ * oth_plan_set_hostwait).  Any number of threads may call it on one plan: they run one after the other. */
 int oth_welch_exec(oth_plan *plan, const void *iq, size_t nsamples, int src_is_device,
                    float *psd_out, uint64_t *nseg_out);
 /* The same step without blocking (ABI 5) - what a gr.sync_block's work() or message handler needs for a Welch scan
@@ -251,7 +278,7 @@ int oth_csd_scale_dev(oth_plan *plan, const float *sums_dev, uint64_t nseg_total
  * of spectrum_sensor_v2.py:85-93, psd_logger.py:43-53, local_worker.py:58-69,
  * multichannel_scanner.py:78-86.  The chain keeps GNU Radio's stream state
  * between calls: leftover samples of a partial vector, the keep_one_in_n
- * counter, the IIR memory and the peak-hold vector.
+ * counter, the IIR memory and the peak-hold vector.  nfft: any length (TRANSFORM LENGTHS above).
  */
 int oth_chain_create(oth_ctx *ctx, int nfft, const float *window, int fftshift, int epilogue,
                      int keep_one_in_n, oth_chain **out);
@@ -322,8 +349,9 @@ int oth_scan_decide_dev_out(oth_ctx *ctx, const float *psd_rows_dev, int nrows, 
                             float *noise_dev, float *power_dev);
 
 /* ---- xcorr (ofdm_cr_tools.py:155-161) ------------------------------------
- * |fftshift(ifft(fft(b,L) * conj(fft(a,L))))[L/2:]|, L a power of two <= 16384;
- * a, b host complex64 of na, nb <= L samples (zero-padded); out float[L - L/2]. */
+ * |fftshift(ifft(fft(b,L) * conj(fft(a,L))))[L/2:]| for any L (TRANSFORM LENGTHS above; `L/2` is the reference's
+ * Python-2 integer division: L - L/2 outputs); a, b host complex64 of na, nb samples, zero-padded to L or, like
+ * np.fft.fft(a, L), cut to their first L; out float[L - L/2]. */
 int oth_xcorr(oth_ctx *ctx, const void *a, size_t na, const void *b, size_t nb, int L, float *out);
 /* fac (ofdm_cr_tools.py:163-166): |fftshift(fft(|fft(data,L)|, L))[L/2:]| */
 int oth_fac(oth_ctx *ctx, const void *data, size_t n, int L, float *out);

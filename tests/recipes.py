@@ -54,12 +54,30 @@ def grid(full):
                                    nseg=nseg, nstreams=ns)
 
 
+def grid_any(full):
+    """Round 6: lengths outside the power-of-two kernels (csrc/fft_any.hip / fft_tl.hip): tiny powers of two, 2-3-5-7-smooth
+    lengths, Bluestein in one launch and through the four-step route, powers of two above 16384, and what is refused."""
+    sizes = (8, 32, 96, 1000, 1021, 1536, 8191, 10007, 15000, 20000, 32768, 65536, 131072, 1048576, 524288 + 2, 2097152)
+    for nfft in sizes:
+        for frac, ov in itertools.product((1, 4), (0, 2)):
+            nperseg = nfft // frac
+            nov = 0 if ov == 0 else nperseg - nperseg // ov
+            for det, two in itertools.product((0, 1), (0, 1)):
+                for nseg, ns in itertools.product((1, 40, 600, 131071) if full else (2, 600), (1, 8) if full else (1,)):
+                    if two and ns != 1:
+                        continue
+                    yield dict(nfft=nfft, nperseg=nperseg, noverlap=nov, window=1, detrend=det, two_channel=two, nseg=nseg,
+                               nstreams=ns)
+        yield dict(nfft=nfft, nperseg=nfft, noverlap=nfft // 2, window=1, detrend=1, two_channel=0, nseg=600, nstreams=1,
+                   kernel=2)      # OTH_KERNEL_TUNED: refused with a reason
+
+
 def table(lib, full):
     lines = []
-    for k in grid(full):
-        key = 'nfft=%d nperseg=%d noverlap=%d window=%s detrend=%s%s nseg=%d streams=%d' % (
+    for k in itertools.chain(grid(full), grid_any(full)):
+        key = 'nfft=%d nperseg=%d noverlap=%d window=%s detrend=%s%s nseg=%d streams=%d%s' % (
             k['nfft'], k['nperseg'], k['noverlap'], WINDOWS[k['window']], DETREND[k['detrend']],
-            ' two-channel' if k['two_channel'] else '', k['nseg'], k['nstreams'])
+            ' two-channel' if k['two_channel'] else '', k['nseg'], k['nstreams'], ' tuned-only' if k.get('kernel') == 2 else '')
         lines.append(key + '  ->  ' + recipe(lib, **k))
     return lines
 

@@ -317,3 +317,155 @@ def test_ref_any_length_scans_plots_and_xcorr_on_the_gpu(ctx, golden):
         assert np.max(np.abs(T.xcorr(a, b, L, ctx=ctx) - ref)) / np.max(ref) < RTOL
         ref = g['fac_%d' % L]
         assert np.max(np.abs(T.fac(a, L, ctx=ctx) - ref)) / np.max(ref) < RTOL
+
+
+# ---- the blocks at fft_len values that are not powers of two (the reference passes fft_len straight to fft.fft_vcc) --------
+
+def test_blocks_accept_any_fft_len(ctx, hip, tmp_path):
+    import ofdm_tools
+    from ofdm_tools import packets
+    # spectrum_sensor_v2 (spectrum_sensor_v2.py:85-93): 1000 points, keep_one_in_n(5), channel powers against the oracle
+    fft_len, Sf = 1000, 1000 * 100
+    blk = ofdm_tools.spectrum_sensor_v2(fft_len, 20, Sf, channel_space=5000, search_bw=2500, trunc_band=Sf - 10000, stats=True,
+                                        ctx=ctx, threaded=False)
+    assert blk.decimation == 5
+    x = R.synth_iq(fft_len * 40 + 13, 17)
+    assert blk.feed(x, max_items=3777) == len(x)
+    st = R.ScannerState(fft_len, Sf, 5000, 2500, trunc_band=Sf - 10000)
+    rows = R.chain_sensor_v2(x, fft_len, decim=5)
+    for r in rows:
+        st.scan(r.astype(np.float32))
+    assert blk._scanner.n_measurements == len(rows) == 8
+    assert np.allclose(blk.power_level_ch, st.plc, rtol=1e-4)
+    # multichannel_scanner (multichannel_scanner.py:78-86) at 12000 points
+    fft_len, Sf = 12000, 1200000
+    st = R.ScannerState(fft_len, Sf, 25e3, 12.5e3, tune_freq=0, trunc_band=Sf)
+    subj = [st.ax_ch[i] for i in (3, 9, 20, 31, 40)]
+    blk = ofdm_tools.multichannel_scanner(fft_len, 1000, Sf, channel_space=25e3, search_bw=12.5e3, tune_freq=0, trunc_band=Sf,
+                                          subject_channels=subj, ctx=ctx, threaded=False)
+    x = R.synth_iq(fft_len * 3, 3000)
+    blk.feed(x, max_items=fft_len)
+    for r in R.chain_sensor_v2(x, fft_len, decim=blk.decimation):
+        st.scan(r.astype(np.float32))
+    assert np.allclose(blk.power_level_ch, st.plc, rtol=1e-4)
+    assert blk.top4 == R.publish_top4(st.plc, st.ax_ch, subj)[1]
+    # psd_logger (psd_logger.py:43-56,85) at a prime length: Blackman-Harris, |X|, running peak, np.save per vector
+    n = 1021
+    path = str(tmp_path / 'psd_log.npy')
+    blk = ofdm_tools.psd_logger(n, 1000, n * 1000, ctx=ctx, threaded=False, mat_file=path)
+    x = R.synth_iq(n * 7, 9)
+    blk.feed(x, max_items=n)
+    _, peak = R.chain_psd_logger(x, n)
+    assert relerr(blk.peak_vals, peak[-1]) < RTOL and relerr(np.load(path), peak[-1]) < RTOL
+    # local_worker (local_worker.py:58-71,147-172) at 3000 points: IIR + log row, fragments of the float32 payload
+    N, Sf, alpha = 3000, 3000000, 0.4
+    blk = ofdm_tools.local_worker(N, Sf, alpha, Sf / N, 1472, True, ctx=ctx, threaded=False)
+    frames = []
+    blk.msg_connect('pdus', lambda m: frames.append(m[1]))
+    x = R.synth_iq(N * 6, 10)
+    blk.feed(x, max_items=N)
+    lin, _ = R.chain_local_worker(x, N, Sf, alpha)
+    k = -10 * np.log10(N) - 10 * np.log10(Sf)
+    assert relerr(10 ** ((blk.last_db.astype(np.float64) - k) / 10), lin[-1]) < RTOL
+    assert frames[-9:] == R.worker_fragments(blk.last_db, 1470, N, True)      # ceil(12000 / 1470) = 9
+    assert np.array_equal(np.frombuffer(packets.reassemble(frames[-9:]), '<f4'), blk.last_db)
+    # ascii_plot's chain (ascii_plot.py:57-70) at 1536 points
+    N, Sf = 1536, 1536 * 30
+    blk = ofdm_tools.ascii_plot(N, Sf, 433.0e6, 0.3, 10, 64, 20, ctx=ctx, threaded=False)
+    x = R.synth_iq(N * 31 + 5, 77)
+    blk.feed(x, max_items=4000)
+    lin, db = R.chain_ascii_plot(x, N, Sf, 0.3, decim=3)
+    assert relerr(blk._chain.iir(), lin[-1]) < RTOL and blk.last_plot
+
+
+class _Rx(object):
+    def __init__(self):
+        self.tuned = []
+
+    def set_center_freq(self, f, chan):
+        self.tuned.append(f)
+
+
+def test_sweeper_estimator_and_legacy_sensor_accept_any_fft_len(ctx, hip, tmp_path):
+    import ofdm_tools
+    # spectrum_sweeper (spectrum_sweeper.py:62-70,260-276): fft_len 3000 -> flat-top of 750 points zero-padded to 3000
+    rx = _Rx()
+    fft_len, Sf, tSf = 3000, 2000000, 1750000
+    blk = ofdm_tools.spectrum_sweeper(rx, 'rtl', fft_len, Sf, tSf, 100e6, 107e6, 15, 0.0, 8, 0, 1472, ctx=ctx, threaded=False)
+    pts, tune, excess = R.sweeper_geometry(fft_len, Sf, tSf, 100e6, 107e6, 8)
+    assert (blk.vector_probe_pts, blk.tune_frequencies, blk.excess_bins) == (pts, tune, excess)
+    vectors = [R.synth_iq(pts, 2000 + i) for i in range(len(tune))]
+    it = iter(vectors)
+    blk.get_samples = lambda: next(it)
+    psd = blk.sweep_once(sleep=lambda s: None)
+    ref = R.sweeper_stitch(vectors, fft_len, Sf, excess, 0.0)
+    assert psd.shape == ref.shape and relerr(10 ** (psd / 10), 10 ** (ref / 10)) < RTOL
+    # coherence_estimator -> coherence_detector (coherence_detector.py:184-202,254-274) at N = 1000
+    N, Sf, tune_f = 1000, 2000000, 433000000
+    x = R.synth_iq(N * 40, 11)
+    y = (0.7 * np.roll(x, 5) + 0.5 * R.synth_iq(len(x), 12, tones=(), dc=0)).astype(np.complex64)
+    est = ofdm_tools.coherence_estimator(N, Sf, block_len=len(x), ctx=ctx)
+    est.work([x, y], [])
+    _, cref, _, _, _ = R.coherence_np(x, y, fs=Sf, nperseg=N, nfft=N)
+    assert np.max(np.abs(est.cxy - np.fft.fftshift(cref))) < RTOL
+    det = ofdm_tools.coherence_detector(N, Sf, threshold=1.2, threshold_mtm=0.2, tune_freq=tune_f,
+                                        subject_channels=[tune_f + 0.1234 * Sf, tune_f - 0.31 * Sf])
+    quiet = np.zeros(N, np.float32)
+    det.work([est.cxy.reshape(1, N), quiet.reshape(1, N), quiet.reshape(1, N)], [])
+    coh, outcome, _ = R.coherence_scanner(np.fft.fftshift(cref), quiet, quiet, det.idx_subject_channels, 1.2, 0.2)
+    assert det.get_subject_channels_outcome() == outcome
+    assert np.allclose(det.subject_channels_coherence, coh, atol=2e-4)
+
+
+def test_eight_threads_block_in_exec_on_one_plan(ctx, hip):
+    """Advisor, round 5: oth_welch_exec takes a ticket and collects it from a four-slot output ring outside the context
+    lock; with five or more threads blocked in it on ONE plan the fifth launch rewrote the first caller's row.  Blocking
+    calls of one plan now run one after the other (a plan mutex across enqueue + collect): eight threads, one cached plan,
+    each its own input - every caller gets ITS spectrum, none an OTH_ERR_STATE."""
+    import threading
+    n = 4096
+    plan = ctx.cached_plan(('t8', n), lambda: ctx.welch_plan(n, window=_win('hann', n)))
+    assert ctx.cached_plan(('t8', n), lambda: None) is plan
+    xs = [R.synth_iq(n * 40, 800 + i, tones=((1.0 + i, 0.05 * (i + 1)),)) for i in range(8)]
+    refs = [R.welch_np(x, nperseg=n, nfft=n)[1] for x in xs]
+    errs, bad = [None] * 8, []
+
+    def run(i):
+        try:
+            worst = 0.0
+            for _ in range(25):
+                worst = max(worst, relerr(plan.exec(xs[i]), refs[i]))
+            errs[i] = worst
+        except Exception as e:      # noqa: BLE001
+            bad.append((i, repr(e)))
+    th = [threading.Thread(target=run, args=(i,)) for i in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not bad, bad
+    assert all(e is not None and e < RTOL for e in errs), errs
+    # the low-CPU wait mode gives the same answer
+    plan.set_hostwait(True)
+    assert relerr(plan.exec(xs[0]), refs[0]) < RTOL
+    plan.set_hostwait(False)
+
+
+def test_plan_cache_is_lru_and_keeps_plans_that_owe_a_ticket(ctx, hip):
+    made = []
+
+    def mk(n):
+        def f():
+            made.append(n)
+            return ctx.welch_plan(n)
+        return f
+    x = R.synth_iq(4096, 3)
+    p64 = ctx.cached_plan(('lru', 64), mk(64), limit=3)
+    t = p64.exec_async(x)                       # owes a result from here on
+    for n in (128, 256, 512, 1024):
+        ctx.cached_plan(('lru', n), mk(n), limit=3)
+    assert p64.h                                # survived four insertions past the limit
+    assert p64.wait(t).shape == (64,) and p64.outstanding == 0
+    ctx.cached_plan(('lru', 2048), mk(2048), limit=3)
+    assert not p64.h                            # collected: now it is the oldest and goes
+    assert made == [64, 128, 256, 512, 1024, 2048]
