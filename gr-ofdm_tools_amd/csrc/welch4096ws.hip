@@ -309,7 +309,13 @@ __global__ __launch_bounds__(TWS, 4) void welch4096ws_kernel(WelchArgs p) {
             // the probe loads go out behind the chunk head's (one memory round trip for both); per-wave totals into
             // image 1, which no step writes before the barrier of step 0; one extra workgroup barrier (the consumers
             // take it in front of their loop)
-            const PilotProbes probes = inline_pilot_load(xb, p.nseg, 2048, t);
+            // Contiguous runs (short launches - fewer than 32 segments per workgroup - and OTH_SCHED_CONTIGUOUS): the eight
+            // probes are spread over THIS workgroup's run, so the pilot follows an offset that moves through the launch
+            // (round 6: a drift of 1200 sigma over 2047 segments read 1.05e-4 with one pilot per launch; every segment is
+            // one workgroup's, so the pilots need not agree between workgroups).  Chunked schedules keep the launch-wide
+            // probes: a workgroup's chunks lie anywhere in the stream.
+            const bool own = sched == 0 && have;
+            const PilotProbes probes = inline_pilot_load(own ? xb + (size_t)sb * 2048 : xb, own ? (long long)(se - sb) : p.nseg, 2048, t);
             inline_pilot_store(probes, t, img + LDS_X);
             lds_barrier();
             pv = inline_pilot_value(img + LDS_X);

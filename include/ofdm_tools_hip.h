@@ -85,13 +85,18 @@ extern "C" {
                                    bin inside 1e-4 at 1 ... 9 segments and |m| = 35 sigma, every bin at 2e-7 with 2047
                                    segments and a DC line of 3000 sigma (70 dB above the signal), bins 0, +-1 at 1e-6
                                    where SciPy on complex64 input reads 1e-4 ... 5e-3.  That is for a CONSTANT
-                                   offset.  The pilot is one value per launch and stream: an offset that MOVES by D
-                                   within one launch leaves a line of about D / 2 (a step: of D, in the one or two
-                                   segments that hold it) to the float32 transform - which holds for the exact
-                                   time-domain form as well, the line then being real signal.  Measured over four
-                                   noise seeds at 2047 segments of 4096 points: every bin inside 1e-4 for offsets
-                                   moving by up to 1000 sigma, inside 2e-4 for a 3000-sigma opening transient and a
-                                   drift of 1200 sigma (default 4.7e-5 ... 1.05e-4, time-domain builds 5e-6 ... 1.1e-4).
+                                   offset.  The pilot is one value per stream and launch - per workgroup where a
+                                   workgroup walks one contiguous run of segments (launches of fewer than 32 segments
+                                   per resident workgroup, OTH_SCHED_CONTIGUOUS: the 4096-point role-split kernel spreads
+                                   its probes over its own run, round 6) - so an offset that MOVES by D within the reach
+                                   of one pilot leaves a line of about D / 2 (a step: of D, in the one or two segments
+                                   that hold it) to the float32 transform; the exact time-domain form sees the same
+                                   line as real signal.  Measured over eight noise seeds at 2047 segments of 4096 points:
+                                   every bin inside 1e-4 for a 3000-sigma opening transient (worst 8.9e-5; SciPy on
+                                   complex64: 1.08e-4) and 2e-7 for drifts of up to 1200 sigma on the default plan; the
+                                   time-domain builds within 4 ulp of the spectrum's peak amplitude on every bin and
+                                   1e-4 on every bin at or above the median (tests/test_hip_parity.py
+                                   test_pilot_under_a_transient_and_a_drifting_offset, profiles/r06_moving_offset.txt).
                                    Launches of fewer than 8 segments per stream detrend before the window (their own
                                    mean per segment); with 1-3 segments and an offset moving by 100 sigma every bin
                                    stays within 4 ulp of the row's peak amplitude (what a single float32 transform of a

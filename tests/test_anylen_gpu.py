@@ -85,7 +85,7 @@ def test_two_level_routes_across_workspace_chunks(ctx, hip, n, variant):
 
 def test_routes_are_the_documented_ones(ctx):
     want = {96: 'direct', 15000: 'direct', 97: 'bluestein', 8191: 'bluestein', 10007: 'bluestein2', 20000: 'bluestein2',
-            32768: 'twolevel', 131072: 'twolevel', 32: 'direct'}
+            32768: 'twolevel:r16', 65536: 'twolevel:r16', 131072: 'twolevel', 32: 'direct'}
     for n, kind in want.items():
         plan = ctx.welch_plan(n)
         plan.exec(R.synth_iq(2 * n, 1))

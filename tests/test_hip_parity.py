@@ -387,7 +387,9 @@ def test_welch_exactly_one_segment_and_too_short(ctx, hip):
 
 
 def test_welch_bad_plans_are_rejected(ctx, hip):
-    for kw in (dict(nfft=1000), dict(nfft=32), dict(nfft=32768), dict(nfft=1024, nperseg=2048),
+    # (round 6: nfft = 1000, 32, 32768 are plans now - tests/test_anylen_gpu.py; what stays refused is a length the
+    # any-length engine cannot reach, and the argument errors)
+    for kw in (dict(nfft=0), dict(nfft=(1 << 21)), dict(nfft=600001), dict(nfft=1024, nperseg=2048),
                dict(nfft=1024, noverlap=1024), dict(nfft=1024, trim_bins=512), dict(nfft=1024, fs=0.0)):
         with pytest.raises(hip.HipError):
             ctx.welch_plan(**kw)
@@ -1436,15 +1438,22 @@ def test_detrend_pilot_and_fast_build_of_every_kernel(ctx, hip):
 
 def test_pilot_under_a_transient_and_a_drifting_offset(ctx, hip):
     """An offset that MOVES within one launch (4096-point Hann, 50 % overlap, 2047 segments; the default plan = the
-    frequency-domain build on x - pilot, and the exact time-domain builds beside it).  The pilot is the average of eight
-    probe means spread over the launch, so it sits in the middle of a drift and a one-segment transient moves it by an
-    eighth; what is left in a segment is real signal whose float32 rounding no constant removes - the exact
-    time-domain form included.  Four noise seeds (round 4 asserted 1e-4 on ONE seed, on which the time-domain build
-    happened to read 5e-5; on seed 1 it reads 1.1e-4):
-      * offsets moving by up to 1000 sigma (an opening segment 60 dB above the signal's total power; a drift of 400
-        sigma): every bin inside 1e-4 on both forms;
-      * 3000 sigma / a drift of 1200 sigma: the default inside 2e-4 (measured on MI355X, four seeds: default
-        4.7e-5 ... 1.05e-4, time-domain 5e-6 ... 2.3e-4) - the bound the header states for moving offsets.
+    frequency-domain build on x - pilot, and the exact time-domain builds beside it), eight noise seeds, offsets moving
+    by up to 3000 sigma (an opening segment 70 dB above the signal's total power) and drifts of up to 1200 sigma.
+      * The DEFAULT plan: every bin inside the contract's 1e-4, every seed, every case (round 5 held it to 2e-4: one
+        pilot per launch left a 600-sigma line to the float32 transform at the ends of a drift.  Round 6: a launch this
+        short runs contiguous runs of ~4 segments per workgroup, and each workgroup now spreads its pilot probes over
+        its OWN run - welch4096ws.hip - so the pilot follows the drift: 1.05e-4 -> 1.9e-7; measured worst over the eight
+        seeds 8.9e-5, on the 3000-sigma transient, where SciPy on complex64 reads up to 1.08e-4).
+      * The TIME-DOMAIN builds ('td': what a window with a wide spectrum or a launch of fewer than eight segments
+        takes) are gated too (round 5 printed them): the plain 1e-4 on every bin at or above the spectrum's median, and
+        on EVERY bin an amplitude error of at most 4 ulp of the spectrum's peak amplitude - the single-row criterion
+        (check_single_rows), which is the regime here: the segment that holds the transient's edge puts bins +-1 a factor
+        5e5 above the median while its own mean removal leaves bin 0 at 0.4 x the median, and ANY float32 transform
+        leaves ~1 ulp of the largest amplitude in every bin (measured: 2.3e-4 of bin 0 = 0.85 ulp of the peak; SciPy on
+        complex64, the reference's own arithmetic, 9.4e-5 of the same bin) - and the bound tied to that arithmetic,
+        max(1e-4, 1.5 x relerr(welch_c64)), on every bin but the one the edge empties (bin 0).
+    tools/moving_offset_probe.py prints the table (profiles/r06_moving_offset.txt).
     Few segments (1, 2, 3: below kFdMinSegments the plan takes the time-domain builds, advisor round 4) with an offset
     moving by 100 sigma: the rows are single float32 periodograms of a strong ramp - held to 4 ulp of the row's peak
     amplitude on every bin and to 1.5 x what the reference's own arithmetic (SciPy on complex64: 5e-5 ... 7e-4 on these
@@ -1455,23 +1464,30 @@ def test_pilot_under_a_transient_and_a_drifting_offset(ctx, hip):
     opening[:N] = 1.0
     ramp = np.linspace(0.0, 1.0, n)
     worst = {}
-    for seed in (5150, 1, 2, 3):
+    for seed in (5150, 1, 2, 3, 4, 5, 6, 7):
         rng = np.random.default_rng(seed)
         noise = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.sqrt(0.5)
-        for name, dc, gate in (('transient 1000', 1000.0 * opening, RTOL), ('drift 400', 400.0 * ramp, RTOL),
-                               ('transient 3000', 3000.0 * opening, 2 * RTOL), ('drift 1200', 1200.0 * ramp, 2 * RTOL)):
+        for name, dc in (('transient 1000', 1000.0 * opening), ('drift 400', 400.0 * ramp),
+                         ('transient 3000', 3000.0 * opening), ('drift 1200', 1200.0 * ramp)):
             x = (noise + dc * np.exp(0.54j)).astype(np.complex64)
             _, ref = R.welch_np(x, nperseg=N, nfft=N)
+            c64 = relerr(R.welch_c64(x, nperseg=N, nfft=N), ref)      # what the reference's own float32 arithmetic loses
             for force in (None, 'td'):
                 plan = ctx.welch_plan(N, window=hann(N), kernel=hip.KERNEL_TUNED)
                 plan.set_tuning(force)
                 plan.set_schedule(hip.SCHED_CONTIGUOUS)      # fixed summation order: the same digits on every run
-                err = relerr(plan.exec(x), ref)
+                got = plan.exec(x).astype(np.float64)
                 plan.close()
-                worst[(name, force or 'auto')] = max(worst.get((name, force or 'auto'), 0.0), err)
-                if gate == RTOL or force is None:      # (the exact form at 3000 / 1200 sigma is recorded, not gated:
-                    assert err < gate, (seed, name, force, err)      # 1.1e-4 ... 2.3e-4 depending on the summation order)
-    print('moving offsets, worst of four seeds: ' + ', '.join('%s %s %.1e' % (k[0], k[1], v) for k, v in sorted(worst.items())))
+                rel = np.abs(got - ref) / ref
+                worst[(name, force or 'auto')] = max(worst.get((name, force or 'auto'), 0.0), float(rel.max()))
+                if force is None:
+                    assert rel.max() < RTOL, (seed, name, rel.max())
+                    continue
+                amp = np.abs(np.sqrt(got) - np.sqrt(ref)) / np.sqrt(ref.max())
+                assert amp.max() <= 4 * 2.0 ** -23, (seed, name, amp.max() * 2.0 ** 23)
+                assert rel[ref >= np.median(ref)].max() < RTOL, (seed, name)
+                assert rel[1:].max() < max(RTOL, 1.5 * c64), (seed, name, float(rel[1:].max()), c64)
+    print('moving offsets, worst of eight seeds: ' + ', '.join('%s %s %.1e' % (k[0], k[1], v) for k, v in sorted(worst.items())))
     # one, two, three segments under an offset that moves by 100 sigma within the launch
     rng = np.random.default_rng(77)
     for nfft in (2048, 4096, 16384):
