@@ -1447,7 +1447,7 @@ def test_pilot_under_a_transient_and_a_drifting_offset(ctx, hip):
         seeds 8.9e-5, on the 3000-sigma transient, where SciPy on complex64 reads up to 1.08e-4).
       * The TIME-DOMAIN builds ('td': what a window with a wide spectrum or a launch of fewer than eight segments
         takes) are gated too (round 5 printed them): the plain 1e-4 on every bin at or above the spectrum's median, and
-        on EVERY bin an amplitude error of at most 4 ulp of the spectrum's peak amplitude - the single-row criterion
+        on every bin outside 1e-4 an amplitude error of at most 4 ulp of the spectrum's peak amplitude - the single-row criterion
         (check_single_rows), which is the regime here: the segment that holds the transient's edge puts bins +-1 a factor
         5e5 above the median while its own mean removal leaves bin 0 at 0.4 x the median, and ANY float32 transform
         leaves ~1 ulp of the largest amplitude in every bin (measured: 2.3e-4 of bin 0 = 0.85 ulp of the peak; SciPy on
@@ -1484,7 +1484,8 @@ def test_pilot_under_a_transient_and_a_drifting_offset(ctx, hip):
                     assert rel.max() < RTOL, (seed, name, rel.max())
                     continue
                 amp = np.abs(np.sqrt(got) - np.sqrt(ref)) / np.sqrt(ref.max())
-                assert amp.max() <= 4 * 2.0 ** -23, (seed, name, amp.max() * 2.0 ** 23)
+                weak = rel >= RTOL      # bins outside the plain 1e-4: within 4 ulp of the peak amplitude, and below the median
+                assert np.all(amp[weak] <= 4 * 2.0 ** -23), (seed, name, amp[weak].max() * 2.0 ** 23)
                 assert rel[ref >= np.median(ref)].max() < RTOL, (seed, name)
                 assert rel[1:].max() < max(RTOL, 1.5 * c64), (seed, name, float(rel[1:].max()), c64)
     print('moving offsets, worst of eight seeds: ' + ', '.join('%s %s %.1e' % (k[0], k[1], v) for k, v in sorted(worst.items())))
