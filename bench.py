@@ -19,6 +19,11 @@ N = 1  workload "C2" (the configuration BASELINE.json's metric is quoted on): on
        the launch (oth__debug_last_recipe) and whose `traffic` is the figure of the builder's rocprofv3 PMC passes of
        the same configuration (profiles/traffic.json: not measured by this run); `h2d_inclusive` (host buffer -> PSD through the streaming entry point);
        `cpu_baseline` (+ `_parallel`, `_c5`).
+N > 1  --workload c5: BASELINE config 5 over the ranks (64 channel streams, stream c on rank c mod N, PSD rows + decision
+       stage per rank, one all-gather of rows + noise floors + channel powers: BatchScanPlan.scan_sharded); --workload c2: the
+       2^28-sample stream cut into one contiguous run of segments per rank (sweep.welch_long_stream: one all-gather of raw
+       sums).  Both STRONG scaling, each with `ranks_seen`, a prefix parity number and a `scaling_base` naming the N = 1 key
+       to divide by.  Default (the driver's line):
 N > 1  workload "C4" (BASELINE config 4 = the north star's 8-segment sweep), STRONG scaling: a FIXED sweep of
        8 RF segments x 2^27 samples, segment i on rank i mod N, the same Welch parameters + fftshift + 256-bin
        trim + dB (spectrum_sweeper.py:260-276), then ONE all-gather (RCCL) of the 3584-bin rows into tune order
@@ -245,6 +250,12 @@ def main():
     ap.add_argument('--log2-samples', type=int, default=LOG2_SAMPLES, help='C2 stream length (N = 1)')
     ap.add_argument('--sweep-log2-samples', type=int, default=SWEEP_LOG2_SAMPLES,
                     help='samples per RF segment of the 8-segment sweep (N > 1, and the sweep_c4 key at N = 1)')
+    ap.add_argument('--workload', choices=('c4', 'c5', 'c2'), default='c4',
+                    help='N > 1 only: c4 = the 8-segment sweep (default; the driver\'s line), c5 = BASELINE config 5 with its 64 '
+                         'channel rows over the ranks (BatchScanPlan.scan_sharded: one all-gather of rows + floors + powers), '
+                         'c2 = the 2^28-sample stream cut into one run of segments per rank (sweep.welch_long_stream: one '
+                         'all-gather of raw sums)')
+    ap.add_argument('--scan-log2-samples', type=int, default=22, help='samples per channel stream of --workload c5')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='N = 1: skip the sweep_c4, csd_c3, scan_c5, host-visible and h2d_inclusive keys')
@@ -399,6 +410,26 @@ def main():
                             'algorithmic_bytes_per_launch': 8 * S,
                             'whole_sweep_frac': 8.0 * total / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                'parity_prefix_max_rel_err': err}
+        if ref_call:
+            # Eight transforms per 4096 new samples: this workload cannot approach the byte roofline, its ceiling is VALU issue
+            # (verdict r5).  achieved = VALU wave-instructions per second - the instruction count per launch is the builder's
+            # PMC figure (profiles/traffic.json, scaled by the launch size; not measured by this run), the time is this run's;
+            # peak = 1024 SIMDs x one wave-instruction per 2 cycles at the 2.4 GHz peak engine clock.  The HBM figure stays
+            # beside it as `hbm`.
+            try:
+                tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))['C4ref']
+                instr = tj['valu_wave_instructions_per_launch'] * (8.0 * S) / tj['algorithmic_bytes_per_launch']
+                src = tj['valu_source']
+            except (OSError, ValueError, KeyError):
+                instr, src = None, None
+            hbm = {k: out['roofline'][k] for k in ('achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'whole_sweep_frac')}
+            peak = 1024 * 2.4e9 / 2 / 1e9
+            ach_i = instr / (kavg * 1e-3) / 1e9 if (instr and kavg) else None
+            out['roofline'].update({'bound': 'valu', 'achieved': ach_i, 'peak': peak, 'unit': 'G wave-instructions/s',
+                                    'frac': ach_i / peak if ach_i else None, 'traffic': None,
+                                    'instructions_per_launch': instr, 'instructions_source': src, 'hbm': hbm})
+            for k in ('traffic_source', 'whole_sweep_frac'):
+                out['roofline'].pop(k, None)
         del seg
         return out, S
 
@@ -540,8 +571,125 @@ def main():
                              'whole_step_frac': 8.0 * total / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                 'parity_prefix_max_rel_err': err}
 
+    # ---------------------------------------------------------------- N > 1: config 5 and the long stream over the ranks ----
+    def scan_sharded_bench(steps, warmup):
+        """SURVEY 8e row 3 (multichannel_scanner.py:78-100 batched over ranks): channel stream c on rank c mod N, PSD rows +
+        decision stage local, ONE all-gather of rows + noise floors + channel powers per step.  STRONG scaling: 64 streams."""
+        nch, S, N = 64, 1 << args.scan_log2_samples, 16384
+        Sf = 1000000
+        mine = scan_batch.shard_channels(nch, rank, world)
+        iq = torch.empty((max(len(mine), 1) * S, 2), dtype=torch.float32, device=dev)
+        for j, c in enumerate(mine):
+            ctx.synth_iq(iq.data_ptr() + 8 * j * S, S, 3000 + c, TONES, DC)
+        bp = scan_batch.BatchScanPlan(ctx, N, Sf, 15625.0, 10e3, thr_leveler=10)
+        got = [None]
+
+        def step():
+            got[0] = bp.scan_sharded(iq.data_ptr(), S, S, nch, rank, world, dev)
+
+        if mine:
+            rows0 = torch.zeros((len(mine), N), dtype=torch.float32, device=dev)
+            ramp(lambda: bp.psd_rows_dev(iq.data_ptr(), S, len(mine), S, rows0.data_ptr()))
+        for _ in range(warmup):
+            step()
+        ctx.set_timing(True)
+        ctx.get_timing(reset=True)
+        wall, per = timed_steps(torch, dist, dev, step, fence, steps, multi)
+        kern_ms, launches = ctx.get_timing(reset=True)
+        ctx.set_timing(False)
+        rows, noise, power = got[0]
+        assert tuple(rows.shape) == (nch, N) and bool(torch.isfinite(rows).all()) and bool((noise > 0).all())
+        err = None
+        if rank == 0:      # channel 0 (this rank's first stream), prefix of 2^20 samples, against the oracle
+            from oracle import ref_cpu as R
+            m = min(S, 1 << 20)
+            pre = iq[:m].cpu().numpy().view(np.complex64).reshape(-1)
+            d_pre, d_row = ctx.alloc(m * 8), ctx.alloc(N * 4)
+            try:
+                ctx.h2d(d_pre, pre)
+                bp.psd_rows_dev(d_pre, m, 1, m, d_row)
+                got_row = ctx.d2h(d_row, (N,), np.float32)
+            finally:
+                ctx.free(d_pre)
+                ctx.free(d_row)
+            ref_row = R.chain_sensor_v2(pre, N).mean(axis=0)
+            err = float(np.max(np.abs(got_row - ref_row) / ref_row))
+        med = statistics.median(per)
+        kavg = kern_ms / max(launches, 1)
+        local_bytes = 8.0 * len(mine) * S
+        ach = local_bytes / (kavg * 1e-3) / 1e9 if kavg else 0.0
+        return {'value': nch * S / (med * 1e-3) / 1e6, 'ms': med, 'wall_ms': 1e3 * wall / steps, 'kavg': kavg, 'launches': int(launches),
+                'ach': ach, 'alg_bytes': local_bytes, 'kernel': bp.plan.last_recipe(), 'err': err,
+                'workload': 'C5 over %d ranks: 64 channel streams x 2^%d samples, stream c on rank c mod %d, 16384-pt rectangular '
+                            '|X|^2/N^2 mean + decision stage per rank, all_gather of rows + noise floors + channel powers '
+                            '(BatchScanPlan.scan_sharded)' % (world, args.scan_log2_samples, world),
+                'parallelism': 'channel-stream-per-gpu x%d' % world,
+                'scaling_base': 'scan_c5.value of the --gpus 1 line (the same 64 streams on one GPU; same stream length when '
+                                '--scan-log2-samples is 22)'}
+
+    def long_stream_bench(steps, warmup):
+        """ONE stream of 2^log2 samples cut into contiguous runs of segments, one per rank (run g holds its
+        neighbour's first 2048 samples again), raw sums per rank, ONE all-gather, rank-order sum, scaling.  STRONG scaling."""
+        n = 1 << args.log2_samples
+        first, nloc, _, nseg_local = sweep.time_shard(n, NFFT, NFFT // 2, rank, world)
+        iq = torch.empty((max(nloc, NFFT), 2), dtype=torch.float32, device=dev)
+        ctx.synth_iq(iq.data_ptr(), max(nloc, NFFT), 1002 + rank, TONES, DC)      # (every run its own noise: the result is a PSD of the whole)
+        plan = ctx.welch_plan(NFFT, window=hann, fs=1.0)
+        got = [None]
+
+        def step():
+            got[0] = sweep.welch_long_stream(plan, iq.data_ptr(), first, n, dev, rank, world)
+
+        scratch = torch.zeros(NFFT, dtype=torch.float32, device=dev)
+        if nseg_local:
+            ramp(lambda: plan.partial_dev(iq.data_ptr(), nloc, scratch.data_ptr()))
+        for _ in range(warmup):
+            step()
+        ctx.set_timing(True)
+        ctx.get_timing(reset=True)
+        wall, per = timed_steps(torch, dist, dev, step, fence, steps, multi)
+        kern_ms, launches = ctx.get_timing(reset=True)
+        ctx.set_timing(False)
+        psd, nseg_total = got[0]
+        assert nseg_total == plan.nseg(n) and bool(torch.isfinite(psd).all()) and int(psd.numel()) == NFFT
+        err = None
+        if rank == 0:
+            from oracle import ref_cpu as R
+            pre = iq[:1 << 20].cpu().numpy().view(np.complex64).reshape(-1)
+            _, ref = R.welch_np(pre, fs=1.0, nperseg=NFFT, nfft=NFFT)
+            err = float(np.max(np.abs(ctx.welch_plan(NFFT, window=hann, fs=1.0).exec(pre) - ref) / ref))
+        med = statistics.median(per)
+        kavg = kern_ms / max(launches, 1)
+        local_bytes = 8.0 * nseg_local * (NFFT // 2)
+        ach = local_bytes / (kavg * 1e-3) / 1e9 if kavg else 0.0
+        return {'value': n / (med * 1e-3) / 1e6, 'ms': med, 'wall_ms': 1e3 * wall / steps, 'kavg': kavg, 'launches': int(launches),
+                'ach': ach, 'alg_bytes': local_bytes, 'kernel': plan.last_recipe(), 'err': err,
+                'workload': 'C2 over %d ranks: one 2^%d-sample stream, contiguous runs of ceil(nseg / %d) segments per rank with a '
+                            '2048-sample halo, 4096-pt Hann Welch 50%% overlap, all_gather of the raw |X|^2 sums, rank-order sum, '
+                            'density scaling (sweep.welch_long_stream)' % (world, args.log2_samples, world),
+                'parallelism': 'time-shard-per-gpu x%d' % world,
+                'scaling_base': '`value` of the --gpus 1 line (the same stream on one GPU)'}
+
     result = None
-    if multi:
+    if multi and args.workload != 'c4':
+        seen = ranks_seen()
+        r = (scan_sharded_bench if args.workload == 'c5' else long_stream_bench)(args.steps, args.warmup)
+        if rank == 0:
+            result = {
+                'metric': 'IQ Msamples/s Welch-PSD (4096-pt, 50% ovlp)' if args.workload == 'c2' else
+                          'IQ Msamples/s batched scanner (64 x 16384-pt PSD + per-bin threshold)',
+                'value': r['value'], 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': r['ms'], 'wall_ms_per_step': r['wall_ms'], 'higher_is_better': True, 'scaling': 'strong',
+                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': r['workload'], 'parallelism': r['parallelism']},
+                'roofline': {'bound': 'hbm', 'achieved': r['ach'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                             'frac': r['ach'] / HBM_PEAK_GBPS, 'traffic': None, 'kernel': r['kernel'] + ' (rank 0\'s launch)',
+                             'kernel_avg_ms': r['kavg'], 'launches': r['launches'],
+                             'algorithmic_bytes_per_launch': r['alg_bytes']},
+                'parity_prefix_max_rel_err': r['err'], 'ranks_seen': seen, 'scaling_base': r['scaling_base'],
+                'cpu_baseline': None, 'device': ctx.device_name(),
+            }
+    elif multi:
         seen = ranks_seen()
         sw, S = sweep_bench(args.steps, args.warmup)
         if rank == 0:

@@ -1115,3 +1115,32 @@ def test_bench_gpus_4_rehearsal_two_segments_per_rank(tmp_path):
     assert r['ranks_seen']['distinct_devices'] == 1 and r['ranks_seen']['backend'] == 'gloo'
     assert 'parallelism' in r['config'] and r['config']['parallelism'] == 'segment-per-gpu x4'
     assert r['parity_prefix_max_rel_err'] < RTOL and 'kernel=welch4096:ws' in r['roofline']['kernel']
+
+
+@pytest.mark.parametrize('workload,ranks', [('c5', 2), ('c5', 4), ('c2', 2), ('c2', 4)])
+def test_bench_workloads_c5_and_c2_over_ranks_rehearsal(workload, ranks):
+    """Round 6: `bench.py --gpus N --workload c5 | c2` - the batched scanner (multichannel_scanner.py:78-100:
+    64 channel rows over the ranks through BatchScanPlan.scan_sharded) and the long stream (row 2: sweep.welch_long_stream over
+    time_shard) - rehearsed at 2 and 4 ranks on this one-GPU box (every rank on device 0, gloo), as the C4 sweep is."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['BENCH_REHEARSE'] = '1'
+    size = ['--scan-log2-samples', '18'] if workload == 'c5' else ['--log2-samples', '23']
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(ranks), '--workload', workload, '--steps', '4',
+                        '--warmup', '1', '--ramp-ms', '10'] + size, env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == ranks and r['steps'] == 4 and r['scaling'] == 'strong' and r['value'] > 0
+    assert r['ranks_seen']['world_size'] == ranks and r['ranks_seen']['backend'] == 'gloo'
+    assert r['parity_prefix_max_rel_err'] < RTOL
+    if workload == 'c5':
+        assert r['config']['parallelism'] == 'channel-stream-per-gpu x%d' % ranks and 'scan_c5.value' in r['scaling_base']
+        assert 'welch16k1x' in r['roofline']['kernel']
+    else:
+        assert r['config']['parallelism'] == 'time-shard-per-gpu x%d' % ranks and '--gpus 1' in r['scaling_base']
+        assert 'kernel=welch4096:ws' in r['roofline']['kernel']
