@@ -15,10 +15,11 @@ N = 1  workload "C2" (the configuration BASELINE.json's metric is quoted on): on
        block actually makes, spectrum_sweeper.py:263: flattop, nperseg = 1024 zero-padded to 4096, step 512),
        `csd_c3` (BASELINE config 3: two-channel cross spectrum / coherence, 2 x 2^26 samples, 16 B per sample
        pair), `scan_c5` (BASELINE config 5: 64 channel streams x 2^22 samples, 16384-pt rectangular |X|^2/N^2 mean +
-       the device decision stage), each with its own `roofline` whose `kernel` is the recipe the library recorded for
+       the device decision stage), `c1` (BASELINE config 1 at its own size: 2^20 samples, 1024-pt rectangular chain, the 128
+       eight-row means + a7 channel sums), each with its own `roofline` whose `kernel` is the recipe the library recorded for
        the launch (oth__debug_last_recipe) and whose `traffic` is the figure of the builder's rocprofv3 PMC passes of
        the same configuration (profiles/traffic.json: not measured by this run); `h2d_inclusive` (host buffer -> PSD through the streaming entry point);
-       `cpu_baseline` (+ `_parallel`, `_c5`).
+       `cpu_baseline` (+ `_parallel`, `_c5`, `_c1`).
 N > 1  --workload c5: BASELINE config 5 over the ranks (64 channel streams, stream c on rank c mod N, PSD rows + decision
        stage per rank, one all-gather of rows + noise floors + channel powers: BatchScanPlan.scan_sharded); --workload c2: the
        2^28-sample stream cut into one contiguous run of segments per rank (sweep.welch_long_stream: one all-gather of raw
@@ -148,6 +149,38 @@ def cpu_baseline_c5(nfft=16384, nch=4, log2_samples=22):
             'sample': '%d of the 64 channel streams of scan_c5 (2^%d samples each), %d-pt rect FFT + |X|^2/N^2 + mean in '
                       'single precision (scipy.fft on complex64, one (rows, N) batch per stream), median of 3'
                       % (nch, log2_samples, nfft)}
+
+
+def cpu_baseline_c1(nfft=1024, log2_samples=20):
+    """BASELINE config 1 on the CPU, one core: the GNU Radio chain of spectrum_sensor_v2 restated in the arithmetic GNU Radio
+    uses (single precision, scipy.fft on complex64: stream_to_vector -> fft_vcc(rect, shift) -> |.|^2 -> 1/N^2,
+    spectrum_sensor_v2.py:85-93), the 128 eight-row means and per mean row the a7 channel sums (oracle.src_power: moving
+    average + slice sums, ofdm_cr_tools.py:232-249) - the whole 2^20-sample configuration, median of 5."""
+    import numpy as np
+    import scipy.fft as sfft
+    from oracle import ref_cpu as R
+    n, Sf, cs, sbw = 1 << log2_samples, 1000000, 25e3, 12.5e3
+    x = R.synth_iq(n, 1001)
+    Fr = float(Sf) / nfft
+    bb = R.frange(-Sf // 2, Sf // 2, cs)
+
+    def run():
+        v = x.reshape(-1, nfft)
+        X = sfft.fft(v, axis=1)
+        p = np.fft.fftshift((X.real * X.real + X.imag * X.imag) * np.float32(1.0 / float(nfft ** 2)), axes=1)
+        mean8 = p.reshape(-1, 8, nfft).mean(axis=1)
+        return [R.src_power(row, nfft, Fr, Sf, bb, sbw / Fr) for row in mean8]
+
+    run()
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    return {'value': n / sorted(times)[2] / 1e6, 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
+            'sample': 'the whole C1 configuration: 2^%d samples, %d-pt rect FFT + |X|^2/N^2 in single precision (scipy.fft on '
+                      'complex64), 128 eight-row means, 40 channel sums per mean row (Python, as the reference); median of 5'
+                      % (log2_samples, nfft)}
 
 
 def free_port():
@@ -670,6 +703,58 @@ def main():
                 'parallelism': 'time-shard-per-gpu x%d' % world,
                 'scaling_base': '`value` of the --gpus 1 line (the same stream on one GPU)'}
 
+    # ---------------------------------------------------------------- config 1 at its own size ---------------
+    def c1_bench(steps, warmup):
+        """SURVEY 8d C1 (examples/spectrum_sensor_test.grc: samp_rate 1e6, channel spacing 25 kHz, search bandwidth 12.5 kHz):
+        2^20 samples -> 1024 vectors of 1024 points (rect, shifted, |X|^2 / N^2) -> 128 eight-row means -> moving average +
+        40 channel sums per mean row, all on the device: the 8-vector runs are the streams of ONE Welch launch without overlap
+        (the batched scanner's form), the a7 stage is oth_scan_decide_dev_out.  A 8 MiB workload: launch-bound, not
+        bandwidth-bound - `frac` says how far."""
+        n, N, Sf, cs, sbw = 1 << 20, 1024, 1000000, 25e3, 12.5e3
+        iq = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        ctx.synth_iq(iq.data_ptr(), n, 1001, TONES, DC)
+        bp = scan_batch.BatchScanPlan(ctx, N, Sf, cs, sbw, thr_leveler=10)
+        lo, hi = bp._slices()
+        rows = torch.zeros((128, N), dtype=torch.float32, device=dev)
+        noise = torch.zeros(128, dtype=torch.float32, device=dev)
+        power = torch.zeros((128, len(lo)), dtype=torch.float32, device=dev)
+
+        def step():
+            bp.psd_rows_dev(iq.data_ptr(), 8192, 128, 8192, rows.data_ptr())
+            ctx.scan_decide_dev_out(rows.data_ptr(), 128, N, bp.scanner.srch_bins, bp.thr_leveler, lo, hi, noise.data_ptr(),
+                                    power.data_ptr())
+
+        ramp(step)
+        for _ in range(warmup):
+            step()
+        ctx.set_timing(True)
+        ctx.get_timing(reset=True)
+        wall, per = timed_steps(torch, dist, dev, step, fence, steps, False)
+        kern_ms, launches = ctx.get_timing(reset=True)
+        ctx.set_timing(False)
+        from oracle import ref_cpu as R
+        x = iq.cpu().numpy().view(np.complex64).reshape(-1)
+        ref_mean = R.chain_sensor_v2(x, N).reshape(128, 8, N).mean(axis=1)
+        got_rows, got_pw = rows.cpu().numpy(), power.cpu().numpy()
+        ref_pw = np.array([R.src_power(r.astype(np.float32), N, bp.scanner.Fr, Sf, bp.scanner.bb_freqs, bp.scanner.srch_bins)
+                           for r in ref_mean])
+        err = {'mean_rows': float(np.max(np.abs(got_rows - ref_mean) / ref_mean)),
+               'channel_power': float(np.max(np.abs(got_pw - ref_pw) / ref_pw))}
+        med = statistics.median(per)
+        kavg = kern_ms / max(launches, 1)
+        ach = 8.0 * n / (kavg * 1e-3) / 1e9 if kavg else 0.0
+        return {'value': n / (med * 1e-3) / 1e6, 'unit': 'Msamples/s', 'ms_per_step': med, 'wall_ms_per_step': 1e3 * wall / steps,
+                'steps': steps, 'kernel_avg_ms': kavg, 'launches': int(launches),
+                'config': {'workload': 'C1 at its own size: 2^20 complex64 samples, 1024-pt rectangular |fftshift(FFT)|^2 / N^2, 1024 '
+                                       'vectors -> 128 eight-row means (one launch, 128 streams of 8 vectors) + moving average and %d '
+                                       'channel sums per mean row on the device (Sf 1e6, 25 kHz / 12.5 kHz)' % len(lo)},
+                'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
+                             'traffic': None, 'kernel': bp.plan.last_recipe(), 'kernel_avg_ms': kavg, 'launches': int(launches),
+                             'algorithmic_bytes_per_launch': 8 * n,
+                             'whole_step_frac': 8.0 * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             'note': '8 MiB per launch: a handful of microseconds of HBM time - the step is launch latency'},
+                'parity_max_rel_err': err}
+
     result = None
     if multi and args.workload != 'c4':
         seen = ranks_seen()
@@ -833,9 +918,12 @@ def main():
             torch.cuda.empty_cache()
             result['scan_c5'] = scan_bench(max(10, args.steps // 4), max(3, args.warmup // 4))
             torch.cuda.empty_cache()
+            result['c1'] = c1_bench(max(10, args.steps // 4), max(3, args.warmup // 4))
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             result['cpu_baseline'], result['cpu_baseline_parallel'] = cpu_baseline(NFFT)
             result['cpu_baseline_c5'] = cpu_baseline_c5()
+            result['cpu_baseline_c1'] = cpu_baseline_c1()
         else:
             result['cpu_baseline'] = None
     if multi:

@@ -160,6 +160,10 @@ struct oth_chain {
     uint64_t nrows_of[kRing] = {0, 0, 0, 0};
     uint64_t next_ticket = 1;
     AnyTables any;                     // any.sh.kind != ANY_NONE: the chain's length runs through fft_any.hip
+    // round 6: what a work()-sized push costs
+    uint64_t ops = 0;                  // stream operations (asynchronous copies + kernel launches) the last push enqueued
+    bool noop[kRing] = {false, false, false, false};      // the slot's push enqueued nothing (every vector dropped): ready at once
+    bool leftover_stale = false;       // the partial vector in d_buf was not copied (it is not a kept one): never emit it
 };
 
 namespace {
@@ -2359,7 +2363,8 @@ int oth_chain_set_keep_one_in_n(oth_chain *h, int n) {
     CtxGuard guard_(h ? h->ctx : nullptr);
     if (!h) return fail(nullptr, OTH_ERR_INVALID, "chain is NULL");
     if (n < 1) return fail(h->ctx, OTH_ERR_INVALID, "keep_one_in_n must be >= 1");
-    h->keep_n = h->count = n;   // keep_one_in_n::set_n restarts the count
+    h->keep_n = h->count = n;   // keep_one_in_n::set_n restarts the count (a partial vector whose samples were skipped as
+                                // dropped stays unemitted: chain_feed's leftover_stale)
     return OTH_OK;
     OTH_CATCH((h ? h->ctx : nullptr))
 }
@@ -2405,6 +2410,7 @@ int oth_chain_reset(oth_chain *h) {
     HIPCHK(c, hipMemsetAsync(h->d_peak_init, 0, sizeof(int), c->stream));
     h->peak_flag_set = false;
     h->leftover = 0;
+    h->leftover_stale = false;
     h->count = h->keep_n;
     return OTH_OK;
     OTH_CATCH((h ? h->ctx : nullptr))
@@ -2498,6 +2504,8 @@ static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec
         Timed tm(c);      // the whole push: transform kernel + cross-team reduction + state / rows
         HIPCHK(c, big ? (x1 ? launch_chain16k1x(N, a, h->rect, c->stream) : launch_chain16k(N, a, h->rect, c->stream))
                       : launch_seg(N, a, 2, false, c->stream));
+        h->ops += 1;
+        if (a.acc_mode != 3) h->ops += (groups ? 2 : 1) + ((a.acc_mode == 1 && give > 8) ? 1 : 0);      // [reduce +] state [+ rows]
         if (a.acc_mode != 3)
             HIPCHK(c, launch_chain_tail(h->d_partial, groups ? h->d_tail : nullptr, (int)W, N, big ? (x1 ? (N == 16384 ? 4 : 5) : (N == 16384 ? 2 : 3)) : 0,
                                         h->fftshift, a.acc_mode, a.acc_end,
@@ -2506,6 +2514,7 @@ static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec
     }
     if (a.acc_mode == 2 && !h->peak_flag_set) {      // the coverage path (rows_epilogue_kernel) reads the flag
         HIPCHK(c, launch_set_flag(h->d_peak_init, 1, c->stream));
+        h->ops += 1;
         h->peak_flag_set = true;
     }
     return OTH_OK;
@@ -2546,13 +2555,18 @@ static int chain_launch(oth_chain *h, const float2 *x, long long first_vec, long
         Timed tm(c);
         HIPCHK(c, launch_pgram(N, a, c->stream));
     }
-    if (h->do_iir || h->do_peak)
+    h->ops += h->any.sh.kind == ANY_NONE ? 1 : 3;      // (the any-length routes: one to three launches per chunk)
+    if (h->do_iir || h->do_peak) {
         HIPCHK(c, launch_rows_epilogue(h->d_rows, nrows, N, h->alpha, h->kdb, h->d_iir, h->d_peak, h->d_peak_init,
                                        h->do_iir, h->do_peak, c->stream));
+        h->ops += h->do_peak ? 2 : 1;
+    }
     if (h->do_peak && nrows > 0) h->peak_flag_set = true;
-    if (rows_last && give > 0)
+    if (rows_last && give > 0) {      // (rows_last may be pinned host memory - the asynchronous work() form: hipMemcpyDefault)
         HIPCHK(c, hipMemcpyAsync(rows_last, h->d_rows + (size_t)(nrows - give) * N, sizeof(float) * (size_t)give * N,
-                                 hipMemcpyDeviceToDevice, c->stream));
+                                 hipMemcpyDefault, c->stream));
+        h->ops += 1;
+    }
     return OTH_OK;
 }
 
@@ -2570,6 +2584,7 @@ static int chain_feed(oth_chain *h, const float2 *src, size_t nsamples, float *r
         const size_t take = nsamples < (size_t)N - h->leftover ? nsamples : (size_t)N - h->leftover;
         HIPCHK(c, hipMemcpyAsync(h->d_buf + h->leftover, src, take * sizeof(float2), hipMemcpyDeviceToDevice,
                                  c->stream));
+        h->ops += 1;
         h->leftover += take;
         src += take;
         nsamples -= take;
@@ -2583,9 +2598,10 @@ static int chain_feed(oth_chain *h, const float2 *src, size_t nsamples, float *r
     long long k_head = 0;
     if (head) {
         if (--h->count == 0) {
-            k_head = 1;
+            k_head = h->leftover_stale ? 0 : 1;      // (stale: its first samples were never copied - see chain_push_dropped)
             h->count = h->keep_n;
         }
+        h->leftover_stale = false;
     }
     long long k_body = 0, first = h->count - 1;
     if (nvec > first) k_body = 1 + (nvec - 1 - first) / h->keep_n;
@@ -2604,7 +2620,9 @@ static int chain_feed(oth_chain *h, const float2 *src, size_t nsamples, float *r
     const size_t used = (size_t)nvec * N, keep = nsamples - used;
     if (keep) {      // d_buf is free again: a completed head vector has been consumed by the launch above (stream order)
         HIPCHK(c, hipMemcpyAsync(h->d_buf, src + used, keep * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+        h->ops += 1;
         h->leftover = keep;
+        h->leftover_stale = false;
     }
     if (nrows_out) *nrows_out = (uint64_t)(k_head + k_body);
     return OTH_OK;
@@ -2620,6 +2638,7 @@ int oth_chain_push_dev(oth_chain *h, const void *iq_dev, size_t nsamples, float 
     if (!iq_dev && nsamples) return fail(c, OTH_ERR_INVALID, "iq is NULL");
     if (!nsamples) return OTH_OK;
     if (use_device(c)) return OTH_ERR_HIP;
+    h->ops = 0;
     return chain_feed(h, (const float2 *)iq_dev, nsamples, rows_out_dev, rows_out_dev ? rows_capacity : 0, nrows_out);
     OTH_CATCH((h ? h->ctx : nullptr))
 }
@@ -2637,6 +2656,7 @@ int oth_chain_push(oth_chain *h, const void *iq, size_t nsamples, int src_is_dev
     const int N = h->nfft;
     const float2 *src = (const float2 *)iq;
     int rc;
+    h->ops = 0;
     if (!src_is_device) {
         if ((rc = ensure(c, &h->d_stage, &h->stage_cap, nsamples * sizeof(float2)))) return rc;
         HIPCHK(c, hipMemcpyAsync(h->d_stage, iq, nsamples * sizeof(float2), hipMemcpyHostToDevice, c->stream));
@@ -2657,8 +2677,48 @@ int oth_chain_push(oth_chain *h, const void *iq, size_t nsamples, int src_is_dev
     OTH_CATCH((h ? h->ctx : nullptr))
 }
 
-// sync_block.work() form: copy the scheduler's buffer into a pinned slot, enqueue H2D + kernels + the D2H of the
-// latest row, record an event and return.  The watcher collects the row with oth_chain_poll / oth_chain_wait.
+// A push of which nothing will ever be looked at: no vector it completes is a kept one (keep_one_in_n) and the partial vector it
+// leaves behind is not one either.  Then nothing needs to reach the device - only the stream position moves on.  This is the
+// common case of a sensor with a low sens_per_sec: spectrum_sensor_v2.py:86-87 keeps one vector in int(Sf / N / sens_per_sec)
+// (97 of 98 at 1 MS/s, 1024 points, 10 PSDs per second), and GNU Radio's work() chunks hold 4-32 of them.
+// -> true and the state advanced, or false and nothing touched.
+static bool chain_push_dropped(oth_chain *h, size_t nsamples) {
+    const size_t N = (size_t)h->nfft;
+    size_t L = h->leftover, rest = nsamples;
+    long long count = h->count;
+    bool stale = h->leftover_stale;
+    if (L) {
+        const size_t take = rest < N - L ? rest : N - L;
+        L += take;
+        rest -= take;
+        if (L == N) {
+            if (--count == 0) {
+                if (!stale) return false;      // the head vector is a kept one
+                count = h->keep_n;
+            }
+            L = 0;
+            stale = false;
+        } else {
+            if (count == 1 && !stale) return false;      // still inside a vector that will be kept: its samples are needed
+            h->leftover = L;
+            h->leftover_stale = true;      // (a dropped vector's samples: d_buf is not written)
+            return true;
+        }
+    }
+    const long long nvec = (long long)(rest / N);
+    if (nvec > count - 1) return false;      // a vector of the body is kept
+    count -= nvec;
+    const size_t keep = rest - (size_t)nvec * N;
+    if (keep && count == 1) return false;      // the vector that begins here will be kept
+    h->leftover = keep;
+    h->leftover_stale = keep != 0;
+    h->count = (int)count;
+    return true;
+}
+
+// sync_block.work() form: copy the scheduler's buffer into a pinned slot, enqueue H2D + kernels, record an event and return.
+// The latest row is written by the last kernel straight into the slot's pinned host row (round 6: one stream operation less
+// than a D2H copy behind it); the watcher collects it with oth_chain_poll / oth_chain_wait.
 int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uint64_t *ticket_out) {
     OTH_TRY
     CtxGuard guard_(h ? h->ctx : nullptr);
@@ -2667,16 +2727,26 @@ int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uin
     if (!ticket_out) return fail(c, OTH_ERR_INVALID, "ticket_out is NULL");
     *ticket_out = 0;
     if (!iq_host && nsamples) return fail(c, OTH_ERR_INVALID, "iq is NULL");
-    if (use_device(c)) return OTH_ERR_HIP;
     const int N = h->nfft;
     const uint64_t ticket = h->next_ticket;
     const int slot = (int)(ticket % oth_chain::kRing);
+    h->ops = 0;
+    if (nsamples && chain_push_dropped(h, nsamples)) {      // nothing to compute: no copy, no launch, no event
+        h->noop[slot] = true;
+        h->ticket_of[slot] = ticket;
+        h->nrows_of[slot] = 0;
+        h->next_ticket = ticket + 1;
+        *ticket_out = ticket;
+        return OTH_OK;
+    }
+    if (use_device(c)) return OTH_ERR_HIP;
     if (!h->ev[slot]) {
         HIPCHK(c, hipEventCreateWithFlags(&h->ev[slot], hipEventDisableTiming));
         HIPCHK(c, hipHostMalloc((void **)&h->h_row[slot], sizeof(float) * N, hipHostMallocDefault));
-    } else if (h->ticket_of[slot]) {
+    } else if (h->ticket_of[slot] && !h->noop[slot]) {
         HIPCHK(c, hipEventSynchronize(h->ev[slot]));      // only when the GPU is kRing pushes behind
     }
+    h->noop[slot] = false;
     const size_t bytes = nsamples * sizeof(float2);
     const bool pinned_src = bytes > kPinnedStageMax && host_ptr_is_pinned(iq_host);
     const bool direct = bytes > kPinnedStageMax && !pinned_src;      // the runtime stages pageable memory itself
@@ -2693,7 +2763,6 @@ int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uin
     uint64_t nrows = 0;
     if (nsamples) {
         if ((rc = ensure(c, &h->d_stage, &h->stage_cap, bytes))) return rc;
-        if ((rc = ensure(c, &h->d_out, &h->out_cap, sizeof(float) * N))) return rc;
         if (wait_copy) {
             if ((rc = copy_in_and_wait(c, h->d_stage, iq_host, bytes))) return rc;
         } else if (direct) {      // the runtime's staged copy returns once the caller's buffer has been read
@@ -2702,9 +2771,9 @@ int oth_chain_push_async(oth_chain *h, const void *iq_host, size_t nsamples, uin
             memcpy(h->h_in[slot], iq_host, bytes);      // the scheduler's buffer dies when work() returns
             HIPCHK(c, hipMemcpyAsync(h->d_stage, h->h_in[slot], bytes, hipMemcpyHostToDevice, c->stream));
         }
-        if ((rc = chain_feed(h, h->d_stage, nsamples, h->d_out, 1, &nrows))) return rc;
-        if (nrows)
-            HIPCHK(c, hipMemcpyAsync(h->h_row[slot], h->d_out, sizeof(float) * N, hipMemcpyDeviceToHost, c->stream));
+        h->ops += 1;
+        // the latest row goes from the closing kernel straight into the slot's pinned row (device-visible host memory)
+        if ((rc = chain_feed(h, h->d_stage, nsamples, h->h_row[slot], 1, &nrows))) return rc;
     }
     HIPCHK(c, hipEventRecord(h->ev[slot], c->stream));
     h->ticket_of[slot] = ticket;
@@ -2720,6 +2789,11 @@ static int chain_collect(oth_chain *h, uint64_t ticket, float *row_out, uint64_t
     const int slot = (int)(ticket % oth_chain::kRing);
     if (!ticket || h->ticket_of[slot] != ticket)
         return fail(c, OTH_ERR_STATE, "ticket unknown or overwritten (the ring keeps the last 4 pushes: latest wins)");
+    if (h->noop[slot]) {      // the push enqueued nothing (all its vectors dropped): done when it returned
+        if (ready) *ready = 1;
+        if (nrows_out) *nrows_out = 0;
+        return OTH_OK;
+    }
     hipError_t e = wait ? hipEventSynchronize(h->ev[slot]) : hipEventQuery(h->ev[slot]);
     if (e == hipErrorNotReady) {
         if (ready) *ready = 0;
@@ -2751,6 +2825,10 @@ int oth_chain_wait(oth_chain *h, uint64_t ticket, float *row_out, uint64_t *nrow
         const int slot = (int)(ticket % oth_chain::kRing);
         if (!ticket || h->ticket_of[slot] != ticket)
             return fail(h->ctx, OTH_ERR_STATE, "ticket unknown or overwritten (the ring keeps the last 4 pushes: latest wins)");
+        if (h->noop[slot]) {
+            if (nrows_out) *nrows_out = 0;
+            return OTH_OK;
+        }
         ev = h->ev[slot];
     }
     hipError_t e = hipEventSynchronize(ev);
@@ -2769,6 +2847,15 @@ int oth_chain_ticket_rows(oth_chain *h, uint64_t ticket, uint64_t *nrows_out) {
     if (!ticket || h->ticket_of[slot] != ticket)
         return fail(h->ctx, OTH_ERR_STATE, "ticket unknown or overwritten (the ring keeps the last 4 pushes: latest wins)");
     *nrows_out = h->nrows_of[slot];
+    return OTH_OK;
+    OTH_CATCH((h ? h->ctx : nullptr))
+}
+
+int oth_chain_last_push_ops(oth_chain *h, uint64_t *ops_out) {
+    OTH_TRY
+    CtxGuard guard_(h ? h->ctx : nullptr);
+    if (!h || !ops_out) return fail(h ? h->ctx : nullptr, OTH_ERR_INVALID, "bad argument");
+    *ops_out = h->ops;
     return OTH_OK;
     OTH_CATCH((h ? h->ctx : nullptr))
 }

@@ -95,6 +95,7 @@ SIGNATURES = {
     'oth_chain_poll': (C.c_int, [_p, C.c_uint64, _f, _u64p, C.POINTER(C.c_int)]),
     'oth_chain_wait': (C.c_int, [_p, C.c_uint64, _f, _u64p]),
     'oth_chain_ticket_rows': (C.c_int, [_p, C.c_uint64, _u64p]),
+    'oth_chain_last_push_ops': (C.c_int, [_p, _u64p]),
     'oth_chain_get_peak': (C.c_int, [_p, _f]),
     'oth_chain_get_iir': (C.c_int, [_p, _f]),
     'oth_rows_group_mean': (C.c_int, [_p, _f, C.c_size_t, C.c_int, C.c_int, _f]),
@@ -639,6 +640,12 @@ class Chain(object):
         self.ctx.check(self.ctx.lib.oth_chain_push_async(self.h, x.ctypes.data_as(_p), len(x), C.byref(t)),
                        'oth_chain_push_async')
         return int(t.value)
+
+    def last_push_ops(self):
+        """Stream operations (asynchronous copies + kernel launches) the last push enqueued."""
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.oth_chain_last_push_ops(self.h, C.byref(n)), 'oth_chain_last_push_ops')
+        return int(n.value)
 
     def ticket_rows(self, ticket):
         """Rows the push behind `ticket` produces (known at enqueue time; never waits)."""

@@ -304,8 +304,9 @@ int oth_chain_push_dev(oth_chain *chain, const void *iq_dev, size_t nsamples, fl
                        size_t rows_capacity, uint64_t *nrows_out);
 /* The sync_block.work() form (python/spectrum_sensor.py:71-75: must not block; input valid only during the
  * call; consumers behind message_sink(dont_block) + msg_queue(2) see the latest vector,
- * spectrum_sensor_v2.py:71-72,97,404-414): the samples are copied into a pinned ring slot, H2D copy + kernels +
- * the D2H copy of the LATEST row are enqueued, an event is recorded and the call returns a ticket.  poll() is
+ * spectrum_sensor_v2.py:71-72,97,404-414): the samples are copied into a pinned ring slot, the H2D copy + the kernels
+ * are enqueued - the closing kernel writes the LATEST row straight into the slot's pinned host row - an event is
+ * recorded and the call returns a ticket.  A push none of whose vectors survives keep_one_in_n enqueues nothing at all.  poll() is
  * non-blocking (ready = 0 while the GPU is still working); wait() blocks without holding the context.  The ring
  * keeps the last four tickets: an older one returns OTH_ERR_STATE (it lost against newer vectors). */
 /* (Pushes above 1 MiB of PAGEABLE host memory skip the pinned slot and use the runtime's staged copy, which returns once
@@ -317,6 +318,11 @@ int oth_chain_wait(oth_chain *chain, uint64_t ticket, float *row_out, uint64_t *
 /* rows the push behind `ticket` produces (known when it is enqueued; never waits): lets a consumer that counts
  * vectors - the waterfall's keep_one_in_n(sens_per_sec), spectrum_sensor_v2.py:102 - count the ones it drops too */
 int oth_chain_ticket_rows(oth_chain *chain, uint64_t ticket, uint64_t *nrows_out);
+/* Stream operations (asynchronous copies + kernel launches; event records not counted) the LAST push of this chain
+ * enqueued (ABI 6) - what a work()-sized push costs the scheduler thread: 0 for a push all of whose vectors keep_one_in_n
+ * drops (nothing is copied or launched; the ticket is ready at once), 2 for a chain without state (H2D + one kernel that
+ * writes the latest row into pinned host memory), 3 with the IIR / peak-hold state (tests/test_blocks_gpu.py). */
+int oth_chain_last_push_ops(oth_chain *chain, uint64_t *ops_out);
 int oth_chain_get_peak(oth_chain *chain, float *peak_out);    /* float[nfft] */
 int oth_chain_get_iir(oth_chain *chain, float *lin_out);      /* float[nfft], linear IIR state */
 /* mean of each `group` consecutive rows (BASELINE config 1 "8-seg avg") */
