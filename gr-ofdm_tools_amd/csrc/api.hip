@@ -651,7 +651,8 @@ int any_partial_rows(const AnyShape &sh, long long nseg, int cu_count) {
         occ = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
         w = (long long)cu_count * occ;
     } else {
-        w = 64;
+        static const char *e = getenv("OTH_ANY_TL_W");      // (A/B of the partial-row count of the two-level routes)
+        w = e && atoi(e) > 0 ? atoi(e) : 64;
     }
     if (w > nseg) w = nseg;
     if (w > 65535) w = 65535;
