@@ -182,6 +182,10 @@ __global__ __launch_bounds__(256) void finalize_wide_kernel(FinalizeArgs a) {
     finalize_signal<false>(a);      // the stores above are wave 0's (threads < POS)
 }
 
+// (Determinism note: the group sums below are rounded to float32 before the second stage adds them in double, so a launch
+// that takes this stage - W >= 1024 rows of 256 ... 1024 points, or W > 32 rows of the four-channel path - differs from the
+// one-stage form by up to ~6e-8 relative per group: results are bit-reproducible for a given launch shape, not across the
+// W threshold.  Far inside the parity tolerance; stated so that "fixed order" is not read as "one order for every shape".)
 // Stage 1 of the cross-workgroup reduction when there are many partial rows: row group g of
 // kReduceGroups sums its rows (fixed order) into scratch[stream][g][ch][nfft]; finalize_kernel then
 // runs over the kReduceGroups rows.  256 threads = 64 float4 columns x 4 row lanes.
@@ -678,6 +682,9 @@ __global__ __launch_bounds__(256) void bin_threshold_ma_kernel(const float *psd,
 #define OTH_MA_TILE 4096
 #endif
 constexpr int kMaTile = OTH_MA_TILE, kMaRun = OTH_MA_RUN, kMaMaxM = 1024, kMaThreads = kMaTile / kMaRun;
+// movavg_run_kernel holds 67.6 KB of STATIC LDS: more than the 64 KB a workgroup may have on every target but gfx950
+// (160 KB per CU) - this library is built for gfx950 only (Makefile ARCH); a change of --offload-arch must shrink the tile
+static_assert((kMaTile + kMaMaxM) * 5 / 4 * sizeof(float) + (kMaTile * 9 / 8) * sizeof(double) <= 160 * 1024, "movavg_run_kernel's LDS");
 __device__ __forceinline__ int ma_pad(int k) { return k + k / kMaRun; }      // one pad word per run: a thread stride of kMaRun + 1 words
 __global__ __launch_bounds__(kMaThreads) void movavg_run_kernel(const float *psd, int nfft, double srch_bins, double *movavg,
                                                          float *tile_min) {
