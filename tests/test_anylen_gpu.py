@@ -469,3 +469,52 @@ def test_plan_cache_is_lru_and_keeps_plans_that_owe_a_ticket(ctx, hip):
     ctx.cached_plan(('lru', 2048), mk(2048), limit=3)
     assert not p64.h                            # collected: now it is the oldest and goes
     assert made == [64, 128, 256, 512, 1024, 2048]
+
+
+def test_fuzz_any_length_shapes_against_the_oracle(ctx, hip):
+    """120 random plans outside the power-of-two kernels - lengths 1 ... 40000 (small primes, prime powers, 2-3-5-7-smooth
+    numbers, primes next to the route boundaries 16384 / 8192), nperseg <= nfft, any overlap, detrend on / off, window
+    kinds, shift + trim - each against the float64 oracle on its own seeded input (the coverage routes have to be RIGHT)."""
+    rng = np.random.default_rng(20260)
+    special = [1, 2, 3, 5, 6, 7, 9, 10, 11, 15, 25, 27, 49, 63, 65, 100, 121, 127, 129, 243, 255, 257, 343, 625, 1023, 1025, 2187,
+               4095, 4097, 8191, 8193, 16383, 16385, 16807, 15625, 14406, 13122, 16380, 32767, 32769, 40000]
+    sizes = special + [int(v) for v in rng.integers(12, 20000, 79)]
+    worst = {}
+    for i, n in enumerate(sizes):
+        if (n & (n - 1)) == 0 and 64 <= n <= 16384:
+            n += 1                                     # (the power-of-two kernels have their own fuzz: tools/fuzz_shapes.py)
+        nper = n if rng.random() < 0.5 else int(rng.integers(max(1, n // 4), n + 1))
+        nov = int(rng.integers(0, nper)) if rng.random() < 0.7 else nper // 2
+        detrend = bool(rng.random() < 0.6) and nper >= 8
+        wname = ('hann', 'flattop', 'boxcar')[int(rng.integers(0, 3))]
+        nseg = int(rng.integers(1, 12)) if n > 4096 else int(rng.integers(1, 60))
+        step = nper - nov
+        x = R.synth_iq(nper + step * (nseg - 1) + int(rng.integers(0, step)), 5000 + i)
+        shift = bool(rng.random() < 0.5)
+        trim = int(rng.integers(0, max(1, n // 3))) if rng.random() < 0.3 else 0
+        w = _win(wname, nper)
+        _, ref = R.welch_np(x, window=w, nperseg=nper, noverlap=nov, nfft=n, detrend='constant' if detrend else False)
+        if shift:
+            ref = np.fft.fftshift(ref)
+        ref = ref[trim:n - trim]
+        plan = ctx.welch_plan(n, nperseg=nper, noverlap=nov, window=w, detrend=hip.DETREND_CONSTANT if detrend else hip.DETREND_NONE,
+                              fftshift=shift, trim_bins=trim)
+        got = plan.exec(x)
+        route = _route(plan).split(':')[1]
+        assert plan.last_nseg == nseg, (n, nper, nov, plan.last_nseg, nseg)
+        # Every bin: the plain 1e-4, or - the regime of few segments under the 2.0-amplitude tone, where any float32
+        # transform leaves about an ulp of the LARGEST amplitude in every bin (check_single_rows) - an amplitude error of at
+        # most 4 ulp of the spectrum's peak (Bluestein: 8, two transforms of 2-4 x the length); bins at or above the median
+        # always the plain 1e-4.  (Bins the detrend / window empties to rounding level are measured against the peak.)
+        rel = np.abs(got - ref) / np.maximum(ref, 1e-9 * ref.max())
+        amp = np.abs(np.sqrt(np.maximum(got, 0)) - np.sqrt(ref)) / np.sqrt(ref.max())
+        ulps = 8 if route.startswith('bluestein') else 4
+        weak = rel >= RTOL
+        worst[route] = max(worst.get(route, 0.0), float(rel[~weak].max()) if (~weak).any() else 0.0)
+        assert np.all(amp[weak] <= ulps * 2.0 ** -23), (n, nper, nov, detrend, wname, shift, trim, route, float(rel.max()),
+                                                       float(amp[weak].max() * 2.0 ** 23))
+        assert not np.any(weak & (ref >= np.median(ref))), (n, nper, nov, detrend, wname, route, float(rel.max()))
+        assert nseg < 8 or not weak.any(), (n, nper, nov, nseg, route, float(rel.max()))      # averages of 8+ segments: plain 1e-4 everywhere
+        plan.close()
+    print('fuzz worst by route: ' + ', '.join('%s %.1e' % kv for kv in sorted(worst.items())))
+    assert set(worst) >= {'direct', 'bluestein', 'bluestein2'}
