@@ -140,8 +140,8 @@ template <int T> __device__ __forceinline__ bool any_point(const AnyArgs &a, int
 }
 
 // One Stockham pass of radix R on the tile: its C columns are transformed together.
-template <int T, int R>
-__device__ __forceinline__ void any_pass(float2 *buf, const AnyFftDesc &f, const AnyPass &p, int tid) {
+template <int T, int R, bool TWLDS>
+__device__ __forceinline__ void any_pass(float2 *buf, const float2 *twl, const AnyFftDesc &f, const AnyPass &p, int tid) {
     constexpr int Q = (16 + R - 1) / R;       // butterflies per thread: the tile has at most 16 T points
     const int logC = f.logC, cmask = (1 << logC) - 1;
     const int nbf = p.nbf;                    // butterflies per column = n / R
@@ -157,9 +157,15 @@ __device__ __forceinline__ void any_pass(float2 *buf, const AnyFftDesc &f, const
             if (p.NS > 1) {
                 int jq, jn;
                 any_divmod(j, p.NS, p.inv_ns, jq, jn);
-                const int k = jn * p.inner;              // twiddle W_(NS R)^(jn m) = table[m k], m k < order
+                const int k = jn * p.inner;              // twiddle W_(NS R)^(jn m) = W_n^(m k), m k < n
+                if constexpr (TWLDS) {                   // the n twiddles of this transform staged in LDS (any_fft_kernel)
 #pragma unroll
-                for (int m = 1; m < R; ++m) v[q][m] = cmul(v[q][m], f.tw[m * k]);
+                    for (int m = 1; m < R; ++m) v[q][m] = cmul(v[q][m], twl[m * k]);
+                } else {                                 // gathered from the order-L table in L2
+                    const int kg = k * f.tws;
+#pragma unroll
+                    for (int m = 1; m < R; ++m) v[q][m] = cmul(v[q][m], f.tw[m * kg]);
+                }
             }
             dft_small<R>(v[q]);
         }
@@ -181,28 +187,37 @@ __device__ __forceinline__ void any_pass(float2 *buf, const AnyFftDesc &f, const
 }
 
 // all passes of the descriptor; the caller has synchronised the workgroup after filling buf, and may read any point after
-template <int T> __device__ __forceinline__ void any_fft_lds(float2 *buf, const AnyFftDesc &f, int tid) {
+template <int T, bool TWLDS> __device__ __forceinline__ void any_fft_lds(float2 *buf, const float2 *twl, const AnyFftDesc &f, int tid) {
     for (int ip = 0; ip < f.npass; ++ip) {
         const AnyPass &p = f.pass[ip];
         switch (p.R) {
-            case 16: any_pass<T, 16>(buf, f, p, tid); break;
-            case 8: any_pass<T, 8>(buf, f, p, tid); break;
-            case 4: any_pass<T, 4>(buf, f, p, tid); break;
-            case 2: any_pass<T, 2>(buf, f, p, tid); break;
-            case 3: any_pass<T, 3>(buf, f, p, tid); break;
-            case 5: any_pass<T, 5>(buf, f, p, tid); break;
-            default: any_pass<T, 7>(buf, f, p, tid); break;
+            case 16: any_pass<T, 16, TWLDS>(buf, twl, f, p, tid); break;
+            case 8: any_pass<T, 8, TWLDS>(buf, twl, f, p, tid); break;
+            case 4: any_pass<T, 4, TWLDS>(buf, twl, f, p, tid); break;
+            case 2: any_pass<T, 2, TWLDS>(buf, twl, f, p, tid); break;
+            case 3: any_pass<T, 3, TWLDS>(buf, twl, f, p, tid); break;
+            case 5: any_pass<T, 5, TWLDS>(buf, twl, f, p, tid); break;
+            default: any_pass<T, 7, TWLDS>(buf, twl, f, p, tid); break;
         }
     }
 }
 
 // STORE: 0 plain (workspace, optional four-step twiddle), 1 accumulate one channel, 2 accumulate two channels,
 // 3 periodogram rows
-template <int T, int STORE> __global__ __launch_bounds__(T) void any_fft_kernel(AnyArgs a) {
+template <int T, int STORE, bool TWLDS> __global__ __launch_bounds__(T) void any_fft_kernel(AnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char any_smem[];
     float2 *buf = reinterpret_cast<float2 *>(any_smem);
     const int tid = threadIdx.x, t = blockIdx.x;
     const int E = a.f.n << a.f.logC;
+    // The n twiddles W_n^j of the tile's transform, staged once per workgroup behind the tile where LDS allows (the host
+    // decides: AnyFftDesc.tw_lds): a pass then gathers them from LDS instead of the order-L table in L2 - R - 1 dependent
+    // L2 round trips per butterfly and pass were most of a small transform's time (w1000: 2.57 ms -> see DESIGN 4.6).
+    const float2 *twl = nullptr;
+    if constexpr (TWLDS) {
+        float2 *stage = buf + E;
+        for (int j = tid; j < a.f.n; j += T) stage[j] = a.f.tw[j * a.f.tws];
+        twl = stage;      // (the first __syncthreads() of the segment loop orders it in front of the first pass)
+    }
     constexpr int NACC = STORE == 2 ? 4 : (STORE == 1 ? 1 : 0);
     float acc[NACC > 0 ? NACC : 1][16];
     float2 X0[STORE == 2 ? 16 : 1];
@@ -228,7 +243,7 @@ template <int T, int STORE> __global__ __launch_bounds__(T) void any_fft_kernel(
             } else {
                 src = a.ws + (size_t)ch * a.ws_ch_stride + (size_t)s * a.ws_seg_stride;
             }
-#pragma unroll
+#pragma unroll 4
             for (int q = 0; q < 16; ++q) {
                 int i, c, lds;
                 if (any_point<T>(a, tid, q, E, i, c, lds)) {
@@ -250,9 +265,9 @@ template <int T, int STORE> __global__ __launch_bounds__(T) void any_fft_kernel(
                 }
             }
             __syncthreads();
-            any_fft_lds<T>(buf, a.f, tid);
+            any_fft_lds<T, TWLDS>(buf, twl, a.f, tid);
             if (a.mid_op) {      // Bluestein: multiply by B / M, conjugate, transform again
-#pragma unroll
+#pragma unroll 4
                 for (int q = 0; q < 16; ++q) {
                     int i, c, lds;
                     if (any_point<T>(a, tid, q, E, i, c, lds)) {
@@ -262,10 +277,10 @@ template <int T, int STORE> __global__ __launch_bounds__(T) void any_fft_kernel(
                     }
                 }
                 __syncthreads();
-                any_fft_lds<T>(buf, a.f, tid);
+                any_fft_lds<T, TWLDS>(buf, twl, a.f, tid);
             }
-            // ---- store
-#pragma unroll
+            // ---- store (the accumulating forms index registers by q: fully unrolled; the others four points at a time)
+#pragma unroll(STORE == 1 || STORE == 2 ? 16 : 4)
             for (int q = 0; q < 16; ++q) {
                 int i, c, lds;
                 if (any_point<T>(a, tid, q, E, i, c, lds)) {
@@ -309,19 +324,32 @@ template <int T, int STORE> __global__ __launch_bounds__(T) void any_fft_kernel(
         }
     }
     if constexpr (NACC > 0) {
-        // the workgroup's sums: partial[row g = blockIdx.y][channel][position], added to what earlier chunks left
+        // the workgroup's sums: partial[row g = blockIdx.y][channel][position], added to what earlier chunks left.  The sums
+        // pass through the (now free) LDS tile two channels at a time, each thread through its own slots, so that the
+        // read-modify-write loop need not index registers and runs four points at a time (sixteen unrolled updates with
+        // their addresses held the kernel at 146-226 registers)
         float *dst = a.partial + (size_t)blockIdx.y * NACC * a.nbins;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            int i, c, lds;
-            if (any_point<T>(a, tid, q, E, i, c, lds)) {
-                const int nat = i * a.nat_i + t * a.nat_t + c * a.nat_c;      // the bin (filter: Bluestein's M > N outputs)
-                const int pp = i * a.pp_i + t * a.pp_t + c * a.pp_c;          // where the partial row keeps it
-                if (nat < a.nbins) {
+        for (int half = 0; half < (NACC + 1) / 2; ++half) {
 #pragma unroll
-                    for (int c4 = 0; c4 < NACC; ++c4) {
-                        float *d = dst + (size_t)c4 * a.nbins + pp;
-                        *d = a.first_chunk ? acc[c4][q] : *d + acc[c4][q];
+            for (int q = 0; q < 16; ++q) {
+                int i, c, lds;
+                if (any_point<T>(a, tid, q, E, i, c, lds)) buf[lds] = make_float2(acc[2 * half][q], NACC > 1 ? acc[NACC > 1 ? 2 * half + 1 : 0][q] : 0.f);
+            }
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                int i, c, lds;
+                if (any_point<T>(a, tid, q, E, i, c, lds)) {
+                    const int nat = i * a.nat_i + t * a.nat_t + c * a.nat_c;      // the bin (filter: Bluestein's M > N outputs)
+                    const int pp = i * a.pp_i + t * a.pp_t + c * a.pp_c;          // where the partial row keeps it
+                    if (nat < a.nbins) {
+                        const float2 sums = buf[lds];
+                        float *d0 = dst + (size_t)(2 * half) * a.nbins + pp;
+                        *d0 = a.first_chunk ? sums.x : *d0 + sums.x;
+                        if (NACC > 1) {
+                            float *d1 = d0 + a.nbins;
+                            *d1 = a.first_chunk ? sums.y : *d1 + sums.y;
+                        }
                     }
                 }
             }
@@ -464,13 +492,17 @@ void any_make_desc(int n, int C, const float2 *tw, int order, AnyFftDesc *d) {
     }
     d->npass = np;
     int NS = 1;
-    const int tws = order / n;
+    d->tws = order / n;
+    // twiddles in LDS when tile + table stay inside 64 KiB (no opt-in, two or more workgroups per CU) or the tile alone
+    // already needs the opt-in and both fit the CU's 160 KiB
+    const size_t tile = (size_t)n * C * sizeof(float2), both = tile + (size_t)n * sizeof(float2);
+    d->tw_lds = (both <= 64 * 1024 || (tile > 64 * 1024 && both <= 150 * 1024)) ? 1 : 0;
     for (int i = 0; i < np; ++i) {
         AnyPass &p = d->pass[i];
         p.R = rad[i];
         p.NS = NS;
         p.nbf = n / rad[i];
-        p.inner = (n / (NS * rad[i])) * tws;
+        p.inner = n / (NS * rad[i]);
         p.inv_ns = 1.0f / (float)NS;
         NS *= rad[i];
     }
@@ -486,13 +518,18 @@ hipError_t launch_any_fft(const AnyArgs &a, int tiles, int gy, int gz, int store
     const int points = a.f.n << a.f.logC;
     if (points > kAnyMaxTile || tiles < 1 || gy < 1 || gz < 1) return hipErrorInvalidValue;
     const int T = any_threads_for(points);
-    const size_t lds = (size_t)points * sizeof(float2);
+    const size_t lds = ((size_t)points + (a.f.tw_lds ? (size_t)a.f.n : 0)) * sizeof(float2);
     const dim3 grid(tiles, gy, gz);
     hipError_t e;
-#define OTH_ANY_LAUNCH(TT, ST)                                                                    \
-    do {                                                                                          \
-        if ((e = any_allow_lds(any_fft_kernel<TT, ST>, lds)) != hipSuccess) return e;             \
-        hipLaunchKernelGGL((any_fft_kernel<TT, ST>), grid, dim3(TT), lds, s, a);                  \
+#define OTH_ANY_LAUNCH(TT, ST)                                                                            \
+    do {                                                                                                  \
+        if (a.f.tw_lds) {                                                                                 \
+            if ((e = any_allow_lds(any_fft_kernel<TT, ST, true>, lds)) != hipSuccess) return e;           \
+            hipLaunchKernelGGL((any_fft_kernel<TT, ST, true>), grid, dim3(TT), lds, s, a);                \
+        } else {                                                                                          \
+            if ((e = any_allow_lds(any_fft_kernel<TT, ST, false>, lds)) != hipSuccess) return e;          \
+            hipLaunchKernelGGL((any_fft_kernel<TT, ST, false>), grid, dim3(TT), lds, s, a);               \
+        }                                                                                                 \
     } while (0)
 #define OTH_ANY_T(ST)                                     \
     do {                                                  \

@@ -254,11 +254,13 @@ struct AnyPass {
     int R;               // radix: 16, 8, 4, 2, 3, 5, 7
     int NS;              // length of the sub-transforms this pass combines
     int nbf;             // butterflies per column = n / R
-    int inner;           // twiddle index step: n / (NS R) x (table order / n)
+    int inner;           // twiddle index step in units of W_n: n / (NS R)
     float inv_ns;
 };
 struct AnyFftDesc {
     int n, logC, npass;
+    int tws;             // table order / n: W_n^j = tw[j tws]
+    int tw_lds;          // 1: the kernel stages the n twiddles W_n^j in LDS behind the tile
     const float2 *tw;    // W_order^k
     AnyPass pass[kAnyMaxPasses];
 };
