@@ -7,8 +7,8 @@
 //   L = L1 L2, L1 = 256, L2 = 256 (65536) or 128 (32768); sample n = n1 L2 + n2, bin k = k1 + L1 k2.
 //   tl_k1_kernel   one workgroup = 16 adjacent columns n2 (128 contiguous bytes per row n1) x 16 threads: thread (c, a) loads
 //                  n1 = a + 16 b (window, detrend, zero padding), dft16 over b, x W256^(a kb), exchange through LDS across
-//                  the sixteen a, dft16 over a -> k1 = kb + 16 ka, x W_L^(k1 n2), workspace row k1.  The segment leaves
-//                  the chip once: workspace [segment][k1][n2].
+//                  the sixteen a, dft16 over a -> k1 = kb + 16 ka, x W_L^(k1 n2), workspace.  The segment leaves the chip
+//                  once: workspace [segment][column tile][k1][16 columns] - a workgroup's output is one 32 KiB block.
 //   tl_k2_kernel   row k1 of the workspace (L2 contiguous points) per team of 16 (L2 = 256) or 8 (128) lanes of one wave:
 //                  dft16 over b, twiddle, exchange inside the wave, dft16 (two dft8) -> k2; |X|^2 added over the
 //                  workgroup's segments; partial rows in [k1][k2] order (finalize layout 6).
@@ -86,12 +86,15 @@ template <int L2> __global__ __launch_bounds__(256) void tl_k1_kernel(TlArgs p) 
         for (int a2 = 0; a2 < 16; ++a2) u[a2] = lds[a * TL_RS + a2 * 16 + c];
         __syncthreads();
         dft16(u);                                             // X1[kb + 16 ka] at u[r16(ka)]
-        float2 *dst = p.ws + (size_t)s * p.ws_seg_stride + (size_t)a * L2 + n2;
+        // workspace [segment][column tile][k1][16 columns]: this workgroup's 256 rows x 128 B are ONE contiguous 32 KiB block
+        // (row-major [k1][n2] made every store instruction four 128-byte pieces 2 KiB apart, and the sixteen tiles of a row
+        // arrived at different times), and tl_k2's loads of rows k1 .. k1 + 15 of a tile are 2 KiB contiguous
+        float2 *dst = p.ws + (size_t)s * p.ws_seg_stride + ((size_t)blockIdx.x * TL_L1 + a) * 16 + c;
 #pragma unroll
         for (int ka = 0; ka < 16; ++ka) {
             const int i = ka >> 2, j = ka & 3;
             const float2 w = i == 0 ? bj[j] : cmul(wi[i], bj[j]);
-            dst[(size_t)(16 * ka) * L2] = cmul(u[r16(ka)], w);
+            dst[16 * 16 * ka] = cmul(u[r16(ka)], w);
         }
     }
 }
@@ -110,10 +113,14 @@ template <int L2> __global__ __launch_bounds__(256) void tl_k2_kernel(TlArgs p) 
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     for (long long s = blockIdx.y; s < p.nseg; s += gridDim.y) {
-        const float2 *row = p.ws + (size_t)s * p.ws_seg_stride + (size_t)k1 * L2;
+        // point p = a + TEAM b of row k1 sits in column tile p / 16 at column p % 16 (tl_k1's workspace layout)
+        const float2 *row = p.ws + (size_t)s * p.ws_seg_stride + (size_t)k1 * 16;
         float2 v[16];
 #pragma unroll
-        for (int b = 0; b < 16; ++b) v[b] = row[a + TEAM * b];
+        for (int b = 0; b < 16; ++b) {
+            const int pt = a + TEAM * b;
+            v[b] = row[(size_t)(pt >> 4) * (TL_L1 * 16) + (pt & 15)];
+        }
         dft16(v);                                            // Z_a[kb], kb < 16, at v[r16(kb)]
         scatter_pow16<TS>(v, team + a, w1, w4);              // team[kb][a] = Z_a[kb] W_L2^(a kb)
         wave_lds_sync();
