@@ -350,7 +350,7 @@ struct W4096Variant {
     const char *tag;
     hipError_t (*launch)(const WelchArgs &, hipStream_t);
     int (*blocks_per_cu)();
-    int chunk;      // default segments per chunk of the dynamic schedule (same-box A/B, tools/ab_variants.py)
+    int chunk;      // default segments per chunk of the dynamic schedule (same-box A/B, tools/archive/ab_variants.py)
     int rows;       // rows of partial sums each workgroup writes
     bool fd;        // detrends in the frequency domain: needs WelchArgs.fd (a window with a confined spectrum)
     bool inline_pilot = false;      // forms the pilot of the constant detrend in its own prologue (WelchArgs.pilot_inline)
@@ -361,7 +361,7 @@ const W4096Variant kVariants[] = {
     {"ws", launch_welch_tuned4096_ws, tuned4096_blocks_per_cu_ws, 20, 1, true, true},     // step 2048, confined window spectrum
 #ifdef OTH_EXPERIMENTS
     {"ws2", launch_welch_tuned4096_ws2, tuned4096_blocks_per_cu_ws2, 20, 2, true},  // the same in one 1024-thread workgroup per CU (A/B, +7 %)
-    {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16, 1, false},      // stamped build (tools/diag_stamps.py)
+    {"diag", launch_welch_tuned4096_diag, tuned4096_blocks_per_cu_diag, 16, 1, false},      // stamped build (tools/archive/diag_stamps.py)
     {"exp1", launch_welch_tuned4096_exp1, tuned4096_blocks_per_cu_exp1, 16, 1, false},
     {"exp2", launch_welch_tuned4096_exp2, tuned4096_blocks_per_cu_exp2, 16, 1, false},
     {"exp3", launch_welch_tuned4096_exp3, tuned4096_blocks_per_cu_exp3, 16, 1, false},
@@ -2497,7 +2497,7 @@ static int chain_launch_fused(oth_chain *h, const float2 *x, long long first_vec
     // 16384 points: the one-exchange pipelined loop (welch16k1x.hip, round 4); OTH_CHAIN16K=old keeps the 4 x 4096 build
     // (A/B).  At 8192 points the chain stays on the 2 x 4096 build: the 8-wave one-exchange loop with the chain's epilogue
     // spills 20 registers and measured 48.8-49.3 % against 53.4-54.1 % (windowed), 52.5 against 53.0 % (rectangular) on
-    // the same box (round 5, tools/ab_8k.sh; OTH_CHAIN16K=x1 selects it for the A/B)
+    // the same box (round 5, tools/archive/ab_8k.sh; OTH_CHAIN16K=x1 selects it for the A/B)
     static const char *chain16k_mode = getenv("OTH_CHAIN16K");
     const bool x1 = (N == 16384 && !(chain16k_mode && !strcmp(chain16k_mode, "old"))) ||
                     (N == 8192 && chain16k_mode && !strcmp(chain16k_mode, "x1"));

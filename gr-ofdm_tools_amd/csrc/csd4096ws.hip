@@ -64,7 +64,7 @@ static_assert((2 * CS_PAIR_BYTES) % 16 == 0, "the detrend table is read as float
 
 enum { CS_STOP = 0, CS_DATA = 1, CS_BUBBLE = 2 };
 
-// -DOTH_CSDWS_DIAG=1 (tools/csd_phases.py): per-wave cycle counts of the phases of a step, accumulated in scalar
+// -DOTH_CSDWS_DIAG=1 (tools/archive/csd_phases.py): per-wave cycle counts of the phases of a step, accumulated in scalar
 // registers and written behind the partial sums (1 KiB per workgroup: 16 waves x 8 counters)
 #ifndef OTH_CSDWS_DIAG
 #define OTH_CSDWS_DIAG 0

@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void bin_threshold_ma_kernel(const float *psd,
 // (35 us -> 5 us for 64 rows of 16384 at M = 163).
 #ifndef OTH_MA_RUN
 #define OTH_MA_RUN 8       // outputs per thread: 8.9 us for config 5's 64 rows of 16384 against 11.2 at 16 and 15.4 at 32 (tile 4096;
-#endif                   // tiles of 1024 / 2048 at 4-16 per thread: 7.8-10.3 us - the kernel is a latency chain, tools/decide_probe.py)
+#endif                   // tiles of 1024 / 2048 at 4-16 per thread: 7.8-10.3 us - the kernel is a latency chain, tools/archive/decide_probe.py)
 #ifndef OTH_MA_TILE
 #define OTH_MA_TILE 4096
 #endif

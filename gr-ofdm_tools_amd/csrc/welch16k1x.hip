@@ -43,7 +43,7 @@
 #define OTH_X1H_WIN_EARLY 0  // 50 %-overlap kernel, A/B: 1 = the window values of a step are requested at the end of the step before (no gain: 16384 points 0.3874-0.3907 against 0.3855-0.3876 ms, 8192 points 0.3694-0.3753 against 0.3789 ms on the builds without a pilot, and the PILOT builds then spill 16 registers)
 #endif
 #ifndef OTH_X1_DIAG
-#define OTH_X1_DIAG 0        // 1: per-wave phase cycle counters behind the partial sums (tools/diag_x1.py)
+#define OTH_X1_DIAG 0        // 1: per-wave phase cycle counters behind the partial sums (tools/archive/diag_x1.py)
 #endif
 #if OTH_X1_DIAG
 #define X1_STAMP(i)                                                      \
@@ -452,7 +452,7 @@ template <int STRIDE> __device__ __forceinline__ void lds_issue16(f2v (&r)[16], 
 #undef OTH_LDS_READ
 }
 
-// The software-pipelined form (the default).  Per-wave phase stamps of the plain loop above (tools/diag_x1.py,
+// The software-pipelined form (the default).  Per-wave phase stamps of the plain loop above (tools/archive/diag_x1.py,
 // profiles/r04_x1_phases.txt) showed the two halves of a segment badly matched: between barrier 1 and barrier 2 every
 // wave only multiplies by the pass-1 twiddles and writes exchange A - the CU's LDS store path is the limit (16 waves x
 // 16 ds_write_b64) and the SIMDs idle - while everything else (passes 2, 3, 4, the accumulation, the next pass 1)

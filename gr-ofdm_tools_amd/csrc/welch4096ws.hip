@@ -49,7 +49,7 @@
 #define OTH_WS_SPREAD 0      // A/B: 2 = four loads before and four after the producer's butterfly; 3 = 2 + 4 + 2 (after the exchange writes)
 #endif
 #ifndef OTH_WS_DIAG
-#define OTH_WS_DIAG 0        // 1: per-wave phase cycle counters behind the partial sums (tools/diag_ws.py)
+#define OTH_WS_DIAG 0        // 1: per-wave phase cycle counters behind the partial sums (tools/archive/diag_ws.py)
 #endif
 // wave priorities: producer latency sections / butterflies, consumer latency sections / butterflies
 #ifndef OTH_WS_PAL

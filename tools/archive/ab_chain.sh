@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/ab_chain.sh <out-file-under-gpurun_out> <lib-tag> [<lib-tag> ...]
+# usage (GPU box, repo root): tools/archive/ab_chain.sh <out-file-under-gpurun_out> <lib-tag> [<lib-tag> ...]
 # Accuracy (tools/acc_rows.py) and whole-push time (tools/prof_driver.py chainN) of the periodogram chain for A/B
 # library builds lib/libofdmtools_hip_<tag>.so ("default" = the shipped library).
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/ab_env.sh <out-file-under-gpurun_out> <config> <reps> <rounds> <VAR> <value> [<value> ...]
+# usage (GPU box, repo root): tools/archive/ab_env.sh <out-file-under-gpurun_out> <config> <reps> <rounds> <VAR> <value> [<value> ...]
 # Interleaved same-box A/B of tools/prof_driver.py <config> over values of one environment variable (e.g. PROF_DETREND
 # default exact): <rounds> passes over the values, one line per run, then the mean per value.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; CFG=$2; REPS=$3; ROUNDS=$4; VAR=$5; shift 5

@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/ab_half.sh <tag> [rounds]   - interleaved w16384 / w8192, shipped library against lib/libofdmtools_hip_<tag>.so
+# usage (GPU box): bash tools/archive/ab_half.sh <tag> [rounds]   - interleaved w16384 / w8192, shipped library against lib/libofdmtools_hip_<tag>.so
 TAG=$1; R=${2:-3}
 for i in $(seq 1 $R); do
   for cfg in w16384 w8192; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/ab_libs.sh <out-file-under-gpurun_out> <config> <reps> <rounds> <lib-tag> [<lib-tag> ...]
+# usage (GPU box, repo root): tools/archive/ab_libs.sh <out-file-under-gpurun_out> <config> <reps> <rounds> <lib-tag> [<lib-tag> ...]
 # Interleaved same-box A/B of tools/prof_driver.py <config> over library builds lib/libofdmtools_hip_<tag>.so
 # ("default" = the shipped library): <rounds> passes over the tags, one line per run.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; CFG=$2; REPS=$3; ROUNDS=$4; shift 4

@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/ab_many.sh <lib-tag> <rounds> <config> [<config> ...]   - interleaved prof_driver runs, shipped library against lib/libofdmtools_hip_<tag>.so
+# usage (GPU box): bash tools/archive/ab_many.sh <lib-tag> <rounds> <config> [<config> ...]   - interleaved prof_driver runs, shipped library against lib/libofdmtools_hip_<tag>.so
 TAG=$1; R=$2; shift 2
 for i in $(seq 1 $R); do
   for cfg in "$@"; do

@@ -5,7 +5,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'gr-ofdm_tools_amd'))
 from ofdm_tools import _hip, windows  # noqa: E402
 

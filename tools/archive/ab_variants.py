@@ -4,7 +4,7 @@ usage: ab_variants.py [log2_samples] [rounds] [variant[:sched[:chunk[:tail]]] ..
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'gr-ofdm_tools_amd'))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402

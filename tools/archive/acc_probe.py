@@ -6,7 +6,7 @@ tests/test_hip_parity.py::check_single_rows.  usage: acc_probe.py   (OFDM_TOOLS_
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'gr-ofdm_tools_amd'))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402

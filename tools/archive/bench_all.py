@@ -6,7 +6,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'gr-ofdm_tools_amd'))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402

@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'gr-ofdm_tools_amd'))
 from ofdm_tools import _hip, scan_batch  # noqa: E402
 

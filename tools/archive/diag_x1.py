@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Phase shares of welch16k1x_kernel (BASELINE config 5) from a -DOTH_X1_DIAG=1 build:
   make -C gr-ofdm_tools_amd variant TAG=x1diag VSRC=welch16k1x VFLAGS=-DOTH_X1_DIAG=1
-  OFDM_TOOLS_HIP_LIB=gr-ofdm_tools_amd/lib/libofdmtools_hip_x1diag.so python3 tools/diag_x1.py"""
+  OFDM_TOOLS_HIP_LIB=gr-ofdm_tools_amd/lib/libofdmtools_hip_x1diag.so python3 tools/archive/diag_x1.py"""
 import ctypes as C
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'gr-ofdm_tools_amd'))
 import numpy as np  # noqa: E402
 from ofdm_tools import _hip  # noqa: E402

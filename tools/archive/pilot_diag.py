@@ -5,7 +5,7 @@ the float64 oracle (tests/test_hip_parity.py::test_pilot_under_a_transient_and_a
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'gr-ofdm_tools_amd'))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
