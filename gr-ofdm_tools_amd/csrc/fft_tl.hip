@@ -23,7 +23,7 @@ constexpr int TL_L1 = 256;
 constexpr int TL_RS = 272;      // float2 per kb region of the K1 exchange image: 16 a x 16 c + 16 (bank rotation)
 }
 
-template <int L2> __global__ __launch_bounds__(256) void tl_k1_kernel(TlArgs p) {
+template <int L2> __global__ __launch_bounds__(256, 4) void tl_k1_kernel(TlArgs p) {
     constexpr int L = TL_L1 * L2;
     __shared__ float2 lds[16 * TL_RS];
     const int tid = threadIdx.x, c = tid & 15, a = tid >> 4;
@@ -31,18 +31,7 @@ template <int L2> __global__ __launch_bounds__(256) void tl_k1_kernel(TlArgs p) 
     // W256^a and W256^(4a): the inner twiddles of the 256-point column transform
     const float2 w1 = p.tw[a * (L / 256)], w4 = p.tw[4 * a * (L / 256)];
     // four-step twiddles W_L^((a + 16 ka) n2) = base pw^ka
-    const float2 base = p.tw[a * n2], pw = p.tw[16 * n2];
-    float2 bj[4], wi[4];
-    {
-        const float2 p2 = cmul(pw, pw), p3 = cmul(p2, pw);
-        bj[0] = base;
-        bj[1] = cmul(base, pw);
-        bj[2] = cmul(base, p2);
-        bj[3] = cmul(base, p3);
-        wi[1] = cmul(p2, p2);
-        wi[2] = cmul(wi[1], wi[1]);
-        wi[3] = cmul(wi[2], wi[1]);
-    }
+    float2 base = p.tw[a * n2], pw = p.tw[16 * n2];
     for (long long s = blockIdx.y; s < p.nseg; s += gridDim.y) {
         const float2 *src = p.x + p.first + s * p.seg_step;
         float2 mhi = make_float2(0.f, 0.f), mlo = make_float2(0.f, 0.f);
@@ -90,6 +79,20 @@ template <int L2> __global__ __launch_bounds__(256) void tl_k1_kernel(TlArgs p) 
         // (row-major [k1][n2] made every store instruction four 128-byte pieces 2 KiB apart, and the sixteen tiles of a row
         // arrived at different times), and tl_k2's loads of rows k1 .. k1 + 15 of a tile are 2 KiB contiguous
         float2 *dst = p.ws + (size_t)s * p.ws_seg_stride + ((size_t)blockIdx.x * TL_L1 + a) * 16 + c;
+        // the sixteen four-step twiddles are multiplied out of the two seeds HERE, behind the second butterfly: held from
+        // the kernel's prologue they were fourteen registers of a kernel at the 128-register line (nine products per segment)
+        asm volatile("" : "+v"(base.x), "+v"(base.y), "+v"(pw.x), "+v"(pw.y));
+        float2 bj[4], wi[4];
+        {
+            const float2 p2 = cmul(pw, pw), p3 = cmul(p2, pw);
+            bj[0] = base;
+            bj[1] = cmul(base, pw);
+            bj[2] = cmul(base, p2);
+            bj[3] = cmul(base, p3);
+            wi[1] = cmul(p2, p2);
+            wi[2] = cmul(wi[1], wi[1]);
+            wi[3] = cmul(wi[2], wi[1]);
+        }
 #pragma unroll
         for (int ka = 0; ka < 16; ++ka) {
             const int i = ka >> 2, j = ka & 3;
