@@ -363,7 +363,18 @@ __global__ __launch_bounds__(64) void any_mean_kernel(const float2 *x, const flo
     const long long s = blockIdx.x;
     const float2 *src = (blockIdx.y ? y : x) + first + s * seg_step;
     double sr = 0.0, si = 0.0;
-    for (int n = threadIdx.x; n < nperseg; n += 64) {
+    int n = threadIdx.x;
+    for (; n + 448 < nperseg; n += 512) {      // eight independent loads per trip (one at a time a 1000-point segment took
+        float2 v[8];                           // sixteen dependent memory round trips: 13 % of the whole call)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[n + 64 * u];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            sr += (double)v[u].x + (double)v[u + 1].x;
+            si += (double)v[u].y + (double)v[u + 1].y;
+        }
+    }
+    for (; n < nperseg; n += 64) {
         const float2 v = src[n];
         sr += (double)v.x;
         si += (double)v.y;
