@@ -24,6 +24,7 @@
 //
 // The two pairs run the same chunk schedule (Px draws the tickets, Py reads them), so x_s and y_s are always in
 // the same step.  Frequency-domain detrend as in welch4096ws.hip (needs WelchArgs.fd).
+#include <mutex>
 #include <type_traits>
 #include "fft4096.hip.h"
 
@@ -479,27 +480,46 @@ int csd4096ws_blocks_per_cu() {
     return cached = n;
 }
 
-hipError_t launch_csd_tuned4096ws(const WelchArgs &a, hipStream_t s) {
+hipError_t launch_csd_tuned4096ws(const WelchArgs &a_in, hipStream_t s) {
+    WelchArgs a = a_in;
     const dim3 grid(a.wg_per_stream, a.nstreams);
     static bool armed[64] = {};        // 140 KiB of dynamic LDS needs the opt-in, once per device
+    // A plan WITHOUT detrend runs the detrending build on an all-zero window-spectrum table (round 6): X - mean * 0 is X
+    // bit for bit, the per-wave sums cost the step ~1 %, and the build without them - csd4096ws_kernel<false, false> - was
+    // the one two-channel build that spilled (five registers around the producer's chunk boundary; verdict r5).
+    static float4 *zero_fd[64] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63, armed[63] = false;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     bool &big_lds = armed[dev];
     if (!big_lds) {
         hipError_t e = hipSuccess;
         for (const void *fn : {reinterpret_cast<const void *>(csd4096ws_kernel<true, true>),
-                               reinterpret_cast<const void *>(csd4096ws_kernel<true, false>),
-                               reinterpret_cast<const void *>(csd4096ws_kernel<false, false>)})
+                               reinterpret_cast<const void *>(csd4096ws_kernel<true, false>)})
             if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_LDS_BYTES);
         if (e != hipSuccess) return e;
         big_lds = true;
     }
-    if (a.detrend && (a.pilot || a.pilot_inline))
+    if (!a.detrend) {
+        {
+            static std::mutex once;      // contexts of several threads may come here at the same time
+            std::lock_guard<std::mutex> g(once);
+            if (!zero_fd[dev]) {
+                float4 *z = nullptr;
+                hipError_t e = hipMalloc(&z, 256 * sizeof(float4));
+                if (e == hipSuccess) e = hipMemset(z, 0, 256 * sizeof(float4));      // synchronous: visible to every stream after it
+                if (e != hipSuccess) return e;
+                zero_fd[dev] = z;
+            }
+        }
+        a.fd = zero_fd[dev];
+        a.detrend = 1;
+        a.pilot = nullptr;
+        a.pilot_inline = 0;
+    }
+    if (a.pilot || a.pilot_inline)
         hipLaunchKernelGGL((csd4096ws_kernel<true, true>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
-    else if (a.detrend)
-        hipLaunchKernelGGL((csd4096ws_kernel<true, false>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
     else
-        hipLaunchKernelGGL((csd4096ws_kernel<false, false>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
+        hipLaunchKernelGGL((csd4096ws_kernel<true, false>), grid, dim3(TCS), CS_LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
