@@ -16,7 +16,8 @@ N = 1  workload "C2" (the configuration BASELINE.json's metric is quoted on): on
        `csd_c3` (BASELINE config 3: two-channel cross spectrum / coherence, 2 x 2^26 samples, 16 B per sample
        pair), `scan_c5` (BASELINE config 5: 64 channel streams x 2^22 samples, 16384-pt rectangular |X|^2/N^2 mean +
        the device decision stage), `c1` (BASELINE config 1 at its own size: 2^20 samples, 1024-pt rectangular chain, the 128
-       eight-row means + a7 channel sums), each with its own `roofline` whose `kernel` is the recipe the library recorded for
+       eight-row means + a7 channel sums), `welch_32768` / `welch_65536` (the four-step route above the tuned kernels, 2^27
+       samples), each with its own `roofline` whose `kernel` is the recipe the library recorded for
        the launch (oth__debug_last_recipe) and whose `traffic` is the figure of the builder's rocprofv3 PMC passes of
        the same configuration (profiles/traffic.json: not measured by this run); `h2d_inclusive` (host buffer -> PSD through the streaming entry point);
        `cpu_baseline` (+ `_parallel`, `_c5`, `_c1`).
@@ -755,6 +756,51 @@ def main():
                              'note': '8 MiB per launch: a handful of microseconds of HBM time - the step is launch latency'},
                 'parity_max_rel_err': err}
 
+    # ---------------------------------------------------------------- the lengths above the tuned kernels ----
+    def big_welch_bench(nfft, steps, warmup):
+        """Round 6: Hann Welch, 50 % overlap, detrend constant at 32768 / 65536 points - what fast_spectrum_scan(n_fft=0) picks for
+        blocks of 16 Ki ... 64 Ki samples (ofdm_cr_tools.py:474-475) and a flowgraph reaches with --nfft - on 2^27 resident samples.
+        A call is SEVERAL launches (sub-block sums, K1, K2 per 128 MiB workspace chunk: csrc/fft_tl.hip): `kernel_avg_ms` is the
+        HIP-event time of one call's launches together, `achieved` = 8 B x samples / that."""
+        n = 1 << 27
+        iq = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        ctx.synth_iq(iq.data_ptr(), n, 1002, TONES, DC)
+        plan = ctx.welch_plan(nfft, window=windows.get_window('hann', nfft), fs=1.0)
+        out = torch.zeros(nfft, dtype=torch.float32, device=dev)
+
+        def step():
+            plan.exec_dev(iq.data_ptr(), n, out.data_ptr())
+
+        ramp(step)
+        for _ in range(warmup):
+            step()
+        ctx.set_timing(True)
+        ctx.get_timing(reset=True)
+        wall, per = timed_steps(torch, dist, dev, step, fence, steps, False)
+        kern_ms, calls = ctx.get_timing(reset=True)
+        ctx.set_timing(False)
+        from oracle import ref_cpu as R
+        pre = iq[:1 << 21].cpu().numpy().view(np.complex64).reshape(-1)
+        _, ref = R.welch_np(pre, fs=1.0, nperseg=nfft, nfft=nfft)
+        err = float(np.max(np.abs(ctx.welch_plan(nfft, window=windows.get_window('hann', nfft), fs=1.0).exec(pre) - ref) / ref))
+        med = statistics.median(per)
+        kavg = kern_ms / max(calls, 1)
+        ach = 8.0 * n / (kavg * 1e-3) / 1e9 if kavg else 0.0
+        traffic, tsrc = profile_traffic('w%d' % nfft, 8 * n)
+        plan_recipe[nfft] = plan.last_recipe() + ' (sub-block sums + K1 + K2 per workspace chunk, summed)'
+        plan.close()
+        return {'value': n / (med * 1e-3) / 1e6, 'unit': 'Msamples/s', 'ms_per_step': med, 'wall_ms_per_step': 1e3 * wall / steps,
+                'steps': steps, 'kernel_avg_ms': kavg, 'calls': int(calls),
+                'config': {'workload': '2^27-sample complex64 stream, %d-pt Hann Welch, 50%% overlap, detrend constant, density '
+                                       '(four-step route: a 512 / 256 KiB segment crosses the chip once between the halves)' % nfft},
+                'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
+                             'traffic': traffic, 'traffic_source': tsrc, 'kernel': plan_recipe[nfft],
+                             'kernel_avg_ms': kavg, 'launches': int(calls), 'algorithmic_bytes_per_launch': 8 * n,
+                             'whole_step_frac': 8.0 * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                'parity_prefix_max_rel_err': err}
+
+    plan_recipe = {}
+
     result = None
     if multi and args.workload != 'c4':
         seen = ranks_seen()
@@ -920,6 +966,9 @@ def main():
             torch.cuda.empty_cache()
             result['c1'] = c1_bench(max(10, args.steps // 4), max(3, args.warmup // 4))
             torch.cuda.empty_cache()
+            for nf in (32768, 65536):
+                result['welch_%d' % nf] = big_welch_bench(nf, max(5, args.steps // 10), max(2, args.warmup // 10))
+                torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             result['cpu_baseline'], result['cpu_baseline_parallel'] = cpu_baseline(NFFT)
             result['cpu_baseline_c5'] = cpu_baseline_c5()
