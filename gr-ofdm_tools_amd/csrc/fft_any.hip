@@ -219,6 +219,7 @@ template <int T, int STORE, bool TWLDS> __global__ __launch_bounds__(T) void any
         twl = stage;      // (the first __syncthreads() of the segment loop orders it in front of the first pass)
     }
     constexpr int NACC = STORE == 2 ? 4 : (STORE == 1 ? 1 : 0);
+    constexpr int kStoreUnroll = (STORE == 1 || STORE == 2) ? 16 : 4;
     float acc[NACC > 0 ? NACC : 1][16];
     float2 X0[STORE == 2 ? 16 : 1];
     if constexpr (NACC > 0) {
@@ -280,7 +281,7 @@ template <int T, int STORE, bool TWLDS> __global__ __launch_bounds__(T) void any
                 any_fft_lds<T, TWLDS>(buf, twl, a.f, tid);
             }
             // ---- store (the accumulating forms index registers by q: fully unrolled; the others four points at a time)
-#pragma unroll(STORE == 1 || STORE == 2 ? 16 : 4)
+#pragma unroll kStoreUnroll
             for (int q = 0; q < 16; ++q) {
                 int i, c, lds;
                 if (any_point<T>(a, tid, q, E, i, c, lds)) {
