@@ -518,3 +518,55 @@ def test_fuzz_any_length_shapes_against_the_oracle(ctx, hip):
         plan.close()
     print('fuzz worst by route: ' + ', '.join('%s %.1e' % kv for kv in sorted(worst.items())))
     assert set(worst) >= {'direct', 'bluestein', 'bluestein2'}
+
+
+def test_any_length_results_do_not_depend_on_timing_under_a_bandwidth_hog(ctx, hip):
+    """The dynamic side of the hazard question for the round-6 kernels (csrc/fft_any.hip, fft_tl.hip: workgroup barriers
+    between Stockham passes, wave-level exchanges in tl_k2, the workspace hand-over between launches, read-modify-write of
+    the partial rows across chunks): every route - all of them walk fixed runs of segments, so their sums are bit-reproducible
+    - is run alone and then again and again while a second context streams 8 GiB reads over the same HBM; the results must be
+    IDENTICAL bit for bit (tests/test_hip_parity.py does the same for the tuned builds)."""
+    import threading
+    n = 1 << 23
+    d = ctx.alloc((n + 5) * 8)
+    hog = hip.Context(0)
+    hog_bytes = 8 << 30
+    hog_buf = hog.alloc(hog_bytes)
+    try:
+        ctx.synth_iq(d, n + 5, 4343, R.TONES, R.DC)
+        plans = []
+        for nfft, variant in ((1000, None), (12000, None), (4099, None), (20000, None), (32768, None), (65536, None), (32768, 'anycov'),
+                              (131072, None)):
+            for det in (hip.DETREND_CONSTANT, hip.DETREND_NONE):
+                plan = ctx.welch_plan(nfft, window=_win('hann', nfft), detrend=det)
+                if variant:
+                    plan.set_tuning(variant)
+                m = n if nfft <= 65536 and not variant else n // 8      # (the coverage routes above 16384 are slow: fewer segments)
+                plans.append(('welch %d %s det %d' % (nfft, variant or '', det), plan, lambda p=plan, m=m: p.exec_device_src(d, m)))
+        csd = ctx.welch_plan(3000, window=_win('hann', 3000))
+        plans.append(('csd 3000', csd, lambda: np.concatenate([np.asarray(v).view(np.float32).ravel()
+                                                             for v in csd.csd_device_src(d + 40, d, n // 4)])))
+        ch = ctx.chain(1536, None, True, hip.EPI_MAG2, 16)
+        plans.append(('chain 1536', ch, lambda: ch.push(ctx.d2h(d, (1536 * 16 * 20,), np.complex64), 4)[0].ravel()))      # whole groups of 16 vectors: every push alike
+        quiet = [run().copy() for _, _, run in plans]
+        stop = threading.Event()
+
+        def stream_reads():
+            while not stop.is_set():
+                hog.stream_read_probe(hog_buf, hog_bytes, 4)
+        th = threading.Thread(target=stream_reads, daemon=True)
+        th.start()
+        try:
+            for rep in range(6):
+                for (name, _, run), want in zip(plans, quiet):
+                    got = run()
+                    assert got.tobytes() == want.tobytes(), (name, rep, float(np.max(np.abs(got - want) / np.abs(want))))
+        finally:
+            stop.set()
+            th.join(60)
+        for _, plan, _ in plans:
+            plan.close()
+    finally:
+        ctx.free(d)
+        hog.free(hog_buf)
+        hog.close()
