@@ -647,8 +647,12 @@ int any_tables_init(oth_ctx *c, int nfft, AnyTables *t) {
 int any_partial_rows(const AnyShape &sh, long long nseg, int cu_count) {
     long long w;
     if (sh.kind == ANY_DIRECT || sh.kind == ANY_BLUESTEIN) {
-        long long occ = 65536 / ((long long)sh.L * 8);      // workgroups per CU by LDS footprint
-        occ = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
+        // workgroups per CU by LDS footprint (tile + the staged twiddles where any_make_desc puts them there), at most 16:
+        // the single-column builds hold ~100 registers, five 64-thread workgroups per SIMD
+        const long long tile = (long long)sh.L * 8, both = 2 * tile;
+        const long long lds = (both <= 64 * 1024 || (tile > 64 * 1024 && both <= 150 * 1024)) ? both : tile;
+        long long occ = (150 * 1024) / lds;
+        occ = occ < 1 ? 1 : (occ > 16 ? 16 : occ);
         w = (long long)cu_count * occ;
     } else {
         static const char *e = getenv("OTH_ANY_TL_W");      // (A/B of the partial-row count of the two-level routes)

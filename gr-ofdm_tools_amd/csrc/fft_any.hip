@@ -124,9 +124,15 @@ __device__ __forceinline__ int any_lds(int i, int c, int logC, int cmask) { retu
 
 // The q-th point of thread tid: (i, c) and its LDS index.  Column tiles (cs == 1: the C columns are adjacent in memory)
 // walk the LDS linearly; row tiles (cs != 1: each of the C transforms is contiguous) walk i first.
-template <int T> __device__ __forceinline__ bool any_point(const AnyArgs &a, int tid, int q, int E, int &i, int &c, int &lds) {
+template <int T, bool C1> __device__ __forceinline__ bool any_point(const AnyArgs &a, int tid, int q, int E, int &i, int &c, int &lds) {
     const int e = tid + q * T;
     if (e >= E) return false;
+    if constexpr (C1) {      // one transform per tile (the direct and one-launch Bluestein routes): no column arithmetic at all
+        i = e;
+        c = 0;
+        lds = e;
+        return true;
+    }
     const int logC = a.f.logC, cmask = (1 << logC) - 1;
     if (a.cs == 1) {
         i = e >> logC;
@@ -140,10 +146,10 @@ template <int T> __device__ __forceinline__ bool any_point(const AnyArgs &a, int
 }
 
 // One Stockham pass of radix R on the tile: its C columns are transformed together.
-template <int T, int R, bool TWLDS>
+template <int T, int R, bool TWLDS, bool C1>
 __device__ __forceinline__ void any_pass(float2 *buf, const float2 *twl, const AnyFftDesc &f, const AnyPass &p, int tid) {
     constexpr int Q = (16 + R - 1) / R;       // butterflies per thread: the tile has at most 16 T points
-    const int logC = f.logC, cmask = (1 << logC) - 1;
+    const int logC = C1 ? 0 : f.logC, cmask = C1 ? 0 : (1 << logC) - 1;      // C1: one column - the index arithmetic folds away
     const int nbf = p.nbf;                    // butterflies per column = n / R
     const int NBF = nbf << logC;
     float2 v[Q][R];
@@ -187,28 +193,28 @@ __device__ __forceinline__ void any_pass(float2 *buf, const float2 *twl, const A
 }
 
 // all passes of the descriptor; the caller has synchronised the workgroup after filling buf, and may read any point after
-template <int T, bool TWLDS> __device__ __forceinline__ void any_fft_lds(float2 *buf, const float2 *twl, const AnyFftDesc &f, int tid) {
+template <int T, bool TWLDS, bool C1> __device__ __forceinline__ void any_fft_lds(float2 *buf, const float2 *twl, const AnyFftDesc &f, int tid) {
     for (int ip = 0; ip < f.npass; ++ip) {
         const AnyPass &p = f.pass[ip];
         switch (p.R) {
-            case 16: any_pass<T, 16, TWLDS>(buf, twl, f, p, tid); break;
-            case 8: any_pass<T, 8, TWLDS>(buf, twl, f, p, tid); break;
-            case 4: any_pass<T, 4, TWLDS>(buf, twl, f, p, tid); break;
-            case 2: any_pass<T, 2, TWLDS>(buf, twl, f, p, tid); break;
-            case 3: any_pass<T, 3, TWLDS>(buf, twl, f, p, tid); break;
-            case 5: any_pass<T, 5, TWLDS>(buf, twl, f, p, tid); break;
-            default: any_pass<T, 7, TWLDS>(buf, twl, f, p, tid); break;
+            case 16: any_pass<T, 16, TWLDS, C1>(buf, twl, f, p, tid); break;
+            case 8: any_pass<T, 8, TWLDS, C1>(buf, twl, f, p, tid); break;
+            case 4: any_pass<T, 4, TWLDS, C1>(buf, twl, f, p, tid); break;
+            case 2: any_pass<T, 2, TWLDS, C1>(buf, twl, f, p, tid); break;
+            case 3: any_pass<T, 3, TWLDS, C1>(buf, twl, f, p, tid); break;
+            case 5: any_pass<T, 5, TWLDS, C1>(buf, twl, f, p, tid); break;
+            default: any_pass<T, 7, TWLDS, C1>(buf, twl, f, p, tid); break;
         }
     }
 }
 
 // STORE: 0 plain (workspace, optional four-step twiddle), 1 accumulate one channel, 2 accumulate two channels,
 // 3 periodogram rows
-template <int T, int STORE, bool TWLDS> __global__ __launch_bounds__(T) void any_fft_kernel(AnyArgs a) {
+template <int T, int STORE, bool TWLDS, bool C1> __global__ __launch_bounds__(T) void any_fft_kernel(AnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char any_smem[];
     float2 *buf = reinterpret_cast<float2 *>(any_smem);
     const int tid = threadIdx.x, t = blockIdx.x;
-    const int E = a.f.n << a.f.logC;
+    const int E = C1 ? a.f.n : a.f.n << a.f.logC;
     // The n twiddles W_n^j of the tile's transform, staged once per workgroup behind the tile where LDS allows (the host
     // decides: AnyFftDesc.tw_lds): a pass then gathers them from LDS instead of the order-L table in L2 - R - 1 dependent
     // L2 round trips per butterfly and pass were most of a small transform's time (w1000: 2.57 ms -> see DESIGN 4.6).
@@ -247,7 +253,7 @@ template <int T, int STORE, bool TWLDS> __global__ __launch_bounds__(T) void any
 #pragma unroll 4
             for (int q = 0; q < 16; ++q) {
                 int i, c, lds;
-                if (any_point<T>(a, tid, q, E, i, c, lds)) {
+                if (any_point<T, C1>(a, tid, q, E, i, c, lds)) {
                     const int n = i * a.es + t * a.tile_stride + c * a.cs;
                     float2 v;
                     if (a.load_op == 1) {
@@ -266,25 +272,25 @@ template <int T, int STORE, bool TWLDS> __global__ __launch_bounds__(T) void any
                 }
             }
             __syncthreads();
-            any_fft_lds<T, TWLDS>(buf, twl, a.f, tid);
+            any_fft_lds<T, TWLDS, C1>(buf, twl, a.f, tid);
             if (a.mid_op) {      // Bluestein: multiply by B / M, conjugate, transform again
 #pragma unroll 4
                 for (int q = 0; q < 16; ++q) {
                     int i, c, lds;
-                    if (any_point<T>(a, tid, q, E, i, c, lds)) {
+                    if (any_point<T, C1>(a, tid, q, E, i, c, lds)) {
                         const int nat = i * a.nat_i + t * a.nat_t + c * a.nat_c;
                         const float2 v = cmul(buf[lds], a.midtab[nat]);
                         buf[lds] = make_float2(v.x, -v.y);
                     }
                 }
                 __syncthreads();
-                any_fft_lds<T, TWLDS>(buf, twl, a.f, tid);
+                any_fft_lds<T, TWLDS, C1>(buf, twl, a.f, tid);
             }
             // ---- store (the accumulating forms index registers by q: fully unrolled; the others four points at a time)
 #pragma unroll kStoreUnroll
             for (int q = 0; q < 16; ++q) {
                 int i, c, lds;
-                if (any_point<T>(a, tid, q, E, i, c, lds)) {
+                if (any_point<T, C1>(a, tid, q, E, i, c, lds)) {
                     float2 v = buf[lds];
                     if constexpr (STORE == 0) {
                         if (a.twbig) v = cmul(v, a.twbig[i * (t * a.tw_t + c * a.tw_c)]);
@@ -335,12 +341,12 @@ template <int T, int STORE, bool TWLDS> __global__ __launch_bounds__(T) void any
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 int i, c, lds;
-                if (any_point<T>(a, tid, q, E, i, c, lds)) buf[lds] = make_float2(acc[2 * half][q], NACC > 1 ? acc[NACC > 1 ? 2 * half + 1 : 0][q] : 0.f);
+                if (any_point<T, C1>(a, tid, q, E, i, c, lds)) buf[lds] = make_float2(acc[2 * half][q], NACC > 1 ? acc[NACC > 1 ? 2 * half + 1 : 0][q] : 0.f);
             }
 #pragma unroll 4
             for (int q = 0; q < 16; ++q) {
                 int i, c, lds;
-                if (any_point<T>(a, tid, q, E, i, c, lds)) {
+                if (any_point<T, C1>(a, tid, q, E, i, c, lds)) {
                     const int nat = i * a.nat_i + t * a.nat_t + c * a.nat_c;      // the bin (filter: Bluestein's M > N outputs)
                     const int pp = i * a.pp_i + t * a.pp_t + c * a.pp_c;          // where the partial row keeps it
                     if (nat < a.nbins) {
@@ -533,15 +539,22 @@ hipError_t launch_any_fft(const AnyArgs &a, int tiles, int gy, int gz, int store
     const size_t lds = ((size_t)points + (a.f.tw_lds ? (size_t)a.f.n : 0)) * sizeof(float2);
     const dim3 grid(tiles, gy, gz);
     hipError_t e;
-#define OTH_ANY_LAUNCH(TT, ST)                                                                            \
-    do {                                                                                                  \
-        if (a.f.tw_lds) {                                                                                 \
-            if ((e = any_allow_lds(any_fft_kernel<TT, ST, true>, lds)) != hipSuccess) return e;           \
-            hipLaunchKernelGGL((any_fft_kernel<TT, ST, true>), grid, dim3(TT), lds, s, a);                \
-        } else {                                                                                          \
-            if ((e = any_allow_lds(any_fft_kernel<TT, ST, false>, lds)) != hipSuccess) return e;          \
-            hipLaunchKernelGGL((any_fft_kernel<TT, ST, false>), grid, dim3(TT), lds, s, a);               \
-        }                                                                                                 \
+#define OTH_ANY_LAUNCH1(TT, ST, TW, CC)                                                                     \
+    do {                                                                                                    \
+        if ((e = any_allow_lds(any_fft_kernel<TT, ST, TW, CC>, lds)) != hipSuccess) return e;               \
+        hipLaunchKernelGGL((any_fft_kernel<TT, ST, TW, CC>), grid, dim3(TT), lds, s, a);                    \
+    } while (0)
+    // one transform per tile (logC == 0, column mode): the builds without column arithmetic
+#define OTH_ANY_LAUNCH(TT, ST)                                                                              \
+    do {                                                                                                    \
+        const bool c1 = a.f.logC == 0 && a.cs == 1;                                                         \
+        if (a.f.tw_lds) {                                                                                   \
+            if (c1) OTH_ANY_LAUNCH1(TT, ST, true, true);                                                    \
+            else OTH_ANY_LAUNCH1(TT, ST, true, false);                                                      \
+        } else {                                                                                            \
+            if (c1) OTH_ANY_LAUNCH1(TT, ST, false, true);                                                   \
+            else OTH_ANY_LAUNCH1(TT, ST, false, false);                                                     \
+        }                                                                                                   \
     } while (0)
 #define OTH_ANY_T(ST)                                     \
     do {                                                  \
@@ -558,6 +571,7 @@ hipError_t launch_any_fft(const AnyArgs &a, int tiles, int gy, int gz, int store
     }
 #undef OTH_ANY_T
 #undef OTH_ANY_LAUNCH
+#undef OTH_ANY_LAUNCH1
     return hipGetLastError();
 }
 
