@@ -153,15 +153,17 @@ __device__ __forceinline__ void any_pass(float2 *buf, const float2 *twl, const A
     const int nbf = p.nbf;                    // butterflies per column = n / R
     const int NBF = nbf << logC;
     float2 v[Q][R];
+    int dst[Q];      // LDS row of output 0 of butterfly q (kept from the read half: the quotient costs ten instructions)
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int bf = tid + q * T;
+        dst[q] = 0;
         if (bf < NBF) {
             const int c = bf & cmask, j = bf >> logC;
 #pragma unroll
             for (int m = 0; m < R; ++m) v[q][m] = buf[any_lds(j + m * nbf, c, logC, cmask)];
+            int jq = 0, jn = j;
             if (p.NS > 1) {
-                int jq, jn;
                 any_divmod(j, p.NS, p.inv_ns, jq, jn);
                 const int k = jn * p.inner;              // twiddle W_(NS R)^(jn m) = W_n^(m k), m k < n
                 if constexpr (TWLDS) {                   // the n twiddles of this transform staged in LDS (any_fft_kernel)
@@ -172,7 +174,11 @@ __device__ __forceinline__ void any_pass(float2 *buf, const float2 *twl, const A
 #pragma unroll
                     for (int m = 1; m < R; ++m) v[q][m] = cmul(v[q][m], f.tw[m * kg]);
                 }
+            } else {
+                jq = j;      // NS == 1: j / 1, j % 1
+                jn = 0;
             }
+            dst[q] = jq * p.NS * R + jn;
             dft_small<R>(v[q]);
         }
     }
@@ -181,12 +187,9 @@ __device__ __forceinline__ void any_pass(float2 *buf, const float2 *twl, const A
     for (int q = 0; q < Q; ++q) {
         const int bf = tid + q * T;
         if (bf < NBF) {
-            const int c = bf & cmask, j = bf >> logC;
-            int jq, jn;
-            any_divmod(j, p.NS, p.inv_ns, jq, jn);
-            const int j0 = jq * p.NS * R + jn;
+            const int c = bf & cmask;
 #pragma unroll
-            for (int m = 0; m < R; ++m) buf[any_lds(j0 + m * p.NS, c, logC, cmask)] = v[q][m];
+            for (int m = 0; m < R; ++m) buf[any_lds(dst[q] + m * p.NS, c, logC, cmask)] = v[q][m];
         }
     }
     __syncthreads();
