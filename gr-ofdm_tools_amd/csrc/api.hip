@@ -665,7 +665,7 @@ int any_partial_rows(const AnyShape &sh, long long nseg, int cu_count) {
 
 // workspace of a chunk: it and the chunk's samples stay in the Infinity Cache (OTH_ANY_WS_MB: A/B of the chunk size)
 size_t any_ws_bytes() {
-    static const char *e = getenv("OTH_ANY_WS_MB");
+    const char *e = getenv("OTH_ANY_WS_MB");      // (read per call: the tests shrink it to cross chunk boundaries on small inputs)
     const long mb = e ? atol(e) : 0;
     return (size_t)(mb > 0 ? mb : 128) << 20;
 }
@@ -687,7 +687,7 @@ int any_run(oth_ctx *c, AnyTables &t, const float2 *x, const float2 *y, long lon
     int rc;
     if (two && (rc = ensure(c, &t.ws, &t.ws_cap, sizeof(float2) * (size_t)L * nch * (size_t)B))) return rc;
     // (the fast two-level route keeps sub-block sums there instead: at most B * seg_step / kTlSub + nperseg / kTlSub of them)
-    const size_t nsums = (size_t)B * (size_t)(seg_step / kTlSub + 1) + (size_t)(nperseg / kTlSub) + 1;
+    const size_t nsums = nch * ((size_t)B * (size_t)(seg_step / kTlSub + 1) + (size_t)(nperseg / kTlSub) + 1);
     if (detrend && (rc = ensure(c, &t.mean, &t.mean_cap, sizeof(float4) * std::max(nch * (size_t)B, nsums)))) return rc;
     AnyFftDesc d_one{}, d_col{}, d_row{};
     if (two) {
@@ -723,19 +723,25 @@ int any_run(oth_ctx *c, AnyTables &t, const float2 *x, const float2 *y, long lon
         a.scale = scale;
         a.fftshift = fftshift;
         const int gy_rows = (int)(nb < 65535 ? nb : 65535);
-        if (sh.kind == ANY_TWOLEVEL && tl_supported(L) && !y && !rows && !coverage_only) {
-            // 32768 / 65536 points, one channel, averages: the register radix-16 kernels of fft_tl.hip
+        if (sh.kind == ANY_TWOLEVEL && tl_supported(L) && !rows && !coverage_only) {
+            // 32768 / 65536 points, averages (one or two channels): the register radix-16 kernels of fft_tl.hip
             const bool blocks = detrend && nperseg % kTlSub == 0 && seg_step % kTlSub == 0;      // (t.mean holds B float4 = B double2)
             TlArgs ta{};
-            ta.x = x, ta.first = cfirst, ta.seg_step = seg_step, ta.nperseg = nperseg, ta.win = win;
-            ta.ws = t.ws, ta.ws_seg_stride = (size_t)L, ta.nseg = nb, ta.tw = t.tw, ta.partial = partial, ta.first_chunk = s0 == 0;
+            ta.x = x, ta.y = y, ta.first = cfirst, ta.seg_step = seg_step, ta.nperseg = nperseg, ta.win = win;
+            ta.ws = t.ws, ta.ws_seg_stride = (size_t)L, ta.ws_ch_stride = (size_t)L * (size_t)B, ta.nseg = nb, ta.tw = t.tw;
+            ta.partial = partial, ta.first_chunk = s0 == 0;
             if (blocks) {
                 ta.nsub = nperseg / kTlSub, ta.sub_step = (int)(seg_step / kTlSub);
+                const long long nblk = (nb - 1) * ta.sub_step + ta.nsub;
+                ta.aux_ch_stride = (size_t)nblk;
                 ta.bsum = reinterpret_cast<const double2 *>(t.mean);
-                HIPCHK(c, launch_tl_blocksum(x, cfirst, (nb - 1) * ta.sub_step + ta.nsub, reinterpret_cast<double2 *>(t.mean), c->stream));
+                for (int ch = 0; ch < nch; ++ch)
+                    HIPCHK(c, launch_tl_blocksum(ch ? y : x, cfirst, nblk, reinterpret_cast<double2 *>(t.mean) + (size_t)ch * nblk, c->stream));
             } else if (detrend) {
                 ta.mean = t.mean;
-                HIPCHK(c, launch_tl_mean(x, cfirst, seg_step, nperseg, nb, t.mean, c->stream));
+                ta.aux_ch_stride = (size_t)B;
+                for (int ch = 0; ch < nch; ++ch)
+                    HIPCHK(c, launch_tl_mean(ch ? y : x, cfirst, seg_step, nperseg, nb, t.mean + (size_t)ch * B, c->stream));
             }
             HIPCHK(c, launch_tl_k1(L, ta, c->stream));
             HIPCHK(c, launch_tl_k2(L, ta, W, c->stream));
@@ -930,7 +936,7 @@ struct LaunchRecipe {
     bool tickets = false;        // draws chunk tickets from the context's queue
     bool two_runs = false;       // "ws2": the stream cut into two runs of segments
     int any_kind = 0;            // RK_ANY: AnyKind
-    bool any_r16 = false;        // ... on fft_tl.hip's register radix-16 kernels (32768 / 65536 points, one channel)
+    bool any_r16 = false;        // ... on fft_tl.hip's register radix-16 kernels (32768 / 65536 points)
 };
 
 int generic_wg_for(int cu_count, int nfft, long long nseg, int nstreams) {
@@ -961,7 +967,7 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
         }
         r.kern = RK_ANY;
         r.any_kind = p.any.kind;
-        r.any_r16 = p.any.kind == ANY_TWOLEVEL && tl_supported(p.any.L) && !csd && p.tune_variant != "anycov";      // fft_tl.hip
+        r.any_r16 = p.any.kind == ANY_TWOLEVEL && tl_supported(p.any.L) && p.tune_variant != "anycov";      // fft_tl.hip
         r.form = p.detrend ? 1 : 0;
         r.W = any_partial_rows(p.any, nseg, cu_count);
         r.layout = p.any.kind == ANY_TWOLEVEL ? 6 : 0;

@@ -12,6 +12,8 @@
 //   tl_k2_kernel   row k1 of the workspace (L2 contiguous points) per team of 16 (L2 = 256) or 8 (128) lanes of one wave:
 //                  dft16 over b, twiddle, exchange inside the wave, dft16 (two dft8) -> k2; |X|^2 added over the
 //                  workgroup's segments; partial rows in [k1][k2] order (finalize layout 6).
+//   two channels   (oth_csd_exec / coherence): K1 per channel on blockIdx.z, K2<CSD> transforms row k1 of x and of y back
+//                  to back and adds |X|^2, |Y|^2, conj(X) Y: partial rows [W][4][L].
 // The workspace holds a chunk of segments (any_run, api.hip) small enough to stay in the Infinity Cache between the two.
 #include "fft4096.hip.h"
 #include "oth_internal.h"
@@ -32,11 +34,12 @@ template <int L2> __global__ __launch_bounds__(256, 4) void tl_k1_kernel(TlArgs 
     const float2 w1 = p.tw[a * (L / 256)], w4 = p.tw[4 * a * (L / 256)];
     // four-step twiddles W_L^((a + 16 ka) n2) = base pw^ka
     float2 base = p.tw[a * n2], pw = p.tw[16 * n2];
+    const int ch = blockIdx.z;      // two-channel plans: channel 1 = y, its sub-block sums / means / workspace one stride further
     for (long long s = blockIdx.y; s < p.nseg; s += gridDim.y) {
-        const float2 *src = p.x + p.first + s * p.seg_step;
+        const float2 *src = (ch ? p.y : p.x) + p.first + s * p.seg_step;
         float2 mhi = make_float2(0.f, 0.f), mlo = make_float2(0.f, 0.f);
         if (p.bsum) {      // the segment's mean from the sums of its sub-blocks (tl_blocksum_kernel): one read of the chunk's
-            const double2 *bs = p.bsum + s * p.sub_step;      // samples for all the overlapping segments
+            const double2 *bs = p.bsum + (size_t)ch * p.aux_ch_stride + s * p.sub_step;      // samples for all the overlapping segments
             double mr = 0.0, mi = 0.0;
             for (int j = 0; j < p.nsub; ++j) {
                 mr += bs[j].x;
@@ -47,7 +50,7 @@ template <int L2> __global__ __launch_bounds__(256, 4) void tl_k1_kernel(TlArgs 
             mhi = make_float2((float)mr, (float)mi);
             mlo = make_float2((float)(mr - (double)mhi.x), (float)(mi - (double)mhi.y));
         } else if (p.mean) {
-            const float4 m = p.mean[s];
+            const float4 m = p.mean[(size_t)ch * p.aux_ch_stride + s];
             mhi = make_float2(m.x, m.y);
             mlo = make_float2(m.z, m.w);
         }
@@ -78,7 +81,7 @@ template <int L2> __global__ __launch_bounds__(256, 4) void tl_k1_kernel(TlArgs 
         // workspace [segment][column tile][k1][16 columns]: this workgroup's 256 rows x 128 B are ONE contiguous 32 KiB block
         // (row-major [k1][n2] made every store instruction four 128-byte pieces 2 KiB apart, and the sixteen tiles of a row
         // arrived at different times), and tl_k2's loads of rows k1 .. k1 + 15 of a tile are 2 KiB contiguous
-        float2 *dst = p.ws + (size_t)s * p.ws_seg_stride + ((size_t)blockIdx.x * TL_L1 + a) * 16 + c;
+        float2 *dst = p.ws + (size_t)ch * p.ws_ch_stride + (size_t)s * p.ws_seg_stride + ((size_t)blockIdx.x * TL_L1 + a) * 16 + c;
         // the sixteen four-step twiddles are multiplied out of the two seeds HERE, behind the second butterfly: held from
         // the kernel's prologue they were fourteen registers of a kernel at the 128-register line (nine products per segment)
         asm volatile("" : "+v"(base.x), "+v"(base.y), "+v"(pw.x), "+v"(pw.y));
@@ -102,73 +105,90 @@ template <int L2> __global__ __launch_bounds__(256, 4) void tl_k1_kernel(TlArgs 
     }
 }
 
-template <int L2> __global__ __launch_bounds__(256) void tl_k2_kernel(TlArgs p) {
+// One row transform of tl_k2: row k1 of the workspace at `row` -> this thread's sixteen outputs X2[kb + 16 ka] in out[]
+// (TEAM 16: kb = a, out[ka]; TEAM 8: kb = a -> out[0..7], kb = a + 8 -> out[8..15], ka = 0..7)
+template <int L2> __device__ __forceinline__ void tl_row_fft(const float2 *row, float2 *team, int a, float2 w1, float2 w4, float2 (&out)[16]) {
+    constexpr int TEAM = L2 / 16, TS = TEAM + 1;
+    float2 v[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const int pt = a + TEAM * b;      // point p of row k1 sits in column tile p / 16 at column p % 16 (tl_k1's workspace layout)
+        v[b] = row[(size_t)(pt >> 4) * (TL_L1 * 16) + (pt & 15)];
+    }
+    dft16(v);                                            // Z_a[kb], kb < 16, at v[r16(kb)]
+    scatter_pow16<TS>(v, team + a, w1, w4);              // team[kb][a] = Z_a[kb] W_L2^(a kb)
+    wave_lds_sync();
+    if constexpr (TEAM == 16) {
+        float2 u[16];
+#pragma unroll
+        for (int a2 = 0; a2 < 16; ++a2) u[a2] = team[a * TS + a2];       // kb = a
+        wave_lds_sync();
+        dft16(u);                                        // X2[kb + 16 ka] at u[r16(ka)]
+#pragma unroll
+        for (int ka = 0; ka < 16; ++ka) out[ka] = u[r16(ka)];
+    } else {
+        float2 u0[8], u1[8];                             // kb = a and kb = a + 8
+#pragma unroll
+        for (int a2 = 0; a2 < 8; ++a2) {
+            u0[a2] = team[a * TS + a2];
+            u1[a2] = team[(a + 8) * TS + a2];
+        }
+        wave_lds_sync();
+        dft8(u0);
+        dft8(u1);
+#pragma unroll
+        for (int ka = 0; ka < 8; ++ka) {
+            out[ka] = u0[ka];
+            out[8 + ka] = u1[ka];
+        }
+    }
+}
+
+// CSD: both channels' rows per segment, the four two-channel sums (partial rows [W][4][L]: xx, yy, re, im)
+template <int L2, bool CSD> __global__ __launch_bounds__(256) void tl_k2_kernel(TlArgs p) {
     constexpr int L = TL_L1 * L2;
     constexpr int TEAM = L2 / 16;                 // lanes per row: 16 (256 points) or 8 (128)
     constexpr int ROWS = 256 / TEAM;              // rows per workgroup
     constexpr int TS = TEAM + 1;                  // float2 per kb line of a team's exchange image
+    constexpr int NACC = CSD ? 4 : 1;
     __shared__ float2 lds[ROWS * 16 * TS];
     const int tid = threadIdx.x, a = tid & (TEAM - 1), r = tid / TEAM;
     const int k1 = blockIdx.x * ROWS + r;
     float2 *team = lds + r * 16 * TS;
     const float2 w1 = p.tw[a * (L / L2)], w4 = p.tw[4 * a * (L / L2)];      // W_L2^a, W_L2^(4a)
-    float acc[16];
+    float acc[NACC][16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int c = 0; c < NACC; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
     for (long long s = blockIdx.y; s < p.nseg; s += gridDim.y) {
-        // point p = a + TEAM b of row k1 sits in column tile p / 16 at column p % 16 (tl_k1's workspace layout)
         const float2 *row = p.ws + (size_t)s * p.ws_seg_stride + (size_t)k1 * 16;
-        float2 v[16];
+        float2 X[16];
+        tl_row_fft<L2>(row, team, a, w1, w4, X);
+        if constexpr (!CSD) {
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const int pt = a + TEAM * b;
-            v[b] = row[(size_t)(pt >> 4) * (TL_L1 * 16) + (pt & 15)];
-        }
-        dft16(v);                                            // Z_a[kb], kb < 16, at v[r16(kb)]
-        scatter_pow16<TS>(v, team + a, w1, w4);              // team[kb][a] = Z_a[kb] W_L2^(a kb)
-        wave_lds_sync();
-        if constexpr (TEAM == 16) {
-            float2 u[16];
-#pragma unroll
-            for (int a2 = 0; a2 < 16; ++a2) u[a2] = team[a * TS + a2];       // kb = a
-            wave_lds_sync();
-            dft16(u);                                        // X2[kb + 16 ka] at u[r16(ka)]
-#pragma unroll
-            for (int ka = 0; ka < 16; ++ka) {
-                const float2 X = u[r16(ka)];
-                acc[ka] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[ka]));
-            }
+            for (int q = 0; q < 16; ++q) acc[0][q] = fmaf(X[q].x, X[q].x, fmaf(X[q].y, X[q].y, acc[0][q]));
         } else {
-            float2 u0[8], u1[8];                             // kb = a and kb = a + 8
+            float2 Y[16];
+            tl_row_fft<L2>(row + p.ws_ch_stride, team, a, w1, w4, Y);
 #pragma unroll
-            for (int a2 = 0; a2 < 8; ++a2) {
-                u0[a2] = team[a * TS + a2];
-                u1[a2] = team[(a + 8) * TS + a2];
-            }
-            wave_lds_sync();
-            dft8(u0);
-            dft8(u1);
-#pragma unroll
-            for (int ka = 0; ka < 8; ++ka) {
-                acc[ka] = fmaf(u0[ka].x, u0[ka].x, fmaf(u0[ka].y, u0[ka].y, acc[ka]));
-                acc[8 + ka] = fmaf(u1[ka].x, u1[ka].x, fmaf(u1[ka].y, u1[ka].y, acc[8 + ka]));
+            for (int q = 0; q < 16; ++q) {
+                acc[0][q] = fmaf(X[q].x, X[q].x, fmaf(X[q].y, X[q].y, acc[0][q]));
+                acc[1][q] = fmaf(Y[q].x, Y[q].x, fmaf(Y[q].y, Y[q].y, acc[1][q]));
+                acc[2][q] = fmaf(X[q].x, Y[q].x, fmaf(X[q].y, Y[q].y, acc[2][q]));       // conj(X) Y
+                acc[3][q] = fmaf(X[q].x, Y[q].y, fmaf(-X[q].y, Y[q].x, acc[3][q]));
             }
         }
     }
-    // partial row g = blockIdx.y, position k1 L2 + k2
-    float *dst = p.partial + (size_t)blockIdx.y * L + (size_t)k1 * L2;
-    if constexpr (TEAM == 16) {
+    // partial row g = blockIdx.y: [channel][position k1 L2 + k2]; out index q <-> k2 = kb + 16 ka as in tl_row_fft
+    float *dst = p.partial + (size_t)blockIdx.y * NACC * L + (size_t)k1 * L2;
 #pragma unroll
-        for (int ka = 0; ka < 16; ++ka) {
-            float *d = dst + a + 16 * ka;
-            *d = p.first_chunk ? acc[ka] : *d + acc[ka];
-        }
-    } else {
+    for (int c = 0; c < NACC; ++c) {
 #pragma unroll
-        for (int ka = 0; ka < 8; ++ka) {
-            float *d0 = dst + a + 16 * ka, *d1 = d0 + 8;
-            *d0 = p.first_chunk ? acc[ka] : *d0 + acc[ka];
-            *d1 = p.first_chunk ? acc[8 + ka] : *d1 + acc[8 + ka];
+        for (int q = 0; q < 16; ++q) {
+            const int k2 = TEAM == 16 ? a + 16 * q : (q < 8 ? a + 16 * q : a + 8 + 16 * (q - 8));
+            float *d = dst + (size_t)c * L + k2;
+            *d = p.first_chunk ? acc[c][q] : *d + acc[c][q];
         }
     }
 }
@@ -250,18 +270,22 @@ hipError_t launch_tl_mean(const float2 *x, long long first, long long seg_step, 
 }
 
 hipError_t launch_tl_k1(int L, const TlArgs &a, hipStream_t s) {
-    const int gy = (int)(a.nseg < 65535 ? a.nseg : 65535);
-    if (L == 65536) hipLaunchKernelGGL(tl_k1_kernel<256>, dim3(16, gy), dim3(256), 0, s, a);
-    else if (L == 32768) hipLaunchKernelGGL(tl_k1_kernel<128>, dim3(8, gy), dim3(256), 0, s, a);
+    const int gy = (int)(a.nseg < 65535 ? a.nseg : 65535), gz = a.y ? 2 : 1;
+    if (L == 65536) hipLaunchKernelGGL(tl_k1_kernel<256>, dim3(16, gy, gz), dim3(256), 0, s, a);
+    else if (L == 32768) hipLaunchKernelGGL(tl_k1_kernel<128>, dim3(8, gy, gz), dim3(256), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 // W partial rows: workgroup (row tile, g) adds the segments g, g + W, ...
 hipError_t launch_tl_k2(int L, const TlArgs &a, int W, hipStream_t s) {
-    if (L == 65536) hipLaunchKernelGGL(tl_k2_kernel<256>, dim3(16, W), dim3(256), 0, s, a);
-    else if (L == 32768) hipLaunchKernelGGL(tl_k2_kernel<128>, dim3(8, W), dim3(256), 0, s, a);
-    else return hipErrorInvalidValue;
+    if (L == 65536) {
+        if (a.y) hipLaunchKernelGGL((tl_k2_kernel<256, true>), dim3(16, W), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((tl_k2_kernel<256, false>), dim3(16, W), dim3(256), 0, s, a);
+    } else if (L == 32768) {
+        if (a.y) hipLaunchKernelGGL((tl_k2_kernel<128, true>), dim3(8, W), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((tl_k2_kernel<128, false>), dim3(8, W), dim3(256), 0, s, a);
+    } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -313,6 +313,9 @@ hipError_t launch_any_abs(float *out, const float2 *src, int n, float scale, hip
 // ---- fft_tl.hip: the four-step route at 32768 / 65536 points on register radix-16 butterflies ---------------------------
 struct TlArgs {
     const float2 *x;           // samples; segment s starts at x[first + s seg_step]
+    const float2 *y;           // second channel (two-channel sums) or nullptr
+    size_t aux_ch_stride;      // entries between the channels' means / sub-block sums
+    size_t ws_ch_stride;       // points between the channels' workspaces
     long long first, seg_step;
     int nperseg;               // samples per segment (zero padded to L)
     const float *win;          // L window values, zero behind nperseg (oth_welch_plan's zero-extended table)
@@ -323,7 +326,7 @@ struct TlArgs {
     size_t ws_seg_stride;
     long long nseg;
     const float2 *tw;          // W_L^k
-    float *partial;            // [W][L] sums, position k1 L2 + k2 (finalize layout 6)
+    float *partial;            // [W][channels 1 | 4][L] sums, position k1 L2 + k2 (finalize layout 6)
     int first_chunk;
 };
 constexpr int kTlSub = 4096;

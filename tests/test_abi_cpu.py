@@ -166,7 +166,7 @@ def test_launch_recipes_table():
                     (20000, 'bluestein2'), (32768, 'twolevel:r16'), (65536, 'twolevel:r16'), (131072, 'twolevel'), (1048576, 'twolevel')):
         f = fields(nfft=n, nperseg=n, noverlap=n // 2)
         assert (f['kernel'], f['form'], f['pilot'], f['layout']) == ('anyfft:' + kind, 'time', 'none', '6' if 'twolevel' in kind else '0'), n
-    assert fields(nfft=65536, nperseg=65536, noverlap=32768, two_channel=1)['kernel'] == 'anyfft:twolevel'
+    assert fields(nfft=65536, nperseg=65536, noverlap=32768, two_channel=1)['kernel'] == 'anyfft:twolevel:r16'
     assert fields(nfft=65536, nperseg=65536, noverlap=32768, variant='anycov')['kernel'] == 'anyfft:twolevel'
     for n in (2097152, 524290, 600000):
         assert '1048576' in recipes.recipe(lib, nfft=n, nperseg=n, noverlap=0), n

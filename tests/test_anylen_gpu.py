@@ -124,7 +124,7 @@ def test_welch_detrend_under_a_dc_line_and_without(ctx, hip, n):
     plan.close()
 
 
-@pytest.mark.parametrize('n', [96, 3000, 4099, 10007, 32768])
+@pytest.mark.parametrize('n', [96, 3000, 4099, 10007, 32768, 65536])
 def test_csd_and_coherence_any_length(ctx, hip, n):
     nseg = 7 if n >= 8192 else 33
     x = R.synth_iq(n // 2 * (nseg + 1), 11)
@@ -132,12 +132,41 @@ def test_csd_and_coherence_any_length(ctx, hip, n):
     y = 0.7 * np.roll(x, 5) + 0.5 * noise
     plan = ctx.welch_plan(n, window=_win('hann', n))
     pxx, pyy, pxy, cxy = plan.csd(x, y)
+    if n in (32768, 65536):                      # both channels on the register radix-16 kernels, four sums per bin
+        assert _route(plan) == 'kernel=anyfft:twolevel:r16' and 'nch=4' in plan.last_recipe()
     _, c_ref, pxx_ref, pyy_ref, pxy_ref = R.coherence_np(x, y, nperseg=n, nfft=n)
     assert relerr(pxx, pxx_ref) < RTOL and relerr(pyy, pyy_ref) < RTOL
     assert np.max(np.abs(pxy - pxy_ref)) / np.max(np.abs(pxy_ref)) < RTOL
     assert np.max(np.abs(pxy - pxy_ref) / np.sqrt(pxx_ref * pyy_ref)) < RTOL
     assert np.max(np.abs(cxy - c_ref)) < RTOL
     plan.close()
+
+
+@pytest.mark.parametrize('n,detrend', [(32768, True), (65536, True), (32768, False)])
+def test_two_channel_fast_route_in_workspace_chunks_matches_the_coverage_kernels(ctx, hip, n, detrend, monkeypatch):
+    """The 32768 / 65536 two-channel route with a workspace of 5 segments per channel (so 4 chunks of partial sums, the last
+    short), segment length a multiple of 4096 (sub-block means) and not (per-segment means): against scipy's form in f64
+    and against the same plan on the coverage kernels (tuning 'anycov')."""
+    monkeypatch.setenv('OTH_ANY_WS_MB', str(5 * 2 * n * 8 >> 20))
+    for nper in (n, n - 1000):
+        step = nper - nper // 2
+        x = R.synth_iq(nper // 2 + step * 18, 3, dc=2 - 1j)
+        y = 0.6 * np.roll(x, 11) + 0.8 * R.synth_iq(len(x), 4, tones=(), dc=0.5)
+        kw = dict(nperseg=nper, window=_win('hann', nper), detrend=detrend)
+        plan = ctx.welch_plan(n, **kw)
+        got = plan.csd(x, y)
+        assert _route(plan) == 'kernel=anyfft:twolevel:r16'
+        _, c_ref, pxx_ref, pyy_ref, pxy_ref = R.coherence_np(x, y, nperseg=nper, nfft=n, detrend='constant' if detrend else False)
+        cov = ctx.welch_plan(n, **kw)
+        cov.set_tuning('anycov')
+        ref = cov.csd(x, y)
+        assert _route(cov) == 'kernel=anyfft:twolevel'
+        for g, r64, r32 in zip(got, (pxx_ref, pyy_ref, pxy_ref, c_ref), ref):
+            scale = np.max(np.abs(r64))
+            assert np.max(np.abs(g - r64)) / scale < RTOL, (nper, detrend)
+            assert np.max(np.abs(g - r32)) / scale < RTOL
+        plan.close()
+        cov.close()
 
 
 @pytest.mark.parametrize('n', [1000, 1536, 12000, 1021, 20000, 32768])
