@@ -937,6 +937,7 @@ struct LaunchRecipe {
     bool two_runs = false;       // "ws2": the stream cut into two runs of segments
     int any_kind = 0;            // RK_ANY: AnyKind
     bool any_r16 = false;        // ... on fft_tl.hip's register radix-16 kernels (32768 / 65536 points)
+    bool any_onewg = false;      // ... 32768 points, one channel, full segments: welch32k.hip (the segment never leaves the CU)
 };
 
 int generic_wg_for(int cu_count, int nfft, long long nseg, int nstreams) {
@@ -967,10 +968,12 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
         }
         r.kern = RK_ANY;
         r.any_kind = p.any.kind;
-        r.any_r16 = p.any.kind == ANY_TWOLEVEL && tl_supported(p.any.L) && p.tune_variant != "anycov";      // fft_tl.hip
+        r.any_onewg = p.any.kind == ANY_TWOLEVEL && p.any.L == 32768 && p.nperseg == 32768 && !csd && p.tune_variant != "anycov" &&
+                      p.tune_variant != "r16";                                                           // welch32k.hip
+        r.any_r16 = !r.any_onewg && p.any.kind == ANY_TWOLEVEL && tl_supported(p.any.L) && p.tune_variant != "anycov";      // fft_tl.hip
         r.form = p.detrend ? 1 : 0;
-        r.W = any_partial_rows(p.any, nseg, cu_count);
-        r.layout = p.any.kind == ANY_TWOLEVEL ? 6 : 0;
+        r.W = r.any_onewg ? welch32k_rows(nseg, cu_count) : any_partial_rows(p.any, nseg, cu_count);
+        r.layout = r.any_onewg ? 7 : (p.any.kind == ANY_TWOLEVEL ? 6 : 0);
         r.nseg_run = nseg;
         *out = r;
         return OTH_OK;
@@ -1160,7 +1163,7 @@ std::string recipe_text(const LaunchRecipe &r, int nfft) {
     if (r.kern == RK_SEGPAD) k += r.seg_kind ? ":full" : ":half";
     if (r.kern == RK_W16K1X) k += std::string(r.x1_plain || r.x1_window ? ":plain" : ":pipe") + (r.x1_window ? ":window" : "");
     if (r.kern == RK_W16K1X_HALF && r.half_ws) k += ":ws";
-    if (r.kern == RK_ANY) k += std::string(":") + kAnyKindName[r.any_kind] + (r.any_r16 ? ":r16" : "");
+    if (r.kern == RK_ANY) k += r.any_onewg ? std::string(":onewg") : std::string(":") + kAnyKindName[r.any_kind] + (r.any_r16 ? ":r16" : "");
     snprintf(buf, sizeof buf, "kernel=%s nfft=%d form=%s pilot=%s sched=%s chunk=%d tail=%d nbig=%lld bpc=%d W=%d rows=%d nch=%d layout=%d",
              k.c_str(), nfft, kForm[r.form], kPilot[r.pilot], kSched[r.sched], r.chunk, r.tail_chunk, r.nbig, r.bpc, r.W, r.rows,
              r.nch, r.layout);
@@ -1226,7 +1229,18 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
         c->queue_clean = false;      // until the finalize launch that follows has re-zeroed them
         c->queue_used = nstreams;
     }
-    if (r.kern == RK_ANY) {
+    if (r.kern == RK_ANY && r.any_onewg) {
+        Timed tm(c);
+        for (int st = 0; st < nstreams; ++st) {
+            W32kArgs a{};
+            a.x = x + (size_t)st * stride;
+            a.first = 0, a.step = p->step, a.nseg = nseg;
+            a.win = p->d_win, a.tw = p->any.tw;
+            a.partial = p->d_partial + (size_t)st * r.W * p->nfft;
+            a.detrend = p->detrend != OTH_DETREND_NONE;
+            HIPCHK(c, launch_welch32k(a, r.W, c->stream));
+        }
+    } else if (r.kern == RK_ANY) {
         Timed tm(c);
         for (int st = 0; st < nstreams; ++st) {
             rc = any_run(c, p->any, x + (size_t)st * stride, csd ? y + (size_t)st * stride : nullptr, 0, p->step, p->nperseg, p->d_win,
@@ -1744,8 +1758,10 @@ int oth_plan_set_tuning(oth_plan *p, const char *variant, int sched, int chunk, 
                      !strcmp(variant, "16k4") || !strcmp(variant, "16kplain") ||  // 16384 points: the 4 x 4096 build / the
                                                                                 // un-pipelined one-exchange build
                      !strcmp(variant, "8kws") || !strcmp(variant, "8k1role") ||  // 8192 points, 50 % overlap: role-split / one-role
-                     !strcmp(variant, "anycov");                                // 32768 / 65536 points: fft_any.hip's coverage kernels
+                     !strcmp(variant, "anycov") ||                              // 32768 / 65536 points: fft_any.hip's coverage kernels
                                                                                 // instead of fft_tl.hip's
+                     !strcmp(variant, "r16");                                   // 32768 points: fft_tl.hip's four-step route instead
+                                                                                // of welch32k.hip
         for (const auto &v : kVariants) known = known || !strcmp(variant, v.tag);
         if (!known) return fail(p->ctx, OTH_ERR_UNSUPPORTED, std::string("unknown kernel build: ") + variant);
     }

@@ -331,6 +331,18 @@ struct TlArgs {
 };
 constexpr int kTlSub = 4096;
 bool tl_supported(int L);
+// welch32k.hip: 32768-point segments inside one workgroup
+struct W32kArgs {
+    const float2 *x;           // samples; segment s starts at x[first + s step]
+    long long first, step;
+    long long nseg;
+    const float *win;          // 32768 window values
+    const float2 *tw;          // W_32768^k, k < 32768
+    float *partial;            // [W][32768] sums, finalize layout 7
+    int detrend;
+};
+int welch32k_rows(long long nseg, int cus);
+hipError_t launch_welch32k(const W32kArgs &a, int W, hipStream_t s);
 hipError_t launch_tl_blocksum(const float2 *x, long long first, long long nblocks, double2 *out, hipStream_t s);
 hipError_t launch_tl_mean(const float2 *x, long long first, long long seg_step, int nperseg, long long nseg, float4 *out, hipStream_t s);
 hipError_t launch_tl_k1(int L, const TlArgs &a, hipStream_t s);

@@ -63,11 +63,14 @@ def test_welch_any_length_against_the_oracle(ctx, hip, n):
 
 
 @pytest.mark.parametrize('n', BIG)
-@pytest.mark.parametrize('variant', [None, 'anycov'])
+@pytest.mark.parametrize('variant', [None, 'r16', 'anycov'])
 def test_two_level_routes_across_workspace_chunks(ctx, hip, n, variant):
-    """32768 / 65536 points: fft_tl.hip's register radix-16 kernels (default) and fft_any.hip's coverage kernels
+    """32768 / 65536 points: the default route (32768, full segments: welch32k.hip's one-workgroup kernel; otherwise
+    fft_tl.hip's register radix-16 four-step kernels, which 'r16' forces at 32768 too) and fft_any.hip's coverage kernels
     ('anycov') on a launch longer than one workspace chunk (64 MiB: 256 / 128 segments), ragged segment count, zero
     padding inside the last row block, with and without the detrend."""
+    if variant == 'r16' and n != 32768:
+        pytest.skip('r16 is the default above 32768')
     nseg = (64 << 20) // (8 * n) + 37
     x = R.synth_iq(n // 2 * (nseg + 1) + 11, 71, dc=3 + 2j)
     for detrend, nper in ((hip.DETREND_CONSTANT, n), (hip.DETREND_NONE, n - 3000)):
@@ -80,12 +83,72 @@ def test_two_level_routes_across_workspace_chunks(ctx, hip, n, variant):
         psd = plan.exec(xs)
         assert plan.last_nseg == (len(xs) - nper // 2) // (nper - nper // 2)
         assert relerr(psd, ref) < RTOL, (detrend, nper)
+        want = 'twolevel' if variant == 'anycov' else ('onewg' if n == 32768 and nper == n and not variant else 'twolevel:r16')
+        assert _route(plan) == 'kernel=anyfft:' + want
         plan.close()
+
+
+def test_welch_32768_inside_one_workgroup(ctx, hip):
+    """welch32k.hip: the whole 32768-point segment in one workgroup's registers (radix 2 + two 16384-point transforms), exact
+    mean in double, partial rows in layout 7.  Against scipy's form in f64: one segment (the single-row criterion) to more
+    segments than workgroups, 50 % / odd / no overlap, a workgroup count that is not a multiple of 8 (no XCD dealing), with
+    and without the detrend under a DC line of 36 sigma, a first sample that is not 16-byte aligned, fftshift + trim + dB,
+    several streams per launch, the streaming form (accumulate / finalize) - and the same plans on the four-step route."""
+    n = 32768
+    w = _win('hann', n)
+    for detrend in (True, False):
+        for nseg, ov in ((1, n // 2), (5, n // 2), (9, 0), (37, 1001), (300, n // 2), (700, n - 4096)):
+            step = n - ov
+            x = R.synth_iq(n + step * (nseg - 1) + 17, 100 + nseg, dc=(30 + 20j) if detrend else R.DC)
+            plan = ctx.welch_plan(n, noverlap=ov, window=w, detrend=detrend)
+            got = plan.exec(x)
+            assert _route(plan) == 'kernel=anyfft:onewg' and plan.last_nseg == nseg
+            _, ref = R.welch_np(x, nperseg=n, nfft=n, noverlap=ov, detrend='constant' if detrend else False)
+            if nseg == 1:
+                check_single_rows(got[None, :], ref[None, :], ulps=4)
+            else:
+                assert relerr(got, ref) < RTOL, (detrend, nseg, ov)
+            four = ctx.welch_plan(n, noverlap=ov, window=w, detrend=detrend)
+            four.set_tuning('r16')
+            other = four.exec(x)
+            assert _route(four) == 'kernel=anyfft:twolevel:r16'
+            if nseg > 1:
+                assert relerr(got, other.astype(np.float64)) < RTOL
+            four.close()
+            plan.close()
+    # device input at an odd sample offset (8-byte aligned only), two streams per launch, shifted + trimmed + dB
+    nseg, trim = 21, 1000
+    m = n // 2 * (nseg + 1)
+    xs = [R.synth_iq(m, 7), R.synth_iq(m, 8, tones=((1.0, 0.2),))]
+    d = ctx.alloc((2 * m + 1) * 8)
+    try:
+        ctx.h2d(d + 8, np.concatenate(xs))
+        plan = ctx.welch_plan(n, window=w, fs=2.5e6, fftshift=True, trim_bins=trim, db=True)
+        out = ctx.alloc(2 * (n - 2 * trim) * 4)
+        assert plan.exec_dev(d + 8, m, out, nstreams=2, stream_stride=m) == nseg
+        got = ctx.d2h(out, (2, n - 2 * trim), np.float32)
+        ctx.free(out)
+        for i in range(2):
+            _, ref = R.welch_np(xs[i], nperseg=n, nfft=n, fs=2.5e6)
+            assert relerr(10.0 ** (got[i].astype(np.float64) / 10.0), np.fft.fftshift(ref)[trim:n - trim]) < RTOL
+        assert _route(plan) == 'kernel=anyfft:onewg'
+        plan.close()
+    finally:
+        ctx.free(d)
+    # streaming: ragged pushes carry the overlap across calls
+    x = R.synth_iq(n // 2 * 41 + 123, 9)
+    plan = ctx.welch_plan(n, window=w)
+    for a, b in ((0, 50000), (50000, 50001), (50001, 400000), (400000, len(x))):
+        plan.accumulate(x[a:b])
+    got = plan.finalize()
+    _, ref = R.welch_np(x, nperseg=n, nfft=n)
+    assert plan.last_nseg == 40 and relerr(got, ref) < RTOL
+    plan.close()
 
 
 def test_routes_are_the_documented_ones(ctx):
     want = {96: 'direct', 15000: 'direct', 97: 'bluestein', 8191: 'bluestein', 10007: 'bluestein2', 20000: 'bluestein2',
-            32768: 'twolevel:r16', 65536: 'twolevel:r16', 131072: 'twolevel', 32: 'direct'}
+            32768: 'onewg', 65536: 'twolevel:r16', 131072: 'twolevel', 32: 'direct'}
     for n, kind in want.items():
         plan = ctx.welch_plan(n)
         plan.exec(R.synth_iq(2 * n, 1))
@@ -564,13 +627,13 @@ def test_any_length_results_do_not_depend_on_timing_under_a_bandwidth_hog(ctx, h
     try:
         ctx.synth_iq(d, n + 5, 4343, R.TONES, R.DC)
         plans = []
-        for nfft, variant in ((1000, None), (12000, None), (4099, None), (20000, None), (32768, None), (65536, None), (32768, 'anycov'),
+        for nfft, variant in ((1000, None), (12000, None), (4099, None), (20000, None), (32768, None), (32768, 'r16'), (65536, None), (32768, 'anycov'),
                               (131072, None)):
             for det in (hip.DETREND_CONSTANT, hip.DETREND_NONE):
                 plan = ctx.welch_plan(nfft, window=_win('hann', nfft), detrend=det)
                 if variant:
                     plan.set_tuning(variant)
-                m = n if nfft <= 65536 and not variant else n // 8      # (the coverage routes above 16384 are slow: fewer segments)
+                m = n if nfft <= 65536 and variant != 'anycov' else n // 8      # (the coverage routes above 16384 are slow: fewer segments)
                 plans.append(('welch %d %s det %d' % (nfft, variant or '', det), plan, lambda p=plan, m=m: p.exec_device_src(d, m)))
         csd = ctx.welch_plan(3000, window=_win('hann', 3000))
         plans.append(('csd 3000', csd, lambda: np.concatenate([np.asarray(v).view(np.float32).ravel()
