@@ -16,7 +16,8 @@ N = 1  workload "C2" (the configuration BASELINE.json's metric is quoted on): on
        `csd_c3` (BASELINE config 3: two-channel cross spectrum / coherence, 2 x 2^26 samples, 16 B per sample
        pair), `scan_c5` (BASELINE config 5: 64 channel streams x 2^22 samples, 16384-pt rectangular |X|^2/N^2 mean +
        the device decision stage), `c1` (BASELINE config 1 at its own size: 2^20 samples, 1024-pt rectangular chain, the 128
-       eight-row means + a7 channel sums), `welch_32768` / `welch_65536` (the four-step route above the tuned kernels, 2^27
+       eight-row means + a7 channel sums), `welch_32768` / `welch_65536` (the lengths above the tuned kernels: one workgroup per
+       segment / the four-step route, 2^27
        samples), each with its own `roofline` whose `kernel` is the recipe the library recorded for
        the launch (oth__debug_last_recipe) and whose `traffic` is the figure of the builder's rocprofv3 PMC passes of
        the same configuration (profiles/traffic.json: not measured by this run); `h2d_inclusive` (host buffer -> PSD through the streaming entry point);
@@ -760,8 +761,9 @@ def main():
     def big_welch_bench(nfft, steps, warmup):
         """Round 6: Hann Welch, 50 % overlap, detrend constant at 32768 / 65536 points - what fast_spectrum_scan(n_fft=0) picks for
         blocks of 16 Ki ... 64 Ki samples (ofdm_cr_tools.py:474-475) and a flowgraph reaches with --nfft - on 2^27 resident samples.
-        A call is SEVERAL launches (sub-block sums, K1, K2 per 128 MiB workspace chunk: csrc/fft_tl.hip): `kernel_avg_ms` is the
-        HIP-event time of one call's launches together, `achieved` = 8 B x samples / that."""
+        32768: one launch, the segment inside one workgroup (csrc/welch32k.hip).  65536: a call is SEVERAL launches (sub-block
+        sums, K1, K2 per 128 MiB workspace chunk: csrc/fft_tl.hip).  `kernel_avg_ms` is the HIP-event time of one call's launches
+        together, `achieved` = 8 B x samples / that."""
         n = 1 << 27
         iq = torch.empty((n, 2), dtype=torch.float32, device=dev)
         ctx.synth_iq(iq.data_ptr(), n, 1002, TONES, DC)
@@ -787,12 +789,13 @@ def main():
         kavg = kern_ms / max(calls, 1)
         ach = 8.0 * n / (kavg * 1e-3) / 1e9 if kavg else 0.0
         traffic, tsrc = profile_traffic('w%d' % nfft, 8 * n)
-        plan_recipe[nfft] = plan.last_recipe() + ' (sub-block sums + K1 + K2 per workspace chunk, summed)'
+        plan_recipe[nfft] = plan.last_recipe() + (' (sub-block sums + K1 + K2 per workspace chunk, summed)' if ':r16' in plan.last_recipe() else '')
         plan.close()
         return {'value': n / (med * 1e-3) / 1e6, 'unit': 'Msamples/s', 'ms_per_step': med, 'wall_ms_per_step': 1e3 * wall / steps,
                 'steps': steps, 'kernel_avg_ms': kavg, 'calls': int(calls),
                 'config': {'workload': '2^27-sample complex64 stream, %d-pt Hann Welch, 50%% overlap, detrend constant, density '
-                                       '(four-step route: a 512 / 256 KiB segment crosses the chip once between the halves)' % nfft},
+                                       '(%s)' % (nfft, 'the 256 KiB segment stays in one workgroup' if nfft == 32768 else
+                                                 'four-step route: a 512 KiB segment crosses the chip once between the halves')},
                 'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
                              'traffic': traffic, 'traffic_source': tsrc, 'kernel': plan_recipe[nfft],
                              'kernel_avg_ms': kavg, 'launches': int(calls), 'algorithmic_bytes_per_launch': 8 * n,

@@ -20,6 +20,7 @@
 // Detrend in the time domain with the exact mean (scipy's detrend='constant'; no pilot needed): every thread adds its 32
 // samples in double, the waves' totals meet in LDS behind one workgroup barrier, the mean is subtracted as a float pair
 // (hi + lo).  That barrier also covers the exchange-A hand-over of the first transform: four workgroup barriers per segment.
+// The twiddle seeds live in LDS (148.8 of 160 KiB with the exchange regions).
 //
 // Samples are read with ordinary (cached) loads: at 50 % overlap every sample is wanted by two segments, and the segments of
 // one round are dealt out so that neighbours run on the same XCD (workgroup b runs on XCD b % 8: it takes slot
@@ -30,7 +31,18 @@ namespace oth {
 namespace {
 
 constexpr int W32_M = 16384, W32_N = 32768;
-constexpr size_t W32_LDS_BYTES = 16 * XREG * sizeof(float2) + 16 * sizeof(double2);
+#ifndef W32_TABLES
+#define W32_TABLES 0      // A/B: 1 = passes 2 and 3 read all fifteen twiddles from the LDS tables instead of rebuilding them from rows 1 and 4
+#endif
+// LDS behind the sixteen exchange regions: the waves' sample totals, the seed W_N^tid of every thread (radix-2 step and, squared,
+// pass 1) and the twiddle tables of passes 2 and 3, [k][lane]: W_1024^(k l) and W_64^(k q), k < 16 - no vector-memory load
+// inside the transforms.  The passes take rows 1 and 4 as seeds and rebuild the other powers (thirteen products, 52
+// instructions per pass); reading all fifteen from the table instead (W32_TABLES=1) is 8 % fewer VALU instructions and 3 %
+// SLOWER same-box (0.562 against 0.545 ms per 2^27 samples: thirty more LDS round trips per transform).
+// Also measured and dropped: requests for the next segment's cache lines issued under the transforms (two or four dwords per
+// thread whose values are never used): 22.7 % of the roofline against 24.7 % without them.
+constexpr size_t W32_LDS_BYTES = 16 * XREG * sizeof(float2) + 16 * sizeof(double2) + 1024 * sizeof(float2) + 16 * 64 * sizeof(float2) +
+                                 16 * 4 * sizeof(float2);
 
 // exp(-2 pi i r / 32), r = 0..15
 constexpr float W32_RE[16] = {1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
@@ -81,6 +93,19 @@ __device__ __forceinline__ void scatter_pow16_exa(const float2 (&v)[16], float2 
     }
 }
 
+// out[STRIDE k] = v[r16(k)] tab[TS k], k = 0..15 (tab[0] = 1); STRIDE 0: the products stay in v.  Four table values at a time:
+// the scheduler may not gather all fifteen reads in front (thirty registers the first transform does not have)
+template <int STRIDE, int TS> __device__ __forceinline__ void scatter_tab16(float2 (&v)[16], float2 *out, const float2 *tab) {
+    if (STRIDE) out[0] = v[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const float2 r = cmul(v[r16(k)], tab[TS * k]);
+        if (STRIDE) out[STRIDE * k] = r;
+        else v[r16(k)] = r;
+        if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Sum over the 64 lanes of a wave, the same value in every lane: DPP row operations on the two halves of the double +
 // v_readlane of the four row totals (wave_total of fft4096.hip.h in double; __shfl_xor would be twelve ds_bpermute and six
 // address registers kept across the loop)
@@ -110,6 +135,9 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
     double2 *msum = reinterpret_cast<double2 *>(lds + 16 * XREG);
+    float2 *dtab = reinterpret_cast<float2 *>(msum + 16);
+    float2 *btab = dtab + 1024;          // [k1][l] = W_1024^(k1 l)
+    float2 *ctab = btab + 16 * 64;       // [k2][q] = W_64^(k2 q)
 
     const int tid = threadIdx.x;
     const int W = gridDim.x, b = blockIdx.x;
@@ -124,6 +152,13 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
         return v;
     };
 
+    {
+        const int t = threadIdx.x;
+        dtab[t] = p.tw[t];
+        btab[t] = p.tw[(32 * (t >> 6) * (t & 63)) & (W32_N - 1)];
+        if (t < 64) ctab[t] = p.tw[(512 * (t >> 2) * (t & 3)) & (W32_N - 1)];
+        __syncthreads();
+    }
     float accA[16], accB[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) accA[k] = accB[k] = 0.f;
@@ -141,16 +176,27 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
         dft16(v);                                              // pass 1: r -> k0
         prio_latency();
         if (handover) lds_barrier();
-        scatter_pow16_exa(v, wa, wa8, p.tw[2 * t], p.tw[8 * t]);       // x W_M^(k0 tid) -> [k0][w][l]
+        {
+            const float2 d = dtab[t], a1 = cmul(d, d), a2 = cmul(a1, a1);      // W_M^tid = (W_N^tid)^2 and its fourth power
+            scatter_pow16_exa(v, wa, wa8, a1, cmul(a2, a2));                   // x W_M^(k0 tid) -> [k0][w][l]
+        }
         lds_barrier();
         dft16_from_lds<64>(v, ra, [] { prio_compute(); });     // pass 2: w -> k1
         prio_latency();
         wave_lds_sync();
-        scatter_pow16<XROW>(v, wb, p.tw[32 * l], p.tw[128 * l]);       // x W_1024^(k1 l) -> row k1, column l of this wave's region
+#if W32_TABLES
+        scatter_tab16<XROW, 64>(v, wb, btab + l);              // x W_1024^(k1 l) -> row k1, column l of this wave's region
+#else
+        scatter_pow16<XROW>(v, wb, btab[64 + l], btab[256 + l]);
+#endif
         wave_lds_sync();
         dft16_from_lds<4>(v, rb, [] { prio_compute(); });      // pass 3: g -> k2
         {
-            twiddle_pow16_inplace(v, p.tw[512 * q], p.tw[2048 * q]);   // x W_64^(k2 q)
+#if W32_TABLES
+            scatter_tab16<0, 4>(v, nullptr, ctab + q);                 // x W_64^(k2 q), in place
+#else
+            twiddle_pow16_inplace(v, ctab[4 + q], ctab[16 + q]);
+#endif
             const float qs1 = q < 2 ? 1.0f : -1.0f;
             const float qal = q == 0 ? 1.0f : (q == 1 ? -1.0f : 0.0f);
             const float qbe = q >= 2 ? 1.0f : 0.0f;
@@ -202,10 +248,11 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
         if (DETREND) {
             double sx = 0.0, sy = 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sx += (double)va[r].x + (double)vb[r].x;
-                sy += (double)va[r].y + (double)vb[r].y;
-                if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // (or the scheduler converts all 64 values first: 128 registers)
+            for (int r = 0; r < 16; r += 2) {
+                // four samples at a time in float, the groups in double: the float rounding of a group is random from group to
+                // group (8192 of them per segment), the mean's error from it ~1e-9 of the offset
+                sx += (double)((va[r].x + vb[r].x) + (va[r + 1].x + vb[r + 1].x));
+                sy += (double)((va[r].y + vb[r].y) + (va[r + 1].y + vb[r + 1].y));
             }
             win_issue(0);
             win_issue(1);
@@ -228,7 +275,7 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
             win_issue(0);
             win_issue(1);
         }
-        float2 d1 = p.tw[opaque(tid)];
+        float2 d1 = dtab[opaque(tid)];
 #pragma unroll
         for (int bt = 0; bt < 4; ++bt) {
             // batch bt + 1 is in flight behind this one (bt < 3): eight younger loads

@@ -13,7 +13,7 @@ import sys
 d, cfg, reps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 log2n = 27
 alg = 8 * 2 ** log2n
-ROUTE = ('tl_', 'any_', 'finalize', 'pilot_mean')
+ROUTE = ('tl_', 'any_', 'finalize', 'pilot_mean', 'welch32k_kernel')
 log = open(d + '/trace.log').read()
 m = re.search(r'recipe: (.*)', log)
 print('Welch %s-pt Hann 50 %% overlap + detrend, 2^%d samples (tools/prof_driver.py %s under rocprofv3, separate passes: '
@@ -34,7 +34,7 @@ if trace:
     if len(fin) >= 2:      # one call = everything after the previous finalize up to and including this one: take the last call
         a, b = fin[-2] + 1, fin[-1] + 1
         for r in ev[a:b]:
-            k = re.sub(r'\(.*', '', r['Kernel_Name'].replace('void ', '').replace('oth::', ''))
+            k = re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').replace('oth::', ''))
             t = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
             c = per_call.setdefault(k, [0, 0.0])
             c[0] += 1
@@ -42,7 +42,7 @@ if trace:
         span = (int(ev[b - 1]['End_Timestamp']) - int(ev[a]['Start_Timestamp'])) / 1e3
 for r in rows:
     if any(p in r['Name'] for p in ROUTE):
-        print('%-70s calls %6s  avg %8.1f us' % (re.sub(r'\(.*', '', r['Name'].replace('void ', ''))[:70], r['Calls'], float(r['AverageNs']) / 1e3))
+        print('%-70s calls %6s  avg %8.1f us' % (re.sub(r'\(.*', '', r['Name'].replace('(anonymous namespace)::', '').replace('void ', ''))[:70], r['Calls'], float(r['AverageNs']) / 1e3))
 print()
 if per_call:
     print('one call (the last of the run), launch by launch:')
@@ -66,7 +66,7 @@ for name in ('fetch', 'write'):
     ncalls = collections.defaultdict(int)
     for r in csv.DictReader(open(fs[0])):
         if any(p in r['Kernel_Name'] for p in ROUTE):
-            k = re.sub(r'\(.*', '', r['Kernel_Name'].replace('void ', '').replace('oth::', ''))
+            k = re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').replace('oth::', ''))
             agg[(k, r['Counter_Name'])] += float(r['Counter_Value'])
             ncalls[(k, r['Counter_Name'])] += 1
     tot[name] = (agg, ncalls)
