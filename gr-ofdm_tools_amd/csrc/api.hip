@@ -102,6 +102,7 @@ struct oth_plan {
     size_t stage_cap = 0;
     // streaming state
     float *d_sum = nullptr;            // raw sum |X|^2, natural order
+    float *d_wpm = nullptr;            // 65536-point plans on welch32k.hip: w[n] + w[n + 32768], then w[n] - w[n + 32768] (n < 32768)
     uint64_t nseg_total = 0;
     size_t carry = 0;                  // samples kept at the front of d_stream
     float2 *d_stream = nullptr;
@@ -968,12 +969,12 @@ int resolve_recipe(const PlanShape &p, bool csd, long long nseg, int nstreams, i
         }
         r.kern = RK_ANY;
         r.any_kind = p.any.kind;
-        r.any_onewg = p.any.kind == ANY_TWOLEVEL && p.any.L == 32768 && p.nperseg == 32768 && !csd && p.tune_variant != "anycov" &&
-                      p.tune_variant != "r16";                                                           // welch32k.hip
+        r.any_onewg = p.any.kind == ANY_TWOLEVEL && (p.any.L == 32768 || p.any.L == 65536) && p.nperseg == p.any.L && !csd &&
+                      p.tune_variant != "anycov" && p.tune_variant != "r16";                             // welch32k.hip
         r.any_r16 = !r.any_onewg && p.any.kind == ANY_TWOLEVEL && tl_supported(p.any.L) && p.tune_variant != "anycov";      // fft_tl.hip
         r.form = p.detrend ? 1 : 0;
-        r.W = r.any_onewg ? welch32k_rows(nseg, cu_count) : any_partial_rows(p.any, nseg, cu_count);
-        r.layout = r.any_onewg ? 7 : (p.any.kind == ANY_TWOLEVEL ? 6 : 0);
+        r.W = r.any_onewg ? welch32k_rows(nseg, cu_count, p.any.L == 65536) : any_partial_rows(p.any, nseg, cu_count);
+        r.layout = r.any_onewg ? (p.any.L == 65536 ? 8 : 7) : (p.any.kind == ANY_TWOLEVEL ? 6 : 0);
         r.nseg_run = nseg;
         *out = r;
         return OTH_OK;
@@ -1238,6 +1239,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
             a.win = p->d_win, a.tw = p->any.tw;
             a.partial = p->d_partial + (size_t)st * r.W * p->nfft;
             a.detrend = p->detrend != OTH_DETREND_NONE;
+            a.front = p->nfft == 65536, a.wpm = p->d_wpm;
             HIPCHK(c, launch_welch32k(a, r.W, c->stream));
         }
     } else if (r.kern == RK_ANY) {
@@ -1676,6 +1678,16 @@ int oth_welch_plan(oth_ctx *c, int nfft, int nperseg, int noverlap, const float 
         if (e == hipSuccess)
             e = hipMemcpyAsync(p->d_fd1x, fd1x.data(), sizeof(float) * fd1x.size(), hipMemcpyHostToDevice, c->stream);
     }
+    std::vector<float> wpm;
+    if (e == hipSuccess && any_route && nfft == 65536 && nperseg == 65536) {
+        wpm.resize(65536);
+        for (int n = 0; n < 32768; ++n) {
+            wpm[n] = (float)((double)w[n] + (double)w[n + 32768]);
+            wpm[32768 + n] = (float)((double)w[n] - (double)w[n + 32768]);
+        }
+        e = hipMalloc(&p->d_wpm, sizeof(float) * wpm.size());
+        if (e == hipSuccess) e = hipMemcpyAsync(p->d_wpm, wpm.data(), sizeof(float) * wpm.size(), hipMemcpyHostToDevice, c->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         oth_plan_destroy(p);
@@ -1694,6 +1706,7 @@ int oth_plan_destroy(oth_plan *p) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (p->d_win) hipFree(p->d_win);
+    if (p->d_wpm) hipFree(p->d_wpm);
     if (p->d_fd) hipFree(p->d_fd);
     if (p->d_fd1x) hipFree(p->d_fd1x);
     if (p->d_pilot) hipFree(p->d_pilot);

@@ -22,12 +22,16 @@ __device__ __forceinline__ int bin_pos(int pos, int layout, int l1 = 0, int l2 =
         const int k1 = pos / l2;
         return k1 + l1 * (pos - k1 * l2);
     }
-    if (layout == 4 || layout == 7) {
+    if (layout == 4 || layout == 7 || layout == 8) {
         // 7 (welch32k.hip): halves A | B of 16384 positions in layout 4 each; A holds bin 2 k, B bin 2 k + 1
-        const int h = layout == 7 ? pos >> 14 : 0;
-        if (layout == 7) pos &= 16383;
-        const int k = ((pos >> 6) & 15) + 16 * ((pos >> 2) & 15) + 256 * (pos >> 10) + 4096 * (((pos & 1) << 1) | ((pos >> 1) & 1));
-        return layout == 7 ? 2 * k + h : k;
+        // 8 (its 65536-point form): halves of 32768 positions in layout 7 each, the first the even bins, the second the odd ones
+        const int h8 = layout == 8 ? pos >> 15 : 0;
+        if (layout == 8) pos &= 32767;
+        const int h7 = layout != 4 ? pos >> 14 : 0;
+        if (layout != 4) pos &= 16383;
+        int k = ((pos >> 6) & 15) + 16 * ((pos >> 2) & 15) + 256 * (pos >> 10) + 4096 * (((pos & 1) << 1) | ((pos >> 1) & 1));
+        if (layout != 4) k = 2 * k + h7;
+        return layout == 8 ? 2 * k + h8 : k;
     }
     if (layout == 5)      // 8192 points: pos = 512 k2 + 64 k0' + 4 (8 h + k1) + q holds bin (2 k0' + h) + 16 k1 + 128 k2 + 2048 bitrev2(q)
         return 2 * ((pos >> 6) & 7) + ((pos >> 5) & 1) + 16 * ((pos >> 2) & 7) + 128 * (pos >> 9) + 2048 * (((pos & 1) << 1) | ((pos >> 1) & 1));

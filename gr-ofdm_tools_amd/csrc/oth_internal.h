@@ -338,10 +338,12 @@ struct W32kArgs {
     long long nseg;
     const float *win;          // 32768 window values
     const float2 *tw;          // W_32768^k, k < 32768
-    float *partial;            // [W][32768] sums, finalize layout 7
+    float *partial;            // [W][32768] sums, finalize layout 7 (front: [W][65536], layout 8)
     int detrend;
+    int front;                 // 1: 65536-point segments, a pair of workgroups each (win: 65536 values, tw: W_65536^k)
+    const float *wpm;          // front + detrend: w[n] + w[n + 32768] (n < 32768), then w[n] - w[n + 32768]
 };
-int welch32k_rows(long long nseg, int cus);
+int welch32k_rows(long long nseg, int cus, bool front = false);
 hipError_t launch_welch32k(const W32kArgs &a, int W, hipStream_t s);
 hipError_t launch_tl_blocksum(const float2 *x, long long first, long long nblocks, double2 *out, hipStream_t s);
 hipError_t launch_tl_mean(const float2 *x, long long first, long long seg_step, int nperseg, long long nseg, float4 *out, hipStream_t s);

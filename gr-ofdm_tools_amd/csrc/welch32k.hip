@@ -25,24 +25,23 @@
 // Samples are read with ordinary (cached) loads: at 50 % overlap every sample is wanted by two segments, and the segments of
 // one round are dealt out so that neighbours run on the same XCD (workgroup b runs on XCD b % 8: it takes slot
 // (b % 8) (W / 8) + b / 8) - the second reader finds the half in that XCD's L2.
+#include <type_traits>
 #include "fft16k.hip.h"
 
 namespace oth {
 namespace {
 
 constexpr int W32_M = 16384, W32_N = 32768;
-#ifndef W32_TABLES
-#define W32_TABLES 0      // A/B: 1 = passes 2 and 3 read all fifteen twiddles from the LDS tables instead of rebuilding them from rows 1 and 4
-#endif
-// LDS behind the sixteen exchange regions: the waves' sample totals, the seed W_N^tid of every thread (radix-2 step and, squared,
-// pass 1) and the twiddle tables of passes 2 and 3, [k][lane]: W_1024^(k l) and W_64^(k q), k < 16 - no vector-memory load
-// inside the transforms.  The passes take rows 1 and 4 as seeds and rebuild the other powers (thirteen products, 52
-// instructions per pass); reading all fifteen from the table instead (W32_TABLES=1) is 8 % fewer VALU instructions and 3 %
-// SLOWER same-box (0.562 against 0.545 ms per 2^27 samples: thirty more LDS round trips per transform).
-// Also measured and dropped: requests for the next segment's cache lines issued under the transforms (two or four dwords per
-// thread whose values are never used): 22.7 % of the roofline against 24.7 % without them.
-constexpr size_t W32_LDS_BYTES = 16 * XREG * sizeof(float2) + 16 * sizeof(double2) + 1024 * sizeof(float2) + 16 * 64 * sizeof(float2) +
-                                 16 * 4 * sizeof(float2);
+// LDS behind the sixteen exchange regions: the waves' sample totals and the twiddle seeds - W_32768^tid of every thread
+// (radix-2 step and, squared, pass 1), W_65536^tid (the front step of the 65536-point form), W and W^4 of passes 2 and 3 per
+// lane (W_1024^l, W_64^q) - so that the transforms wait for no vector-memory load.  Each pass rebuilds its other powers from
+// W and W^4 (thirteen products, 52 instructions).  Measured and dropped: all fifteen twiddles of passes 2 and 3 from LDS
+// tables - 8 % fewer VALU instructions, 3 % SLOWER same-box (0.562 against 0.545 ms per 2^27 samples: thirty more LDS round
+// trips per transform); requests for the next segment's cache lines issued under the transforms (two or four dwords per thread
+// whose values are never used) - 22.7 % of the roofline against 24.7 % without them.
+constexpr size_t W32_LDS_BYTES = 16 * XREG * sizeof(float2) + 16 * sizeof(double2) + 2 * 1024 * sizeof(float2) + 64 * sizeof(float4) +
+                                 4 * sizeof(float4);
+static_assert(W32_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 // exp(-2 pi i r / 32), r = 0..15
 constexpr float W32_RE[16] = {1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
@@ -53,6 +52,24 @@ constexpr float W32_IM[16] = {-0.0f, -0.19509032201612827f, -0.38268343236508977
                               -0.83146961230254524f, -0.92387953251128674f, -0.98078528040323044f, -1.0f, -0.98078528040323044f,
                               -0.92387953251128674f, -0.83146961230254524f, -0.70710678118654752f, -0.55557023301960222f,
                               -0.38268343236508977f, -0.19509032201612827f};
+
+// exp(-2 pi i j / 64), j = 0..31 (the front step of the 65536-point form)
+constexpr float W64_RE[32] = {1.0f, 0.99518472667219693f, 0.98078528040323044f, 0.95694033573220882f, 0.92387953251128674f,
+                              0.88192126434835503f, 0.83146961230254524f, 0.77301045336273699f, 0.70710678118654752f,
+                              0.63439328416364549f, 0.55557023301960222f, 0.47139673682599764f, 0.38268343236508977f,
+                              0.29028467725446233f, 0.19509032201612827f, 0.09801714032956060f, 0.0f, -0.09801714032956060f,
+                              -0.19509032201612827f, -0.29028467725446233f, -0.38268343236508977f, -0.47139673682599764f,
+                              -0.55557023301960222f, -0.63439328416364549f, -0.70710678118654752f, -0.77301045336273699f,
+                              -0.83146961230254524f, -0.88192126434835503f, -0.92387953251128674f, -0.95694033573220882f,
+                              -0.98078528040323044f, -0.99518472667219693f};
+constexpr float W64_IM[32] = {-0.0f, -0.09801714032956060f, -0.19509032201612827f, -0.29028467725446233f, -0.38268343236508977f,
+                              -0.47139673682599764f, -0.55557023301960222f, -0.63439328416364549f, -0.70710678118654752f,
+                              -0.77301045336273699f, -0.83146961230254524f, -0.88192126434835503f, -0.92387953251128674f,
+                              -0.95694033573220882f, -0.98078528040323044f, -0.99518472667219693f, -1.0f, -0.99518472667219693f,
+                              -0.98078528040323044f, -0.95694033573220882f, -0.92387953251128674f, -0.88192126434835503f,
+                              -0.83146961230254524f, -0.77301045336273699f, -0.70710678118654752f, -0.63439328416364549f,
+                              -0.55557023301960222f, -0.47139673682599764f, -0.38268343236508977f, -0.29028467725446233f,
+                              -0.19509032201612827f, -0.09801714032956060f};
 
 // Loads at (uniform row base in scalar registers) + (the lane's 32-bit byte offset): one offset register serves every row
 // of a segment.  Written as inline asm because the compiler, left to itself, forms thirty-two 64-bit row addresses per
@@ -72,6 +89,18 @@ __device__ __forceinline__ void vm_arrived16(f2v (&r)[16]) { asm volatile("s_wai
 // all but the youngest eight loads have landed (the caller has issued the NEXT batch of eight behind this one)
 __device__ __forceinline__ void vm_arrived8_keep8(float (&w)[8]) { asm volatile("s_waitcnt vmcnt(8)" : W32_IO8(w) : : "memory"); }
 __device__ __forceinline__ void vm_arrived8(float (&w)[8]) { asm volatile("s_waitcnt vmcnt(0)" : W32_IO8(w) : : "memory"); }
+// the front step's batch of four rows: x[n] (in place in z), x[n + 32768], w[n], w[n + 32768] - sixteen loads; KEEP = the loads
+// of the next batch already issued behind it (16) or none
+template <int KEEP>
+__device__ __forceinline__ void vm_arrived_front(f2v &z0, f2v &z1, f2v &z2, f2v &z3, f2v (&x2)[4], float (&w1)[4], float (&w2)[4]) {
+    static_assert(KEEP == 0 || KEEP == 16, "");
+    if (KEEP)
+        asm volatile("s_waitcnt vmcnt(16)" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3), "+v"(x2[0]), "+v"(x2[1]), "+v"(x2[2]), "+v"(x2[3]),
+                     "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(w2[0]), "+v"(w2[1]), "+v"(w2[2]), "+v"(w2[3]) : : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3), "+v"(x2[0]), "+v"(x2[1]), "+v"(x2[2]), "+v"(x2[3]),
+                     "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(w2[0]), "+v"(w2[1]), "+v"(w2[2]), "+v"(w2[3]) : : "memory");
+}
 
 // scatter_pow16 (fft4096.hip.h) with the rows k >= 8 addressed from a second base: 8 XREG float2 is past the 64 KiB a
 // ds_write offset reaches, and the compiler otherwise keeps eight more address registers across the loop
@@ -90,19 +119,6 @@ __device__ __forceinline__ void scatter_pow16_exa(const float2 (&v)[16], float2 
         const int i = k >> 2, j = k & 3;
         const float2 w = (i == 0) ? wj[j] : ((j == 0) ? wi[i] : cmul(wi[i], wj[j]));
         (k < 8 ? lo : hi)[XREG * (k & 7)] = cmul(v[r16(k)], w);
-    }
-}
-
-// out[STRIDE k] = v[r16(k)] tab[TS k], k = 0..15 (tab[0] = 1); STRIDE 0: the products stay in v.  Four table values at a time:
-// the scheduler may not gather all fifteen reads in front (thirty registers the first transform does not have)
-template <int STRIDE, int TS> __device__ __forceinline__ void scatter_tab16(float2 (&v)[16], float2 *out, const float2 *tab) {
-    if (STRIDE) out[0] = v[0];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
-        const float2 r = cmul(v[r16(k)], tab[TS * k]);
-        if (STRIDE) out[STRIDE * k] = r;
-        else v[r16(k)] = r;
-        if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -130,18 +146,35 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return t;
 }
 
-template <bool DETREND>
+// FRONT: the 65536-point form.  A 512 KiB segment does not fit a CU, but one more radix-2 step (decimation in frequency) splits
+// it into two INDEPENDENT 32768-point problems - the even bins are FFT_32768(y[n] + y[n + 32768]), the odd bins
+// FFT_32768((y[n] - y[n + 32768]) W_65536^n) - and a PAIR of workgroups takes one each (h = 0 / 1): both read the whole
+// segment (the second reader out of L2: the pair sits on one XCD), form their 32768 points in registers and go on as the
+// 32768-point kernel does; nothing is exchanged between them.  The mean is only known when all 65536 samples have passed, so
+// the front step forms z0 = x w +- x' w' first and takes m (w +- w') off behind the barrier (p.wpm: that table, built by the
+// plan in double) - the rounding of the two forms differs by ~1e-7 of the OFFSET per sample, incoherent from sample to sample.
+template <bool DETREND, bool FRONT = false>
 __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
     double2 *msum = reinterpret_cast<double2 *>(lds + 16 * XREG);
-    float2 *dtab = reinterpret_cast<float2 *>(msum + 16);
-    float2 *btab = dtab + 1024;          // [k1][l] = W_1024^(k1 l)
-    float2 *ctab = btab + 16 * 64;       // [k2][q] = W_64^(k2 q)
+    float2 *dtab = reinterpret_cast<float2 *>(msum + 16);      // W_32768^tid
+    float2 *etab = dtab + 1024;                                // W_65536^tid (FRONT)
+    float4 *btab = reinterpret_cast<float4 *>(etab + 1024);    // (W_1024^l, W_1024^(4 l))
+    float4 *ctab = btab + 64;                                  // (W_64^q, W_64^(4 q))
+    constexpr int TWS = FRONT ? 2 : 1;                         // p.tw[k] = W_L^k, L = 32768 TWS
 
     const int tid = threadIdx.x;
-    const int W = gridDim.x, b = blockIdx.x;
-    const int slot = (W & 7) ? b : (b & 7) * (W >> 3) + (b >> 3);
+    const int b = blockIdx.x;
+    // FRONT: workgroups (slot, h = 0 / 1) of a pair on one XCD (workgroup b runs on XCD b % 8) when the grid allows
+    const int G = gridDim.x, W = FRONT ? G >> 1 : G;           // W: segments in flight = partial rows
+    int slot, h = 0;
+    if (FRONT) {
+        if (G & 15) slot = b >> 1, h = b & 1;
+        else slot = (b & 7) * (G >> 4) + (b >> 4), h = (b >> 3) & 1;
+    } else {
+        slot = (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);
+    }
 
     // Nothing but the thread index and the thirty-two sums is carried around the segment loop in vector registers: the lane's
     // LDS addresses, the twiddle seeds (p.tw[k] = W_N^k: W, W^4 of the three twiddled passes of a 16384-point transform,
@@ -154,9 +187,16 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
 
     {
         const int t = threadIdx.x;
-        dtab[t] = p.tw[t];
-        btab[t] = p.tw[(32 * (t >> 6) * (t & 63)) & (W32_N - 1)];
-        if (t < 64) ctab[t] = p.tw[(512 * (t >> 2) * (t & 3)) & (W32_N - 1)];
+        dtab[t] = p.tw[TWS * t];
+        etab[t] = p.tw[t];
+        if (t < 64) {
+            const float2 e = p.tw[TWS * 32 * t], f = p.tw[TWS * 128 * t];
+            btab[t] = make_float4(e.x, e.y, f.x, f.y);
+        }
+        if (t < 4) {
+            const float2 e = p.tw[TWS * 512 * t], f = p.tw[TWS * 2048 * t];
+            ctab[t] = make_float4(e.x, e.y, f.x, f.y);
+        }
         __syncthreads();
     }
     float accA[16], accB[16];
@@ -184,19 +224,15 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
         dft16_from_lds<64>(v, ra, [] { prio_compute(); });     // pass 2: w -> k1
         prio_latency();
         wave_lds_sync();
-#if W32_TABLES
-        scatter_tab16<XROW, 64>(v, wb, btab + l);              // x W_1024^(k1 l) -> row k1, column l of this wave's region
-#else
-        scatter_pow16<XROW>(v, wb, btab[64 + l], btab[256 + l]);
-#endif
+        {
+            const float4 e = btab[l];
+            scatter_pow16<XROW>(v, wb, make_float2(e.x, e.y), make_float2(e.z, e.w));      // x W_1024^(k1 l) -> row k1, column l of this wave's region
+        }
         wave_lds_sync();
         dft16_from_lds<4>(v, rb, [] { prio_compute(); });      // pass 3: g -> k2
         {
-#if W32_TABLES
-            scatter_tab16<0, 4>(v, nullptr, ctab + q);                 // x W_64^(k2 q), in place
-#else
-            twiddle_pow16_inplace(v, ctab[4 + q], ctab[16 + q]);
-#endif
+            const float4 e = ctab[q];
+            twiddle_pow16_inplace(v, make_float2(e.x, e.y), make_float2(e.z, e.w));      // x W_64^(k2 q)
             const float qs1 = q < 2 ? 1.0f : -1.0f;
             const float qal = q == 0 ? 1.0f : (q == 1 ? -1.0f : 0.0f);
             const float qbe = q >= 2 ? 1.0f : 0.0f;
@@ -209,6 +245,10 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
         }
     };
 
+    // The segment loop, specialised on the half a FRONT workgroup takes (a run-time branch around the odd half's twiddle inside the
+    // loop made the compiler park 25 registers in scratch in front of it)
+    auto run = [&](auto half_) {
+    constexpr int H = decltype(half_)::value;
     for (long long s = slot; s < p.nseg; s += W) {
         const long long off = p.first + s * p.step;
         const float2 *xs = p.x + (((long long)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
@@ -218,6 +258,7 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
         asm volatile("" : "+s"(wn));      // (or thirty-two row bases stay in scalar registers across the loop)
         float2 va[16], vb[16];
         prio_latency();
+        if constexpr (!FRONT) {
         {
             f2v la[16], lb[16];
 #pragma unroll
@@ -298,11 +339,155 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
             }
             if (bt < 2) win_issue(bt + 2);
         }
+        } else {
+            // ---- front step: z[j] at n = tid + 1024 j, j < 32.  Batches of four rows, the next one in flight while one is
+            // used as long as registers allow (the finished z stay: 8 registers per batch)
+            // The thirty-two sums wait in LDS while the front step needs their registers: the wave's OWN exchange region (8.5 KiB;
+            // nobody else touches it between this wave's last pass-3 read and the exchange-A writes of the next transform,
+            // which every wave issues behind a barrier this wave reaches after `unpark`).  Left to the compiler they went to
+            // scratch: 1.7 GB of writes per 2^27 samples.
+            float4 *park = reinterpret_cast<float4 *>(lds + XREG * (opaque(tid) >> 6)) + (opaque(tid) & 63);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                park[64 * i] = make_float4(accA[4 * i], accA[4 * i + 1], accA[4 * i + 2], accA[4 * i + 3]);
+                park[64 * (4 + i)] = make_float4(accB[4 * i], accB[4 * i + 1], accB[4 * i + 2], accB[4 * i + 3]);
+            }
+            asm volatile("" ::: "memory");
+            f2v z[32], x2[2][4];
+            float w1[2][4], w2[2][4];
+            constexpr float sgn = H ? -1.0f : 1.0f;
+            auto issue = [&](int bt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = 4 * bt + i;
+                    load_row8(z[j], ut8, xs + 1024 * j);
+                    load_row8(x2[bt & 1][i], ut8, xs + W32_N + 1024 * j);
+                    load_row4(w1[bt & 1][i], ut4, wn + 1024 * j);
+                    load_row4(w2[bt & 1][i], ut4, wn + W32_N + 1024 * j);
+                }
+            };
+            double sx = 0.0, sy = 0.0;
+            issue(0);
+            issue(1);
+            // DETREND: a pilot - the segment's first sample, a scalar load - comes off every sample as it arrives, so that the
+            // products z0 carry no offset whose float rounding (1e-7 of the OFFSET per sample) would stay behind when the
+            // mean is taken off them afterwards; the mean below is then the small residual mean(x - pilot).  Every workgroup
+            // that touches the segment reads the same sample: same bits.
+            float2 pv = make_float2(0.f, 0.f);
+            if (DETREND) pv = xs[0];
+#pragma unroll
+            for (int bt = 0; bt < 8; ++bt) {
+                constexpr int kLastAhead = DETREND ? 5 : 6;      // batches up to this one are issued while the one before is still to be used (the sums take four registers)
+                const bool next_in_flight = bt + 1 <= kLastAhead;
+                if (bt > kLastAhead) issue(bt);
+                if (next_in_flight && bt + 1 < 8) vm_arrived_front<16>(z[4 * bt], z[4 * bt + 1], z[4 * bt + 2], z[4 * bt + 3], x2[bt & 1], w1[bt & 1], w2[bt & 1]);
+                else vm_arrived_front<0>(z[4 * bt], z[4 * bt + 1], z[4 * bt + 2], z[4 * bt + 3], x2[bt & 1], w1[bt & 1], w2[bt & 1]);
+                if (DETREND) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        z[4 * bt + i].x -= pv.x, z[4 * bt + i].y -= pv.y;
+                        x2[bt & 1][i].x -= pv.x, x2[bt & 1][i].y -= pv.y;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    const int j = 4 * bt + i;
+                    if (DETREND) {
+                        sx += (double)((z[j].x + x2[bt & 1][i].x) + (z[j + 1].x + x2[bt & 1][i + 1].x));
+                        sy += (double)((z[j].y + x2[bt & 1][i].y) + (z[j + 1].y + x2[bt & 1][i + 1].y));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = 4 * bt + i;
+                    const float a = w1[bt & 1][i], c = w2[bt & 1][i] * sgn;
+                    z[j].x = fmaf(x2[bt & 1][i].x, c, z[j].x * a);
+                    z[j].y = fmaf(x2[bt & 1][i].y, c, z[j].y * a);
+                    asm volatile("" : "+v"(z[j]));      // the batch is used up HERE: arithmetic may sink below the next loads otherwise,
+                }                                       // and the batch waits for it in scratch
+                if (DETREND) asm volatile("" : "+v"(sx), "+v"(sy));
+                if (bt + 2 < 8 && bt + 2 <= kLastAhead) issue(bt + 2);
+            }
+            {      // unpark
+                float4 *back = reinterpret_cast<float4 *>(lds + XREG * (opaque(tid) >> 6)) + (opaque(tid) & 63);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 a = back[64 * i], c = back[64 * (4 + i)];
+                    accA[4 * i] = a.x, accA[4 * i + 1] = a.y, accA[4 * i + 2] = a.z, accA[4 * i + 3] = a.w;
+                    accB[4 * i] = c.x, accB[4 * i + 1] = c.y, accB[4 * i + 2] = c.z, accB[4 * i + 3] = c.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(accA[i]), "+v"(accB[i]));
+            }
+            if (DETREND) {
+                // m (w[n] +- w[n + 32768]) off every z: the table in batches of four, two in flight
+                float cq[2][4];
+                const float *wpm = p.wpm + (H ? W32_N : 0);
+                asm volatile("" : "+s"(wpm));
+                auto cissue = [&](int bt) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) load_row4(cq[bt & 1][i], ut4, wpm + 1024 * (4 * bt + i));
+                };
+                cissue(0);
+                cissue(1);
+                sx = wave_sum_f64(sx);
+                sy = wave_sum_f64(sy);
+                if ((opaque(tid) & 63) == 0) msum[opaque(tid) >> 6] = make_double2(sx, sy);
+                lds_barrier();      // (also: every wave is through with the exchanges of the segment before)
+                double tx = 0.0, ty = 0.0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) {
+                    const double2 t = msum[w];
+                    tx += t.x;
+                    ty += t.y;
+                }
+                tx *= 1.0 / (2 * W32_N);
+                ty *= 1.0 / (2 * W32_N);
+                const float2 mhi = make_float2((float)tx, (float)ty);
+                const float2 mlo = make_float2((float)(tx - (double)mhi.x), (float)(ty - (double)mhi.y));
+#pragma unroll
+                for (int bt = 0; bt < 8; ++bt) {
+                    if (bt < 7) asm volatile("s_waitcnt vmcnt(4)" : "+v"(cq[bt & 1][0]), "+v"(cq[bt & 1][1]), "+v"(cq[bt & 1][2]), "+v"(cq[bt & 1][3]) : : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(cq[bt & 1][0]), "+v"(cq[bt & 1][1]), "+v"(cq[bt & 1][2]), "+v"(cq[bt & 1][3]) : : "memory");
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = 4 * bt + i;
+                        const float c = cq[bt & 1][i];
+                        z[j].x = fmaf(-mlo.x, c, fmaf(-mhi.x, c, z[j].x));
+                        z[j].y = fmaf(-mlo.y, c, fmaf(-mhi.y, c, z[j].y));
+                        asm volatile("" : "+v"(z[j]));
+                    }
+                    if (bt < 6) cissue(bt + 2);
+                }
+            }
+            if constexpr (H) {      // the odd bins' half: x W_65536^n, n = tid + 1024 j
+                float2 e1 = etab[opaque(tid)];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    asm volatile("" : "+v"(e1.x), "+v"(e1.y));
+                    const float2 r = cmul(make_float2(z[j].x, z[j].y), cmul(e1, make_float2(W64_RE[j], W64_IM[j])));
+                    z[j].x = r.x, z[j].y = r.y;
+                }
+            }
+            // the 32768-point radix-2 step on z: rows r and 16 + r
+            float2 d1 = dtab[opaque(tid)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                asm volatile("" : "+v"(d1.x), "+v"(d1.y));
+                const float2 y0 = make_float2(z[r].x, z[r].y), y1 = make_float2(z[16 + r].x, z[16 + r].y);
+                va[r] = cadd(y0, y1);
+                vb[r] = cmul(csub(y0, y1), cmul(d1, make_float2(W32_RE[r], W32_IM[r])));
+            }
+        }
         transform(va, accA, !DETREND);
         transform(vb, accB, true);
     }
+    };
+    if (FRONT && h) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
 
-    float *dst = p.partial + (size_t)b * W32_N + tid;
+    // FRONT: row `slot` of [W][65536], half h; position p of that half holds bin 2 (layout-7 bin of p) + h (finalize layout 8)
+    float *dst = p.partial + (FRONT ? (size_t)slot * (2 * W32_N) + (size_t)h * W32_N : (size_t)b * W32_N) + tid;
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) {
         dst[1024 * k2] = accA[k2];
@@ -312,24 +497,32 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
 
 }  // namespace
 
-int welch32k_rows(long long nseg, int cus) {
+int welch32k_rows(long long nseg, int cus, bool front) {
     if (cus < 1) cus = 256;
+    if (front) cus >>= 1;      // a pair of workgroups per 65536-point segment
     return (int)(nseg < cus ? (nseg < 1 ? 1 : nseg) : cus);
 }
 
 hipError_t launch_welch32k(const W32kArgs &a, int W, hipStream_t s) {
-    static bool armed[64] = {};        // 136 KiB of dynamic LDS needs the opt-in, once per device
+    static bool armed[64] = {};        // 153 KiB of dynamic LDS needs the opt-in, once per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!armed[dev]) {
         hipError_t e = hipSuccess;
-        for (const void *fn : {reinterpret_cast<const void *>(welch32k_kernel<true>), reinterpret_cast<const void *>(welch32k_kernel<false>)})
+        for (const void *fn : {reinterpret_cast<const void *>(welch32k_kernel<true, false>), reinterpret_cast<const void *>(welch32k_kernel<false, false>),
+                               reinterpret_cast<const void *>(welch32k_kernel<true, true>), reinterpret_cast<const void *>(welch32k_kernel<false, true>)})
             if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W32_LDS_BYTES);
         if (e != hipSuccess) return e;
         armed[dev] = true;
     }
-    if (a.detrend) hipLaunchKernelGGL(welch32k_kernel<true>, dim3(W), dim3(1024), W32_LDS_BYTES, s, a);
-    else hipLaunchKernelGGL(welch32k_kernel<false>, dim3(W), dim3(1024), W32_LDS_BYTES, s, a);
+    if (a.front) {
+        if (!a.wpm && a.detrend) return hipErrorInvalidValue;
+        if (a.detrend) hipLaunchKernelGGL((welch32k_kernel<true, true>), dim3(2 * W), dim3(1024), W32_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((welch32k_kernel<false, true>), dim3(2 * W), dim3(1024), W32_LDS_BYTES, s, a);
+    } else {
+        if (a.detrend) hipLaunchKernelGGL((welch32k_kernel<true, false>), dim3(W), dim3(1024), W32_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((welch32k_kernel<false, false>), dim3(W), dim3(1024), W32_LDS_BYTES, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -163,12 +163,14 @@ def test_launch_recipes_table():
     assert (c5['kernel'], c5['sched'], c5['layout'], c5['W']) == ('welch16k1x:pipe', 'contiguous', '4', '4')
     # round 6: every other length (csrc/fft_any.hip, fft_tl.hip) - and what is still refused, with the reason
     for n, kind in ((8, 'direct'), (1000, 'direct'), (15000, 'direct'), (1021, 'bluestein'), (8191, 'bluestein'), (10007, 'bluestein2'),
-                    (20000, 'bluestein2'), (32768, 'onewg'), (65536, 'twolevel:r16'), (131072, 'twolevel'), (1048576, 'twolevel')):
+                    (20000, 'bluestein2'), (32768, 'onewg'), (65536, 'onewg'), (131072, 'twolevel'), (1048576, 'twolevel')):
         f = fields(nfft=n, nperseg=n, noverlap=n // 2)
-        assert (f['kernel'], f['form'], f['pilot'], f['layout']) == ('anyfft:' + kind, 'time', 'none', '7' if kind == 'onewg' else ('6' if 'twolevel' in kind else '0')), n
+        assert (f['kernel'], f['form'], f['pilot'], f['layout']) == ('anyfft:' + kind, 'time', 'none', ('8' if n == 65536 else '7') if kind == 'onewg' else ('6' if 'twolevel' in kind else '0')), n
     assert fields(nfft=65536, nperseg=65536, noverlap=32768, two_channel=1)['kernel'] == 'anyfft:twolevel:r16'
     assert fields(nfft=65536, nperseg=65536, noverlap=32768, variant='anycov')['kernel'] == 'anyfft:twolevel'
     assert fields(nfft=32768, nperseg=32768, noverlap=16384, variant='r16')['kernel'] == 'anyfft:twolevel:r16'
+    assert fields(nfft=65536, nperseg=65536, noverlap=32768, variant='r16')['kernel'] == 'anyfft:twolevel:r16'
+    assert fields(nfft=65536, nperseg=65536, noverlap=32768, nseg=1000)['W'] == '128'      # a pair of workgroups per segment
     assert fields(nfft=32768, nperseg=32768, noverlap=16384, two_channel=1)['kernel'] == 'anyfft:twolevel:r16'
     assert fields(nfft=32768, nperseg=8192, noverlap=4096)['kernel'] == 'anyfft:twolevel:r16'      # zero-padded segments
     for n in (2097152, 524290, 600000):

@@ -65,12 +65,10 @@ def test_welch_any_length_against_the_oracle(ctx, hip, n):
 @pytest.mark.parametrize('n', BIG)
 @pytest.mark.parametrize('variant', [None, 'r16', 'anycov'])
 def test_two_level_routes_across_workspace_chunks(ctx, hip, n, variant):
-    """32768 / 65536 points: the default route (32768, full segments: welch32k.hip's one-workgroup kernel; otherwise
-    fft_tl.hip's register radix-16 four-step kernels, which 'r16' forces at 32768 too) and fft_any.hip's coverage kernels
+    """32768 / 65536 points: the default route (full segments: welch32k.hip's one-workgroup kernel; otherwise fft_tl.hip's
+    register radix-16 four-step kernels, which 'r16' forces for full segments too) and fft_any.hip's coverage kernels
     ('anycov') on a launch longer than one workspace chunk (64 MiB: 256 / 128 segments), ragged segment count, zero
     padding inside the last row block, with and without the detrend."""
-    if variant == 'r16' and n != 32768:
-        pytest.skip('r16 is the default above 32768')
     nseg = (64 << 20) // (8 * n) + 37
     x = R.synth_iq(n // 2 * (nseg + 1) + 11, 71, dc=3 + 2j)
     for detrend, nper in ((hip.DETREND_CONSTANT, n), (hip.DETREND_NONE, n - 3000)):
@@ -83,18 +81,20 @@ def test_two_level_routes_across_workspace_chunks(ctx, hip, n, variant):
         psd = plan.exec(xs)
         assert plan.last_nseg == (len(xs) - nper // 2) // (nper - nper // 2)
         assert relerr(psd, ref) < RTOL, (detrend, nper)
-        want = 'twolevel' if variant == 'anycov' else ('onewg' if n == 32768 and nper == n and not variant else 'twolevel:r16')
+        want = 'twolevel' if variant == 'anycov' else ('onewg' if nper == n and not variant else 'twolevel:r16')
         assert _route(plan) == 'kernel=anyfft:' + want
         plan.close()
 
 
-def test_welch_32768_inside_one_workgroup(ctx, hip):
+@pytest.mark.parametrize('n', BIG)
+def test_welch_32768_65536_inside_one_workgroup(ctx, hip, n):
     """welch32k.hip: the whole 32768-point segment in one workgroup's registers (radix 2 + two 16384-point transforms), exact
-    mean in double, partial rows in layout 7.  Against scipy's form in f64: one segment (the single-row criterion) to more
-    segments than workgroups, 50 % / odd / no overlap, a workgroup count that is not a multiple of 8 (no XCD dealing), with
-    and without the detrend under a DC line of 36 sigma, a first sample that is not 16-byte aligned, fftshift + trim + dB,
-    several streams per launch, the streaming form (accumulate / finalize) - and the same plans on the four-step route."""
-    n = 32768
+    mean in double, partial rows in layout 7; 65536 points as a PAIR of workgroups behind one more radix-2 step (even / odd
+    bins; the mean taken off z0 = x w +- x' w' afterwards; layout 8).  Against scipy's form in f64: one segment (the
+    single-row criterion) to more segments than workgroups, 50 % / odd / no overlap, a workgroup count that is not a multiple
+    of 8 / 16 (no XCD dealing), with and without the detrend under a DC line of 36 sigma, a first sample that is not 16-byte
+    aligned, fftshift + trim + dB, several streams per launch, the streaming form (accumulate / finalize) - and the same
+    plans on the four-step route."""
     w = _win('hann', n)
     for detrend in (True, False):
         for nseg, ov in ((1, n // 2), (5, n // 2), (9, 0), (37, 1001), (300, n // 2), (700, n - 4096)):
@@ -138,7 +138,7 @@ def test_welch_32768_inside_one_workgroup(ctx, hip):
     # streaming: ragged pushes carry the overlap across calls
     x = R.synth_iq(n // 2 * 41 + 123, 9)
     plan = ctx.welch_plan(n, window=w)
-    for a, b in ((0, 50000), (50000, 50001), (50001, 400000), (400000, len(x))):
+    for a, b in ((0, 50000), (50000, 50001), (50001, 400000 * (n // 32768)), (400000 * (n // 32768), len(x))):
         plan.accumulate(x[a:b])
     got = plan.finalize()
     _, ref = R.welch_np(x, nperseg=n, nfft=n)
@@ -148,7 +148,7 @@ def test_welch_32768_inside_one_workgroup(ctx, hip):
 
 def test_routes_are_the_documented_ones(ctx):
     want = {96: 'direct', 15000: 'direct', 97: 'bluestein', 8191: 'bluestein', 10007: 'bluestein2', 20000: 'bluestein2',
-            32768: 'onewg', 65536: 'twolevel:r16', 131072: 'twolevel', 32: 'direct'}
+            32768: 'onewg', 65536: 'onewg', 131072: 'twolevel', 32: 'direct'}
     for n, kind in want.items():
         plan = ctx.welch_plan(n)
         plan.exec(R.synth_iq(2 * n, 1))
@@ -627,7 +627,7 @@ def test_any_length_results_do_not_depend_on_timing_under_a_bandwidth_hog(ctx, h
     try:
         ctx.synth_iq(d, n + 5, 4343, R.TONES, R.DC)
         plans = []
-        for nfft, variant in ((1000, None), (12000, None), (4099, None), (20000, None), (32768, None), (32768, 'r16'), (65536, None), (32768, 'anycov'),
+        for nfft, variant in ((1000, None), (12000, None), (4099, None), (20000, None), (32768, None), (32768, 'r16'), (65536, None), (65536, 'r16'), (32768, 'anycov'),
                               (131072, None)):
             for det in (hip.DETREND_CONSTANT, hip.DETREND_NONE):
                 plan = ctx.welch_plan(nfft, window=_win('hann', nfft), detrend=det)

@@ -4,7 +4,7 @@ import sys, time, numpy as np, torch
 sys.path.insert(0, 'gr-ofdm_tools_amd')
 from ofdm_tools import _hip
 ctx = _hip.Context()
-n = 32768
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 g = torch.Generator(device='cuda').manual_seed(1)
 x = torch.randn(1 << 27, 2, device='cuda', generator=g)
 def run(label, ns, **kw):
