@@ -16,8 +16,8 @@ N = 1  workload "C2" (the configuration BASELINE.json's metric is quoted on): on
        `csd_c3` (BASELINE config 3: two-channel cross spectrum / coherence, 2 x 2^26 samples, 16 B per sample
        pair), `scan_c5` (BASELINE config 5: 64 channel streams x 2^22 samples, 16384-pt rectangular |X|^2/N^2 mean +
        the device decision stage), `c1` (BASELINE config 1 at its own size: 2^20 samples, 1024-pt rectangular chain, the 128
-       eight-row means + a7 channel sums), `welch_32768` / `welch_65536` (the lengths above the tuned kernels: one workgroup per
-       segment / the four-step route, 2^27
+       eight-row means + a7 channel sums), `welch_32768` / `welch_65536` (the lengths above the tuned kernels: one workgroup / a
+       pair of workgroups per segment, 2^27
        samples), each with its own `roofline` whose `kernel` is the recipe the library recorded for
        the launch (oth__debug_last_recipe) and whose `traffic` is the figure of the builder's rocprofv3 PMC passes of
        the same configuration (profiles/traffic.json: not measured by this run); `h2d_inclusive` (host buffer -> PSD through the streaming entry point);
@@ -761,9 +761,8 @@ def main():
     def big_welch_bench(nfft, steps, warmup):
         """Round 6: Hann Welch, 50 % overlap, detrend constant at 32768 / 65536 points - what fast_spectrum_scan(n_fft=0) picks for
         blocks of 16 Ki ... 64 Ki samples (ofdm_cr_tools.py:474-475) and a flowgraph reaches with --nfft - on 2^27 resident samples.
-        32768: one launch, the segment inside one workgroup (csrc/welch32k.hip).  65536: a call is SEVERAL launches (sub-block
-        sums, K1, K2 per 128 MiB workspace chunk: csrc/fft_tl.hip).  `kernel_avg_ms` is the HIP-event time of one call's launches
-        together, `achieved` = 8 B x samples / that."""
+        One launch: the segment inside one workgroup (32768) or a pair of workgroups (65536: even / odd bins), csrc/welch32k.hip.
+        `kernel_avg_ms` is the HIP-event time of one call's launches together, `achieved` = 8 B x samples / that."""
         n = 1 << 27
         iq = torch.empty((n, 2), dtype=torch.float32, device=dev)
         ctx.synth_iq(iq.data_ptr(), n, 1002, TONES, DC)
@@ -795,7 +794,7 @@ def main():
                 'steps': steps, 'kernel_avg_ms': kavg, 'calls': int(calls),
                 'config': {'workload': '2^27-sample complex64 stream, %d-pt Hann Welch, 50%% overlap, detrend constant, density '
                                        '(%s)' % (nfft, 'the 256 KiB segment stays in one workgroup' if nfft == 32768 else
-                                                 'four-step route: a 512 KiB segment crosses the chip once between the halves')},
+                                                 'the 512 KiB segment goes to a pair of workgroups: even / odd bins')},
                 'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
                              'traffic': traffic, 'traffic_source': tsrc, 'kernel': plan_recipe[nfft],
                              'kernel_avg_ms': kavg, 'launches': int(calls), 'algorithmic_bytes_per_launch': 8 * n,

@@ -1,4 +1,5 @@
-// welch32k: segment-averaged |FFT_32768((x - mean) w)|^2 with the WHOLE segment inside one workgroup - the first length
+// welch32k: segment-averaged |FFT_32768((x - mean) w)|^2 with the WHOLE segment inside one workgroup - and the 65536-point
+// form on top of it (a pair of workgroups per segment; see `FRONT` at the kernel) - the first lengths
 // above the tuned kernels (fast_spectrum_scan picks it for every block of 32 Ki ... 64 Ki samples, ofdm_cr_tools.py:474-475;
 // --nfft of sdr_webserver/local_hw_gateway.py:284-285), any overlap, scipy.signal.welch semantics (ofdm_cr_tools.py:322,342).
 //
@@ -18,9 +19,9 @@
 // bin 2 k, of half B bin 2 k + 1 (finalize layout 7).
 //
 // Detrend in the time domain with the exact mean (scipy's detrend='constant'; no pilot needed): every thread adds its 32
-// samples in double, the waves' totals meet in LDS behind one workgroup barrier, the mean is subtracted as a float pair
+// samples (groups of four in float, the groups in double), the waves' totals meet in LDS behind one workgroup barrier, the mean is subtracted as a float pair
 // (hi + lo).  That barrier also covers the exchange-A hand-over of the first transform: four workgroup barriers per segment.
-// The twiddle seeds live in LDS (148.8 of 160 KiB with the exchange regions).
+// The twiddle seeds live in LDS (153.4 of 160 KiB with the exchange regions).
 //
 // Samples are read with ordinary (cached) loads: at 50 % overlap every sample is wanted by two segments, and the segments of
 // one round are dealt out so that neighbours run on the same XCD (workgroup b runs on XCD b % 8: it takes slot

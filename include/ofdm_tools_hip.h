@@ -58,7 +58,8 @@ extern "C" {
  *   2-3-5-7-smooth lengths up to 16384     one launch, mixed-radix Stockham in LDS               "anyfft:direct"
  *   powers of two 32768 ... 1048576        four-step L1 x L2 through a workspace in HBM / L2      "anyfft:twolevel"
  *                                          (32768, 65536: register radix-16 kernels,              "anyfft:twolevel:r16")
- *   32768, one channel, nperseg = nfft     the segment inside one workgroup's registers           "anyfft:onewg"
+ *   32768 / 65536, one channel,            the segment inside one workgroup's registers (65536:   "anyfft:onewg"
+ *   nperseg = nfft                         a pair of workgroups, even / odd bins)
  *   every other length n <= 524288         Bluestein through 2^ceil(log2(2 n - 1)) points         "anyfft:bluestein[2]"
  * (the quoted names are what oth__debug_last_recipe reports).  Still refused, OTH_ERR_UNSUPPORTED with the reason in
  * oth_last_error(): powers of two above 1048576 and other lengths above 524288; OTH_KERNEL_TUNED on any of the new
