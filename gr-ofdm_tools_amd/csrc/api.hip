@@ -1207,7 +1207,7 @@ int run_average(oth_plan *p, const float2 *x, const float2 *y, size_t nsamples, 
     p->last_recipe = recipe_text(r, p->nfft);
     // + 1 KiB per row of stamp space behind the sums (only the diagnostic kernel builds write it)
     int rc = ensure(c, &p->d_partial, &p->partial_cap,
-                    sizeof(float) * (size_t)nstreams * r.W * r.rows * r.nch * p->nfft + 1024 * (size_t)nstreams * r.W * r.rows);
+                    sizeof(float) * (size_t)nstreams * r.W * r.rows * r.nch * p->nfft + 2048 * (size_t)nstreams * r.W * r.rows);      // (+ 2 KiB per row: the phase stamps of the diagnostic builds)
     p->last_W = r.W * r.rows * nstreams;
     {
         const int groups = std::max(kReduceGroups, finalize_row_groups(p->nfft, r.W * r.rows, r.nch));

@@ -33,6 +33,24 @@ namespace oth {
 namespace {
 
 constexpr int W32_M = 16384, W32_N = 32768;
+// -DW32_DIAG=1 (make EXP=1 EXTRA=-DW32_DIAG=1; tools/w32_phases.py): cycle counts of eight phases of a step per wave, written
+// behind the partial rows (1 KiB per workgroup)
+#ifndef W32_DIAG
+#define W32_DIAG 0
+#endif
+#if W32_DIAG
+#define W32_STAMP(i)                                                     \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                              \
+        phase[i] += now_ - last_;                                        \
+        last_ = now_;                                                    \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    } while (0)
+#else
+#define W32_STAMP(i) do { } while (0)
+#endif
 // LDS behind the sixteen exchange regions: the waves' sample totals and the twiddle seeds - W_32768^tid of every thread
 // (radix-2 step and, squared, pass 1), W_65536^tid (the front step of the 65536-point form), W and W^4 of passes 2 and 3 per
 // lane (W_1024^l, W_64^q) - so that the transforms wait for no vector-memory load.  Each pass rebuilds its other powers from
@@ -94,13 +112,15 @@ __device__ __forceinline__ void vm_arrived8(float (&w)[8]) { asm volatile("s_wai
 // of the next batch already issued behind it (16) or none
 template <int KEEP>
 __device__ __forceinline__ void vm_arrived_front(f2v &z0, f2v &z1, f2v &z2, f2v &z3, f2v (&x2)[4], float (&w1)[4], float (&w2)[4]) {
-    static_assert(KEEP == 0 || KEEP == 16, "");
-    if (KEEP)
-        asm volatile("s_waitcnt vmcnt(16)" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3), "+v"(x2[0]), "+v"(x2[1]), "+v"(x2[2]), "+v"(x2[3]),
-                     "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(w2[0]), "+v"(w2[1]), "+v"(w2[2]), "+v"(w2[3]) : : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3), "+v"(x2[0]), "+v"(x2[1]), "+v"(x2[2]), "+v"(x2[3]),
-                     "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(w2[0]), "+v"(w2[1]), "+v"(w2[2]), "+v"(w2[3]) : : "memory");
+    static_assert(KEEP == 0 || KEEP == 16 || KEEP == 32 || KEEP == 48, "whole batches of sixteen loads");
+#define W32_FRONT_WAIT(n)                                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3), "+v"(x2[0]), "+v"(x2[1]), "+v"(x2[2]), "+v"(x2[3]), \
+                 "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(w2[0]), "+v"(w2[1]), "+v"(w2[2]), "+v"(w2[3]) : : "memory")
+    if (KEEP == 48) W32_FRONT_WAIT(48);
+    else if (KEEP == 32) W32_FRONT_WAIT(32);
+    else if (KEEP == 16) W32_FRONT_WAIT(16);
+    else W32_FRONT_WAIT(0);
+#undef W32_FRONT_WAIT
 }
 
 // scatter_pow16 (fft4096.hip.h) with the rows k >= 8 addressed from a second base: 8 XREG float2 is past the 64 KiB a
@@ -203,10 +223,14 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
     float accA[16], accB[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) accA[k] = accB[k] = 0.f;
+#if W32_DIAG
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
 
     // one 16384-point transform of v (in place: thread (w, l) holds n = tid + 1024 r) added to acc; `handover`: a workgroup
     // barrier in front of the exchange-A writes (every wave through with the reads of the transform before)
-    auto transform = [&](float2 (&v)[16], float (&acc)[16], bool handover) {
+    auto transform = [&](float2 (&v)[16], float (&acc)[16], bool handover, int ph) {
         const int t = opaque(tid), wv = t >> 6, l = t & 63, g = l >> 2, q = l & 3;
         float2 *wa = lds + t;                                // exchange A write: + XREG k0 (k0 < 8), wa8 + XREG (k0 - 8)
         float2 *wa8 = wa + opaque(8 * XREG);                 // (a VALUE the compiler cannot fold; the pointer stays an LDS pointer)
@@ -216,12 +240,14 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
         prio_compute();
         dft16(v);                                              // pass 1: r -> k0
         prio_latency();
+        W32_STAMP(ph);
         if (handover) lds_barrier();
         {
             const float2 d = dtab[t], a1 = cmul(d, d), a2 = cmul(a1, a1);      // W_M^tid = (W_N^tid)^2 and its fourth power
             scatter_pow16_exa(v, wa, wa8, a1, cmul(a2, a2));                   // x W_M^(k0 tid) -> [k0][w][l]
         }
         lds_barrier();
+        W32_STAMP(ph + 1);
         dft16_from_lds<64>(v, ra, [] { prio_compute(); });     // pass 2: w -> k1
         prio_latency();
         wave_lds_sync();
@@ -244,12 +270,26 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
             const float2 X = v[r16(k2)];
             acc[k2] = fmaf(X.x, X.x, fmaf(X.y, X.y, acc[k2]));
         }
+        W32_STAMP(ph + 2);
     };
 
     // The segment loop, specialised on the half a FRONT workgroup takes (a run-time branch around the odd half's twiddle inside the
     // loop made the compiler park 25 registers in scratch in front of it)
     auto run = [&](auto half_) {
     constexpr int H = decltype(half_)::value;
+    // (!FRONT) The second half of a segment - rows x[n + M] - is requested one transform ahead: while the second transform of
+    // the step before runs, the registers of its first transform's data are free.  The phase stamps (tools/w32_phases.py)
+    // showed 40 % of a step between the first load and the mean's barrier with all 32 rows requested at the top.
+    f2v pre[16];
+    auto prefetch = [&](long long s2) {
+        const long long o2 = p.first + s2 * p.step;
+        const float2 *x2 = p.x + (((long long)__builtin_amdgcn_readfirstlane((int)(o2 >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)o2));
+        const unsigned u8 = ((unsigned)opaque(tid) & 1023u) * 8u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) load_row8(pre[r], u8, x2 + W32_M + 1024 * r);
+    };
+    if (!FRONT && slot < p.nseg) prefetch(slot);
     for (long long s = slot; s < p.nseg; s += W) {
         const long long off = p.first + s * p.step;
         const float2 *xs = p.x + (((long long)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
@@ -261,18 +301,16 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
         prio_latency();
         if constexpr (!FRONT) {
         {
-            f2v la[16], lb[16];
+            f2v la[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                load_row8(la[r], ut8, xs + 1024 * r);
-                load_row8(lb[r], ut8, xs + W32_M + 1024 * r);
-            }
+            for (int r = 0; r < 16; ++r) load_row8(la[r], ut8, xs + 1024 * r);
             vm_arrived16(la);
-            vm_arrived16(lb);
+            vm_arrived16(pre);
+            W32_STAMP(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 va[r] = make_float2(la[r].x, la[r].y);
-                vb[r] = make_float2(lb[r].x, lb[r].y);
+                vb[r] = make_float2(pre[r].x, pre[r].y);
             }
         }
         // window values in batches of four rows (w[n] in wq[.][0..3], w[n + M] in wq[.][4..7]), two batches in flight: all
@@ -313,6 +351,7 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
             ty *= 1.0 / W32_N;
             mhi = make_float2((float)tx, (float)ty);
             mlo = make_float2((float)(tx - (double)mhi.x), (float)(ty - (double)mhi.y));
+            W32_STAMP(1);
         } else {
             win_issue(0);
             win_issue(1);
@@ -354,22 +393,28 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
                 park[64 * (4 + i)] = make_float4(accB[4 * i], accB[4 * i + 1], accB[4 * i + 2], accB[4 * i + 3]);
             }
             asm volatile("" ::: "memory");
-            f2v z[32], x2[2][4];
-            float w1[2][4], w2[2][4];
+            f2v z[32], x2[4][4];
+            float w1[4][4], w2[4][4];
             constexpr float sgn = H ? -1.0f : 1.0f;
             auto issue = [&](int bt) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int j = 4 * bt + i;
                     load_row8(z[j], ut8, xs + 1024 * j);
-                    load_row8(x2[bt & 1][i], ut8, xs + W32_N + 1024 * j);
-                    load_row4(w1[bt & 1][i], ut4, wn + 1024 * j);
-                    load_row4(w2[bt & 1][i], ut4, wn + W32_N + 1024 * j);
+                    load_row8(x2[bt & 3][i], ut8, xs + W32_N + 1024 * j);
+                    load_row4(w1[bt & 3][i], ut4, wn + 1024 * j);
+                    load_row4(w2[bt & 3][i], ut4, wn + W32_N + 1024 * j);
                 }
             };
+            // The sums are parked, so early in the front step almost every register is free: four batches go out at once, and a
+            // batch is issued as soon as the finished z (8 registers per batch) and the batches in flight (24 each) leave room:
+            //   used up:    0      1      2      3      4      5      6      7
+            //   in flight:  1-3    2-4    3,4    4,5    5,6    6      7      -
             double sx = 0.0, sy = 0.0;
             issue(0);
             issue(1);
+            issue(2);
+            issue(3);
             // DETREND: a pilot - the segment's first sample, a scalar load - comes off every sample as it arrives, so that the
             // products z0 carry no offset whose float rounding (1e-7 of the OFFSET per sample) would stay behind when the
             // mean is taken off them afterwards; the mean below is then the small residual mean(x - pilot).  Every workgroup
@@ -378,36 +423,40 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
             if (DETREND) pv = xs[0];
 #pragma unroll
             for (int bt = 0; bt < 8; ++bt) {
-                constexpr int kLastAhead = DETREND ? 5 : 6;      // batches up to this one are issued while the one before is still to be used (the sums take four registers)
-                const bool next_in_flight = bt + 1 <= kLastAhead;
-                if (bt > kLastAhead) issue(bt);
-                if (next_in_flight && bt + 1 < 8) vm_arrived_front<16>(z[4 * bt], z[4 * bt + 1], z[4 * bt + 2], z[4 * bt + 3], x2[bt & 1], w1[bt & 1], w2[bt & 1]);
-                else vm_arrived_front<0>(z[4 * bt], z[4 * bt + 1], z[4 * bt + 2], z[4 * bt + 3], x2[bt & 1], w1[bt & 1], w2[bt & 1]);
+                {
+                    f2v &z0 = z[4 * bt], &z1 = z[4 * bt + 1], &z2 = z[4 * bt + 2], &z3 = z[4 * bt + 3];
+                    if (bt <= 1) vm_arrived_front<48>(z0, z1, z2, z3, x2[bt & 3], w1[bt & 3], w2[bt & 3]);
+                    else if (bt <= 4) vm_arrived_front<32>(z0, z1, z2, z3, x2[bt & 3], w1[bt & 3], w2[bt & 3]);
+                    else if (bt <= 6) vm_arrived_front<16>(z0, z1, z2, z3, x2[bt & 3], w1[bt & 3], w2[bt & 3]);
+                    else vm_arrived_front<0>(z0, z1, z2, z3, x2[bt & 3], w1[bt & 3], w2[bt & 3]);
+                }
                 if (DETREND) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         z[4 * bt + i].x -= pv.x, z[4 * bt + i].y -= pv.y;
-                        x2[bt & 1][i].x -= pv.x, x2[bt & 1][i].y -= pv.y;
+                        x2[bt & 3][i].x -= pv.x, x2[bt & 3][i].y -= pv.y;
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {
                     const int j = 4 * bt + i;
                     if (DETREND) {
-                        sx += (double)((z[j].x + x2[bt & 1][i].x) + (z[j + 1].x + x2[bt & 1][i + 1].x));
-                        sy += (double)((z[j].y + x2[bt & 1][i].y) + (z[j + 1].y + x2[bt & 1][i + 1].y));
+                        sx += (double)((z[j].x + x2[bt & 3][i].x) + (z[j + 1].x + x2[bt & 3][i + 1].x));
+                        sy += (double)((z[j].y + x2[bt & 3][i].y) + (z[j + 1].y + x2[bt & 3][i + 1].y));
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int j = 4 * bt + i;
-                    const float a = w1[bt & 1][i], c = w2[bt & 1][i] * sgn;
-                    z[j].x = fmaf(x2[bt & 1][i].x, c, z[j].x * a);
-                    z[j].y = fmaf(x2[bt & 1][i].y, c, z[j].y * a);
+                    const float a = w1[bt & 3][i], c = w2[bt & 3][i] * sgn;
+                    z[j].x = fmaf(x2[bt & 3][i].x, c, z[j].x * a);
+                    z[j].y = fmaf(x2[bt & 3][i].y, c, z[j].y * a);
                     asm volatile("" : "+v"(z[j]));      // the batch is used up HERE: arithmetic may sink below the next loads otherwise,
                 }                                       // and the batch waits for it in scratch
                 if (DETREND) asm volatile("" : "+v"(sx), "+v"(sy));
-                if (bt + 2 < 8 && bt + 2 <= kLastAhead) issue(bt + 2);
+                if (bt == 0) issue(4);
+                if (bt == 2 || bt == 3) issue(bt + 3);
+                if (bt == 5) issue(7);
             }
             {      // unpark
                 float4 *back = reinterpret_cast<float4 *>(lds + XREG * (opaque(tid) >> 6)) + (opaque(tid) & 63);
@@ -480,13 +529,24 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
                 vb[r] = cmul(csub(y0, y1), cmul(d1, make_float2(W32_RE[r], W32_IM[r])));
             }
         }
-        transform(va, accA, !DETREND);
-        transform(vb, accB, true);
+        W32_STAMP(2);
+        transform(va, accA, !DETREND, 3);
+        if (!FRONT) prefetch(s + W < p.nseg ? s + W : s);      // (no branch: the last step asks for its own rows again)
+        transform(vb, accB, true, 5);
     }
     };
     if (FRONT && h) run(std::integral_constant<int, 1>{});
     else run(std::integral_constant<int, 0>{});
 
+#if W32_DIAG
+    if ((threadIdx.x & 63) == 0) {      // phases: 0 loads, 1 sums + mean barrier, 2 window + radix 2, 3 pass 1 a, 4 exch A + barrier a, 5 rest of a,
+                                        // (5 also: pass 1 b), 6 handover barrier + exch A + barrier b, 7 rest of b
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(p.partial + (size_t)W * (FRONT ? 2 * W32_N : W32_N)) +
+                                 128 * (size_t)b + 8 * (threadIdx.x >> 6);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st[i] = phase[i];
+    }
+#endif
     // FRONT: row `slot` of [W][65536], half h; position p of that half holds bin 2 (layout-7 bin of p) + h (finalize layout 8)
     float *dst = p.partial + (FRONT ? (size_t)slot * (2 * W32_N) + (size_t)h * W32_N : (size_t)b * W32_N) + tid;
 #pragma unroll
