@@ -23,6 +23,11 @@
 // (hi + lo).  That barrier also covers the exchange-A hand-over of the first transform: four workgroup barriers per segment.
 // The twiddle seeds live in LDS (153.4 of 160 KiB with the exchange regions).
 //
+// Measured and NOT kept: the detrend after the transform (pilot off every sample, the waves' sums to LDS without a barrier, the
+// residual mean taken off the 32 bins a cosine-sum window's spectrum reaches, as the tuned kernels do) - parity green, 1 %
+// SLOWER same-box (0.505-0.509 against 0.499-0.502 ms): the time the early waves spend at the mean's barrier moves to the next
+// barrier, it is not idle time of the SIMDs.
+//
 // Samples are read with ordinary (cached) loads: at 50 % overlap every sample is wanted by two segments, and the segments of
 // one round are dealt out so that neighbours run on the same XCD (workgroup b runs on XCD b % 8: it takes slot
 // (b % 8) (W / 8) + b / 8) - the second reader finds the half in that XCD's L2.
