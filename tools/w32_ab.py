@@ -1,5 +1,5 @@
-"""Same-box A/B of the 32768-point kernel's detrend forms (default: after the transform where the window allows; "td": exact
-mean in front of the window) and of the four-step route ("r16"): interleaved launches on 2^27 resident samples."""
+"""Same-box A/B of the one-workgroup route (default; "td" forces the time-domain detrend, which is all this route has) against
+the four-step ("r16"): interleaved launches on 2^27 resident samples."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, 'gr-ofdm_tools_amd')
 from ofdm_tools import _hip
