@@ -563,6 +563,43 @@ def test_plan_cache_is_lru_and_keeps_plans_that_owe_a_ticket(ctx, hip):
     assert made == [64, 128, 256, 512, 1024, 2048]
 
 
+def test_fuzz_one_workgroup_route_against_the_oracle(ctx, hip):
+    """40 random full-segment plans at 32768 / 65536 points (welch32k.hip): any overlap, 1 ... 600 segments (fewer and more than
+    workgroups, counts that are not multiples of 8 / 16), detrend on / off under offsets of 0 ... 300 sigma, four window kinds
+    and a random window, device input at odd sample offsets - each against the float64 oracle, criteria as in the fuzz below."""
+    rng = np.random.default_rng(32768)
+    worst = 0.0
+    for i in range(40):
+        n = (32768, 65536)[i & 1]
+        nov = (n // 2, 0, int(rng.integers(0, n)), n - int(rng.integers(1, 4096)))[int(rng.integers(0, 4))]
+        step = n - nov
+        nseg = int(rng.integers(1, 40)) if step > 4096 else int(rng.integers(1, 600))
+        detrend = bool(rng.random() < 0.6)
+        kind = int(rng.integers(0, 5))
+        w = _win(('hann', 'flattop', 'boxcar', 'blackmanharris')[kind], n) if kind < 4 else rng.random(n).astype(np.float32) + 0.1
+        dc = complex(rng.normal(), rng.normal()) * (10.0 ** rng.uniform(-1, 2.5)) if detrend else R.DC
+        lead = int(rng.integers(0, 3))
+        x = R.synth_iq(lead + n + step * (nseg - 1) + int(rng.integers(0, step)), 7000 + i, dc=dc)
+        _, ref = R.welch_np(x[lead:], window=w, nperseg=n, noverlap=nov, nfft=n, detrend='constant' if detrend else False)
+        plan = ctx.welch_plan(n, noverlap=nov, window=w, detrend=hip.DETREND_CONSTANT if detrend else hip.DETREND_NONE)
+        d = ctx.alloc(len(x) * 8)
+        try:
+            ctx.h2d(d, x)
+            got = plan.exec_device_src(d + 8 * lead, len(x) - lead)
+        finally:
+            ctx.free(d)
+        assert _route(plan) == 'kernel=anyfft:onewg' and plan.last_nseg == nseg, (n, nov, nseg, plan.last_recipe())
+        rel = np.abs(got - ref) / np.maximum(ref, 1e-9 * ref.max())
+        amp = np.abs(np.sqrt(np.maximum(got, 0)) - np.sqrt(ref)) / np.sqrt(ref.max())
+        weak = rel >= RTOL
+        worst = max(worst, float(rel[~weak].max()) if (~weak).any() else 0.0)
+        assert np.all(amp[weak] <= 4 * 2.0 ** -23), (n, nov, nseg, detrend, kind, abs(dc), float(rel.max()), float(amp[weak].max() * 2.0 ** 23))
+        assert not np.any(weak & (ref >= np.median(ref))), (n, nov, nseg, detrend, kind, abs(dc), float(rel.max()))
+        assert nseg < 8 or not weak.any(), (n, nov, nseg, detrend, kind, abs(dc), float(rel.max()))
+        plan.close()
+    print('one-workgroup fuzz: worst relative error outside the few-segment regime %.1e' % worst)
+
+
 def test_fuzz_any_length_shapes_against_the_oracle(ctx, hip):
     """120 random plans outside the power-of-two kernels - lengths 1 ... 40000 (small primes, prime powers, 2-3-5-7-smooth
     numbers, primes next to the route boundaries 16384 / 8192), nperseg <= nfft, any overlap, detrend on / off, window
