@@ -202,10 +202,10 @@ __global__ __launch_bounds__(1024) void welch32k_kernel(W32kArgs p) {
         slot = (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);
     }
 
-    // Nothing but the thread index and the thirty-two sums is carried around the segment loop in vector registers: the lane's
-    // LDS addresses, the twiddle seeds (p.tw[k] = W_N^k: W, W^4 of the three twiddled passes of a 16384-point transform,
-    // W_N^tid of the radix-2 step - L1 / L2 hits) and the window rows are formed again where they are used, from values the
-    // compiler cannot see through (`opaque`) - it would otherwise hoist them out of the loop and spill them.
+    // Nothing but the thread index, the thirty-two sums and (32768 points) the sixteen rows requested ahead is carried around the
+    // segment loop in vector registers: the lane's LDS addresses, the twiddle seeds (from the LDS tables filled below) and the
+    // window rows are formed again where they are used, from values the compiler cannot see through (`opaque`) - it would
+    // otherwise hoist them out of the loop and spill them.
     auto opaque = [](int v) {
         asm volatile("" : "+v"(v));
         return v;
