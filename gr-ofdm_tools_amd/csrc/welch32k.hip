@@ -28,6 +28,10 @@
 // SLOWER same-box (0.505-0.509 against 0.499-0.502 ms): the time the early waves spend at the mean's barrier moves to the next
 // barrier, it is not idle time of the SIMDs.
 //
+// Wave priorities are the 16384-point kernels' (raised around memory / LDS issue, lowered for the butterflies).  A FIXED priority
+// per wave by its rank on the SIMD - to even out who reaches a barrier first - is 3.6 x SLOWER (1.77 against 0.49 ms per 2^27
+// samples): the low ranks starve and every barrier waits for them.
+//
 // Samples are read with ordinary (cached) loads: at 50 % overlap every sample is wanted by two segments, and the segments of
 // one round are dealt out so that neighbours run on the same XCD (workgroup b runs on XCD b % 8: it takes slot
 // (b % 8) (W / 8) + b / 8) - the second reader finds the half in that XCD's L2.
